@@ -1,0 +1,135 @@
+/*
+ * cm_model.h -- flat, pointer-free ("POD") compiled Cassie model.
+ *
+ * One cm_model_t is the constant block a physics step needs: it is produced on
+ * the host by the MJCF-subset compiler (mjcf_loader.cpp), memcpy'd verbatim into
+ * HBM and read by the HIP kernels through wave-uniform (scalar) loads.  The same
+ * struct is what the CPU oracle (oracle/cassie_oracle.c) consumes, so the model
+ * compiler is exercised by both sides.
+ *
+ * It plays the role of the mjModel fields the reference touches
+ * (SURVEY.md 8b field census; reference src/cassiemujoco.c:67-122 dlsym table),
+ * restricted to what the three in-scope models use.
+ *
+ * Plain C so that C, C++ and HIP translation units can all include it.
+ */
+#ifndef CM_MODEL_H
+#define CM_MODEL_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* capacity limits (cassie.xml: nbody 26, njnt 26, nq 35, nv 32;
+ * cassie_tray_box.xml: nbody 28, nq 42, nv 38) */
+#define CM_MAXBODY   32
+#define CM_MAXJNT    32
+#define CM_MAXQ      48
+#define CM_MAXV      40
+#define CM_MAXU      12
+#define CM_MAXEQ     8
+#define CM_MAXGEOM   32      /* collision-capable geoms only */
+#define CM_MAXPAIR   192     /* statically filtered candidate geom pairs */
+#define CM_MAXSITE   16
+#define CM_MAXSENSOR 24
+#define CM_MAXSENSORDATA 40
+#define CM_MAXCON    16      /* contacts kept per env-step */
+#define CM_MAXEFC    63      /* constraint rows per env-step (lane 63 is the qfrc_smooth column) */
+
+/* joint types (same numbering as MuJoCo's mjtJoint) */
+enum { CM_JNT_FREE = 0, CM_JNT_BALL = 1, CM_JNT_SLIDE = 2, CM_JNT_HINGE = 3 };
+/* geom types (same numbering as mjtGeom) */
+enum { CM_GEOM_PLANE = 0, CM_GEOM_HFIELD = 1, CM_GEOM_SPHERE = 2, CM_GEOM_CAPSULE = 3,
+       CM_GEOM_ELLIPSOID = 4, CM_GEOM_CYLINDER = 5, CM_GEOM_BOX = 6, CM_GEOM_MESH = 7 };
+/* sensor types used by the in-scope models (model/cassie.xml:270-292) */
+enum { CM_SENS_ACTUATORPOS = 0, CM_SENS_JOINTPOS = 1, CM_SENS_FRAMEQUAT = 2, CM_SENS_GYRO = 3,
+       CM_SENS_ACCELEROMETER = 4, CM_SENS_MAGNETOMETER = 5, CM_SENS_RANGEFINDER = 6 };
+/* constraint row types (same order as MuJoCo's mjtConstraint for the ones used) */
+enum { CM_CNSTR_EQUALITY = 0, CM_CNSTR_LIMIT_JOINT = 3, CM_CNSTR_CONTACT_FRICTIONLESS = 5,
+       CM_CNSTR_CONTACT_PYRAMIDAL = 6 };
+
+/* option flags */
+#define CM_FLAG_EULERDAMP  1u   /* implicit joint damping in the Euler step (SURVEY App.B 11) */
+#define CM_FLAG_WARMSTART  2u
+#define CM_FLAG_REFSAFE    4u
+
+#define CM_MINVAL 1e-15
+
+typedef struct cm_model {
+    /* sizes */
+    int nq, nv, nu, nbody, njnt, ngeom, npair, neq, nsite, nsensor, nsensordata;
+    int maxdepth;          /* deepest body level (world = 0) */
+    int iterations;        /* PGS sweeps (model/cassie.xml:5 -> 50) */
+    unsigned flags;
+    int hfield_geom;       /* index into geom_* of the hfield geom, -1 if none */
+    int hfield_nrow, hfield_ncol;
+    int pad0;
+    double timestep, tolerance, meaninertia;
+    double gravity[3], magnetic[3];
+    double hfield_size[4]; /* x half-size, y half-size, z top scale, z bottom */
+
+    /* bodies (index 0 = world) */
+    int body_parentid[CM_MAXBODY];
+    int body_rootid[CM_MAXBODY];          /* top-level ancestor (child of world); 0 for world */
+    int body_weldid[CM_MAXBODY];          /* nearest ancestor-or-self that has joints; 0 = static */
+    int body_jntadr[CM_MAXBODY], body_jntnum[CM_MAXBODY];
+    int body_dofadr[CM_MAXBODY], body_dofnum[CM_MAXBODY];
+    int body_depth[CM_MAXBODY];
+    int body_subtreeend[CM_MAXBODY];      /* bodies [b, end) form b's subtree (depth-first ids) */
+    uint64_t body_dofmask[CM_MAXBODY];    /* bit k set <=> dof k moves this body */
+    double body_pos[CM_MAXBODY][3], body_quat[CM_MAXBODY][4];
+    double body_ipos[CM_MAXBODY][3], body_iquat[CM_MAXBODY][4];
+    double body_mass[CM_MAXBODY], body_inertia[CM_MAXBODY][3];
+    double body_invweight0[CM_MAXBODY][2];
+
+    /* joints */
+    int jnt_type[CM_MAXJNT], jnt_qposadr[CM_MAXJNT], jnt_dofadr[CM_MAXJNT];
+    int jnt_bodyid[CM_MAXJNT], jnt_limited[CM_MAXJNT];
+    double jnt_pos[CM_MAXJNT][3], jnt_axis[CM_MAXJNT][3], jnt_range[CM_MAXJNT][2];
+    double jnt_stiffness[CM_MAXJNT], jnt_margin[CM_MAXJNT];
+    double jnt_solref[CM_MAXJNT][2], jnt_solimp[CM_MAXJNT][5];
+    double qpos0[CM_MAXQ], qpos_spring[CM_MAXQ];
+
+    /* dofs */
+    int dof_bodyid[CM_MAXV], dof_jntid[CM_MAXV], dof_parentid[CM_MAXV];
+    double dof_armature[CM_MAXV], dof_damping[CM_MAXV], dof_invweight0[CM_MAXV];
+
+    /* collision geoms (contype|conaffinity != 0) */
+    int geom_type[CM_MAXGEOM], geom_bodyid[CM_MAXGEOM], geom_condim[CM_MAXGEOM];
+    int geom_priority[CM_MAXGEOM], geom_contype[CM_MAXGEOM], geom_conaffinity[CM_MAXGEOM];
+    int geom_fullid[CM_MAXGEOM];          /* id in the host model's full geom list */
+    double geom_pos[CM_MAXGEOM][3], geom_quat[CM_MAXGEOM][4], geom_size[CM_MAXGEOM][3];
+    double geom_friction[CM_MAXGEOM][3], geom_solref[CM_MAXGEOM][2], geom_solimp[CM_MAXGEOM][5];
+    double geom_solmix[CM_MAXGEOM], geom_margin[CM_MAXGEOM], geom_gap[CM_MAXGEOM];
+    double geom_rbound[CM_MAXGEOM];       /* bounding-sphere radius, 0 for planes/hfields */
+
+    /* candidate pairs after the static bitmask / same-body / parent-child filter;
+     * geom1's type <= geom2's type (MuJoCo's narrow-phase convention) and the list
+     * is sorted by (body1, body2, geom1, geom2) so contact order is deterministic */
+    int pair_geom1[CM_MAXPAIR], pair_geom2[CM_MAXPAIR];
+
+    /* equality constraints (connect only) */
+    int eq_body1[CM_MAXEQ], eq_body2[CM_MAXEQ], eq_active[CM_MAXEQ];
+    double eq_data[CM_MAXEQ][6];          /* anchor in body1 frame, anchor in body2 frame */
+    double eq_solref[CM_MAXEQ][2], eq_solimp[CM_MAXEQ][5];
+
+    /* actuators (motor on a hinge joint) */
+    int act_dofid[CM_MAXU], act_qposadr[CM_MAXU], act_ctrllimited[CM_MAXU];
+    double act_gear[CM_MAXU], act_ctrlrange[CM_MAXU][2];
+
+    /* sites */
+    int site_bodyid[CM_MAXSITE];
+    double site_pos[CM_MAXSITE][3], site_quat[CM_MAXSITE][4];
+
+    /* sensors */
+    int sensor_type[CM_MAXSENSOR], sensor_objid[CM_MAXSENSOR];
+    int sensor_adr[CM_MAXSENSOR], sensor_dim[CM_MAXSENSOR];
+    double sensor_cutoff[CM_MAXSENSOR];
+} cm_model_t;
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CM_MODEL_H */

@@ -1,0 +1,93 @@
+/*
+ * cassie_oracle.h -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * Scalar fp64 CPU restatement of one physics step of the reference's hot path:
+ * the mj_step1 + mj_step2 pair that reference src/cassiemujoco.c:1130-1134 calls
+ * through dlsym'd function pointers into MuJoCo 2.1.0 (libmujoco210.so, a closed
+ * third-party binary that is NOT in /root/reference and not installable here).
+ *
+ * PARITY UNPINNED: the reference tree holds no golden vector, test or fixture for
+ * this path and the real library cannot be run in this
+ * container.  This file restates MuJoCo's published computation model (SURVEY.md
+ * App. B) and is pinned only by analytically derivable known answers
+ * (tests/test_oracle_known_answers.py).  It is the checker for the HIP kernels
+ * and the "port" CPU baseline of bench.py -- nothing under cassie-mujoco-sim_amd/
+ * may link or call it.
+ */
+#ifndef CASSIE_ORACLE_H
+#define CASSIE_ORACLE_H
+
+#include "cm_model.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct co_contact {
+    double dist, pos[3], frame[9];
+    double includemargin, friction[5], solref[2], solimp[5];
+    int dim, geom1, geom2, efc_address;
+} co_contact_t;
+
+typedef struct co_data {
+    /* ---- state (inputs of a step) ---- */
+    double time;
+    double qpos[CM_MAXQ], qvel[CM_MAXV], qacc_warmstart[CM_MAXV], ctrl[CM_MAXU];
+    double qfrc_applied[CM_MAXV], xfrc_applied[CM_MAXBODY][6];
+    /* ---- outputs ---- */
+    double qacc[CM_MAXV], sensordata[CM_MAXSENSORDATA];
+    double actuator_length[CM_MAXU], actuator_velocity[CM_MAXU], actuator_force[CM_MAXU];
+    /* ---- position stage ---- */
+    double xpos[CM_MAXBODY][3], xquat[CM_MAXBODY][4], xmat[CM_MAXBODY][9];
+    double xipos[CM_MAXBODY][3], ximat[CM_MAXBODY][9];
+    double xanchor[CM_MAXJNT][3], xaxis[CM_MAXJNT][3];
+    double geom_xpos[CM_MAXGEOM][3], geom_xmat[CM_MAXGEOM][9];
+    double site_xpos[CM_MAXSITE][3], site_xmat[CM_MAXSITE][9];
+    double subtree_com[CM_MAXBODY][3];
+    double cinert[CM_MAXBODY][10], crb[CM_MAXBODY][10], cdof[CM_MAXV][6];
+    double qM[CM_MAXV][CM_MAXV];   /* dense, symmetric */
+    double qLD[CM_MAXV][CM_MAXV];  /* M = L^T D L : strict lower part = L, diagonal = D */
+    /* ---- velocity stage ---- */
+    double cvel[CM_MAXBODY][6], cdof_dot[CM_MAXV][6];
+    double qfrc_bias[CM_MAXV], qfrc_passive[CM_MAXV];
+    /* ---- acceleration stage ---- */
+    double qfrc_actuator[CM_MAXV], qfrc_smooth[CM_MAXV], qacc_smooth[CM_MAXV], qfrc_constraint[CM_MAXV];
+    /* ---- constraints ---- */
+    int ncon, nefc, ne, nl;
+    co_contact_t contact[CM_MAXCON];
+    int efc_type[CM_MAXEFC], efc_id[CM_MAXEFC];
+    double efc_J[CM_MAXEFC][CM_MAXV];
+    double efc_pos[CM_MAXEFC], efc_margin[CM_MAXEFC], efc_diagApprox[CM_MAXEFC];
+    double efc_R[CM_MAXEFC], efc_D[CM_MAXEFC], efc_KBIP[CM_MAXEFC][4];
+    double efc_vel[CM_MAXEFC], efc_aref[CM_MAXEFC], efc_b[CM_MAXEFC], efc_force[CM_MAXEFC];
+    double efc_AR[CM_MAXEFC][CM_MAXEFC];
+    int solver_iter;
+    /* ---- diagnostics ---- */
+    int warn_contact_full, warn_constraint_full, warn_unsupported_pair, diverged;
+    double cacc_imu[6];
+} co_data_t;
+
+/* heightfield samples shared by all envs (row-major nrow x ncol, MuJoCo layout); may be NULL */
+void co_set_hfield(const float *data);
+
+void co_reset(const cm_model_t *m, co_data_t *d);            /* mj_resetData role: qpos = qpos0, rest 0 */
+void co_forward(const cm_model_t *m, co_data_t *d);          /* mj_forward role */
+void co_step(const cm_model_t *m, co_data_t *d);             /* mj_step1 + mj_step2 role (one Euler step) */
+
+/* individual stages, exposed for known-answer tests */
+void co_kinematics(const cm_model_t *m, co_data_t *d);
+void co_com_pos(const cm_model_t *m, co_data_t *d);
+void co_crb(const cm_model_t *m, co_data_t *d);
+void co_factor_m(const cm_model_t *m, co_data_t *d);
+void co_collision(const cm_model_t *m, co_data_t *d);
+void co_make_constraint(const cm_model_t *m, co_data_t *d);
+void co_solve_m(const cm_model_t *m, const double LD[CM_MAXV][CM_MAXV], double *x);
+void co_jac(const cm_model_t *m, const co_data_t *d, int body, const double point[3],
+            double jacp[3][CM_MAXV], double jacr[3][CM_MAXV]);
+void co_integrate_pos(const cm_model_t *m, double *qpos, const double *qvel, double dt);
+unsigned long co_sizeof_data(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
