@@ -1,0 +1,73 @@
+# Build of the MI355X-native Cassie physics library and its test infrastructure.
+#
+#   make            product library  cassie-mujoco-sim_amd/lib/libcassiemujoco.so   (hipcc, gfx950)
+#   make oracle     CPU oracle       oracle/libcassie_oracle.so                     (gcc, test-only)
+#   make emu        wave emulator    tests/emu/libcassie_emu.so                     (g++, test-only)
+#   make models     models/*.cmodel from the reference MJCF (needs /root/reference)
+#
+# The Agility blocks (pd_input / cassie_core_sim / state_output + pack/unpack) exist
+# only as the closed static library shipped with the reference
+# (src/libagilitycassie.a); it is whole-archived into the product .so exactly like
+# the reference's own Makefile does (reference Makefile:18).  On a box without
+# /root/reference the prebuilt .so is used as is.
+
+ROCM      ?= /opt/rocm
+HIPCC     ?= $(ROCM)/bin/hipcc
+ARCH      ?= gfx950
+REF       ?= /root/reference
+AGILITY   ?= $(REF)/src/libagilitycassie.a
+
+PKG   := cassie-mujoco-sim_amd
+CSRC  := $(PKG)/csrc
+LIBD  := $(PKG)/lib
+OBJD  := build
+
+CXXFLAGS := -O2 -std=c++17 -fPIC -Iinclude -I$(CSRC)
+CFLAGS   := -O2 -std=gnu11 -fPIC -Iinclude -I$(CSRC)
+HIPFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Iinclude -I$(CSRC) -ffp-contract=on
+
+HOST_CPP := $(CSRC)/mjcf_loader.cpp $(CSRC)/phys_host.cpp
+HOST_C   := $(wildcard $(CSRC)/*.c)
+HIP_SRC  := $(CSRC)/phys_batch.hip
+OBJS     := $(patsubst $(CSRC)/%.cpp,$(OBJD)/%.o,$(HOST_CPP)) $(patsubst $(CSRC)/%.c,$(OBJD)/%.o,$(HOST_C)) \
+            $(patsubst $(CSRC)/%.hip,$(OBJD)/%.hip.o,$(HIP_SRC))
+
+PRODUCT := $(LIBD)/libcassiemujoco.so
+
+ifneq ($(wildcard $(AGILITY)),)
+AGILITY_LINK := -Wl,--whole-archive $(AGILITY) -Wl,--no-whole-archive
+else
+AGILITY_LINK :=
+endif
+
+.PHONY: all product oracle emu models clean
+all: product oracle emu
+product: $(PRODUCT)
+oracle: oracle/libcassie_oracle.so
+emu: tests/emu/libcassie_emu.so
+
+$(OBJD)/%.o: $(CSRC)/%.cpp $(wildcard $(CSRC)/*.h) $(wildcard include/*.h)
+	@mkdir -p $(OBJD)
+	g++ $(CXXFLAGS) -c $< -o $@
+$(OBJD)/%.o: $(CSRC)/%.c $(wildcard $(CSRC)/*.h) $(wildcard include/*.h)
+	@mkdir -p $(OBJD)
+	gcc $(CFLAGS) -c $< -o $@
+$(OBJD)/%.hip.o: $(CSRC)/%.hip $(wildcard $(CSRC)/*.h) $(wildcard include/*.h)
+	@mkdir -p $(OBJD)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(PRODUCT): $(OBJS)
+	@mkdir -p $(LIBD)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS) $(AGILITY_LINK) -lm -lpthread
+
+oracle/libcassie_oracle.so: oracle/cassie_oracle.c oracle/cassie_oracle.h $(CSRC)/cm_model.h $(wildcard oracle/*.c)
+	gcc -O2 -std=gnu11 -fPIC -shared -fopenmp -I$(CSRC) -Ioracle $(wildcard oracle/*.c) -o $@ -lm
+
+tests/emu/libcassie_emu.so: tests/emu/emu_runtime.cpp tests/emu/wave.h $(CSRC)/physics_kernel.h $(CSRC)/cm_model.h
+	g++ -O2 -std=c++17 -fPIC -shared -Itests/emu -I$(CSRC) tests/emu/emu_runtime.cpp -o $@
+
+models: product
+	python3 tools/make_models.py $(REF)/model models
+
+clean:
+	rm -rf $(OBJD) $(PRODUCT) oracle/libcassie_oracle.so tests/emu/libcassie_emu.so

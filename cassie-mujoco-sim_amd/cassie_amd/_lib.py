@@ -1,0 +1,77 @@
+"""Locates and loads the product shared library and derives the ctypes layout of cm_model_t."""
+import ctypes
+import os
+
+from . import cstruct
+
+PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))      # .../cassie-mujoco-sim_amd
+REPO_DIR = os.path.dirname(PKG_DIR)
+LIB_PATH = os.path.join(PKG_DIR, "lib", "libcassiemujoco.so")
+MODEL_DIR = os.path.join(REPO_DIR, "models")
+
+with open(os.path.join(PKG_DIR, "csrc", "cm_model.h")) as _f:
+    _hdr = _f.read()
+MACROS = cstruct.parse_defines(_hdr)
+CmModel = cstruct.parse_structs(_hdr, MACROS)["cm_model_t"]
+
+_lib = None
+
+
+def lib():
+    """The product library.  Raises (loudly) if it has not been built: there is no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "%s is missing: build it with `make` (or __graft_entry__.build()); "
+                "this package has no pure-Python or CPU fallback" % LIB_PATH)
+        _lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+        _declare(_lib)
+        if _lib.phys_sizeof_model() != ctypes.sizeof(CmModel):
+            raise RuntimeError("cm_model_t layout mismatch between cm_model.h and the built library")
+    return _lib
+
+
+def _declare(L):
+    c = ctypes
+    vp, ip, dp = c.c_void_p, c.POINTER(c.c_int), c.POINTER(c.c_double)
+    L.phys_sizeof_model.restype = c.c_size_t
+    L.phys_last_error.restype = c.c_char_p
+    L.phys_model_load.restype = vp
+    L.phys_model_load.argtypes = [c.c_char_p, c.c_char_p, c.c_int]
+    L.phys_model_copy.restype = vp
+    L.phys_model_copy.argtypes = [vp]
+    L.phys_model_free.argtypes = [vp]
+    L.phys_model_save.argtypes = [vp, c.c_char_p]
+    L.phys_model_set_const.argtypes = [vp]
+    L.phys_model_compile.argtypes = [vp, c.POINTER(CmModel), c.c_char_p, c.c_int]
+    L.phys_model_name2id.argtypes = [vp, c.c_int, c.c_char_p]
+    L.phys_model_id2name.restype = c.c_char_p
+    L.phys_model_id2name.argtypes = [vp, c.c_int, c.c_int]
+    L.phys_model_size.argtypes = [vp, c.c_int]
+    L.phys_model_array.restype = dp
+    L.phys_model_array.argtypes = [vp, c.c_int]
+    L.phys_model_iarray.restype = ip
+    L.phys_model_iarray.argtypes = [vp, c.c_int]
+    L.phys_model_geom_rgba.restype = c.POINTER(c.c_float)
+    L.phys_model_geom_rgba.argtypes = [vp]
+    L.phys_model_hfield_data.restype = c.POINTER(c.c_float)
+    L.phys_model_hfield_data.argtypes = [vp]
+    L.phys_batch_create.restype = vp
+    L.phys_batch_create.argtypes = [c.POINTER(CmModel), c.c_int, c.c_int]
+    L.phys_batch_free.argtypes = [vp]
+    L.phys_batch_nenv.argtypes = [vp]
+    L.phys_batch_field_dim.argtypes = [vp, c.c_int]
+    L.phys_batch_set_model.argtypes = [vp, c.POINTER(CmModel), c.c_int]
+    L.phys_batch_set_hfield.argtypes = [vp, c.POINTER(c.c_float), c.c_int]
+    L.phys_batch_upload.argtypes = [vp, c.c_int, vp, c.c_int, c.c_int]
+    L.phys_batch_download.argtypes = [vp, c.c_int, vp, c.c_int, c.c_int]
+    L.phys_batch_download_warn.argtypes = [vp, vp, vp]
+    L.phys_batch_device_ptr.restype = vp
+    L.phys_batch_device_ptr.argtypes = [vp, c.c_int]
+    L.phys_batch_bind.argtypes = [vp, c.c_int, vp]
+    L.phys_batch_step.argtypes = [vp, c.c_int, vp]
+    L.phys_batch_forward.argtypes = [vp, vp]
+    L.phys_batch_sync.argtypes = [vp]
+    L.phys_batch_set_pd_mode.argtypes = [vp, c.c_int]
+    L.phys_batch_time_steps.argtypes = [vp, c.c_int, c.c_int, c.POINTER(c.c_float)]

@@ -1,0 +1,160 @@
+"""Python face of the inner C ABI (include/cassie_phys.h): Model and Batch.
+
+``Batch`` is the batched, HBM-resident counterpart of the reference's one
+``cassie_sim_t`` per process (reference example/cassiemujoco.py:31-72): N
+environments stepped by one HIP launch.  All heavy lifting is in the shared
+library; this module only moves numpy arrays across the boundary.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from ._lib import CmModel, MODEL_DIR, lib
+
+# field ids (enum in cassie_phys.h)
+(F_QPOS, F_QVEL, F_QACC_WARMSTART, F_TIME, F_CTRL, F_QFRC_APPLIED, F_XFRC_APPLIED, F_QACC, F_SENSORDATA,
+ F_ACTUATOR_VELOCITY, F_XPOS, F_XQUAT, F_PD_PTARGET, F_PD_KP, F_PD_KD) = range(15)
+
+WARN_CONTACT_FULL, WARN_CONSTRAINT_FULL, WARN_UNSUPPORTED_PAIR, WARN_DIVERGED = 1, 2, 4, 8
+
+# joint configuration the reference writes at init (reference src/cassiemujoco.c:1023-1028)
+QPOS_INIT_JOINTS = np.array(
+    [0.0045, 0, 0.4973, 0.9785, -0.0164, 0.01787, -0.2049, -1.1997, 0, 1.4267, 0, -1.5244, 1.5244, -1.5968,
+     -0.0045, 0, 0.4973, 0.9786, 0.00386, -0.01524, -0.2051, -1.1997, 0, 1.4267, 0, -1.5244, 1.5244, -1.5968])
+
+
+def model_path(name):
+    """Resolves 'cassie' / 'cassie_hfield' / 'cassie_tray_box' (or a path) to a loadable model file."""
+    if os.path.exists(name):
+        return name
+    p = os.path.join(MODEL_DIR, name + ".cmodel")
+    if os.path.exists(p):
+        return p
+    raise FileNotFoundError("no model file for %r (looked in %s)" % (name, MODEL_DIR))
+
+
+class Model:
+    """Host model (names, all geoms, ...) plus its compiled pointer-free form ``.pod`` (cm_model_t)."""
+
+    def __init__(self, path_or_name="cassie"):
+        L = lib()
+        err = ctypes.create_string_buffer(1024)
+        self._h = L.phys_model_load(model_path(path_or_name).encode(), err, len(err))
+        if not self._h:
+            raise RuntimeError("model load failed: " + err.value.decode())
+        self.pod = CmModel()
+        self.compile()
+
+    def compile(self):
+        err = ctypes.create_string_buffer(1024)
+        if lib().phys_model_compile(self._h, ctypes.byref(self.pod), err, len(err)) != 0:
+            raise RuntimeError("model compile failed: " + err.value.decode())
+        return self.pod
+
+    def set_const(self):
+        lib().phys_model_set_const(self._h)
+        self.compile()
+
+    def save(self, path):
+        if lib().phys_model_save(self._h, path.encode()) != 0:
+            raise RuntimeError("cannot write " + path)
+
+    def name2id(self, objtype, name):
+        return lib().phys_model_name2id(self._h, objtype, name.encode())
+
+    def size(self, what):
+        return lib().phys_model_size(self._h, what)
+
+    def qpos_init(self):
+        """The state cassie_sim_init leaves the robot in (qpos0 with the nominal joint pose)."""
+        q = np.array(self.pod.qpos0[: self.pod.nq])
+        q[7:35] = QPOS_INIT_JOINTS
+        return q
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().phys_model_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+class Batch:
+    """N environments resident in HBM on one MI355X."""
+
+    def __init__(self, model, nenv, device=0):
+        self.model = model
+        self.nenv = int(nenv)
+        pod = model.pod if isinstance(model, Model) else model
+        self.pod = pod
+        self._h = lib().phys_batch_create(ctypes.byref(pod), self.nenv, device)
+        if not self._h:
+            raise RuntimeError("phys_batch_create failed: " + (lib().phys_last_error() or b"").decode())
+
+    def dim(self, field):
+        return lib().phys_batch_field_dim(self._h, field)
+
+    def set(self, field, arr, env0=0):
+        a = np.ascontiguousarray(arr, dtype=np.float64).reshape(-1, self.dim(field))
+        if lib().phys_batch_upload(self._h, field, a.ctypes.data, env0, a.shape[0]) != 0:
+            raise RuntimeError("upload failed: " + (lib().phys_last_error() or b"").decode())
+
+    def get(self, field, env0=0, n=None):
+        n = self.nenv - env0 if n is None else n
+        out = np.empty((n, self.dim(field)), dtype=np.float64)
+        if lib().phys_batch_download(self._h, field, out.ctypes.data, env0, n) != 0:
+            raise RuntimeError("download failed: " + (lib().phys_last_error() or b"").decode())
+        return out
+
+    def warnings(self):
+        w = np.zeros(self.nenv, dtype=np.int32)
+        info = np.zeros((self.nenv, 4), dtype=np.int32)
+        if lib().phys_batch_download_warn(self._h, w.ctypes.data, info.ctypes.data) != 0:
+            raise RuntimeError("download failed")
+        return w, info
+
+    def device_ptr(self, field):
+        return lib().phys_batch_device_ptr(self._h, field)
+
+    def bind(self, field, device_ptr):
+        if lib().phys_batch_bind(self._h, field, device_ptr) != 0:
+            raise RuntimeError("bind failed")
+
+    def set_model(self, pod, env=-1):
+        if lib().phys_batch_set_model(self._h, ctypes.byref(pod), env) != 0:
+            raise RuntimeError("set_model failed: " + (lib().phys_last_error() or b"").decode())
+
+    def step(self, nsub=1, stream=None):
+        if lib().phys_batch_step(self._h, nsub, stream) != 0:
+            raise RuntimeError("step failed: " + (lib().phys_last_error() or b"").decode())
+
+    def forward(self, stream=None):
+        if lib().phys_batch_forward(self._h, stream) != 0:
+            raise RuntimeError("forward failed: " + (lib().phys_last_error() or b"").decode())
+
+    def set_pd_mode(self, on=True):
+        lib().phys_batch_set_pd_mode(self._h, 1 if on else 0)
+
+    def sync(self):
+        if lib().phys_batch_sync(self._h) != 0:
+            raise RuntimeError("sync failed: " + (lib().phys_last_error() or b"").decode())
+
+    def time_steps(self, nsub, reps):
+        """Mean milliseconds per launch of `nsub` steps, measured with HIP events on the launch stream."""
+        ms = ctypes.c_float(0)
+        if lib().phys_batch_time_steps(self._h, nsub, reps, ctypes.byref(ms)) != 0:
+            raise RuntimeError("timing failed: " + (lib().phys_last_error() or b"").decode())
+        return ms.value
+
+    def close(self):
+        if self._h:
+            lib().phys_batch_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -118,6 +118,7 @@ typedef struct cm_model {
     /* actuators (motor on a hinge joint) */
     int act_dofid[CM_MAXU], act_qposadr[CM_MAXU], act_ctrllimited[CM_MAXU];
     double act_gear[CM_MAXU], act_ctrlrange[CM_MAXU][2];
+    double act_maxrpm[CM_MAXU];           /* actuator user[0]: no-load motor speed (model/cassie.xml:257-267) */
 
     /* sites */
     int site_bodyid[CM_MAXSITE];

@@ -1118,6 +1118,7 @@ bool HostModel::compile(cm_model_t *o, std::string *err) const {
         o->act_dofid[u] = jnt_dofadr[j]; o->act_qposadr[u] = jnt_qposadr[j];
         o->act_ctrllimited[u] = act_ctrllimited[u];
         o->act_gear[u] = act_gear[6 * u];
+        o->act_maxrpm[u] = nuser_actuator > 0 ? act_user[(size_t)nuser_actuator * u] : 0.0;
         o->act_ctrlrange[u][0] = act_ctrlrange[2 * u]; o->act_ctrlrange[u][1] = act_ctrlrange[2 * u + 1];
     }
     for (int s = 0; s < nsite; ++s) {

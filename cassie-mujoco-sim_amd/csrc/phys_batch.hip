@@ -1,0 +1,267 @@
+/*
+ * phys_batch.hip -- device half of the inner C ABI (include/cassie_phys.h): N
+ * Cassie environments resident in HBM and the launch of the one-wave-per-env
+ * step kernel (physics_kernel.h).  Replaces the reference's per-sim
+ * mj_makeData / mj_step1 / mj_step2 / mj_forward / mj_deleteData calls
+ * (reference src/cassiemujoco.c:441-447, :1130-1134, :1029, :452).
+ *
+ * Layout in HBM: every per-env field is one env-major array [nenv][dim] of fp64,
+ * so the wave that owns env e touches one contiguous row per field.  The model
+ * is a single cm_model_t (or one per env for domain randomisation).
+ */
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "cassie_phys.h"
+#include "physics_kernel.h"
+
+void phys_set_last_error(const char *s);
+
+struct phys_batch {
+    int nenv = 0, device = 0;
+    cm_model_t host_model;          /* copy of the shared model (sizes) */
+    cm_model_t *d_models = nullptr; /* 1 or nenv models in HBM */
+    int model_stride = 0;
+    int dim[PHYS_F_COUNT];
+    double *d_field[PHYS_F_COUNT];
+    bool owned[PHYS_F_COUNT];
+    int *d_warn = nullptr, *d_info = nullptr;
+    float *d_hfield = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool use_applied = false;
+    bool pd_mode = false;       /* qfrc_applied / xfrc_applied are passed only once uploaded */
+};
+
+static bool hip_ok(hipError_t e, const char *what) {
+    if (e == hipSuccess) return true;
+    std::string msg = std::string("HIP error in ") + what + ": " + hipGetErrorString(e);
+    phys_set_last_error(msg.c_str());
+    fprintf(stderr, "cassie_phys: %s\n", msg.c_str());
+    return false;
+}
+
+static ck::PhysIO make_io(phys_batch *b, int nsub, int integrate) {
+    ck::PhysIO io;
+    memset(&io, 0, sizeof io);
+    io.models = b->d_models;
+    io.model_stride = b->model_stride;
+    io.nenv = b->nenv; io.nsub = nsub; io.integrate = integrate;
+    io.sq = b->host_model.nq; io.sv = b->host_model.nv; io.su = b->host_model.nu;
+    io.ssd = b->host_model.nsensordata; io.sb = b->host_model.nbody;
+    io.qpos = b->d_field[PHYS_F_QPOS]; io.qvel = b->d_field[PHYS_F_QVEL];
+    io.qacc_warmstart = b->d_field[PHYS_F_QACC_WARMSTART]; io.time = b->d_field[PHYS_F_TIME];
+    io.ctrl = b->d_field[PHYS_F_CTRL];
+    io.qfrc_applied = b->use_applied ? b->d_field[PHYS_F_QFRC_APPLIED] : nullptr;
+    io.xfrc_applied = b->use_applied ? b->d_field[PHYS_F_XFRC_APPLIED] : nullptr;
+    io.qacc = b->d_field[PHYS_F_QACC]; io.sensordata = b->d_field[PHYS_F_SENSORDATA];
+    io.actuator_velocity = b->d_field[PHYS_F_ACTUATOR_VELOCITY];
+    io.warn = b->d_warn; io.info = b->d_info;
+    io.xpos_out = b->d_field[PHYS_F_XPOS]; io.xquat_out = b->d_field[PHYS_F_XQUAT];
+    io.hfield = b->d_hfield;
+    if (b->pd_mode) {
+        io.pd_ptarget = b->d_field[PHYS_F_PD_PTARGET]; io.pd_kp = b->d_field[PHYS_F_PD_KP]; io.pd_kd = b->d_field[PHYS_F_PD_KD];
+    }
+    return io;
+}
+
+static int launch(phys_batch *b, int nsub, int integrate, hipStream_t s) {
+    ck::PhysIO io = make_io(b, nsub, integrate);
+    const dim3 grid(b->nenv), block(WV_WAVE);
+    if (b->host_model.nv <= 32)
+        hipLaunchKernelGGL(ck::cassie_step_kernel<32>, grid, block, 0, s, io);
+    else
+        hipLaunchKernelGGL(ck::cassie_step_kernel<40>, grid, block, 0, s, io);
+    return hip_ok(hipGetLastError(), "cassie_step_kernel launch") ? 0 : -1;
+}
+
+extern "C" {
+
+phys_batch_t *phys_batch_create(const cm_model_t *model, int nenv, int device) {
+    if (!model || nenv <= 0) { phys_set_last_error("phys_batch_create: bad arguments"); return nullptr; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        const char *msg = "phys_batch_create: no HIP device available -- this library has no CPU fallback";
+        phys_set_last_error(msg);
+        fprintf(stderr, "cassie_phys: %s\n", msg);
+        return nullptr;
+    }
+    if (device < 0 || device >= ndev) { phys_set_last_error("phys_batch_create: bad device index"); return nullptr; }
+    if (!hip_ok(hipSetDevice(device), "hipSetDevice")) return nullptr;
+    phys_batch *b = new phys_batch;
+    b->nenv = nenv; b->device = device;
+    b->host_model = *model;
+    const int d[PHYS_F_COUNT] = {model->nq, model->nv, model->nv, 1, model->nu, model->nv, model->nbody * 6,
+                                 model->nv, model->nsensordata, model->nu, model->nbody * 3, model->nbody * 4,
+                                 model->nu, model->nu, model->nu};
+    bool ok = true;
+    for (int f = 0; f < PHYS_F_COUNT; ++f) {
+        b->dim[f] = d[f]; b->d_field[f] = nullptr; b->owned[f] = true;
+        size_t bytes = sizeof(double) * (size_t)nenv * (d[f] > 0 ? d[f] : 1);
+        ok = ok && hip_ok(hipMalloc((void **)&b->d_field[f], bytes), "hipMalloc(field)");
+        if (ok) ok = hip_ok(hipMemset(b->d_field[f], 0, bytes), "hipMemset(field)");
+    }
+    ok = ok && hip_ok(hipMalloc((void **)&b->d_models, sizeof(cm_model_t)), "hipMalloc(model)");
+    ok = ok && hip_ok(hipMemcpy(b->d_models, model, sizeof(cm_model_t), hipMemcpyHostToDevice), "hipMemcpy(model)");
+    ok = ok && hip_ok(hipMalloc((void **)&b->d_warn, sizeof(int) * nenv), "hipMalloc(warn)");
+    ok = ok && hip_ok(hipMemset(b->d_warn, 0, sizeof(int) * nenv), "hipMemset(warn)");
+    ok = ok && hip_ok(hipMalloc((void **)&b->d_info, sizeof(int) * 4 * nenv), "hipMalloc(info)");
+    ok = ok && hip_ok(hipMemset(b->d_info, 0, sizeof(int) * 4 * nenv), "hipMemset(info)");
+    ok = ok && hip_ok(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking), "hipStreamCreate");
+    ok = ok && hip_ok(hipEventCreate(&b->ev0), "hipEventCreate") && hip_ok(hipEventCreate(&b->ev1), "hipEventCreate");
+    if (ok) {
+        /* every env starts at qpos0 */
+        std::vector<double> q0((size_t)nenv * model->nq);
+        for (int e = 0; e < nenv; ++e) memcpy(&q0[(size_t)e * model->nq], model->qpos0, sizeof(double) * model->nq);
+        ok = hip_ok(hipMemcpy(b->d_field[PHYS_F_QPOS], q0.data(), q0.size() * sizeof(double), hipMemcpyHostToDevice),
+                    "hipMemcpy(qpos0)");
+    }
+    if (!ok) { phys_batch_free(b); return nullptr; }
+    return b;
+}
+
+void phys_batch_free(phys_batch_t *b) {
+    if (!b) return;
+    (void)hipSetDevice(b->device);
+    for (int f = 0; f < PHYS_F_COUNT; ++f)
+        if (b->owned[f] && b->d_field[f]) (void)hipFree(b->d_field[f]);
+    if (b->d_models) (void)hipFree(b->d_models);
+    if (b->d_warn) (void)hipFree(b->d_warn);
+    if (b->d_info) (void)hipFree(b->d_info);
+    if (b->d_hfield) (void)hipFree(b->d_hfield);
+    if (b->ev0) (void)hipEventDestroy(b->ev0);
+    if (b->ev1) (void)hipEventDestroy(b->ev1);
+    if (b->stream) (void)hipStreamDestroy(b->stream);
+    delete b;
+}
+
+int phys_batch_nenv(const phys_batch_t *b) { return b ? b->nenv : 0; }
+int phys_batch_field_dim(const phys_batch_t *b, int field) {
+    return (b && field >= 0 && field < PHYS_F_COUNT) ? b->dim[field] : 0;
+}
+
+int phys_batch_set_model(phys_batch_t *b, const cm_model_t *model, int env) {
+    if (!b || !model) return -1;
+    if (model->nq != b->host_model.nq || model->nv != b->host_model.nv || model->nbody != b->host_model.nbody ||
+        model->nu != b->host_model.nu || model->nsensordata != b->host_model.nsensordata) {
+        phys_set_last_error("phys_batch_set_model: model dimensions differ from the batch's");
+        return -1;
+    }
+    (void)hipSetDevice(b->device);
+    if (env < 0) {
+        if (b->model_stride == 1) { /* back to one shared model */
+            (void)hipFree(b->d_models);
+            b->d_models = nullptr;
+            if (!hip_ok(hipMalloc((void **)&b->d_models, sizeof(cm_model_t)), "hipMalloc(model)")) return -1;
+            b->model_stride = 0;
+        }
+        b->host_model = *model;
+        return hip_ok(hipMemcpy(b->d_models, model, sizeof(cm_model_t), hipMemcpyHostToDevice), "hipMemcpy(model)") ? 0 : -1;
+    }
+    if (env >= b->nenv) return -1;
+    if (b->model_stride == 0) { /* expand to one model per env */
+        cm_model_t *all = nullptr;
+        if (!hip_ok(hipMalloc((void **)&all, sizeof(cm_model_t) * (size_t)b->nenv), "hipMalloc(models)")) return -1;
+        std::vector<cm_model_t> tmp((size_t)b->nenv, b->host_model);
+        if (!hip_ok(hipMemcpy(all, tmp.data(), sizeof(cm_model_t) * tmp.size(), hipMemcpyHostToDevice), "hipMemcpy(models)")) return -1;
+        (void)hipFree(b->d_models);
+        b->d_models = all;
+        b->model_stride = 1;
+    }
+    return hip_ok(hipMemcpy(b->d_models + env, model, sizeof(cm_model_t), hipMemcpyHostToDevice), "hipMemcpy(model)") ? 0 : -1;
+}
+
+int phys_batch_set_hfield(phys_batch_t *b, const float *data, int n) {
+    if (!b || !data || n <= 0) return -1;
+    (void)hipSetDevice(b->device);
+    if (!b->d_hfield && !hip_ok(hipMalloc((void **)&b->d_hfield, sizeof(float) * (size_t)n), "hipMalloc(hfield)")) return -1;
+    return hip_ok(hipMemcpy(b->d_hfield, data, sizeof(float) * (size_t)n, hipMemcpyHostToDevice), "hipMemcpy(hfield)") ? 0 : -1;
+}
+
+int phys_batch_upload(phys_batch_t *b, int field, const double *host, int env0, int n) {
+    if (!b || !host || field < 0 || field >= PHYS_F_COUNT || env0 < 0 || n < 0 || env0 + n > b->nenv) return -1;
+    (void)hipSetDevice(b->device);
+    if (field == PHYS_F_QFRC_APPLIED || field == PHYS_F_XFRC_APPLIED) b->use_applied = true;
+    const size_t row = (size_t)b->dim[field];
+    return hip_ok(hipMemcpyAsync(b->d_field[field] + row * env0, host, sizeof(double) * row * n, hipMemcpyHostToDevice,
+                                 b->stream), "upload") &&
+                   hip_ok(hipStreamSynchronize(b->stream), "upload sync")
+               ? 0 : -1;
+}
+
+int phys_batch_download(phys_batch_t *b, int field, double *host, int env0, int n) {
+    if (!b || !host || field < 0 || field >= PHYS_F_COUNT || env0 < 0 || n < 0 || env0 + n > b->nenv) return -1;
+    (void)hipSetDevice(b->device);
+    const size_t row = (size_t)b->dim[field];
+    return hip_ok(hipMemcpyAsync(host, b->d_field[field] + row * env0, sizeof(double) * row * n, hipMemcpyDeviceToHost,
+                                 b->stream), "download") &&
+                   hip_ok(hipStreamSynchronize(b->stream), "download sync")
+               ? 0 : -1;
+}
+
+int phys_batch_download_warn(phys_batch_t *b, int *host_warn, int *host_info) {
+    if (!b) return -1;
+    (void)hipSetDevice(b->device);
+    bool ok = hip_ok(hipStreamSynchronize(b->stream), "sync");
+    if (host_warn) ok = ok && hip_ok(hipMemcpy(host_warn, b->d_warn, sizeof(int) * b->nenv, hipMemcpyDeviceToHost), "warn");
+    if (host_info) ok = ok && hip_ok(hipMemcpy(host_info, b->d_info, sizeof(int) * 4 * b->nenv, hipMemcpyDeviceToHost), "info");
+    return ok ? 0 : -1;
+}
+
+void *phys_batch_device_ptr(phys_batch_t *b, int field) {
+    return (b && field >= 0 && field < PHYS_F_COUNT) ? (void *)b->d_field[field] : nullptr;
+}
+
+int phys_batch_bind(phys_batch_t *b, int field, void *device_ptr) {
+    if (!b || !device_ptr || field < 0 || field >= PHYS_F_COUNT) return -1;
+    (void)hipSetDevice(b->device);
+    if (b->owned[field] && b->d_field[field]) (void)hipFree(b->d_field[field]);
+    b->d_field[field] = (double *)device_ptr;
+    b->owned[field] = false;
+    if (field == PHYS_F_QFRC_APPLIED || field == PHYS_F_XFRC_APPLIED) b->use_applied = true;
+    return 0;
+}
+
+int phys_batch_step(phys_batch_t *b, int nsub, void *stream) {
+    if (!b || nsub <= 0) return -1;
+    (void)hipSetDevice(b->device);
+    return launch(b, nsub, 1, stream ? (hipStream_t)stream : b->stream);
+}
+
+int phys_batch_forward(phys_batch_t *b, void *stream) {
+    if (!b) return -1;
+    (void)hipSetDevice(b->device);
+    return launch(b, 1, 0, stream ? (hipStream_t)stream : b->stream);
+}
+
+int phys_batch_set_pd_mode(phys_batch_t *b, int on) {
+    if (!b) return -1;
+    b->pd_mode = on != 0;
+    return 0;
+}
+
+int phys_batch_sync(phys_batch_t *b) {
+    if (!b) return -1;
+    (void)hipSetDevice(b->device);
+    return hip_ok(hipStreamSynchronize(b->stream), "hipStreamSynchronize") ? 0 : -1;
+}
+
+int phys_batch_time_steps(phys_batch_t *b, int nsub, int reps, float *mean_ms) {
+    if (!b || nsub <= 0 || reps <= 0 || !mean_ms) return -1;
+    (void)hipSetDevice(b->device);
+    if (!hip_ok(hipEventRecord(b->ev0, b->stream), "hipEventRecord")) return -1;
+    for (int r = 0; r < reps; ++r)
+        if (launch(b, nsub, 1, b->stream) != 0) return -1;
+    if (!hip_ok(hipEventRecord(b->ev1, b->stream), "hipEventRecord")) return -1;
+    if (!hip_ok(hipEventSynchronize(b->ev1), "hipEventSynchronize")) return -1;
+    float ms = 0;
+    if (!hip_ok(hipEventElapsedTime(&ms, b->ev0, b->ev1), "hipEventElapsedTime")) return -1;
+    *mean_ms = ms / reps;
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,154 @@
+/*
+ * phys_host.cpp -- host half of the inner C ABI (include/cassie_phys.h): model
+ * lifecycle and the read-write model views the drop-in accessors need.
+ * Replaces the reference's mj_loadXML / mj_copyModel / mj_deleteModel / mj_setConst /
+ * mj_name2id / mj_id2name calls and its direct mjModel field access
+ * (reference src/cassiemujoco.c:851, :1013-1016, :1110, :952, :1244).
+ */
+#include "cassie_phys.h"
+#include "host_model.h"
+
+#include <cstring>
+#include <string>
+
+struct phys_model {
+    cm::HostModel h;
+};
+
+static thread_local std::string g_err;
+static void set_err(char *err, int errlen, const std::string &s) {
+    g_err = s;
+    if (err && errlen > 0) {
+        strncpy(err, s.c_str(), errlen - 1);
+        err[errlen - 1] = 0;
+    }
+}
+void phys_set_last_error(const char *s) { g_err = s ? s : ""; }
+
+extern "C" {
+
+const char *phys_last_error(void) { return g_err.c_str(); }
+size_t phys_sizeof_model(void) { return sizeof(cm_model_t); }
+
+phys_model_t *phys_model_load(const char *path, char *err, int errlen) {
+    phys_model *m = new phys_model;
+    std::string e;
+    if (!path || !cm::load_model_file(path, &m->h, &e)) {
+        set_err(err, errlen, e.empty() ? "no model path" : e);
+        delete m;
+        return nullptr;
+    }
+    return m;
+}
+
+phys_model_t *phys_model_copy(const phys_model_t *src) {
+    if (!src) return nullptr;
+    return new phys_model(*src);
+}
+
+void phys_model_free(phys_model_t *m) { delete m; }
+
+int phys_model_save(const phys_model_t *m, const char *path) { return m && path && m->h.save(path) ? 0 : -1; }
+
+void phys_model_set_const(phys_model_t *m) {
+    if (m) m->h.set_const();
+}
+
+int phys_model_compile(const phys_model_t *m, cm_model_t *out, char *err, int errlen) {
+    std::string e;
+    if (!m || !out || !m->h.compile(out, &e)) {
+        set_err(err, errlen, e.empty() ? "null model" : e);
+        return -1;
+    }
+    return 0;
+}
+
+int phys_model_name2id(const phys_model_t *m, int objtype, const char *name) {
+    return m ? m->h.name2id(objtype, name) : -1;
+}
+const char *phys_model_id2name(const phys_model_t *m, int objtype, int id) {
+    return m ? m->h.id2name(objtype, id) : nullptr;
+}
+
+int phys_model_size(const phys_model_t *m, int what) {
+    if (!m) return 0;
+    const cm::HostModel &h = m->h;
+    switch (what) {
+        case PHYS_NQ: return h.nq;
+        case PHYS_NV: return h.nv;
+        case PHYS_NU: return h.nu;
+        case PHYS_NBODY: return h.nbody;
+        case PHYS_NJNT: return h.njnt;
+        case PHYS_NGEOM: return h.ngeom;
+        case PHYS_NSITE: return h.nsite;
+        case PHYS_NSENSOR: return h.nsensor;
+        case PHYS_NSENSORDATA: return h.nsensordata;
+        case PHYS_NEQ: return h.neq;
+        case PHYS_NHFIELDDATA: return h.nhfielddata;
+        case PHYS_HFIELD_NROW: return h.hfield_nrow;
+        case PHYS_HFIELD_NCOL: return h.hfield_ncol;
+        case PHYS_NUSER_SENSOR: return h.nuser_sensor;
+        case PHYS_NUSER_ACTUATOR: return h.nuser_actuator;
+        case PHYS_NUSER_GEOM: return h.nuser_geom;
+        case PHYS_NCAM: return h.ncam;
+    }
+    return 0;
+}
+
+double *phys_model_array(phys_model_t *m, int which) {
+    if (!m) return nullptr;
+    cm::HostModel &h = m->h;
+    switch (which) {
+        case PHYS_M_BODY_MASS: return h.body_mass.data();
+        case PHYS_M_BODY_IPOS: return h.body_ipos.data();
+        case PHYS_M_BODY_POS: return h.body_pos.data();
+        case PHYS_M_BODY_QUAT: return h.body_quat.data();
+        case PHYS_M_DOF_DAMPING: return h.dof_damping.data();
+        case PHYS_M_JNT_STIFFNESS: return h.jnt_stiffness.data();
+        case PHYS_M_QPOS_SPRING: return h.qpos_spring.data();
+        case PHYS_M_QPOS0: return h.qpos0.data();
+        case PHYS_M_JNT_RANGE: return h.jnt_range.data();
+        case PHYS_M_GEOM_POS: return h.geom_pos.data();
+        case PHYS_M_GEOM_QUAT: return h.geom_quat.data();
+        case PHYS_M_GEOM_SIZE: return h.geom_size.data();
+        case PHYS_M_GEOM_FRICTION: return h.geom_friction.data();
+        case PHYS_M_GEOM_USER: return h.geom_user.data();
+        case PHYS_M_ACTUATOR_GEAR: return h.act_gear.data();
+        case PHYS_M_ACTUATOR_CTRLRANGE: return h.act_ctrlrange.data();
+        case PHYS_M_ACTUATOR_USER: return h.act_user.data();
+        case PHYS_M_SENSOR_USER: return h.sensor_user.data();
+        case PHYS_M_HFIELD_SIZE: return h.hfield_size;
+        case PHYS_M_TIMESTEP: return &h.timestep;
+        case PHYS_M_STAT_CENTER: return h.stat_center;
+        case PHYS_M_STAT_EXTENT: return &h.stat_extent;
+    }
+    return nullptr;
+}
+
+float *phys_model_geom_rgba(phys_model_t *m) { return m ? m->h.geom_rgba.data() : nullptr; }
+float *phys_model_hfield_data(phys_model_t *m) { return m && !m->h.hfield_data.empty() ? m->h.hfield_data.data() : nullptr; }
+
+int *phys_model_iarray(phys_model_t *m, int which) {
+    if (!m) return nullptr;
+    cm::HostModel &h = m->h;
+    switch (which) {
+        case PHYS_MI_JNT_TYPE: return h.jnt_type.data();
+        case PHYS_MI_JNT_QPOSADR: return h.jnt_qposadr.data();
+        case PHYS_MI_JNT_DOFADR: return h.jnt_dofadr.data();
+        case PHYS_MI_GEOM_BODYID: return h.geom_bodyid.data();
+        case PHYS_MI_GEOM_GROUP: return h.geom_group.data();
+        case PHYS_MI_GEOM_TYPE: return h.geom_type.data();
+        case PHYS_MI_SENSOR_OBJID: return h.sensor_objid.data();
+        case PHYS_MI_SENSOR_TYPE: return h.sensor_type.data();
+        case PHYS_MI_SENSOR_ADR: return h.sensor_adr.data();
+        case PHYS_MI_SENSOR_DIM: return h.sensor_dim.data();
+        case PHYS_MI_BODY_PARENTID: return h.body_parentid.data();
+        case PHYS_MI_BODY_JNTADR: return h.body_jntadr.data();
+        case PHYS_MI_BODY_JNTNUM: return h.body_jntnum.data();
+        case PHYS_MI_BODY_DOFADR: return h.body_dofadr.data();
+        case PHYS_MI_BODY_DOFNUM: return h.body_dofnum.data();
+    }
+    return nullptr;
+}
+
+}  // extern "C"

@@ -1,0 +1,107 @@
+/*
+ * cassie_phys.h -- the INNER drop-in boundary: the thin C ABI the host C glue
+ * (cassiemujoco.c-equivalent) calls where the reference calls into MuJoCo.
+ *
+ * The reference has no clean ABI at this seam: it is a dlsym'd function-pointer
+ * table plus direct mjModel/mjData field access (reference src/cassiemujoco.c:67-122,
+ * field census in SURVEY.md 8b).  Each entry point below names the reference
+ * call(s) it replaces.  Plain C types only: handles, pointers, sizes.
+ *
+ * All phys_batch_* entry points run on the MI355X through HIP; creating a batch
+ * without a usable GPU fails loudly (NULL + message on stderr) -- there is no CPU
+ * fallback in this library.
+ */
+#ifndef CASSIE_PHYS_H
+#define CASSIE_PHYS_H
+
+#include <stddef.h>
+#include "cm_model.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ model --- */
+typedef struct phys_model phys_model_t; /* host model: names, all geoms, hfield samples ... */
+
+/* mj_loadXML (reference src/cassiemujoco.c:851, :930, :997).  Accepts the MJCF subset of
+ * the in-scope models (.xml) or the neutral .cmodel text form; NULL + err text on failure. */
+phys_model_t *phys_model_load(const char *path, char *err, int errlen);
+/* mj_copyModel (reference :1013, :1016, :1093) */
+phys_model_t *phys_model_copy(const phys_model_t *src);
+/* mj_deleteModel (reference :883, :1110) */
+void phys_model_free(phys_model_t *m);
+int phys_model_save(const phys_model_t *m, const char *path);
+/* mj_setConst (reference :952, :976): recompute invweight0 / meaninertia after inertial edits */
+void phys_model_set_const(phys_model_t *m);
+/* derive the pointer-free kernel model; returns 0 on success */
+int phys_model_compile(const phys_model_t *m, cm_model_t *out, char *err, int errlen);
+/* mj_name2id / mj_id2name (reference :861-866, :1244, ...); objtype uses mjtObj numbering */
+int phys_model_name2id(const phys_model_t *m, int objtype, const char *name);
+const char *phys_model_id2name(const phys_model_t *m, int objtype, int id);
+
+/* sizes: the mjModel ints the reference reads (nq nv nu nbody njnt ngeom nsensordata ...) */
+enum { PHYS_NQ, PHYS_NV, PHYS_NU, PHYS_NBODY, PHYS_NJNT, PHYS_NGEOM, PHYS_NSITE, PHYS_NSENSOR, PHYS_NSENSORDATA,
+       PHYS_NEQ, PHYS_NHFIELDDATA, PHYS_HFIELD_NROW, PHYS_HFIELD_NCOL, PHYS_NUSER_SENSOR, PHYS_NUSER_ACTUATOR,
+       PHYS_NCAM, PHYS_NUSER_GEOM };
+int phys_model_size(const phys_model_t *m, int what);
+
+/* read-write views of the mjModel arrays the reference exposes through accessors
+ * (reference :1303-1584, :2050-2112).  Layouts follow MuJoCo. */
+enum { PHYS_M_BODY_MASS, PHYS_M_BODY_IPOS, PHYS_M_BODY_POS, PHYS_M_BODY_QUAT, PHYS_M_DOF_DAMPING, PHYS_M_JNT_STIFFNESS,
+       PHYS_M_QPOS_SPRING, PHYS_M_GEOM_POS, PHYS_M_GEOM_QUAT, PHYS_M_GEOM_SIZE, PHYS_M_GEOM_FRICTION,
+       PHYS_M_ACTUATOR_GEAR, PHYS_M_ACTUATOR_CTRLRANGE, PHYS_M_ACTUATOR_USER, PHYS_M_SENSOR_USER, PHYS_M_HFIELD_SIZE,
+       PHYS_M_TIMESTEP, PHYS_M_QPOS0, PHYS_M_JNT_RANGE, PHYS_M_STAT_CENTER, PHYS_M_STAT_EXTENT, PHYS_M_GEOM_USER };
+double *phys_model_array(phys_model_t *m, int which);
+float *phys_model_geom_rgba(phys_model_t *m);
+float *phys_model_hfield_data(phys_model_t *m);
+enum { PHYS_MI_JNT_TYPE, PHYS_MI_JNT_QPOSADR, PHYS_MI_JNT_DOFADR, PHYS_MI_GEOM_BODYID, PHYS_MI_GEOM_GROUP,
+       PHYS_MI_SENSOR_OBJID, PHYS_MI_SENSOR_TYPE, PHYS_MI_SENSOR_ADR, PHYS_MI_SENSOR_DIM, PHYS_MI_BODY_PARENTID,
+       PHYS_MI_GEOM_TYPE, PHYS_MI_BODY_JNTADR, PHYS_MI_BODY_JNTNUM, PHYS_MI_BODY_DOFADR, PHYS_MI_BODY_DOFNUM };
+int *phys_model_iarray(phys_model_t *m, int which);
+
+/* ------------------------------------------------------------ batched data --- */
+typedef struct phys_batch phys_batch_t; /* N envs resident in HBM: the mjData role, batched */
+
+/* per-env arrays (env-major, contiguous rows) */
+enum { PHYS_F_QPOS, PHYS_F_QVEL, PHYS_F_QACC_WARMSTART, PHYS_F_TIME, PHYS_F_CTRL, PHYS_F_QFRC_APPLIED,
+       PHYS_F_XFRC_APPLIED, PHYS_F_QACC, PHYS_F_SENSORDATA, PHYS_F_ACTUATOR_VELOCITY, PHYS_F_XPOS, PHYS_F_XQUAT,
+       PHYS_F_PD_PTARGET, PHYS_F_PD_KP, PHYS_F_PD_KD, /* on-device joint PD, see phys_batch_set_pd_mode */
+       PHYS_F_COUNT };
+
+/* mj_makeData (reference :441-447) for nenv environments on HIP device `device`;
+ * every env starts at qpos0 (mj_resetData role).  NULL + stderr message on failure. */
+phys_batch_t *phys_batch_create(const cm_model_t *model, int nenv, int device);
+void phys_batch_free(phys_batch_t *b);                                  /* mj_deleteData (reference :452) */
+int phys_batch_nenv(const phys_batch_t *b);
+int phys_batch_field_dim(const phys_batch_t *b, int field);            /* doubles per env */
+/* replace the model of one env (env >= 0) or of all envs (env = -1): per-env domain randomisation */
+int phys_batch_set_model(phys_batch_t *b, const cm_model_t *model, int env);
+int phys_batch_set_hfield(phys_batch_t *b, const float *data, int n);
+/* host <-> HBM copies of whole fields or of a row range [env0, env0 + n) */
+int phys_batch_upload(phys_batch_t *b, int field, const double *host, int env0, int n);
+int phys_batch_download(phys_batch_t *b, int field, double *host, int env0, int n);
+int phys_batch_download_warn(phys_batch_t *b, int *host_warn, int *host_info /* [nenv][4] or NULL */);
+/* raw device pointer of a field (for torch / RCCL interop); bind replaces it with caller-owned HBM */
+void *phys_batch_device_ptr(phys_batch_t *b, int field);
+int phys_batch_bind(phys_batch_t *b, int field, void *device_ptr);
+/* mj_step1 + mj_step2, nsub times with ctrl held (reference :1130-1134), on `stream`
+ * (a hipStream_t passed as void*, NULL = the batch's own stream); asynchronous */
+int phys_batch_step(phys_batch_t *b, int nsub, void *stream);
+/* mj_forward (reference :971, :1029, :1223, :3293): no integration */
+int phys_batch_forward(phys_batch_t *b, void *stream);
+int phys_batch_sync(phys_batch_t *b);
+/* on != 0: every substep computes ctrl on the device from PHYS_F_PD_{PTARGET,KP,KD} -- the motor PD law of
+ * pd_input_step (reference include/pd_input.h:34) followed by the speed-torque limit of motor()
+ * (reference src/cassiemujoco.c:638-664), evaluated on the exact joint state; PHYS_F_CTRL is then ignored */
+int phys_batch_set_pd_mode(phys_batch_t *b, int on);
+/* times `reps` launches of nsub steps with HIP events on the launch stream; returns mean ms per launch */
+int phys_batch_time_steps(phys_batch_t *b, int nsub, int reps, float *mean_ms);
+
+size_t phys_sizeof_model(void);
+const char *phys_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

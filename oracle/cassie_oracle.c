@@ -928,3 +928,35 @@ void co_step(const cm_model_t *m, co_data_t *d) {
     d->time += m->timestep;
     for (int k = 0; k < nv; ++k) d->qacc_warmstart[k] = d->qacc[k];
 }
+
+/* ---------------------------------------------- batched helpers (bench / tests) ---- */
+void co_pd_ctrl(const cm_model_t *m, co_data_t *d, const double *ptarget, const double *kp, const double *kd) {
+    for (int u = 0; u < m->nu; ++u) {
+        double ratio = m->act_gear[u], tmax = m->act_ctrlrange[u][1];
+        double q = d->qpos[m->act_qposadr[u]], qd = d->qvel[m->act_dofid[u]];
+        double tau = kp[u] * (ptarget[u] - q) - kd[u] * qd;
+        double wmax = m->act_maxrpm[u] * (2.0 * M_PI / 60.0);
+        double tlim = clampd(2 * tmax * (1 - fabs(ratio * qd) / wmax), 0.0, tmax);
+        d->ctrl[u] = copysign(fmin(fabs(tau / ratio), tlim), tau);
+    }
+}
+
+#ifdef _OPENMP
+#include <omp.h>
+int co_max_threads(void) { return omp_get_max_threads(); }
+#else
+int co_max_threads(void) { return 1; }
+#endif
+
+void co_step_batch(const cm_model_t *m, co_data_t *d, int n, int nsteps, const double *ptarget, const double *kp,
+                   const double *kd, int nthreads) {
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int e = 0; e < n; ++e)
+        for (int s = 0; s < nsteps; ++s) {
+            if (ptarget) co_pd_ctrl(m, &d[e], ptarget + (size_t)e * m->nu, kp + (size_t)e * m->nu, kd + (size_t)e * m->nu);
+            co_step(m, &d[e]);
+        }
+}

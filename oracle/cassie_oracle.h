@@ -86,6 +86,12 @@ void co_jac(const cm_model_t *m, const co_data_t *d, int body, const double poin
             double jacp[3][CM_MAXV], double jacr[3][CM_MAXV]);
 void co_integrate_pos(const cm_model_t *m, double *qpos, const double *qvel, double dt);
 unsigned long co_sizeof_data(void);
+/* joint PD -> motor-side ctrl (pd_input motor law + reference motor() speed-torque limit, no delay line) */
+void co_pd_ctrl(const cm_model_t *m, co_data_t *d, const double *ptarget, const double *kp, const double *kd);
+/* OpenMP over independent envs: nsteps of co_step (optionally with the PD law) for each of n envs */
+void co_step_batch(const cm_model_t *m, co_data_t *d, int n, int nsteps, const double *ptarget, const double *kp,
+                   const double *kd, int nthreads);
+int co_max_threads(void);
 
 #ifdef __cplusplus
 }

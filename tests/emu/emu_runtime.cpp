@@ -1,0 +1,143 @@
+/*
+ * emu_runtime.cpp -- TEST-ONLY wavefront emulator (see tests/emu/wave.h).
+ * Runs physics_kernel.h on the CPU: one coroutine per lane, round-robin
+ * scheduling with a rendezvous at every cross-lane primitive.  Because the
+ * kernel keeps all collectives in wave-uniform control flow, "resume every lane
+ * until its next rendezvous" reproduces the SIMT semantics exactly.
+ */
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "physics_kernel.h"
+
+namespace {
+constexpr int NL = 64;
+constexpr size_t STACK_BYTES = 1 << 20;
+
+struct LaneCtx { void *sp; char *stack; bool done; };
+LaneCtx g_lane[NL];
+void *g_sched_sp;
+int g_cur = 0, g_env = 0;
+double g_xd[NL];
+int g_xi[NL];
+void (*g_body)() = nullptr;
+bool g_mismatch = false;
+
+extern "C" void emu_switch(void **save_sp, void *load_sp);
+asm(R"(
+.text
+.globl emu_switch
+.type emu_switch,@function
+emu_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+)");
+
+void rendezvous() { emu_switch(&g_lane[g_cur].sp, g_sched_sp); }
+
+void lane_entry() {
+    g_body();
+    g_lane[g_cur].done = true;
+    emu_switch(&g_lane[g_cur].sp, g_sched_sp);
+    abort(); /* a finished lane is never resumed */
+}
+
+void run_block(void (*body)()) {
+    g_body = body;
+    for (int l = 0; l < NL; ++l) {
+        if (!g_lane[l].stack) g_lane[l].stack = (char *)aligned_alloc(64, STACK_BYTES);
+        uintptr_t top = ((uintptr_t)g_lane[l].stack + STACK_BYTES) & ~(uintptr_t)15;
+        void **slot = (void **)(top - 16); /* 16-byte aligned return-address slot */
+        *slot = (void *)&lane_entry;
+        void **sp = slot - 6;
+        for (int i = 0; i < 6; ++i) sp[i] = nullptr;
+        g_lane[l].sp = sp;
+        g_lane[l].done = false;
+    }
+    for (;;) {
+        int ndone = 0;
+        for (int l = 0; l < NL; ++l) {
+            if (g_lane[l].done) { ++ndone; continue; }
+            g_cur = l;
+            emu_switch(&g_sched_sp, g_lane[l].sp);
+            if (g_lane[l].done) ++ndone;
+        }
+        if (ndone == NL) break;
+        if (ndone != 0) { g_mismatch = true; fprintf(stderr, "emu: lanes left the kernel at different rendezvous counts (%d done)\n", ndone); abort(); }
+    }
+}
+}  // namespace
+
+namespace wv {
+int lane() { return g_cur; }
+int env_id() { return g_env; }
+void sync() { rendezvous(); }
+double shfl(double v, int src) {
+    g_xd[g_cur] = v;
+    rendezvous();
+    double r = g_xd[src & 63];
+    rendezvous();
+    return r;
+}
+double shfl_xor(double v, int mask) { return shfl(v, g_cur ^ mask); }
+int shfl_i(int v, int src) {
+    g_xi[g_cur] = v;
+    rendezvous();
+    int r = g_xi[src & 63];
+    rendezvous();
+    return r;
+}
+double readlane(double v, int src) { return shfl(v, src); }
+unsigned long long ballot(bool p) {
+    g_xi[g_cur] = p ? 1 : 0;
+    rendezvous();
+    unsigned long long m = 0;
+    for (int l = 0; l < NL; ++l) if (g_xi[l]) m |= 1ull << l;
+    rendezvous();
+    return m;
+}
+double wave_sum(double v) {
+    for (int o = 32; o > 0; o >>= 1) v += shfl_xor(v, o);
+    return v;
+}
+}  // namespace wv
+
+static ck::PhysIO g_io;
+static void body32() { ck::cassie_step_kernel<32>(g_io); }
+static void body40() { ck::cassie_step_kernel<40>(g_io); }
+
+extern "C" int emu_phys_run(const cm_model_t *model, int nenv, int nsub, int integrate, double *qpos, double *qvel,
+                            double *qacc_warmstart, double *time, const double *ctrl, const double *qfrc_applied,
+                            const double *xfrc_applied, double *qacc, double *sensordata, double *actuator_velocity,
+                            int *warn, int *info, double *xpos_out, double *xquat_out, const double *pd_ptarget,
+                            const double *pd_kp, const double *pd_kd) {
+    memset(&g_io, 0, sizeof g_io);
+    g_io.models = model; g_io.model_stride = 0;
+    g_io.nenv = nenv; g_io.nsub = nsub; g_io.integrate = integrate;
+    g_io.sq = model->nq; g_io.sv = model->nv; g_io.su = model->nu; g_io.ssd = model->nsensordata; g_io.sb = model->nbody;
+    g_io.qpos = qpos; g_io.qvel = qvel; g_io.qacc_warmstart = qacc_warmstart; g_io.time = time;
+    g_io.ctrl = ctrl; g_io.qfrc_applied = qfrc_applied; g_io.xfrc_applied = xfrc_applied;
+    g_io.qacc = qacc; g_io.sensordata = sensordata; g_io.actuator_velocity = actuator_velocity;
+    g_io.warn = warn; g_io.info = info; g_io.xpos_out = xpos_out; g_io.xquat_out = xquat_out;
+    g_io.pd_ptarget = pd_ptarget; g_io.pd_kp = pd_kp; g_io.pd_kd = pd_kd;
+    for (int e = 0; e < nenv; ++e) {
+        g_env = e;
+        run_block(model->nv <= 32 ? body32 : body40);
+    }
+    return 0;
+}
+extern "C" unsigned long emu_sizeof_shared32(void) { return sizeof(ck::EnvShared<32>); }

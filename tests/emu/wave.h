@@ -1,0 +1,35 @@
+/*
+ * tests/emu/wave.h -- TEST-ONLY stand-in for cassie-mujoco-sim_amd/csrc/wave.h.
+ *
+ * Lets the CPU-only test suite execute the *same* physics_kernel.h source the
+ * GPU runs, lane by lane, so kernel logic errors are caught before a GPU box is
+ * used.  64 lanes run as 64 coroutines; every cross-lane primitive is a
+ * rendezvous of all 64.  Nothing here is linked into the product library (the
+ * product builds with -Icsrc only and therefore sees the real wave.h).
+ */
+#ifndef CASSIE_WAVE_H
+#define CASSIE_WAVE_H
+
+#include <cmath>
+#include <cstddef>
+#include <cstdint>
+
+#define WV_DEVICE inline
+#define WV_GLOBAL
+#define WV_SHARED static
+#define WV_WAVE 64
+#define __launch_bounds__(x)
+
+namespace wv {
+int lane();
+int env_id();
+void sync();
+double shfl(double v, int src_lane);
+double shfl_xor(double v, int mask);
+int shfl_i(int v, int src_lane);
+double readlane(double v, int src);
+unsigned long long ballot(bool p);
+double wave_sum(double v);
+inline int popc64(unsigned long long x) { return __builtin_popcountll(x); }
+}  // namespace wv
+#endif

@@ -1,0 +1,50 @@
+"""ctypes access to the CPU wave emulator running the real physics_kernel.h -- test infrastructure only."""
+import ctypes
+import os
+
+import numpy as np
+
+from cassie_amd._lib import CmModel, REPO_DIR
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = ctypes.CDLL(os.path.join(REPO_DIR, "tests", "emu", "libcassie_emu.so"))
+        _lib.emu_phys_run.argtypes = [ctypes.POINTER(CmModel)] + [ctypes.c_int] * 3 + [ctypes.c_void_p] * 17
+    return _lib
+
+
+class EmuBatch:
+    """Same state arrays as cassie_amd.Batch, stepped by the emulated kernel."""
+
+    def __init__(self, pod, nenv):
+        self.pod, self.nenv = pod, nenv
+        z = lambda n: np.zeros((nenv, n))
+        self.qpos = np.tile(np.array(pod.qpos0[: pod.nq]), (nenv, 1))
+        self.qvel, self.qacc_warmstart, self.qacc = z(pod.nv), z(pod.nv), z(pod.nv)
+        self.ctrl, self.actuator_velocity = z(pod.nu), z(pod.nu)
+        self.sensordata = z(pod.nsensordata)
+        self.time = np.zeros(nenv)
+        self.qfrc_applied, self.xfrc_applied = None, None
+        self.warn = np.zeros(nenv, dtype=np.int32)
+        self.info = np.zeros((nenv, 4), dtype=np.int32)
+        self.xpos = z(pod.nbody * 3)
+        self.xquat = z(pod.nbody * 4)
+        self.pd_ptarget = self.pd_kp = self.pd_kd = None
+
+    def _run(self, nsub, integrate):
+        p = lambda a: None if a is None else a.ctypes.data
+        lib().emu_phys_run(ctypes.byref(self.pod), self.nenv, nsub, integrate, p(self.qpos), p(self.qvel),
+                           p(self.qacc_warmstart), p(self.time), p(self.ctrl), p(self.qfrc_applied),
+                           p(self.xfrc_applied), p(self.qacc), p(self.sensordata), p(self.actuator_velocity),
+                           p(self.warn), p(self.info), p(self.xpos), p(self.xquat), p(self.pd_ptarget), p(self.pd_kp),
+                           p(self.pd_kd))
+
+    def step(self, nsub=1):
+        self._run(nsub, 1)
+
+    def forward(self):
+        self._run(1, 0)

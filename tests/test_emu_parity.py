@@ -1,0 +1,125 @@
+"""The real kernel source (physics_kernel.h), executed lane-by-lane on the CPU wave
+emulator, against the scalar oracle.  Catches kernel logic errors without a GPU."""
+import numpy as np
+import pytest
+
+from emu_py import EmuBatch
+from oracle_py import Oracle
+
+
+def _drive(cassie, nsteps, teacher, seed, ctrl_scale=1.0, nenv=1):
+    pod = cassie.pod
+    rng = np.random.default_rng(seed)
+    q0 = cassie.qpos_init()
+    orcs = [Oracle(pod, q0) for _ in range(nenv)]
+    emu = EmuBatch(pod, nenv)
+    emu.qpos[:] = q0
+    v0 = rng.uniform(-0.3, 0.3, (nenv, pod.nv))
+    emu.qvel[:] = v0
+    for e, o in enumerate(orcs):
+        o.qvel[:] = v0[e]
+    hi = np.array([pod.act_ctrlrange[u][1] for u in range(pod.nu)])
+    worst = dict(q=0.0, v=0.0, s=0.0)
+    for s in range(nsteps):
+        if s % 10 == 0:
+            c = ctrl_scale * hi * rng.uniform(-1, 1, (nenv, pod.nu))
+            emu.ctrl[:] = c
+            for e, o in enumerate(orcs):
+                o.ctrl[:] = c[e]
+        emu.step()
+        for e, o in enumerate(orcs):
+            o.step()
+            assert (emu.info[e, 0], emu.info[e, 1], emu.info[e, 2]) == (o.d.ncon, o.d.nefc, o.d.solver_iter)
+            worst["q"] = max(worst["q"], np.max(np.abs(emu.qpos[e] - o.qpos)))
+            worst["v"] = max(worst["v"], np.max(np.abs(emu.qvel[e] - o.qvel)))
+            worst["s"] = max(worst["s"], np.max(np.abs(emu.sensordata[e] - o.sensordata)))
+            if teacher:
+                emu.qpos[e], emu.qvel[e], emu.qacc_warmstart[e] = o.qpos, o.qvel, o.qacc_warmstart
+    assert not emu.warn.any()
+    return worst
+
+
+def test_teacher_forced_steps(cassie):
+    w = _drive(cassie, 300, True, seed=1, nenv=2)
+    assert w["q"] < 1e-14 and w["v"] < 1e-10 and w["s"] < 1e-9, w
+
+
+def test_free_running_600_steps_with_contacts(cassie):
+    w = _drive(cassie, 600, False, seed=2)
+    # north_star bar is 1e-6 relative over 1000 steps; the emulated kernel is far inside it
+    assert w["q"] < 1e-9 and w["v"] < 1e-7, w
+
+
+def test_forward_only_matches_and_leaves_state(cassie):
+    pod = cassie.pod
+    o = Oracle(pod, cassie.qpos_init())
+    o.forward()
+    emu = EmuBatch(pod, 1)
+    emu.qpos[:] = cassie.qpos_init()
+    q_before = emu.qpos.copy()
+    emu.forward()
+    assert np.array_equal(q_before, emu.qpos)
+    assert np.allclose(emu.qacc[0], o.qacc, rtol=1e-9, atol=1e-9)
+    assert np.allclose(emu.sensordata[0], o.sensordata, atol=1e-10)
+
+
+def test_multi_substep_launch_equals_single_steps(cassie):
+    pod = cassie.pod
+    a, b = EmuBatch(pod, 1), EmuBatch(pod, 1)
+    for x in (a, b):
+        x.qpos[:] = cassie.qpos_init()
+        x.ctrl[:] = 0.5
+    a.step(nsub=25)
+    for _ in range(25):
+        b.step()
+    assert np.array_equal(a.qpos, b.qpos) and np.array_equal(a.qvel, b.qvel)
+    assert abs(a.time[0] - 25 * pod.timestep) < 1e-15
+
+
+def test_applied_forces(cassie):
+    pod = cassie.pod
+    rng = np.random.default_rng(5)
+    o = Oracle(pod, cassie.qpos_init())
+    emu = EmuBatch(pod, 1)
+    emu.qpos[:] = cassie.qpos_init()
+    emu.qfrc_applied = rng.uniform(-5, 5, (1, pod.nv))
+    emu.xfrc_applied = np.zeros((1, pod.nbody * 6))
+    emu.xfrc_applied[0, 6 * 1: 6 * 1 + 6] = [10, -5, 30, 1, 2, -1]       # pelvis
+    emu.xfrc_applied[0, 6 * 13: 6 * 13 + 3] = [0, 0, 20]                  # left foot
+    o.qfrc_applied[:] = emu.qfrc_applied[0]
+    o.xfrc_applied[:] = emu.xfrc_applied.reshape(pod.nbody, 6)
+    for _ in range(20):
+        emu.step()
+        o.step()
+    assert np.max(np.abs(emu.qpos[0] - o.qpos)) < 1e-12
+    assert np.max(np.abs(emu.qvel[0] - o.qvel)) < 1e-10
+
+
+def test_divergence_flag_is_sticky_and_state_untouched(cassie):
+    emu = EmuBatch(cassie.pod, 1)
+    emu.qpos[:] = cassie.qpos_init()
+    emu.qvel[0, 3] = np.nan
+    q = emu.qpos.copy()
+    emu.step(3)
+    assert emu.warn[0] & 8
+    assert np.array_equal(q, emu.qpos)
+
+
+def test_on_device_pd_mode(cassie):
+    """PD targets instead of torques: kernel-side PD + motor speed-torque limit vs the oracle's co_pd_ctrl."""
+    pod = cassie.pod
+    rng = np.random.default_rng(9)
+    offset = np.array([0.0045, 0, 0.4973, -1.1997, -1.5968] * 2)
+    kp = np.array([70, 70, 100, 100, 50] * 2, dtype=float)
+    kd = np.array([7, 7, 8, 8, 5] * 2, dtype=float)
+    pt = offset + rng.uniform(-0.3, 0.3, 10)
+    o = Oracle(pod, cassie.qpos_init())
+    emu = EmuBatch(pod, 1)
+    emu.qpos[:] = cassie.qpos_init()
+    emu.pd_ptarget, emu.pd_kp, emu.pd_kd = pt[None].copy(), kp[None].copy(), kd[None].copy()
+    for _ in range(120):
+        o.pd_ctrl(pt, kp, kd)
+        o.step()
+        emu.step()
+    assert np.max(np.abs(emu.qpos[0] - o.qpos)) < 1e-11
+    assert o.qpos[2] > 0.8          # still standing-ish under PD after 60 ms
