@@ -148,6 +148,13 @@ class Batch:
             raise RuntimeError("timing failed: " + (lib().phys_last_error() or b"").decode())
         return ms.value
 
+    def profile_step(self):
+        """Runs one step and returns the per-env shader-clock stamps [nenv][16] taken at the stage boundaries."""
+        st = np.zeros((self.nenv, 16), dtype=np.int64)
+        if lib().phys_batch_profile_step(self._h, st.ctypes.data) != 0:
+            raise RuntimeError("profile_step failed")
+        return st
+
     def close(self):
         if self._h:
             lib().phys_batch_free(self._h)

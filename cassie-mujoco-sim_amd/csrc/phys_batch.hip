@@ -33,8 +33,9 @@ struct phys_batch {
     float *d_hfield = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    bool use_applied = false;
-    bool pd_mode = false;       /* qfrc_applied / xfrc_applied are passed only once uploaded */
+    bool use_applied = false;       /* qfrc_applied / xfrc_applied are passed only once uploaded */
+    bool pd_mode = false;
+    long long *d_prof = nullptr;
 };
 
 static bool hip_ok(hipError_t e, const char *what) {
@@ -66,6 +67,7 @@ static ck::PhysIO make_io(phys_batch *b, int nsub, int integrate) {
     if (b->pd_mode) {
         io.pd_ptarget = b->d_field[PHYS_F_PD_PTARGET]; io.pd_kp = b->d_field[PHYS_F_PD_KP]; io.pd_kd = b->d_field[PHYS_F_PD_KD];
     }
+    io.prof = b->d_prof;
     return io;
 }
 
@@ -248,6 +250,20 @@ int phys_batch_sync(phys_batch_t *b) {
     if (!b) return -1;
     (void)hipSetDevice(b->device);
     return hip_ok(hipStreamSynchronize(b->stream), "hipStreamSynchronize") ? 0 : -1;
+}
+
+int phys_batch_profile_step(phys_batch_t *b, long long *host_stamps) {
+    if (!b || !host_stamps) return -1;
+    (void)hipSetDevice(b->device);
+    const size_t bytes = sizeof(long long) * ck::NSTAMP * (size_t)b->nenv;
+    if (!hip_ok(hipMalloc((void **)&b->d_prof, bytes), "hipMalloc(prof)")) return -1;
+    (void)hipMemset(b->d_prof, 0, bytes);
+    int rc = launch(b, 1, 1, b->stream);
+    bool ok = rc == 0 && hip_ok(hipStreamSynchronize(b->stream), "sync") &&
+              hip_ok(hipMemcpy(host_stamps, b->d_prof, bytes, hipMemcpyDeviceToHost), "prof download");
+    (void)hipFree(b->d_prof);
+    b->d_prof = nullptr;
+    return ok ? 0 : -1;
 }
 
 int phys_batch_time_steps(phys_batch_t *b, int nsub, int reps, float *mean_ms) {

@@ -38,6 +38,8 @@ constexpr int NROW = 64;       /* rows 0..62 constraints, column 63 = qfrc_smoot
 constexpr int AP = 65;         /* padded leading dimension of A and Y^T (bank-conflict free columns) */
 
 /* warning bits reported per env */
+constexpr int NSTAMP = 16;
+#define CK_STAMP(i) do { if (io.prof && lane == 0) io.prof[(size_t)env * NSTAMP + (i)] = wv::clock(); } while (0)
 enum { WARN_CONTACT_FULL = 1, WARN_CONSTRAINT_FULL = 2, WARN_UNSUPPORTED_PAIR = 4, WARN_DIVERGED = 8 };
 
 struct PhysIO {
@@ -59,6 +61,7 @@ struct PhysIO {
      * speed-torque limit -- the motor law of pd_input_step followed by
      * motor() (reference src/cassiemujoco.c:638-664) on the exact joint state */
     const double *pd_ptarget, *pd_kp, *pd_kd; /* [nenv][nu] each */
+    long long *prof;            /* optional [nenv][NSTAMP] shader-clock stamps of the last substep (may be null) */
 };
 
 template <int NVP>
@@ -315,6 +318,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
             wv::sync();
         }
 
+        CK_STAMP(0);
         /* ================= P1 kinematics: lane = body, level by level ================= */
         const int b = lane;
         const bool isbody = b < nbody;
@@ -388,6 +392,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
             wv::sync();
         }
 
+        CK_STAMP(1);
         /* geoms (lane = collision geom) and sites (lane = site) */
         if (lane < m->ngeom) {
             const int g = lane, gb = m->geom_bodyid[g];
@@ -484,6 +489,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
         for (int e = lane; e < NVP * (NVP + 1); e += WV_WAVE) (&S.x.s.M[0][0])[e] = 0.0;
         wv::sync();
 
+        CK_STAMP(2);
         /* ================= P2 CRBA ================= */
         if (isbody) {
             double acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -505,6 +511,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
         }
         wv::sync();
 
+        CK_STAMP(3);
         /* ================= P3 factor M and M + h*diag(damping) ================= */
         for (int e = lane; e < NVP * (NVP + 1); e += WV_WAVE) {
             const int r = e / (NVP + 1), c = e % (NVP + 1);
@@ -523,6 +530,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
         }
         if (isdof) S.rsd[k_] = 1.0 / sqrt(S.LD[k_][k_]);
 
+        CK_STAMP(4);
         /* ================= P4 collision: lane = candidate pair ================= */
         int ncon = 0;
         for (int p0 = 0; p0 < m->npair; p0 += WV_WAVE) {
@@ -623,6 +631,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
         }
         if (ncon > CM_MAXCON) { ncon = CM_MAXCON; warn |= WARN_CONTACT_FULL; }
 
+        CK_STAMP(5);
         /* ================= P6 velocity recursion: cvel, cdof_dot, bias acceleration ================= */
         if (b == 0) for (int i = 0; i < 6; ++i) { S.x.s.cvel[0][i] = 0; S.x.s.cacc[0][i] = (i < 3) ? 0.0 : -m->gravity[i - 3]; }
         wv::sync();
@@ -683,6 +692,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
             for (int i = 0; i < 6; ++i) qfrc_bias += cd[i] * acc[i];
         }
 
+        CK_STAMP(6);
         /* ================= P6/P7/P8 passive + actuation -> qfrc_smooth (lane = dof) ================= */
         if (isdof) {
             const int jt = m->jnt_type[kjnt];
@@ -722,6 +732,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
         }
         wv::sync();
 
+        CK_STAMP(7);
         /* ================= P5 constraint rows: lane = row ================= */
         /* row descriptor assignment is wave-uniform bookkeeping; every lane keeps its own row */
         const int r_ = lane;
@@ -893,6 +904,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
         }
         wv::sync(); /* every reader of the body-stage tiles is done: region x becomes A */
 
+        CK_STAMP(8);
         /* ================= half solve: Y = D^-1/2 L^-T [J^T | qfrc_smooth], lane = column ================= */
         for (int k = nv - 1; k >= 0; --k) {
             const double xk = S.Yt[k][r_];
@@ -901,6 +913,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
         }
         wv::sync();
 
+        CK_STAMP(9);
         /* ================= P9: A = Y^T Y + diag(R), b = Y^T y63 - aref (lane = column s) ================= */
         double yown[NVP];
 #pragma unroll
@@ -921,6 +934,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
         }
         wv::sync();
 
+        CK_STAMP(10);
         /* ================= P10: warm start + projected Gauss-Seidel, one row per lane ================= */
         const bool isrow = rtype >= 0;
         const bool clampf = isrow && rtype != CM_CNSTR_EQUALITY;
@@ -962,6 +976,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
             }
         }
 
+        CK_STAMP(11);
         /* ================= qacc = L^-1 D^-1/2 (y63 + Y f)  (lane = dof) ================= */
         double qacc;
         {
@@ -984,6 +999,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
         if (isdof) S.qacc[k_] = qacc;
         wv::sync();
 
+        CK_STAMP(12);
         /* ---- sensors, part 2: accelerometer needs qacc; cutoffs; store ---- */
         if (issens) {
             if (stype == CM_SENS_ACCELEROMETER) {
@@ -1020,6 +1036,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
         if (isdof) io.qacc[(size_t)env * io.sv + k_] = qacc;
         if (!io.integrate) break;
 
+        CK_STAMP(13);
         /* ================= P12 semi-implicit Euler with implicit joint damping ================= */
         double qacc_int = qacc;
         if (m->flags & CM_FLAG_EULERDAMP) {
@@ -1055,6 +1072,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
         }
         time += h;
         wv::sync();
+        CK_STAMP(14);
     }
 
     /* ---------------- store state ---------------- */

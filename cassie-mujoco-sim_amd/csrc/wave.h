@@ -45,6 +45,8 @@ WV_DEVICE double wave_sum(double v) {
     return v;
 }
 
+WV_DEVICE long long clock() { return (long long)__builtin_readcyclecounter(); }
+
 WV_DEVICE int popc64(unsigned long long x) { return __popcll(x); }
 
 }  // namespace wv

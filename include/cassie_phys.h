@@ -98,6 +98,9 @@ int phys_batch_set_pd_mode(phys_batch_t *b, int on);
 /* times `reps` launches of nsub steps with HIP events on the launch stream; returns mean ms per launch */
 int phys_batch_time_steps(phys_batch_t *b, int nsub, int reps, float *mean_ms);
 
+/* per-stage shader-clock stamps of the next launches: [nenv][16] long long on the host after the call (profiling aid) */
+int phys_batch_profile_step(phys_batch_t *b, long long *host_stamps);
+
 size_t phys_sizeof_model(void);
 const char *phys_last_error(void);
 

@@ -30,6 +30,7 @@ int shfl_i(int v, int src_lane);
 double readlane(double v, int src);
 unsigned long long ballot(bool p);
 double wave_sum(double v);
+inline long long clock() { return 0; }
 inline int popc64(unsigned long long x) { return __builtin_popcountll(x); }
 }  // namespace wv
 #endif

@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Per-stage shader-clock breakdown of the step kernel (profiling aid; needs a GPU)."""
+import os, sys
+import numpy as np
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "cassie-mujoco-sim_amd"))
+from cassie_amd import Batch, Model
+from cassie_amd import phys as P
+names = ["kinematics", "geoms+com+cinert+cdof", "crba", "factor", "collision", "velocity+rne", "qfrc_smooth",
+         "rows+J", "halfsolve", "A", "pgs", "qacc", "sensors", "euler"]
+m = Model("cassie")
+for n in (int(a) for a in (sys.argv[1:] or ["512", "4096"])):
+    b = Batch(m, n)
+    b.set(P.F_QPOS, np.tile(m.qpos_init(), (n, 1)))
+    rng = np.random.default_rng(0)
+    b.set(P.F_PD_PTARGET, np.array([0.0045, 0, 0.4973, -1.1997, -1.5968] * 2) + rng.uniform(-0.3, 0.3, (n, 10)))
+    b.set(P.F_PD_KP, np.tile([70, 70, 100, 100, 50] * 2, (n, 1)))
+    b.set(P.F_PD_KD, np.tile([7, 7, 8, 8, 5] * 2, (n, 1)))
+    b.set_pd_mode(True)
+    b.step(300); b.sync()
+    ms = b.time_steps(1, 50)
+    st = b.profile_step()
+    w, info = b.warnings()
+    d = np.diff(st[:, :15], axis=1).astype(float)
+    tot = (st[:, 14] - st[:, 0]).astype(float)
+    print("nenv %d: %.3f ms/step launch; per-env kernel cycles mean %.0f (min %.0f max %.0f); nefc mean %.1f iters mean %.1f"
+          % (n, ms, tot.mean(), tot.min(), tot.max(), info[:, 1].mean(), info[:, 2].mean()))
+    span = st[:, 14].max() - st[:, 0].min()
+    print("  whole-launch span in clock ticks: %d" % span)
+    for i, nm in enumerate(names):
+        print("  %-24s %9.0f cycles  %5.1f%%" % (nm, d[:, i].mean(), 100 * d[:, i].mean() / tot.mean()))
+    b.close()
