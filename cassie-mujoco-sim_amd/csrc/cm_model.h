@@ -95,6 +95,9 @@ typedef struct cm_model {
     /* dofs */
     int dof_bodyid[CM_MAXV], dof_jntid[CM_MAXV], dof_parentid[CM_MAXV];
     double dof_armature[CM_MAXV], dof_damping[CM_MAXV], dof_invweight0[CM_MAXV];
+    uint64_t dof_ancmask[CM_MAXV];        /* proper ancestors of dof k in the dof tree (M's row pattern) */
+    uint64_t dof_descmask[CM_MAXV];       /* dofs that have k as ancestor, plus k itself (M's column pattern) */
+    uint64_t dof_velmask[CM_MAXV];        /* ancestors of k that belong to other joints (velocity seen by joint k) */
 
     /* collision geoms (contype|conaffinity != 0) */
     int geom_type[CM_MAXGEOM], geom_bodyid[CM_MAXGEOM], geom_condim[CM_MAXGEOM];

@@ -1057,6 +1057,27 @@ bool HostModel::compile(cm_model_t *o, std::string *err) const {
         o->dof_bodyid[d] = dof_bodyid[d]; o->dof_jntid[d] = dof_jntid[d]; o->dof_parentid[d] = dof_parentid[d];
         o->dof_armature[d] = dof_armature[d]; o->dof_damping[d] = dof_damping[d]; o->dof_invweight0[d] = dof_invweight0[d];
     }
+    for (int d = 0; d < nv; ++d) {
+        uint64_t anc = 0, vel = 0;
+        for (int a = dof_parentid[d]; a >= 0; a = dof_parentid[a]) {
+            anc |= 1ull << a;
+            if (dof_jntid[a] != dof_jntid[d]) vel |= 1ull << a;
+        }
+        o->dof_ancmask[d] = anc;
+        o->dof_velmask[d] = vel;
+    }
+    for (int d = 0; d < nv; ++d) {
+        uint64_t desc = 1ull << d;
+        for (int k = 0; k < nv; ++k)
+            if ((o->dof_ancmask[k] >> d) & 1ull) desc |= 1ull << k;
+        o->dof_descmask[d] = desc;
+    }
+    /* the kernels implement the impedance sigmoid for exponents 1 and 2 only (all in-scope models use 2) */
+    auto power_ok = [](double p) { return p == 1.0 || p == 2.0; };
+    for (int j = 0; j < njnt; ++j) if (!power_ok(jnt_solimp[5 * j + 4])) return fail("solimp power other than 1 or 2 is not supported");
+    for (int e = 0; e < neq; ++e) if (!power_ok(eq_solimp[5 * e + 4])) return fail("solimp power other than 1 or 2 is not supported");
+    for (int g = 0; g < ngeom; ++g)
+        if ((geom_contype[g] || geom_conaffinity[g]) && !power_ok(geom_solimp[5 * g + 4])) return fail("solimp power other than 1 or 2 is not supported");
     /* collision geoms */
     std::vector<int> cg;
     for (int g = 0; g < ngeom; ++g)

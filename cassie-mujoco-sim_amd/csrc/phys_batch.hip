@@ -257,7 +257,7 @@ int phys_batch_profile_step(phys_batch_t *b, long long *host_stamps) {
     (void)hipSetDevice(b->device);
     const size_t bytes = sizeof(long long) * ck::NSTAMP * (size_t)b->nenv;
     if (!hip_ok(hipMalloc((void **)&b->d_prof, bytes), "hipMalloc(prof)")) return -1;
-    (void)hipMemset(b->d_prof, 0, bytes);
+    (void)hipMemsetAsync(b->d_prof, 0, bytes, b->stream);
     int rc = launch(b, 1, 1, b->stream);
     bool ok = rc == 0 && hip_ok(hipStreamSynchronize(b->stream), "sync") &&
               hip_ok(hipMemcpy(host_stamps, b->d_prof, bytes, hipMemcpyDeviceToHost), "prof download");
