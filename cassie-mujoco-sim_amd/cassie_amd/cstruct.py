@@ -12,6 +12,12 @@ import ctypes
 import re
 
 _BASE = {
+    "bool": ctypes.c_bool,
+    "short": ctypes.c_short,
+    "ushort": ctypes.c_ushort,
+    "uchar": ctypes.c_ubyte,
+    "uint": ctypes.c_uint,
+    "DiagnosticCodes": ctypes.c_short,
     "int": ctypes.c_int,
     "unsigned": ctypes.c_uint,
     "double": ctypes.c_double,
@@ -45,6 +51,7 @@ def parse_structs(text, macros, known_types=None):
             decl = " ".join(decl.split())
             if not decl:
                 continue
+            decl = decl.replace("unsigned short", "ushort").replace("unsigned char", "uchar").replace("unsigned int", "uint")
             tname, rest = decl.split(" ", 1)
             if tname not in types:
                 raise ValueError("unknown type %r in struct %s" % (tname, name))

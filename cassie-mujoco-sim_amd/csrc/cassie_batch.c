@@ -1,0 +1,249 @@
+/*
+ * cassie_batch.c -- N environments behind the reference's step semantics
+ * (cassie_sim_step_pd / cassie_sim_step / cassie_sim_step_ethercat, reference
+ * src/cassiemujoco.c:1115-1157), batched:
+ *
+ *   host threads (one contiguous slice of envs each, so an env's 8 KB of block state stays in one
+ *   core's cache):      pd_input -> cassie_core_sim -> motor model -> encoder models      [pre]
+ *   HIP stream:         ctrl H2D -> physics kernel (all envs) -> sensordata / actuator_velocity D2H
+ *   host threads:       state_output (the estimator only needs the pre-step measurement, so it runs
+ *                       while the kernel is in flight)                                       [post]
+ *
+ * Per env the sequence of operations and therefore every output is identical to a stand-alone
+ * cassie_sim_t driven with the same inputs.
+ */
+#define _GNU_SOURCE
+#include <pthread.h>
+#include <sched.h>
+#include <stdatomic.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+
+#include "cassie_batch.h"
+
+static const double qpos_nominal_joints[28] = {
+    0.0045, 0, 0.4973, 0.9785, -0.0164, 0.01787, -0.2049, -1.1997, 0, 1.4267, 0, -1.5244, 1.5244, -1.5968,
+    -0.0045, 0, 0.4973, 0.9786, 0.00386, -0.01524, -0.2051, -1.1997, 0, 1.4267, 0, -1.5244, 1.5244, -1.5968};
+
+typedef void (*job_fn)(struct cassie_batch *b, int e0, int e1);
+
+struct cassie_batch {
+    phys_model_t *m;
+    cm_model_t pod;
+    cassie_hostmodel_t hm;
+    phys_batch_t *pb;
+    int nenv, nthreads, nsd, nu;
+    cassie_hostenv_t **env;
+    double *sensordata, *actvel, *ctrl; /* pinned host mirrors [nenv][dim] */
+    cassie_out_t *ytmp;
+    /* fork-join pool */
+    pthread_t *threads;
+    int *tid_arg;
+    atomic_int generation, done, quit;
+    job_fn job;
+    /* per-call arguments */
+    const pd_in_t *u_pd;
+    const cassie_user_in_t *u_user;
+    const cassie_in_t *u_in;
+    state_out_t *y_state;
+    cassie_out_t *y_out;
+};
+
+static void slice(const struct cassie_batch *b, int t, int *e0, int *e1)
+{
+    long n = b->nenv, T = b->nthreads;
+    *e0 = (int)(n * t / T);
+    *e1 = (int)(n * (t + 1) / T);
+}
+
+static void *worker(void *arg)
+{
+    struct cassie_batch *b = ((void **)arg)[0];
+    int tid = (int)(long)((void **)arg)[1];
+    free(arg);
+    int seen = 0;
+    for (;;) {
+        int spins = 0;
+        while (atomic_load_explicit(&b->generation, memory_order_acquire) == seen) {
+            if (atomic_load_explicit(&b->quit, memory_order_relaxed)) return NULL;
+            if (++spins > 4000) { sched_yield(); spins = 0; }
+        }
+        seen = atomic_load_explicit(&b->generation, memory_order_acquire);
+        int e0, e1;
+        slice(b, tid, &e0, &e1);
+        b->job(b, e0, e1);
+        atomic_fetch_add_explicit(&b->done, 1, memory_order_release);
+    }
+}
+
+static void run_parallel(struct cassie_batch *b, job_fn fn)
+{
+    b->job = fn;
+    atomic_store_explicit(&b->done, 0, memory_order_relaxed);
+    atomic_fetch_add_explicit(&b->generation, 1, memory_order_release);
+    int e0, e1;
+    slice(b, 0, &e0, &e1);
+    fn(b, e0, e1);
+    int spins = 0;
+    while (atomic_load_explicit(&b->done, memory_order_acquire) < b->nthreads - 1)
+        if (++spins > 4000) { sched_yield(); spins = 0; }
+}
+
+static void job_pd_pre(struct cassie_batch *b, int e0, int e1)
+{
+    for (int e = e0; e < e1; ++e)
+        cassie_hostenv_step_pd_pre(b->env[e], &b->hm, &b->u_pd[e], b->sensordata + (size_t)e * b->nsd,
+                                   b->actvel + (size_t)e * b->nu, b->ctrl + (size_t)e * b->nu, &b->ytmp[e]);
+}
+static void job_pd_post(struct cassie_batch *b, int e0, int e1)
+{
+    for (int e = e0; e < e1; ++e) cassie_hostenv_step_pd_post(b->env[e], &b->ytmp[e], &b->y_state[e]);
+}
+static void job_user(struct cassie_batch *b, int e0, int e1)
+{
+    for (int e = e0; e < e1; ++e)
+        cassie_hostenv_step(b->env[e], &b->hm, &b->u_user[e], b->sensordata + (size_t)e * b->nsd,
+                            b->actvel + (size_t)e * b->nu, b->ctrl + (size_t)e * b->nu, &b->y_out[e]);
+}
+static void job_ethercat(struct cassie_batch *b, int e0, int e1)
+{
+    for (int e = e0; e < e1; ++e)
+        cassie_hostenv_ethercat(b->env[e], &b->hm, &b->u_in[e], b->sensordata + (size_t)e * b->nsd,
+                                b->actvel + (size_t)e * b->nu, b->ctrl + (size_t)e * b->nu, &b->y_out[e]);
+}
+
+/* ctrl up, one physics step for every env, measurements for the next step down -- all asynchronous */
+static int launch_physics(struct cassie_batch *b)
+{
+    int rc = phys_batch_upload_async(b->pb, PHYS_F_CTRL, b->ctrl, 0, b->nenv);
+    rc |= phys_batch_step(b->pb, 1, NULL);
+    rc |= phys_batch_download_async(b->pb, PHYS_F_SENSORDATA, b->sensordata, 0, b->nenv);
+    rc |= phys_batch_download_async(b->pb, PHYS_F_ACTUATOR_VELOCITY, b->actvel, 0, b->nenv);
+    return rc;
+}
+
+cassie_batch_t *cassie_batch_create(const char *modelfile, int nenv, int device, int nthreads)
+{
+    char err[512] = "";
+    if (nenv <= 0) return NULL;
+    struct cassie_batch *b = calloc(1, sizeof *b);
+    if (!b) return NULL;
+    b->m = phys_model_load(modelfile, err, sizeof err);
+    if (!b->m) { fprintf(stderr, "cassie_batch_create: %s\n", err); free(b); return NULL; }
+    if (phys_model_compile(b->m, &b->pod, err, sizeof err) != 0 || cassie_hostmodel_from_model(b->m, &b->hm) != 0) {
+        fprintf(stderr, "cassie_batch_create: model not usable: %s\n", err);
+        cassie_batch_free(b);
+        return NULL;
+    }
+    b->nenv = nenv; b->nsd = b->pod.nsensordata; b->nu = b->pod.nu;
+    b->pb = phys_batch_create(&b->pod, nenv, device);
+    if (!b->pb) { fprintf(stderr, "cassie_batch_create: %s\n", phys_last_error()); cassie_batch_free(b); return NULL; }
+    b->sensordata = phys_host_alloc(sizeof(double) * (size_t)nenv * b->nsd);
+    b->actvel = phys_host_alloc(sizeof(double) * (size_t)nenv * b->nu);
+    b->ctrl = phys_host_alloc(sizeof(double) * (size_t)nenv * b->nu);
+    b->ytmp = calloc((size_t)nenv, sizeof(cassie_out_t));
+    b->env = calloc((size_t)nenv, sizeof *b->env);
+    if (!b->sensordata || !b->actvel || !b->ctrl || !b->ytmp || !b->env) { cassie_batch_free(b); return NULL; }
+    for (int e = 0; e < nenv; ++e)
+        if (!(b->env[e] = cassie_hostenv_alloc())) { cassie_batch_free(b); return NULL; }
+    /* initial state of every env: what cassie_sim_init leaves (reference :1023-1029) */
+    double *q = malloc(sizeof(double) * (size_t)nenv * b->pod.nq);
+    if (!q) { cassie_batch_free(b); return NULL; }
+    for (int e = 0; e < nenv; ++e) {
+        memcpy(q + (size_t)e * b->pod.nq, b->pod.qpos0, sizeof(double) * b->pod.nq);
+        memcpy(q + (size_t)e * b->pod.nq + 7, qpos_nominal_joints, sizeof qpos_nominal_joints);
+    }
+    phys_batch_upload(b->pb, PHYS_F_QPOS, q, 0, nenv);
+    free(q);
+    phys_batch_forward(b->pb, NULL);
+    phys_batch_download(b->pb, PHYS_F_SENSORDATA, b->sensordata, 0, nenv);
+    phys_batch_download(b->pb, PHYS_F_ACTUATOR_VELOCITY, b->actvel, 0, nenv);
+
+    long cores = sysconf(_SC_NPROCESSORS_ONLN);
+    if (nthreads <= 0) nthreads = cores > 0 ? (int)cores : 1;
+    if (nthreads > nenv) nthreads = nenv;
+    b->nthreads = nthreads;
+    b->threads = calloc((size_t)nthreads, sizeof(pthread_t));
+    for (int t = 1; t < nthreads; ++t) {
+        void **arg = malloc(2 * sizeof(void *));
+        arg[0] = b; arg[1] = (void *)(long)t;
+        if (pthread_create(&b->threads[t], NULL, worker, arg) != 0) { b->nthreads = t; free(arg); break; }
+    }
+    return b;
+}
+
+void cassie_batch_free(cassie_batch_t *b)
+{
+    if (!b) return;
+    if (b->threads) {
+        atomic_store(&b->quit, 1);
+        for (int t = 1; t < b->nthreads; ++t) pthread_join(b->threads[t], NULL);
+        free(b->threads);
+    }
+    if (b->pb) { phys_batch_sync(b->pb); phys_batch_free(b->pb); }
+    if (b->env) { for (int e = 0; e < b->nenv; ++e) cassie_hostenv_free(b->env[e]); free(b->env); }
+    phys_host_free(b->sensordata); phys_host_free(b->actvel); phys_host_free(b->ctrl);
+    free(b->ytmp);
+    if (b->m) phys_model_free(b->m);
+    free(b);
+}
+
+int cassie_batch_nenv(const cassie_batch_t *b) { return b ? b->nenv : 0; }
+int cassie_batch_nthreads(const cassie_batch_t *b) { return b ? b->nthreads : 0; }
+phys_batch_t *cassie_batch_phys(cassie_batch_t *b) { return b ? b->pb : NULL; }
+phys_model_t *cassie_batch_model(cassie_batch_t *b) { return b ? b->m : NULL; }
+cassie_hostenv_t *cassie_batch_hostenv(cassie_batch_t *b, int env) { return (b && env >= 0 && env < b->nenv) ? b->env[env] : NULL; }
+
+int cassie_batch_step_pd(cassie_batch_t *b, const pd_in_t *u, state_out_t *y)
+{
+    if (!b || !u || !y) return -1;
+    b->u_pd = u; b->y_state = y;
+    run_parallel(b, job_pd_pre);
+    int rc = launch_physics(b);
+    run_parallel(b, job_pd_post); /* estimator overlaps the kernel and the copies */
+    rc |= phys_batch_sync(b->pb);
+    return rc;
+}
+
+int cassie_batch_step(cassie_batch_t *b, const cassie_user_in_t *u, cassie_out_t *y)
+{
+    if (!b || !u || !y) return -1;
+    b->u_user = u; b->y_out = y;
+    run_parallel(b, job_user);
+    int rc = launch_physics(b);
+    rc |= phys_batch_sync(b->pb);
+    return rc;
+}
+
+int cassie_batch_step_ethercat(cassie_batch_t *b, const cassie_in_t *u, cassie_out_t *y)
+{
+    if (!b || !u || !y) return -1;
+    b->u_in = u; b->y_out = y;
+    run_parallel(b, job_ethercat);
+    int rc = launch_physics(b);
+    rc |= phys_batch_sync(b->pb);
+    return rc;
+}
+
+int cassie_batch_full_reset(cassie_batch_t *b, const unsigned char *mask)
+{
+    if (!b) return -1;
+    const int nq = b->pod.nq, nv = b->pod.nv;
+    double *q = malloc(sizeof(double) * nq), *z = calloc((size_t)(nv > 6 * b->pod.nbody ? nv : 6 * b->pod.nbody), sizeof(double));
+    if (!q || !z) { free(q); free(z); return -1; }
+    memcpy(q, b->pod.qpos0, sizeof(double) * nq);
+    q[0] = 0; q[1] = 0; q[2] = 1.01; q[3] = 1; q[4] = q[5] = q[6] = 0; /* reference :2010 */
+    memcpy(q + 7, qpos_nominal_joints, sizeof qpos_nominal_joints);
+    int rc = 0;
+    for (int e = 0; e < b->nenv; ++e) {
+        if (mask && !mask[e]) continue;
+        rc |= phys_batch_upload(b->pb, PHYS_F_QPOS, q, e, 1);
+        rc |= phys_batch_upload(b->pb, PHYS_F_QVEL, z, e, 1);
+        rc |= phys_batch_upload(b->pb, PHYS_F_CTRL, z, e, 1);
+        cassie_hostenv_reset(b->env[e]);
+    }
+    free(q); free(z);
+    return rc;
+}

@@ -30,6 +30,7 @@ extern "C" {
 #define CM_MAXV      40
 #define CM_MAXU      12
 #define CM_MAXEQ     8
+#define CM_MAXEQROW  24      /* 3 rows per connect */
 #define CM_MAXGEOM   32      /* collision-capable geoms only */
 #define CM_MAXPAIR   192     /* statically filtered candidate geom pairs */
 #define CM_MAXSITE   16
@@ -132,6 +133,24 @@ typedef struct cm_model {
     int sensor_adr[CM_MAXSENSOR], sensor_dim[CM_MAXSENSOR];
     double sensor_cutoff[CM_MAXSENSOR];
 } cm_model_t;
+
+/* Optional per-env "extended" outputs of a step (what the reference reads out of mjData for its
+ * derived getters: contact list + forces, body velocities, site frames, com; SURVEY.md 8b field census). */
+typedef struct cm_ext {
+    int ncon, nefc, solver_iter, pad;
+    int con_geom1[CM_MAXCON], con_geom2[CM_MAXCON]; /* ids in the FULL geom list */
+    int con_dim[CM_MAXCON], con_pad[CM_MAXCON];
+    double con_dist[CM_MAXCON], con_pos[CM_MAXCON][3], con_frame[CM_MAXCON][9];
+    double con_force[CM_MAXCON][3];       /* contact-frame force: normal, tangent 1, tangent 2 (mj_contactForce role) */
+    double cvel[CM_MAXBODY][6];           /* com-frame spatial velocity [rot; lin] */
+    double subtree_com[CM_MAXBODY][3];    /* valid at tree roots */
+    double site_xpos[CM_MAXSITE][3], site_xmat[CM_MAXSITE][9];
+    double xipos[CM_MAXBODY][3];
+    double cdof[CM_MAXV][6], cdof_dot[CM_MAXV][6]; /* motion axes at the tree com and their time derivatives */
+    double qM[CM_MAXV][CM_MAXV];          /* dense joint-space inertia (mj_fullM role) */
+    double eq_J[CM_MAXEQROW][CM_MAXV], eq_pos[CM_MAXEQROW]; /* equality rows: Jacobian and residual */
+    int eq_id[CM_MAXEQROW], ne, pad2;
+} cm_ext_t;
 
 #ifdef __cplusplus
 }

@@ -20,7 +20,7 @@ namespace cm {
 /* object kinds for name lookups (numeric values follow mjtObj where the
  * reference passes them through cassie_sim_mj_name2id) */
 enum ObjType { OBJ_BODY = 1, OBJ_JOINT = 3, OBJ_GEOM = 5, OBJ_SITE = 6, OBJ_CAMERA = 7,
-               OBJ_HFIELD = 14, OBJ_EQUALITY = 17, OBJ_ACTUATOR = 19, OBJ_SENSOR = 20 };
+               OBJ_HFIELD = 11, OBJ_EQUALITY = 16, OBJ_ACTUATOR = 18, OBJ_SENSOR = 19 }; /* MuJoCo 2.1.0 mjtObj values */
 
 struct HostModel {
     /* sizes */

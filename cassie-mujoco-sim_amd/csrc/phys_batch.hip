@@ -36,6 +36,7 @@ struct phys_batch {
     bool use_applied = false;       /* qfrc_applied / xfrc_applied are passed only once uploaded */
     bool pd_mode = false;
     long long *d_prof = nullptr;
+    cm_ext_t *d_ext = nullptr;
 };
 
 static bool hip_ok(hipError_t e, const char *what) {
@@ -68,6 +69,7 @@ static ck::PhysIO make_io(phys_batch *b, int nsub, int integrate) {
         io.pd_ptarget = b->d_field[PHYS_F_PD_PTARGET]; io.pd_kp = b->d_field[PHYS_F_PD_KP]; io.pd_kd = b->d_field[PHYS_F_PD_KD];
     }
     io.prof = b->d_prof;
+    io.ext = b->d_ext;
     return io;
 }
 
@@ -135,6 +137,7 @@ void phys_batch_free(phys_batch_t *b) {
     if (b->d_warn) (void)hipFree(b->d_warn);
     if (b->d_info) (void)hipFree(b->d_info);
     if (b->d_hfield) (void)hipFree(b->d_hfield);
+    if (b->d_ext) (void)hipFree(b->d_ext);
     if (b->ev0) (void)hipEventDestroy(b->ev0);
     if (b->ev1) (void)hipEventDestroy(b->ev1);
     if (b->stream) (void)hipStreamDestroy(b->stream);
@@ -205,6 +208,31 @@ int phys_batch_download(phys_batch_t *b, int field, double *host, int env0, int 
                ? 0 : -1;
 }
 
+int phys_batch_upload_async(phys_batch_t *b, int field, const double *host, int env0, int n) {
+    if (!b || !host || field < 0 || field >= PHYS_F_COUNT || env0 < 0 || n < 0 || env0 + n > b->nenv) return -1;
+    (void)hipSetDevice(b->device);
+    if (field == PHYS_F_QFRC_APPLIED || field == PHYS_F_XFRC_APPLIED) b->use_applied = true;
+    const size_t row = (size_t)b->dim[field];
+    return hip_ok(hipMemcpyAsync(b->d_field[field] + row * env0, host, sizeof(double) * row * n, hipMemcpyHostToDevice,
+                                 b->stream), "upload_async") ? 0 : -1;
+}
+
+int phys_batch_download_async(phys_batch_t *b, int field, double *host, int env0, int n) {
+    if (!b || !host || field < 0 || field >= PHYS_F_COUNT || env0 < 0 || n < 0 || env0 + n > b->nenv) return -1;
+    (void)hipSetDevice(b->device);
+    const size_t row = (size_t)b->dim[field];
+    return hip_ok(hipMemcpyAsync(host, b->d_field[field] + row * env0, sizeof(double) * row * n, hipMemcpyDeviceToHost,
+                                 b->stream), "download_async") ? 0 : -1;
+}
+
+void *phys_host_alloc(size_t bytes) {
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+    memset(p, 0, bytes);
+    return p;
+}
+void phys_host_free(void *p) { if (p) (void)hipHostFree(p); }
+
 int phys_batch_download_warn(phys_batch_t *b, int *host_warn, int *host_info) {
     if (!b) return -1;
     (void)hipSetDevice(b->device);
@@ -250,6 +278,28 @@ int phys_batch_sync(phys_batch_t *b) {
     if (!b) return -1;
     (void)hipSetDevice(b->device);
     return hip_ok(hipStreamSynchronize(b->stream), "hipStreamSynchronize") ? 0 : -1;
+}
+
+int phys_batch_enable_ext(phys_batch_t *b, int on) {
+    if (!b) return -1;
+    (void)hipSetDevice(b->device);
+    if (on && !b->d_ext) {
+        if (!hip_ok(hipMalloc((void **)&b->d_ext, sizeof(cm_ext_t) * (size_t)b->nenv), "hipMalloc(ext)")) return -1;
+        (void)hipMemset(b->d_ext, 0, sizeof(cm_ext_t) * (size_t)b->nenv);
+    } else if (!on && b->d_ext) {
+        (void)hipStreamSynchronize(b->stream);
+        (void)hipFree(b->d_ext);
+        b->d_ext = nullptr;
+    }
+    return 0;
+}
+
+int phys_batch_download_ext(phys_batch_t *b, cm_ext_t *host, int env0, int n) {
+    if (!b || !host || !b->d_ext || env0 < 0 || n < 0 || env0 + n > b->nenv) return -1;
+    (void)hipSetDevice(b->device);
+    return hip_ok(hipMemcpyAsync(host, b->d_ext + env0, sizeof(cm_ext_t) * (size_t)n, hipMemcpyDeviceToHost, b->stream), "ext download") &&
+                   hip_ok(hipStreamSynchronize(b->stream), "ext sync")
+               ? 0 : -1;
 }
 
 int phys_batch_profile_step(phys_batch_t *b, long long *host_stamps) {

@@ -66,6 +66,7 @@ struct PhysIO {
      * speed-torque limit -- the motor law of pd_input_step followed by
      * motor() (reference src/cassiemujoco.c:638-664) on the exact joint state */
     const double *pd_ptarget, *pd_kp, *pd_kd; /* [nenv][nu] each */
+    cm_ext_t *ext;              /* optional [nenv] extended outputs (may be null) */
     long long *prof;            /* optional [nenv][NSTAMP] shader-clock stamps of the last substep (may be null) */
 };
 
@@ -537,6 +538,11 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
             col[i] = v;
             colh[i] = (i == k_) ? v + h * kdamp : v;
         }
+        if (io.ext && isdof) {
+            cm_ext_t *ex = io.ext + env;
+#pragma unroll
+            for (int i = 0; i < NVP; ++i) if (i < nv && i >= k_) { ex->qM[i][k_] = col[i]; ex->qM[k_][i] = col[i]; }
+        }
         CK_STAMP(3);
 
         /* ================= P3 factor M and M + hB in registers; park the factors in LDS ================= */
@@ -775,6 +781,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
                 }
             }
         }
+        const int nefc_before_contacts = nefc;
         for (int c = 0; c < ncon; ++c) {
             const int dim = S.c_dim[c];
             if (dim != 1 && dim != 3) { warn |= WARN_UNSUPPORTED_PAIR; continue; }
@@ -933,6 +940,48 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
             for (int i = 0; i < 3; ++i) io.xpos_out[((size_t)env * io.sb + b) * 3 + i] = S.x.s.xpos[b][i];
             if (io.xquat_out) for (int i = 0; i < 4; ++i) io.xquat_out[((size_t)env * io.sb + b) * 4 + i] = S.x.s.xquat[b][i];
         }
+        if (io.ext) {
+            cm_ext_t *ex = io.ext + env;
+            if (isbody) for (int i = 0; i < 6; ++i) ex->cvel[b][i] = S.x.s.cvel[b][i];
+            if (isbody) for (int i = 0; i < 3; ++i) { ex->subtree_com[b][i] = S.com[broot > 0 ? broot : 0][i]; ex->xipos[b][i] = S.x.s.xipos[b][i]; }
+            if (lane < m->nsite) {
+                const int sb = m->site_bodyid[lane];
+                double sp[3] = {m->site_pos[lane][0], m->site_pos[lane][1], m->site_pos[lane][2]};
+                double sq[4] = {m->site_quat[lane][0], m->site_quat[lane][1], m->site_quat[lane][2], m->site_quat[lane][3]};
+                double t[3], q[4], mm[9];
+                mulmatvec3(t, S.x.s.xmat[sb], sp);
+                for (int i = 0; i < 3; ++i) ex->site_xpos[lane][i] = t[i] + S.x.s.xpos[sb][i];
+                mulquat(q, S.x.s.xquat[sb], sq);
+                quat2mat(mm, q);
+                for (int i = 0; i < 9; ++i) ex->site_xmat[lane][i] = mm[i];
+            }
+            if (isdof) for (int i = 0; i < 6; ++i) { ex->cdof[k_][i] = cd[i]; ex->cdof_dot[k_][i] = cdd[i]; }
+            if (rtype == CM_CNSTR_EQUALITY && r_ < CM_MAXEQROW) {
+                ex->eq_pos[r_] = rpos; ex->eq_id[r_] = rid;
+#pragma unroll
+                for (int k = 0; k < NVP; ++k) if (k < nv) ex->eq_J[r_][k] = ycol[k];
+            }
+            if (lane == 0) { int ne = 0; for (int e = 0; e < m->neq; ++e) if (m->eq_active[e] && ne + 3 <= CM_MAXEFC) ne += 3; ex->ne = ne; }
+            if (lane < ncon) {
+                ex->con_geom1[lane] = m->geom_fullid[S.c_g1[lane]]; ex->con_geom2[lane] = m->geom_fullid[S.c_g2[lane]];
+                ex->con_dim[lane] = S.c_dim[lane]; ex->con_dist[lane] = S.c_dist[lane];
+                for (int i = 0; i < 3; ++i) ex->con_pos[lane][i] = S.c_pos[lane][i];
+                for (int i = 0; i < 9; ++i) ex->con_frame[lane][i] = S.c_frame[lane][i];
+            }
+        }
+        /* first constraint row of every contact (lane = contact), for the contact-force read-out */
+        int caddr = -1;
+        {
+            int acc = nefc_before_contacts;
+            for (int c = 0; c < ncon; ++c) {
+                const int dim = S.c_dim[c];
+                if (dim != 1 && dim != 3) continue;
+                const int nrow = dim == 1 ? 1 : 2 * (dim - 1);
+                if (acc + nrow > CM_MAXEFC) continue;
+                if (c == lane) caddr = acc;
+                acc += nrow;
+            }
+        }
         wv::sync(); /* every reader of the body-stage tiles is done: region x becomes the Y staging tile */
         CK_STAMP(8);
 
@@ -1019,6 +1068,21 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
                 ++iters;
                 if (improvement < m->tolerance) break;
             }
+        }
+        if (io.ext) {
+            /* decode the pyramid: normal = sum of the edge forces, tangents = mu (f+ - f-) */
+            cm_ext_t *ex = io.ext + env;
+            const int a0 = caddr >= 0 ? caddr : 0;
+            const double f0 = wv::shfl(f, a0), f1 = wv::shfl(f, (a0 + 1) & 63), f2 = wv::shfl(f, (a0 + 2) & 63), f3 = wv::shfl(f, (a0 + 3) & 63);
+            if (lane < ncon) {
+                double fn = 0, ft1 = 0, ft2 = 0;
+                if (caddr >= 0) {
+                    if (S.c_dim[lane] == 1) fn = f0;
+                    else { const double mu = S.c_fri[lane][0]; fn = f0 + f1 + f2 + f3; ft1 = mu * (f0 - f1); ft2 = mu * (f2 - f3); }
+                }
+                ex->con_force[lane][0] = fn; ex->con_force[lane][1] = ft1; ex->con_force[lane][2] = ft2;
+            }
+            if (lane == 0) { ex->ncon = ncon; ex->nefc = nefc; ex->solver_iter = iters; }
         }
         CK_STAMP(11);
 

@@ -1,0 +1,82 @@
+/*
+ * cassie_batch.h -- batched form of the reference's step entry points.
+ *
+ * The reference steps one cassie_sim_t per call and users parallelise by running one
+ * process per simulator.  This header is the batched counterpart of
+ * cassie_sim_step_pd / cassie_sim_step / cassie_sim_step_ethercat (reference
+ * src/cassiemujoco.c:1115-1157): N environments, physics on the MI355X through
+ * include/cassie_phys.h, the host-side blocks (pd_input, cassie_core_sim, encoder + motor
+ * models, state_output) on a pool of host threads, overlapped with the kernel.
+ * Results per env are identical to N independent cassie_sim_t objects.
+ */
+#ifndef CASSIE_BATCH_H
+#define CASSIE_BATCH_H
+
+#include "cassie_io_types.h"
+#include "cassie_phys.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- one environment's host-side state: everything of `struct cassie_sim` that is not mjModel/mjData
+ *      (reference src/cassiemujoco.c:255-265): Agility block states, cassie_out, filters, torque delay ---- */
+typedef struct cassie_hostenv cassie_hostenv_t;
+
+/* constants the encoder / motor models read from the model (reference :558-664) */
+typedef struct cassie_hostmodel {
+    int drive_bits[10], joint_bits[6]; /* encoder resolutions (sensor user data) */
+    double gear[10], tmax[10], wmax[10]; /* gear ratio, motor-side torque limit, no-load speed [rad/s] */
+} cassie_hostmodel_t;
+
+int cassie_hostmodel_from_model(const phys_model_t *m, cassie_hostmodel_t *out);
+cassie_hostenv_t *cassie_hostenv_alloc(void);          /* cassie_out_init + block alloc + setup (reference :989-991, :1020, :1032-1034) */
+void cassie_hostenv_free(cassie_hostenv_t *e);
+void cassie_hostenv_copy(cassie_hostenv_t *dst, const cassie_hostenv_t *src);
+cassie_out_t *cassie_hostenv_cassie_out(cassie_hostenv_t *e);
+drive_filter_t *cassie_hostenv_drive_filter(cassie_hostenv_t *e);   /* [10] */
+joint_filter_t *cassie_hostenv_joint_filter(cassie_hostenv_t *e);   /* [6] */
+double *cassie_hostenv_torque_delay(cassie_hostenv_t *e);           /* [10][6] */
+cassie_core_sim_t *cassie_hostenv_core(cassie_hostenv_t *e);
+state_output_t *cassie_hostenv_estimator(cassie_hostenv_t *e);
+pd_input_t *cassie_hostenv_pd(cassie_hostenv_t *e);
+void cassie_hostenv_reset(cassie_hostenv_t *e);        /* host part of cassie_sim_full_reset (reference :2026-2032) */
+
+/* cassie_motor_data + cassie_sensor_data + measurement copy-out: the host half of cassie_sim_step_ethercat
+ * (reference :1115-1127).  sensordata / actuator_velocity are the physics outputs of the previous step; ctrl
+ * receives the 10 delayed motor-side torques for the next physics step. */
+void cassie_hostenv_ethercat(cassie_hostenv_t *e, const cassie_hostmodel_t *hm, const cassie_in_t *u,
+                             const double *sensordata, const double *actuator_velocity, double *ctrl, cassie_out_t *y);
+/* + cassie_core_sim_step in front (reference :1137-1145) */
+void cassie_hostenv_step(cassie_hostenv_t *e, const cassie_hostmodel_t *hm, const cassie_user_in_t *u,
+                         const double *sensordata, const double *actuator_velocity, double *ctrl, cassie_out_t *y);
+/* + pd_input_step in front (reference :1147-1154); the estimator runs separately so it can overlap the kernel */
+void cassie_hostenv_step_pd_pre(cassie_hostenv_t *e, const cassie_hostmodel_t *hm, const pd_in_t *u,
+                                const double *sensordata, const double *actuator_velocity, double *ctrl, cassie_out_t *y);
+void cassie_hostenv_step_pd_post(cassie_hostenv_t *e, const cassie_out_t *y, state_out_t *out); /* state_output_step, :1156 */
+
+/* ---- N environments ---- */
+typedef struct cassie_batch cassie_batch_t;
+
+/* modelfile: MJCF (.xml) or .cmodel; nthreads <= 0 picks the number of online cores (capped at nenv).
+ * Every env starts like cassie_sim_init leaves a simulator.  NULL + stderr message on failure. */
+cassie_batch_t *cassie_batch_create(const char *modelfile, int nenv, int device, int nthreads);
+void cassie_batch_free(cassie_batch_t *b);
+int cassie_batch_nenv(const cassie_batch_t *b);
+int cassie_batch_nthreads(const cassie_batch_t *b);
+phys_batch_t *cassie_batch_phys(cassie_batch_t *b);   /* the HBM-resident state, for direct field access */
+phys_model_t *cassie_batch_model(cassie_batch_t *b);
+cassie_hostenv_t *cassie_batch_hostenv(cassie_batch_t *b, int env);
+
+/* one cassie_sim_step_pd for every env: u and y are dense arrays of nenv structs */
+int cassie_batch_step_pd(cassie_batch_t *b, const pd_in_t *u, state_out_t *y);
+/* one cassie_sim_step / cassie_sim_step_ethercat for every env */
+int cassie_batch_step(cassie_batch_t *b, const cassie_user_in_t *u, cassie_out_t *y);
+int cassie_batch_step_ethercat(cassie_batch_t *b, const cassie_in_t *u, cassie_out_t *y);
+/* cassie_sim_full_reset for the envs whose mask byte is non-zero (mask NULL = all) */
+int cassie_batch_full_reset(cassie_batch_t *b, const unsigned char *mask);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

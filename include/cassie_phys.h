@@ -81,6 +81,12 @@ int phys_batch_set_hfield(phys_batch_t *b, const float *data, int n);
 /* host <-> HBM copies of whole fields or of a row range [env0, env0 + n) */
 int phys_batch_upload(phys_batch_t *b, int field, const double *host, int env0, int n);
 int phys_batch_download(phys_batch_t *b, int field, double *host, int env0, int n);
+/* asynchronous variants on the batch's stream (no host synchronisation; pair with phys_batch_sync);
+ * use phys_host_alloc'd (pinned) buffers for true overlap */
+int phys_batch_upload_async(phys_batch_t *b, int field, const double *host, int env0, int n);
+int phys_batch_download_async(phys_batch_t *b, int field, double *host, int env0, int n);
+void *phys_host_alloc(size_t bytes);   /* pinned host memory (hipHostMalloc) */
+void phys_host_free(void *p);
 int phys_batch_download_warn(phys_batch_t *b, int *host_warn, int *host_info /* [nenv][4] or NULL */);
 /* raw device pointer of a field (for torch / RCCL interop); bind replaces it with caller-owned HBM */
 void *phys_batch_device_ptr(phys_batch_t *b, int field);
@@ -97,6 +103,11 @@ int phys_batch_sync(phys_batch_t *b);
 int phys_batch_set_pd_mode(phys_batch_t *b, int on);
 /* times `reps` launches of nsub steps with HIP events on the launch stream; returns mean ms per launch */
 int phys_batch_time_steps(phys_batch_t *b, int nsub, int reps, float *mean_ms);
+
+/* extended per-env outputs (cm_ext_t: contacts + contact forces, body velocities, site frames, com): enable once,
+ * then every step/forward refreshes them in HBM; download copies envs [env0, env0 + n) to the host */
+int phys_batch_enable_ext(phys_batch_t *b, int on);
+int phys_batch_download_ext(phys_batch_t *b, cm_ext_t *host, int env0, int n);
 
 /* per-stage shader-clock stamps of the next launches: [nenv][16] long long on the host after the call (profiling aid) */
 int phys_batch_profile_step(phys_batch_t *b, long long *host_stamps);

@@ -1,0 +1,2 @@
+/* source-compatibility shim: the reference ships this header (include/state_out_t.h); the definitions live in cassie_io_types.h */
+#include "cassie_io_types.h"

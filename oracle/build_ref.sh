@@ -1,0 +1,24 @@
+#!/bin/bash
+# oracle/build_ref.sh -- TEST INFRASTRUCTURE.  Builds oracle/_ref/libref_hostpath.so from the reference's
+# OWN code where it lies under /root/reference (nothing is copied into the repository; oracle/_ref/ is
+# git-ignored):
+#   * the encoder / motor models are taken verbatim from src/cassiemujoco.c by pattern (the filter
+#     constants and types, the NUM_* defines, and the functions drive_encoder / joint_encoder / motor),
+#     written to oracle/_ref/ref_extract.inc at build time and compiled inside oracle/ref_hostpath_harness.c,
+#     which supplies the few mjModel / mjData fields those functions touch;
+#   * the Agility blocks come from src/libagilitycassie.a (closed binary, whole-archived).
+# The full reference library cannot be built: it needs MuJoCo 2.1.0 headers and binaries.
+set -e
+REF=${REF:-/root/reference}
+HERE=$(cd "$(dirname "$0")" && pwd)
+SRC=$REF/src/cassiemujoco.c
+[ -f "$SRC" ] || { echo "reference not present at $REF: nothing to build"; exit 0; }
+mkdir -p "$HERE/_ref"
+{
+  sed -n '/^#define DRIVE_FILTER_NB/,/^} joint_filter_t;/p' "$SRC"
+  grep -E '^#define (NUM_DRIVES|NUM_JOINTS|TORQUE_DELAY_CYCLES) ' "$SRC"
+  sed -n '/^static void drive_encoder/,/^static void window_close_callback/p' "$SRC" | sed '$d'
+} > "$HERE/_ref/ref_extract.inc"
+gcc -O2 -std=gnu11 -fPIC -shared -I"$HERE/../include" -I"$HERE/_ref" "$HERE/ref_hostpath_harness.c" \
+    -Wl,--whole-archive "$REF/src/libagilitycassie.a" -Wl,--no-whole-archive -lm -o "$HERE/_ref/libref_hostpath.so"
+echo "built $HERE/_ref/libref_hostpath.so"

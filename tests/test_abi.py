@@ -1,0 +1,88 @@
+"""The drop-in boundary without a GPU: the shared library loads, exports every symbol the headers under
+include/ declare and every symbol the reference's unmodified ctypes wrapper binds, and the frozen struct
+layouts have the reference's sizes and offsets."""
+import ctypes
+import glob
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+from cassie_amd import iotypes as T
+from cassie_amd._lib import LIB_PATH, REPO_DIR, lib
+
+REF_EXAMPLE = "/root/reference/example"
+
+
+def declared_functions():
+    names = set()
+    for h in glob.glob(os.path.join(REPO_DIR, "include", "*.h")):
+        text = re.sub(r"/\*.*?\*/", " ", open(h).read(), flags=re.S)
+        for m in re.finditer(r"^[A-Za-z_][\w \*]*?\b(\w+)\s*\([^;{]*\)\s*;", text, flags=re.M):
+            if m.group(1) not in ("defined", "sizeof"):
+                names.add(m.group(1))
+    return names
+
+
+def test_library_exports_every_declared_symbol(built):
+    L = lib()
+    decl = declared_functions()
+    assert len(decl) > 250
+    missing = [n for n in sorted(decl) if not hasattr(L, n)]
+    assert not missing, missing
+
+
+def test_struct_sizes_and_offsets():
+    assert ctypes.sizeof(T.cassie_out_t) == 1336 and ctypes.sizeof(T.cassie_in_t) == 192
+    assert ctypes.sizeof(T.cassie_user_in_t) == 104 and ctypes.sizeof(T.pd_in_t) == 952
+    assert ctypes.sizeof(T.state_out_t) == 992 and ctypes.sizeof(T.elmo_out_t) == 64
+    assert ctypes.sizeof(T.ALL["cassie_leg_out_t"]) == 376 and ctypes.sizeof(T.ALL["cassie_pelvis_out_t"]) == 568
+    o = T.cassie_out_t
+    assert (o.leftLeg.offset, o.rightLeg.offset, o.isCalibrated.offset, o.messages.offset) == (568, 944, 1320, 1322)
+    p = T.ALL["cassie_pelvis_out_t"]
+    assert (p.radio.offset, p.vectorNav.offset) == (288, 424)
+    assert ctypes.sizeof(T.drive_filter_t) == 36 and ctypes.sizeof(T.joint_filter_t) == 56
+
+
+def test_pack_unpack_roundtrip(built):
+    """pack_* / unpack_* come from the Agility static library linked into the product: wire lengths of
+    reference include/*_t.h:20 and a float32 round trip."""
+    L = lib()
+    u = T.pd_in_t()
+    for i in range(5):
+        u.leftLeg.motorPd.pTarget[i] = 0.25 * (i + 1)
+        u.rightLeg.motorPd.dGain[i] = 8.0 - i
+    buf = (ctypes.c_ubyte * 476)()
+    L.pack_pd_in_t(ctypes.byref(u), buf)
+    v = T.pd_in_t()
+    L.unpack_pd_in_t(buf, ctypes.byref(v))
+    assert bytes(u) == bytes(v)          # values are exactly representable in float32
+
+
+def test_no_gpu_means_loud_failure_not_a_fallback(built):
+    """On a box without a GPU the simulator must refuse to start (NULL), never run on the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    L = lib()
+    L.cassie_sim_init.restype = ctypes.c_void_p
+    L.cassie_sim_init.argtypes = [ctypes.c_char_p, ctypes.c_bool]
+    path = os.path.join(REPO_DIR, "models", "cassie.cmodel").encode()
+    assert L.cassie_sim_init(path, False) is None
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_EXAMPLE), reason="reference wrapper not present on this box")
+def test_reference_ctypes_wrapper_imports_against_this_library(built, tmp_path):
+    """The unmodified reference binding (example/cassiemujoco_ctypes.py) dlopens './libcassiemujoco.so' and
+    resolves 187 symbols at import time: it must import cleanly against this library."""
+    import shutil
+    # the binding loads the library from its own directory, so stage it (temporary copy, nothing enters the repo)
+    shutil.copy(os.path.join(REF_EXAMPLE, "cassiemujoco_ctypes.py"), tmp_path / "cassiemujoco_ctypes.py")
+    os.symlink(LIB_PATH, tmp_path / "libcassiemujoco.so")
+    code = ("import sys; sys.path.insert(0, %r); import cassiemujoco_ctypes as m; "
+            "print(len([n for n in dir(m) if n.startswith('cassie_')]))" % str(tmp_path))
+    out = subprocess.run([sys.executable, "-c", code], cwd=tmp_path, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert int(out.stdout.strip()) > 150

@@ -1,0 +1,186 @@
+"""GPU tests of the drop-in C ABI (include/cassiemujoco.h) and of the batched step (include/cassie_batch.h).
+
+The single-simulator path is checked against a CPU re-play of the same pipeline built from the pieces that
+are pinned elsewhere: the host chain (bit-exact vs the reference's code, tests/test_hostpath.py) and the
+oracle physics (tests/test_model.py, tests/test_gpu_parity.py)."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+from cassie_amd import iotypes as T
+from cassie_amd._lib import REPO_DIR, lib
+from oracle_py import Oracle
+from test_hostpath import HostModel
+
+pytestmark = pytest.mark.gpu
+MODEL = os.path.join(REPO_DIR, "models", "cassie.cmodel").encode()
+VP = ctypes.c_void_p
+DP = ctypes.POINTER(ctypes.c_double)
+
+
+@pytest.fixture(scope="module")
+def L(built):
+    L = lib()
+    L.cassie_sim_init.restype = VP
+    L.cassie_sim_init.argtypes = [ctypes.c_char_p, ctypes.c_bool]
+    L.cassie_sim_free.argtypes = [VP]
+    for f in ("cassie_sim_qpos", "cassie_sim_qvel", "cassie_sim_time", "cassie_sim_sensordata", "cassie_sim_act_vel"):
+        getattr(L, f).restype = DP
+        getattr(L, f).argtypes = [VP]
+    L.cassie_sim_step.argtypes = [VP, VP, VP]
+    L.cassie_sim_step_pd.argtypes = [VP, VP, VP]
+    L.cassie_sim_foot_forces.argtypes = [VP, VP]
+    L.cassie_sim_heeltoe_forces.argtypes = [VP, VP, VP]
+    L.cassie_sim_cm_position.argtypes = [VP, VP]
+    L.cassie_sim_full_mass_matrix.argtypes = [VP, VP]
+    L.cassie_sim_get_jacobian.argtypes = [VP, VP, ctypes.c_char_p]
+    L.cassie_sim_foot_positions.argtypes = [VP, VP]
+    L.cassie_state_alloc.restype = VP
+    L.cassie_get_state.argtypes = [VP, VP]
+    L.cassie_set_state.argtypes = [VP, VP]
+    L.cassie_state_free.argtypes = [VP]
+    L.cassie_batch_create.restype = VP
+    L.cassie_batch_create.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    L.cassie_batch_free.argtypes = [VP]
+    L.cassie_batch_step_pd.argtypes = [VP, VP, VP]
+    L.cassie_batch_phys.restype = VP
+    L.cassie_batch_phys.argtypes = [VP]
+    L.cassie_hostenv_alloc.restype = VP
+    L.cassie_hostenv_step.argtypes = [VP] * 7
+    L.cassie_hostmodel_from_model.argtypes = [VP, VP]
+    return L
+
+
+def pd_input(rng, scale=0.2):
+    u = T.pd_in_t()
+    off = [0.0045, 0, 0.4973, -1.1997, -1.5968]
+    for leg in (u.leftLeg, u.rightLeg):
+        for i in range(5):
+            leg.motorPd.pTarget[i] = off[i] + scale * rng.uniform(-1, 1)
+            leg.motorPd.pGain[i] = [70, 70, 100, 100, 50][i]
+            leg.motorPd.dGain[i] = [7, 7, 8, 8, 5][i]
+    return u
+
+
+def test_config1_zero_torque_cassie_sim_step_1000_steps(L, cassie):
+    """BASELINE.json configs[0]: one env, zero-torque cassie_sim_step x 1000, replayed on the CPU."""
+    c = L.cassie_sim_init(MODEL, False)
+    assert c
+    hm = HostModel()
+    assert L.cassie_hostmodel_from_model(cassie._h, ctypes.byref(hm)) == 0
+    env = L.cassie_hostenv_alloc()
+    o = Oracle(cassie.pod, cassie.qpos_init())
+    o.forward()
+    u = T.cassie_user_in_t()
+    worst = 0.0
+    for t in range(1000):
+        y = T.cassie_out_t()
+        L.cassie_sim_step(c, ctypes.byref(y), ctypes.byref(u))
+        # CPU replay: host chain on the oracle's previous sensordata, then one oracle step
+        yr = T.cassie_out_t()
+        sd, av = np.ascontiguousarray(o.sensordata), np.ascontiguousarray(o.actuator_velocity)
+        ctrl = np.zeros(10)
+        L.cassie_hostenv_step(env, ctypes.byref(hm), ctypes.byref(u), sd.ctypes.data, av.ctypes.data, ctrl.ctypes.data, ctypes.byref(yr))
+        o.ctrl[:] = ctrl
+        o.step()
+        q = np.ctypeslib.as_array(L.cassie_sim_qpos(c), (35,))
+        worst = max(worst, np.max(np.abs(q - o.qpos)))
+        # encoder read-outs agree to one count (a 1e-13 physics difference can flip the truncation)
+        assert abs(y.leftLeg.kneeDrive.position - yr.leftLeg.kneeDrive.position) <= 2 * np.pi / (1 << 13) / 16 + 1e-12
+        assert abs(y.pelvis.vectorNav.linearAcceleration[2] - yr.pelvis.vectorNav.linearAcceleration[2]) < 1e-6
+    assert worst < 1e-8, worst
+    assert abs(L.cassie_sim_time(c)[0] - 0.5) < 1e-12
+    L.cassie_sim_free(c)
+
+
+def test_step_pd_stands_and_reports_sane_state(L):
+    c = L.cassie_sim_init(MODEL, False)
+    u = pd_input(np.random.default_rng(0), scale=0.0)
+    y = T.state_out_t()
+    for _ in range(600):
+        L.cassie_sim_step_pd(c, ctypes.byref(y), ctypes.byref(u))
+    q = np.ctypeslib.as_array(L.cassie_sim_qpos(c), (35,))
+    assert 0.5 < q[2] < 1.1                          # on its feet under plain joint PD after 0.3 s (no balance controller)
+    assert np.allclose(list(y.motor.position), q[[7, 8, 9, 14, 20, 21, 22, 23, 28, 34]], atol=2e-3)
+    # on the ground: foot forces carry the weight, heel + toe split adds up to the foot total (reference test_heelforce.c:56-57)
+    ff = np.zeros(12); toe = np.zeros(6); heel = np.zeros(6)
+    L.cassie_sim_foot_forces(c, ff.ctypes.data)
+    L.cassie_sim_heeltoe_forces(c, toe.ctypes.data, heel.ctypes.data)
+    total = ff[2] + ff[8]
+    assert 150 < total < 600
+    assert np.allclose(toe[:3] + heel[:3], ff[0:3], atol=1e-9) and np.allclose(toe[3:] + heel[3:], ff[6:9], atol=1e-9)
+    L.cassie_sim_free(c)
+
+
+def test_derived_getters_against_oracle(L, cassie):
+    c = L.cassie_sim_init(MODEL, False)
+    o = Oracle(cassie.pod, cassie.qpos_init())
+    o.forward()
+    cm = np.zeros(3)
+    L.cassie_sim_cm_position(c, cm.ctypes.data)
+    from oracle_py import arr
+    assert np.allclose(cm, arr(o.d.subtree_com)[1], atol=1e-12)
+    M = np.zeros(1024)
+    L.cassie_sim_full_mass_matrix(c, M.ctypes.data)
+    M = M.reshape(32, 32)
+    assert np.allclose(M, o.qM, atol=1e-12) and abs(M[0, 0] - 33.312) < 1e-9
+    jac = np.zeros(3 * 32)
+    L.cassie_sim_get_jacobian(c, jac.ctypes.data, b"left-foot")
+    # finite-difference check of the left-foot position Jacobian on a hinge dof (left knee, dof 12)
+    eps = 1e-6
+    o2 = Oracle(cassie.pod, cassie.qpos_init())
+    o2.qpos[14] += eps
+    o2.forward()
+    lf = cassie.name2id(1, "left-foot")
+    fd = (o2.xpos[lf] - o.xpos[lf]) / eps
+    assert np.allclose(jac.reshape(3, 32)[:, 12], fd, atol=1e-5)
+    fp = np.zeros(6)
+    L.cassie_sim_foot_positions(c, fp.ctypes.data)
+    assert np.allclose(fp[:2], o.xpos[lf][:2], atol=1e-12)
+    L.cassie_sim_free(c)
+
+
+def test_get_set_state_replays_identically(L):
+    c = L.cassie_sim_init(MODEL, False)
+    rng = np.random.default_rng(3)
+    us = [pd_input(rng) for _ in range(4)]
+    y = T.state_out_t()
+    for k in range(200):
+        L.cassie_sim_step_pd(c, ctypes.byref(y), ctypes.byref(us[k // 50]))
+    s = L.cassie_state_alloc()
+    L.cassie_get_state(c, s)
+    ya, yb = T.state_out_t(), T.state_out_t()
+    for k in range(100):
+        L.cassie_sim_step_pd(c, ctypes.byref(ya), ctypes.byref(us[2]))
+    qa = np.ctypeslib.as_array(L.cassie_sim_qpos(c), (35,)).copy()
+    L.cassie_set_state(c, s)
+    for k in range(100):
+        L.cassie_sim_step_pd(c, ctypes.byref(yb), ctypes.byref(us[2]))
+    qb = np.ctypeslib.as_array(L.cassie_sim_qpos(c), (35,)).copy()
+    assert np.array_equal(qa, qb) and bytes(ya) == bytes(yb)
+    L.cassie_state_free(s)
+    L.cassie_sim_free(c)
+
+
+def test_batch_step_pd_equals_independent_simulators(L):
+    n, steps = 6, 300
+    rng = np.random.default_rng(7)
+    b = L.cassie_batch_create(MODEL, n, 0, 3)
+    assert b
+    sims = [L.cassie_sim_init(MODEL, False) for _ in range(n)]
+    U = (T.pd_in_t * n)()
+    Y = (T.state_out_t * n)()
+    for k in range(steps):
+        if k % 50 == 0:
+            for e in range(n):
+                U[e] = pd_input(rng, scale=0.3)
+        assert L.cassie_batch_step_pd(b, ctypes.byref(U), ctypes.byref(Y)) == 0
+        for e in range(n):
+            y = T.state_out_t()
+            L.cassie_sim_step_pd(sims[e], ctypes.byref(y), ctypes.byref(U[e]))
+            assert bytes(y) == bytes(Y[e]), (k, e)
+    for s in sims:
+        L.cassie_sim_free(s)
+    L.cassie_batch_free(b)
