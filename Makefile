@@ -60,8 +60,8 @@ $(PRODUCT): $(OBJS)
 	@mkdir -p $(LIBD)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS) $(AGILITY_LINK) -lm -lpthread
 
-oracle/libcassie_oracle.so: oracle/cassie_oracle.c oracle/cassie_oracle.h $(CSRC)/cm_model.h $(wildcard oracle/*.c)
-	gcc -O2 -std=gnu11 -fPIC -shared -fopenmp -I$(CSRC) -Ioracle $(wildcard oracle/*.c) -o $@ -lm
+oracle/libcassie_oracle.so: oracle/cassie_oracle.c oracle/cassie_oracle.h $(CSRC)/cm_model.h
+	gcc -O2 -std=gnu11 -fPIC -shared -fopenmp -I$(CSRC) -Ioracle oracle/cassie_oracle.c -o $@ -lm
 
 tests/emu/libcassie_emu.so: tests/emu/emu_runtime.cpp tests/emu/wave.h $(CSRC)/physics_kernel.h $(CSRC)/cm_model.h
 	g++ -O2 -std=c++17 -fPIC -shared -Itests/emu -I$(CSRC) tests/emu/emu_runtime.cpp -o $@

@@ -27,6 +27,32 @@ static const double qpos_nominal_joints[28] = {
     0.0045, 0, 0.4973, 0.9785, -0.0164, 0.01787, -0.2049, -1.1997, 0, 1.4267, 0, -1.5244, 1.5244, -1.5968,
     -0.0045, 0, 0.4973, 0.9786, 0.00386, -0.01524, -0.2051, -1.1997, 0, 1.4267, 0, -1.5244, 1.5244, -1.5968};
 
+/* cores this process may really use: the smaller of its affinity mask and its cgroup CPU quota */
+int cassie_host_cpu_count(void)
+{
+    long n = sysconf(_SC_NPROCESSORS_ONLN);
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) { int c = CPU_COUNT(&set); if (c > 0 && c < n) n = c; }
+    FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r");
+    if (f) {
+        char q[64];
+        long period = 0;
+        if (fscanf(f, "%63s %ld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
+            long quota = atol(q), c = (quota + period - 1) / period;
+            if (c > 0 && c < n) n = c;
+        }
+        fclose(f);
+    } else if ((f = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r"))) {
+        long quota = -1, period = 0;
+        if (fscanf(f, "%ld", &quota) != 1) quota = -1;
+        fclose(f);
+        FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r");
+        if (g) { if (fscanf(g, "%ld", &period) != 1) period = 0; fclose(g); }
+        if (quota > 0 && period > 0) { long c = (quota + period - 1) / period; if (c > 0 && c < n) n = c; }
+    }
+    return n > 0 ? (int)n : 1;
+}
+
 typedef void (*job_fn)(struct cassie_batch *b, int e0, int e1);
 
 struct cassie_batch {
@@ -161,8 +187,7 @@ cassie_batch_t *cassie_batch_create(const char *modelfile, int nenv, int device,
     phys_batch_download(b->pb, PHYS_F_SENSORDATA, b->sensordata, 0, nenv);
     phys_batch_download(b->pb, PHYS_F_ACTUATOR_VELOCITY, b->actvel, 0, nenv);
 
-    long cores = sysconf(_SC_NPROCESSORS_ONLN);
-    if (nthreads <= 0) nthreads = cores > 0 ? (int)cores : 1;
+    if (nthreads <= 0) nthreads = cassie_host_cpu_count();
     if (nthreads > nenv) nthreads = nenv;
     b->nthreads = nthreads;
     b->threads = calloc((size_t)nthreads, sizeof(pthread_t));

@@ -55,10 +55,13 @@ void cassie_hostenv_step_pd_pre(cassie_hostenv_t *e, const cassie_hostmodel_t *h
                                 const double *sensordata, const double *actuator_velocity, double *ctrl, cassie_out_t *y);
 void cassie_hostenv_step_pd_post(cassie_hostenv_t *e, const cassie_out_t *y, state_out_t *out); /* state_output_step, :1156 */
 
+/* cores this process may really use: min(affinity mask, cgroup CPU quota) */
+int cassie_host_cpu_count(void);
+
 /* ---- N environments ---- */
 typedef struct cassie_batch cassie_batch_t;
 
-/* modelfile: MJCF (.xml) or .cmodel; nthreads <= 0 picks the number of online cores (capped at nenv).
+/* modelfile: MJCF (.xml) or .cmodel; nthreads <= 0 picks cassie_host_cpu_count() (capped at nenv).
  * Every env starts like cassie_sim_init leaves a simulator.  NULL + stderr message on failure. */
 cassie_batch_t *cassie_batch_create(const char *modelfile, int nenv, int device, int nthreads);
 void cassie_batch_free(cassie_batch_t *b);
