@@ -49,6 +49,22 @@ def pd_targets(env_ids, npolicy):
     return out
 
 
+def shard_env_ids(rank, world, envs_per_rank):
+    """Contiguous block of global env ids owned by `rank` (weak scaling: the per-rank count is fixed)."""
+    return np.arange(rank * envs_per_rank, (rank + 1) * envs_per_rank)
+
+
+def gather_observations(obs, world, out=None):
+    """All-gather of the per-rank observation block [n, 96] into [world * n, 96], rank-major = global env order.
+    RCCL over xGMI on GPUs ('nccl' backend), gloo in the CPU tests."""
+    import torch
+    import torch.distributed as dist
+    if out is None:
+        out = torch.empty((world * obs.shape[0], obs.shape[1]), dtype=obs.dtype, device=obs.device)
+    dist.all_gather_into_tensor(out, obs)
+    return out
+
+
 def cpu_baseline(model, budget_s=12.0):
     """Times the CPU oracle on a bounded sample of the same workload, all host cores (OpenMP over envs)."""
     import oracle_py
@@ -145,7 +161,7 @@ def main():
     model = Model("cassie")
     pod = model.pod
     n = args.envs_per_gpu
-    env_ids = np.arange(rank * n, (rank + 1) * n)
+    env_ids = shard_env_ids(rank, world, n)
     total_steps = args.warmup + args.steps
     npolicy = (total_steps + HOLD - 1) // HOLD + 1
 
@@ -173,8 +189,7 @@ def main():
             if s % HOLD == 0:
                 b.bind(P.F_PD_PTARGET, targets[s // HOLD].data_ptr())
                 if world > 1 and s > 0:
-                    obs = torch.cat((qpos, qvel, sens), dim=1)
-                    dist.all_gather_into_tensor(obs_all, obs)
+                    gather_observations(torch.cat((qpos, qvel, sens), dim=1), world, obs_all)
             b.step(1, stream)
 
     def fence():
