@@ -76,10 +76,21 @@ static ck::PhysIO make_io(phys_batch *b, int nsub, int integrate) {
 static int launch(phys_batch *b, int nsub, int integrate, hipStream_t s) {
     ck::PhysIO io = make_io(b, nsub, integrate);
     const dim3 grid(b->nenv), block(WV_WAVE);
-    if (b->host_model.nv <= 32)
-        hipLaunchKernelGGL(ck::cassie_step_kernel<32>, grid, block, 0, s, io);
+    /* the compile-time-topology instantiations are used only when the model's dof tree is exactly theirs */
+    const cm_model_t &hm = b->host_model;
+    auto matches = [&](const unsigned long long *table, int nv) {
+        if (hm.nv != nv) return false;
+        for (int k = 0; k < nv; ++k) if (hm.dof_ancmask[k] != table[k]) return false;
+        return true;
+    };
+    if (matches(ck::TopoCassie32::table, ck::TopoCassie32::nv))
+        hipLaunchKernelGGL((ck::cassie_step_kernel<32, ck::TopoCassie32>), grid, block, 0, s, io);
+    else if (matches(ck::TopoCassieTray38::table, ck::TopoCassieTray38::nv))
+        hipLaunchKernelGGL((ck::cassie_step_kernel<40, ck::TopoCassieTray38>), grid, block, 0, s, io);
+    else if (hm.nv <= 32)
+        hipLaunchKernelGGL((ck::cassie_step_kernel<32, ck::TopoRuntime>), grid, block, 0, s, io);
     else
-        hipLaunchKernelGGL(ck::cassie_step_kernel<40>, grid, block, 0, s, io);
+        hipLaunchKernelGGL((ck::cassie_step_kernel<40, ck::TopoRuntime>), grid, block, 0, s, io);
     return hip_ok(hipGetLastError(), "cassie_step_kernel launch") ? 0 : -1;
 }
 

@@ -35,6 +35,7 @@
 #include <wave.h> /* csrc/wave.h in the product build; tests/emu/wave.h under the CPU wave emulator */
 
 #include "cm_model.h"
+#include "topo_static.h"
 
 namespace ck {
 
@@ -42,6 +43,7 @@ constexpr int NB = CM_MAXBODY;
 constexpr int NG = CM_MAXGEOM;
 constexpr int NROW = 64;       /* rows 0..62 constraints, column 63 = qfrc_smooth */
 constexpr int NSTAMP = 16;
+#define CK_TRI(k, i) ((k) * ((k) + 1) / 2 + (i))
 #define CK_STAMP(i) do { if (io.prof && lane == 0) io.prof[(size_t)env * NSTAMP + (i)] = wv::clock(); } while (0)
 
 /* warning bits reported per env */
@@ -84,9 +86,10 @@ struct EnvShared {
             double xfrc[NB][6];
         } s;
         double Yr[NROW][YP];        /* Y staged row-major by constraint row for broadcast reads */
-        double LH[NVP][NVP + 1];    /* factor of M + hB, parked here for the Euler solve */
     } x;
-    double L[NVP][NVP + 1];         /* L^T D L factor of M: strict lower part = L (row k, col i) */
+    /* L^T D L factors of M and of M + hB, packed lower-triangular by rows: entry (k, i <= k) at k(k+1)/2 + i */
+    double Lp[NVP * (NVP + 1) / 2], LHp[NVP * (NVP + 1) / 2];
+    double accel[2][28];            /* accelerometer partial results that must outlive the body tiles */
     double dinv[NVP], rsd[NVP], dinvH[NVP]; /* 1/D, 1/sqrt(D) of M; 1/D of M + hB */
     double cdof[NVP][6];
     double com[NB][3];              /* subtree com, valid at root bodies */
@@ -243,32 +246,63 @@ WV_DEVICE double impedance(const double *solimp, double pos, double margin) {
     return dmin + y * (dmax - dmin);
 }
 
-/* L^T D L factorisation of a tree-sparse matrix held one column per lane in
- * registers (lane j owns col[i] = A[i][j], i >= j).  Pivot row entries travel by
- * readlane; the (k,i) loop nest is fully unrolled and skips pairs outside the
- * ancestor pattern with wave-uniform tests.  On exit col[k] (k > j) = L[k][j] and
- * col[j] = D[j]. */
-template <int NVP>
-WV_DEVICE void factor_in_registers(const cm_model_t *m, double (&col)[NVP], int lane, int nv) {
+/* dof-tree sparsity: compile-time tables for the in-scope models (topo_static.h), or the model's own
+ * masks for anything else */
+struct TopoRuntime { static constexpr bool is_static = false; static constexpr int nv = 0; };
+
+template <class TOPO>
+WV_DEVICE unsigned long long anc_mask(const cm_model_t *m, int k) {
+    if constexpr (TOPO::is_static) return TOPO::table[k];
+    else return m->dof_ancmask[k];
+}
+
+/* L^T D L factorisation of a tree-sparse matrix held one column per lane in registers (lane j owns
+ * col[i] = A[i][j], i >= j).  Pivot-row entries travel by readlane; the (k, i) loop nest is fully
+ * unrolled over the ancestor pattern.  No lane predication is needed: entries above the diagonal
+ * (col[i] in lanes j > i) are never read, so they may absorb harmless updates.  On exit col[k] holds
+ * L[k][j] for k > j; the pivots are returned through dinv / rsd (wave-uniform, written by lane 0). */
+template <int NVP, class TOPO>
+WV_DEVICE void factor_in_registers(const cm_model_t *m, double (&col)[NVP], int lane, int nv, double *dinv, double *rsd) {
 #pragma unroll
-    for (int k = NVP - 1; k >= 1; --k) {
-        if (k >= nv) continue;
-        const unsigned long long anc = m->dof_ancmask[k];
-        if (anc == 0ull) continue;
+    for (int k = NVP - 1; k >= 0; --k) {
+        if (TOPO::is_static ? k >= TOPO::nv : k >= nv) continue;
+        const unsigned long long anc = anc_mask<TOPO>(m, k);
         const double inv = 1.0 / wv::readlane(col[k], k);
-        const double mine = (lane < k) ? col[k] : 0.0; /* A[k][j] */
+        if (lane == 0) { dinv[k] = inv; if (rsd) rsd[k] = sqrt(inv); }
+        if (anc == 0ull) continue;
 #pragma unroll
         for (int i = k - 1; i >= 0; --i) {
             if (!((anc >> i) & 1ull)) continue;
             const double t = wv::readlane(col[k], i) * inv; /* A[k][i] / D_k */
-            if (lane <= i) col[i] -= t * mine;
+            col[i] -= t * col[k];
         }
-        if (lane < k) col[k] = mine * inv;
+        col[k] *= inv;
+    }
+}
+
+/* One PGS sweep over rows I, I+1, ... : nested so that the first row index >= nrows ends the sweep with a
+ * single branch (rows are contiguous).  Every lane evaluates its own candidate update; only row I's is
+ * consumed, through readlane. */
+template <int I>
+WV_DEVICE void pgs_rows(const double (&arow)[CM_MAXEFC], int nrows, int r_, double invAii, double halfAii, double flo,
+                        double &f, double &res, double &improvement) {
+    if constexpr (I < CM_MAXEFC) {
+        if (I < nrows) {
+            const double fn = fmax(f - res * invAii, flo);
+            double delta = fn - f;
+            double change = delta * (halfAii * delta + res);
+            if (change > 1e-10) { delta = 0; change = 0; } /* never accept a cost increase */
+            const double dlt = wv::readlane(delta, I), chg = wv::readlane(change, I);
+            if (r_ == I) f += dlt;
+            improvement -= chg;
+            res += arow[I] * dlt;
+            pgs_rows<I + 1>(arow, nrows, r_, invAii, halfAii, flo, f, res, improvement);
+        }
     }
 }
 
 /* ======================================================== the env step ==== */
-template <int NVP>
+template <int NVP, class TOPO>
 WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
     const cm_model_t *m = io.models + (size_t)env * io.model_stride;
     const int lane = wv::lane();
@@ -285,7 +319,8 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
     if (lane < nu) S.ctrl[lane] = io.ctrl[(size_t)env * io.su + lane];
     double time = io.time[env];
 
-    /* ---------------- per-lane model constants, loaded once per launch ---------------- */
+    /* ---------------- per-lane model indices (the fp64 constants are loaded where they are used, to keep
+     * register live ranges short: the kernel runs one wave per SIMD and lives on its 512 VGPRs) ---------------- */
     /* lane = body */
     const int b = lane;
     const bool isbody = b < nbody;
@@ -296,20 +331,9 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
     const int bj0 = (isbody && bjn > 0) ? m->body_jntadr[b] : 0;
     const int bend = isbody ? m->body_subtreeend[b] : 0;
     const unsigned long long bdofmask = isbody ? m->body_dofmask[b] : 0ull;
-    const double bmass = (isbody && b > 0) ? m->body_mass[b] : 0.0;
-    double bpos[3] = {0, 0, 0}, bquat[4] = {1, 0, 0, 0}, bipos[3] = {0, 0, 0}, biquat[4] = {1, 0, 0, 0}, binert[3] = {0, 0, 0};
-    if (isbody) {
-        for (int i = 0; i < 3; ++i) { bpos[i] = m->body_pos[b][i]; bipos[i] = m->body_ipos[b][i]; binert[i] = m->body_inertia[b][i]; }
-        for (int i = 0; i < 4; ++i) { bquat[i] = m->body_quat[b][i]; biquat[i] = m->body_iquat[b][i]; }
-    }
     /* first joint of the body (every Cassie body but the pelvis has at most one) */
     const int bjt = (isbody && bjn > 0) ? m->jnt_type[bj0] : -1;
     const int bjq = (isbody && bjn > 0) ? m->jnt_qposadr[bj0] : 0;
-    double bjpos[3] = {0, 0, 0}, bjaxis[3] = {0, 0, 1}, bjq0 = 0;
-    if (isbody && bjn > 0) {
-        for (int i = 0; i < 3; ++i) { bjpos[i] = m->jnt_pos[bj0][i]; bjaxis[i] = m->jnt_axis[bj0][i]; }
-        bjq0 = m->qpos0[bjq];
-    }
     /* lane = dof */
     const int k_ = lane;
     const bool isdof = k_ < nv;
@@ -322,16 +346,9 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
     const int kbend = isdof ? m->body_subtreeend[kbody] : 0;
     const unsigned long long kdesc = isdof ? m->dof_descmask[k_] : 0ull;
     const unsigned long long kvelmask = isdof ? m->dof_velmask[k_] : 0ull;
-    const double karm = isdof ? m->dof_armature[k_] : 0.0;
-    const double kdamp = isdof ? m->dof_damping[k_] : 0.0;
-    const double kstiff = (isdof && (kjt == CM_JNT_HINGE || kjt == CM_JNT_SLIDE)) ? m->jnt_stiffness[kjnt] : 0.0;
-    const double kspring = isdof ? m->qpos_spring[kqa] : 0.0;
     /* actuator acting on this dof (at most one per dof in the supported subset) */
     int kact = -1;
     for (int u = 0; u < nu; ++u) if (isdof && m->act_dofid[u] == k_) kact = u;
-    const double kgear = kact >= 0 ? m->act_gear[kact] : 0.0;
-    const double kclo = kact >= 0 ? m->act_ctrlrange[kact][0] : 0.0, kchi = kact >= 0 ? m->act_ctrlrange[kact][1] : 0.0;
-    const bool kclim = kact >= 0 && m->act_ctrllimited[kact];
     wv::sync();
 
     for (int sub = 0; sub < io.nsub; ++sub) {
@@ -358,6 +375,16 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
 
         /* ================= P1 kinematics: lane = body, level by level ================= */
         /* joint-local rotation of the body's first joint, all lanes at once (hoists sin/cos out of the recursion) */
+        double bpos[3] = {0, 0, 0}, bquat[4] = {1, 0, 0, 0}, bipos[3] = {0, 0, 0}, biquat[4] = {1, 0, 0, 0};
+        double bjpos[3] = {0, 0, 0}, bjaxis[3] = {0, 0, 1}, bjq0 = 0;
+        if (isbody) {
+            for (int i = 0; i < 3; ++i) { bpos[i] = m->body_pos[b][i]; bipos[i] = m->body_ipos[b][i]; }
+            for (int i = 0; i < 4; ++i) { bquat[i] = m->body_quat[b][i]; biquat[i] = m->body_iquat[b][i]; }
+            if (bjn > 0) {
+                for (int i = 0; i < 3; ++i) { bjpos[i] = m->jnt_pos[bj0][i]; bjaxis[i] = m->jnt_axis[bj0][i]; }
+                bjq0 = m->qpos0[bjq];
+            }
+        }
         double qloc[4] = {1, 0, 0, 0}, slide = 0;
         if (bjt == CM_JNT_HINGE) {
             const double ang = S.qpos[bjq] - bjq0;
@@ -451,6 +478,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
         }
 
         /* ================= com of every kinematic tree (wave reduction per root) ================= */
+        const double bmass = (isbody && b > 0) ? m->body_mass[b] : 0.0;
         {
             double wx = 0, wy = 0, wz = 0;
             if (isbody && b > 0) { wx = bmass * S.x.s.xipos[b][0]; wy = bmass * S.x.s.xipos[b][1]; wz = bmass * S.x.s.xipos[b][2]; }
@@ -468,10 +496,10 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
         wv::sync();
 
         /* ================= cinert (lane = body), cdof (lane = dof) ================= */
-        double ci[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         if (isbody) {
+            double ci[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
             if (b > 0) {
-                const double I0 = binert[0], I1 = binert[1], I2 = binert[2];
+                const double I0 = m->body_inertia[b][0], I1 = m->body_inertia[b][1], I2 = m->body_inertia[b][2];
                 const double *c = S.com[broot];
                 double dif[3] = {S.x.s.xipos[b][0] - c[0], S.x.s.xipos[b][1] - c[1], S.x.s.xipos[b][2] - c[2]};
                 double d2 = dot3(dif, dif);
@@ -528,6 +556,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
         }
         wv::sync();
         double col[NVP], colh[NVP]; /* col[i] = M[i][lane] (i >= lane); colh: same for M + h*diag(damping) */
+        const double karm = isdof ? m->dof_armature[k_] : 0.0, kdamp0 = isdof ? m->dof_damping[k_] : 0.0;
 #pragma unroll
         for (int i = 0; i < NVP; ++i) {
             double v = 0;
@@ -536,7 +565,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
                 if (i == k_) v += karm;
             }
             col[i] = v;
-            colh[i] = (i == k_) ? v + h * kdamp : v;
+            colh[i] = (i == k_) ? v + h * kdamp0 : v;
         }
         if (io.ext && isdof) {
             cm_ext_t *ex = io.ext + env;
@@ -546,14 +575,13 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
         CK_STAMP(3);
 
         /* ================= P3 factor M and M + hB in registers; park the factors in LDS ================= */
-        factor_in_registers<NVP>(m, col, lane, nv);
-        factor_in_registers<NVP>(m, colh, lane, nv);
+        factor_in_registers<NVP, TOPO>(m, col, lane, nv, S.dinv, S.rsd);
+        factor_in_registers<NVP, TOPO>(m, colh, lane, nv, S.dinvH, nullptr);
         if (isdof) {
 #pragma unroll
-            for (int k = 0; k < NVP; ++k) {
-                if (k >= nv) continue;
-                if (k > k_) S.L[k][k_] = col[k];
-                else if (k == k_) { S.L[k][k] = col[k]; S.dinv[k] = 1.0 / col[k]; S.rsd[k] = 1.0 / sqrt(col[k]); S.dinvH[k] = 1.0 / colh[k]; }
+            for (int k = 1; k < NVP; ++k) {
+                if (TOPO::is_static ? k >= TOPO::nv : k >= nv) continue;
+                if (k > k_) { S.Lp[CK_TRI(k, k_)] = col[k]; S.LHp[CK_TRI(k, k_)] = colh[k]; }
             }
         }
         CK_STAMP(4);
@@ -695,7 +723,8 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
         if (isbody) {
             double f6[6] = {0, 0, 0, 0, 0, 0};
             if (b > 0) {
-                double t1[6], t2[6], t3[6];
+                double t1[6], t2[6], t3[6], ci[10];
+                for (int i = 0; i < 10; ++i) ci[i] = S.x.s.cinert[b][i];
                 mul_inert_vec(t1, ci, mycacc);
                 mul_inert_vec(t2, ci, mycvel);
                 cross_force(t3, mycvel, t2);
@@ -714,14 +743,17 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
 
         /* ================= P6/P7/P8 passive + actuation -> qfrc_smooth (lane = dof) ================= */
         if (isdof) {
-            double f = -kdamp * S.qvel[k_];
-            if (kstiff != 0) f += -kstiff * (S.qpos[kqa] - kspring);
+            double f = -m->dof_damping[k_] * S.qvel[k_];
+            if (kjt == CM_JNT_HINGE || kjt == CM_JNT_SLIDE) {
+                const double kstiff = m->jnt_stiffness[kjnt];
+                if (kstiff != 0) f += -kstiff * (S.qpos[kqa] - m->qpos_spring[kqa]);
+            }
             f -= qfrc_bias;
             if (io.qfrc_applied) f += io.qfrc_applied[(size_t)env * io.sv + k_];
             if (kact >= 0) {
                 double c = S.ctrl[kact];
-                if (kclim) c = clampd(c, kclo, kchi);
-                f += kgear * c;
+                if (m->act_ctrllimited[kact]) c = clampd(c, m->act_ctrlrange[kact][0], m->act_ctrlrange[kact][1]);
+                f += m->act_gear[kact] * c;
             }
             S.qfrc_smooth[k_] = f;
         }
@@ -737,9 +769,10 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
                     if (xf[0] == 0 && xf[1] == 0 && xf[2] == 0 && xf[3] == 0 && xf[4] == 0 && xf[5] == 0) continue;
                     const double *c = S.com[m->body_rootid[bb]];
                     double off[3] = {S.x.s.xipos[bb][0] - c[0], S.x.s.xipos[bb][1] - c[1], S.x.s.xipos[bb][2] - c[2]};
-                    double t[3];
-                    cross3(t, cd, off);
-                    for (int i = 0; i < 3; ++i) f += (cd[3 + i] + t[i]) * xf[i] + cd[i] * xf[3 + i];
+                    double t[3], cdk[6];
+                    for (int i = 0; i < 6; ++i) cdk[i] = S.cdof[k_][i];
+                    cross3(t, cdk, off);
+                    for (int i = 0; i < 3; ++i) f += (cdk[3 + i] + t[i]) * xf[i] + cdk[i] * xf[3 + i];
                 }
                 S.qfrc_smooth[k_] += f;
             }
@@ -899,20 +932,25 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
         }
         const double raref = rtype >= 0 ? -rB * jvel - rK * rimp * (rpos - rmargin) : 0.0;
 
-        /* ---- sensors, part 1 (lane = sensor): everything that does not need qacc ---- */
+        /* ---- sensors, part 1 (lane = sensor): everything that does not need qacc is final here; the
+         *      accelerometer parks its partial results in LDS because the body tiles are about to be recycled ---- */
         const bool issens = lane < m->nsensor;
         const int stype = issens ? m->sensor_type[lane] : -1;
         const int sobj = issens ? m->sensor_objid[lane] : 0;
-        double sout[4] = {0, 0, 0, 0};
-        double acc_lin[3] = {0, 0, 0}, acc_ang[3] = {0, 0, 0}, acc_dif[3] = {0, 0, 0};
-        double sxmat[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, scvel[6] = {0, 0, 0, 0, 0, 0};
+        int aslot = -1; /* which accelerometer this lane is (two supported) */
+        if (stype == CM_SENS_ACCELEROMETER) {
+            aslot = 0;
+            for (int s2 = 0; s2 < lane; ++s2) if (m->sensor_type[s2] == CM_SENS_ACCELEROMETER) ++aslot;
+            if (aslot > 1) { aslot = -1; warn |= WARN_UNSUPPORTED_PAIR; }
+        }
         if (issens) {
+            double sout[4] = {0, 0, 0, 0};
             if (stype == CM_SENS_ACTUATORPOS) sout[0] = m->act_gear[sobj] * S.qpos[m->act_qposadr[sobj]];
             else if (stype == CM_SENS_JOINTPOS) sout[0] = S.qpos[m->jnt_qposadr[sobj]];
             else if (stype >= CM_SENS_FRAMEQUAT && stype <= CM_SENS_MAGNETOMETER) {
                 const int sb = m->site_bodyid[sobj];
                 double sq[4] = {m->site_quat[sobj][0], m->site_quat[sobj][1], m->site_quat[sobj][2], m->site_quat[sobj][3]};
-                double q[4];
+                double q[4], sxmat[9], scvel[6];
                 mulquat(q, S.x.s.xquat[sb], sq);
                 quat2mat(sxmat, q);
                 for (int i = 0; i < 6; ++i) scvel[i] = S.x.s.cvel[sb][i];
@@ -921,9 +959,9 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
                 else if (stype == CM_SENS_MAGNETOMETER) {
                     double mg[3] = {m->magnetic[0], m->magnetic[1], m->magnetic[2]};
                     mulmatTvec3(sout, sxmat, mg);
-                } else {
+                } else if (aslot >= 0) {
                     /* accelerometer: velocity-product part of the body's com-frame acceleration (incl. -gravity) */
-                    acc_lin[0] = -m->gravity[0]; acc_lin[1] = -m->gravity[1]; acc_lin[2] = -m->gravity[2];
+                    double acc_lin[3] = {-m->gravity[0], -m->gravity[1], -m->gravity[2]}, acc_ang[3] = {0, 0, 0};
                     for (unsigned long long mk = m->body_dofmask[sb]; mk; mk &= mk - 1) {
                         const int k = wv::popc64((mk & (0ull - mk)) - 1);
                         const double qv = S.qvel[k];
@@ -932,7 +970,20 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
                     double sp[3] = {m->site_pos[sobj][0], m->site_pos[sobj][1], m->site_pos[sobj][2]}, t[3];
                     mulmatvec3(t, S.x.s.xmat[sb], sp);
                     const double *c = S.com[m->body_rootid[sb]];
-                    for (int i = 0; i < 3; ++i) acc_dif[i] = t[i] + S.x.s.xpos[sb][i] - c[i];
+                    double *pa = S.accel[aslot];
+                    for (int i = 0; i < 3; ++i) { pa[i] = acc_ang[i]; pa[3 + i] = acc_lin[i]; pa[6 + i] = t[i] + S.x.s.xpos[sb][i] - c[i]; }
+                    for (int i = 0; i < 9; ++i) pa[9 + i] = sxmat[i];
+                    for (int i = 0; i < 6; ++i) pa[18 + i] = scvel[i];
+                }
+            }
+            if (stype != CM_SENS_ACCELEROMETER) {
+                const double cut = m->sensor_cutoff[lane];
+                const int dim = m->sensor_dim[lane], adr = m->sensor_adr[lane];
+                for (int i = 0; i < 4; ++i) {
+                    if (i >= dim) continue;
+                    double v = sout[i];
+                    if (cut > 0 && stype != CM_SENS_FRAMEQUAT) v = clampd(v, -cut, cut);
+                    io.sensordata[(size_t)env * io.ssd + adr + i] = v;
                 }
             }
         }
@@ -955,7 +1006,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
                 quat2mat(mm, q);
                 for (int i = 0; i < 9; ++i) ex->site_xmat[lane][i] = mm[i];
             }
-            if (isdof) for (int i = 0; i < 6; ++i) { ex->cdof[k_][i] = cd[i]; ex->cdof_dot[k_][i] = cdd[i]; }
+            if (isdof) for (int i = 0; i < 6; ++i) { ex->cdof[k_][i] = S.cdof[k_][i]; ex->cdof_dot[k_][i] = S.x.s.cdof_dot[k_][i]; }
             if (rtype == CM_CNSTR_EQUALITY && r_ < CM_MAXEQROW) {
                 ex->eq_pos[r_] = rpos; ex->eq_id[r_] = rid;
 #pragma unroll
@@ -988,13 +1039,13 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
         /* ================= half solve in registers: Y = D^-1/2 L^-T [J^T | qfrc_smooth], lane = column ================= */
 #pragma unroll
         for (int k = NVP - 1; k >= 0; --k) {
-            if (k >= nv) continue;
-            const unsigned long long anc = m->dof_ancmask[k];
+            if (TOPO::is_static ? k >= TOPO::nv : k >= nv) continue;
+            const unsigned long long anc = anc_mask<TOPO>(m, k);
             const double xk = ycol[k];
 #pragma unroll
             for (int i = k - 1; i >= 0; --i) {
                 if (!((anc >> i) & 1ull)) continue;
-                ycol[i] -= S.L[k][i] * xk;
+                ycol[i] -= S.Lp[CK_TRI(k, i)] * xk;
             }
             ycol[k] = xk * S.rsd[k];
         }
@@ -1010,8 +1061,18 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
         for (int r = 0; r < CM_MAXEFC; ++r) {
             double acc = 0;
             if (r < nefc) {
+                /* stage the whole broadcast row first (all LDS reads in flight together), then four independent
+                 * partial sums: one wave per SIMD has nothing else to hide LDS or fp64 latency behind */
+                double yr[NVP];
 #pragma unroll
-                for (int k = 0; k < NVP; ++k) acc += S.x.Yr[r][k] * ycol[k];
+                for (int k = 0; k < NVP; ++k) yr[k] = S.x.Yr[r][k];
+                double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+#pragma unroll
+                for (int k = 0; k < NVP; k += 4) {
+                    a0 += yr[k] * ycol[k]; a1 += yr[k + 1] * ycol[k + 1];
+                    a2 += yr[k + 2] * ycol[k + 2]; a3 += yr[k + 3] * ycol[k + 3];
+                }
+                acc = (a0 + a1) + (a2 + a3);
                 if (r == r_) { acc += rR; Aii = acc; }
             }
             arow[r] = acc;
@@ -1048,27 +1109,18 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
                 else if (isrow) res = rb + af;
             }
             const double scale = 1.0 / (m->meaninertia * (nv > 1 ? nv : 1));
+            const double halfAii = 0.5 * Aii;
+            const double flo = clampf ? 0.0 : -1e300; /* lower bound of this row's force */
             while (iters < m->iterations) {
+                const int nrows = wv::opaque(nefc); /* keeps the row-bound tests out of loop-invariant hoisting */
                 double improvement = 0;
-#pragma unroll
-                for (int i = 0; i < CM_MAXEFC; ++i) {
-                    if (i >= nefc) continue;
-                    double fn = f - res * invAii;
-                    if (clampf && fn < 0) fn = 0;
-                    double delta = fn - f;
-                    double change = 0.5 * delta * delta * Aii + delta * res;
-                    if (change > 1e-10) { delta = 0; change = 0; }
-                    if (r_ != i) { delta = 0; change = 0; }
-                    f += delta;
-                    improvement -= change;
-                    const double dlt = wv::readlane(delta, i);
-                    if (isrow) res += arow[i] * dlt;
-                }
-                improvement = wv::wave_sum(improvement) * scale;
+                pgs_rows<0>(arow, nrows, r_, invAii, halfAii, flo, f, res, improvement);
+                improvement *= scale;
                 ++iters;
                 if (improvement < m->tolerance) break;
             }
         }
+        CK_STAMP(11);
         if (io.ext) {
             /* decode the pyramid: normal = sum of the edge forces, tangents = mu (f+ - f-) */
             cm_ext_t *ex = io.ext + env;
@@ -1084,7 +1136,6 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
             }
             if (lane == 0) { ex->ncon = ncon; ex->nefc = nefc; ex->solver_iter = iters; }
         }
-        CK_STAMP(11);
 
         /* ================= qacc = L^-1 D^-1/2 (y63 + Y f)  (lane = dof) ================= */
         double qacc;
@@ -1099,9 +1150,9 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
             if (isdof) z *= S.rsd[k_];
 #pragma unroll
             for (int i = 0; i < NVP - 1; ++i) {
-                if (i >= nv - 1) continue;
+                if (TOPO::is_static ? i >= TOPO::nv - 1 : i >= nv - 1) continue;
                 const double zi = wv::readlane(z, i);
-                if (isdof && k_ > i) z -= S.L[k_][i] * zi;
+                if (isdof && k_ > i) z -= S.Lp[CK_TRI(k_, i)] * zi;
             }
             qacc = z;
         }
@@ -1110,35 +1161,30 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
             if (wv::ballot(badv) != 0ull) { warn |= WARN_DIVERGED; break; }
         }
         if (isdof) S.qacc[k_] = qacc;
-        wv::sync(); /* Y is dead: region x becomes the factor of M + hB */
+        wv::sync();
         CK_STAMP(12);
 
-        /* ---- sensors, part 2: accelerometer needs qacc; cutoffs; store ---- */
-        if (issens) {
-            if (stype == CM_SENS_ACCELEROMETER) {
-                const int sb = m->site_bodyid[sobj];
-                for (unsigned long long mk = m->body_dofmask[sb]; mk; mk &= mk - 1) {
-                    const int k = wv::popc64((mk & (0ull - mk)) - 1);
-                    const double qa = S.qacc[k];
-                    for (int i = 0; i < 3; ++i) { acc_ang[i] += S.cdof[k][i] * qa; acc_lin[i] += S.cdof[k][3 + i] * qa; }
-                }
-                double t[3], lin[3], vlin[3], corr[3];
-                cross3(t, acc_dif, acc_ang);
-                for (int i = 0; i < 3; ++i) lin[i] = acc_lin[i] - t[i];
-                cross3(t, acc_dif, scvel);
-                for (int i = 0; i < 3; ++i) vlin[i] = scvel[3 + i] - t[i];
-                cross3(corr, scvel, vlin);
-                for (int i = 0; i < 3; ++i) lin[i] += corr[i];
-                mulmatTvec3(sout, sxmat, lin);
+        /* ---- sensors, part 2: the accelerometer needs qacc ---- */
+        if (aslot >= 0) {
+            const int sb = m->site_bodyid[sobj];
+            const double *pa = S.accel[aslot];
+            double acc_ang[3] = {pa[0], pa[1], pa[2]}, acc_lin[3] = {pa[3], pa[4], pa[5]}, acc_dif[3] = {pa[6], pa[7], pa[8]};
+            for (unsigned long long mk = m->body_dofmask[sb]; mk; mk &= mk - 1) {
+                const int k = wv::popc64((mk & (0ull - mk)) - 1);
+                const double qa = S.qacc[k];
+                for (int i = 0; i < 3; ++i) { acc_ang[i] += S.cdof[k][i] * qa; acc_lin[i] += S.cdof[k][3 + i] * qa; }
             }
+            double t[3], lin[3], vlin[3], corr[3], outv[3];
+            cross3(t, acc_dif, acc_ang);
+            for (int i = 0; i < 3; ++i) lin[i] = acc_lin[i] - t[i];
+            cross3(t, acc_dif, pa + 18);
+            for (int i = 0; i < 3; ++i) vlin[i] = pa[21 + i] - t[i];
+            cross3(corr, pa + 18, vlin);
+            for (int i = 0; i < 3; ++i) lin[i] += corr[i];
+            mulmatTvec3(outv, pa + 9, lin);
             const double cut = m->sensor_cutoff[lane];
-            const int dim = m->sensor_dim[lane], adr = m->sensor_adr[lane];
-            for (int i = 0; i < 4; ++i) {
-                if (i >= dim) continue;
-                double v = sout[i];
-                if (cut > 0 && stype != CM_SENS_FRAMEQUAT) v = clampd(v, -cut, cut);
-                io.sensordata[(size_t)env * io.ssd + adr + i] = v;
-            }
+            const int adr = m->sensor_adr[lane];
+            for (int i = 0; i < 3; ++i) io.sensordata[(size_t)env * io.ssd + adr + i] = cut > 0 ? clampd(outv[i], -cut, cut) : outv[i];
         }
         if (lane < nu) io.actuator_velocity[(size_t)env * io.su + lane] = m->act_gear[lane] * S.qvel[m->act_dofid[lane]];
         if (io.info && lane == 0) {
@@ -1153,24 +1199,19 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
         double qacc_int = qacc;
         if (m->flags & CM_FLAG_EULERDAMP) {
             /* (M + hB) x = M qacc  <=>  x = qacc - (M + hB)^-1 (hB qacc) */
-            if (isdof) {
-#pragma unroll
-                for (int k = 0; k < NVP; ++k) if (k < nv && k > k_) S.x.LH[k][k_] = colh[k];
-            }
-            wv::sync();
-            double w = isdof ? h * kdamp * qacc : 0.0;
+            double w = isdof ? h * m->dof_damping[k_] * qacc : 0.0;
 #pragma unroll
             for (int k = NVP - 1; k >= 1; --k) { /* L^-T */
-                if (k >= nv) continue;
+                if (TOPO::is_static ? k >= TOPO::nv : k >= nv) continue;
                 const double wk = wv::readlane(w, k);
-                if (lane < k) w -= S.x.LH[k][lane] * wk;
+                if (lane < k) w -= S.LHp[CK_TRI(k, lane)] * wk;
             }
             if (isdof) w *= S.dinvH[k_];
 #pragma unroll
             for (int i = 0; i < NVP - 1; ++i) { /* L^-1 */
-                if (i >= nv - 1) continue;
+                if (TOPO::is_static ? i >= TOPO::nv - 1 : i >= nv - 1) continue;
                 const double wi = wv::readlane(w, i);
-                if (isdof && k_ > i) w -= S.x.LH[k_][i] * wi;
+                if (isdof && k_ > i) w -= S.LHp[CK_TRI(k_, i)] * wi;
             }
             qacc_int = qacc - w;
         }
@@ -1222,12 +1263,12 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
 }
 
 /* one single-wave workgroup per environment */
-template <int NVP>
+template <int NVP, class TOPO>
 WV_GLOBAL void __launch_bounds__(WV_WAVE) cassie_step_kernel(PhysIO io) {
     WV_SHARED EnvShared<NVP> S;
     const int env = wv::env_id();
     if (env >= io.nenv) return;
-    env_step<NVP>(io, S, env);
+    env_step<NVP, TOPO>(io, S, env);
 }
 
 }  // namespace ck

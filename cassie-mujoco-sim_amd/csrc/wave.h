@@ -45,6 +45,9 @@ WV_DEVICE double wave_sum(double v) {
     return v;
 }
 
+/* value-preserving move the optimiser cannot see through (wave-uniform ints only) */
+WV_DEVICE int opaque(int x) { asm volatile("" : "+s"(x)); return x; }
+
 WV_DEVICE long long clock() { return (long long)__builtin_readcyclecounter(); }
 
 WV_DEVICE int popc64(unsigned long long x) { return __popcll(x); }

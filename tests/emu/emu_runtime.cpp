@@ -117,8 +117,17 @@ double wave_sum(double v) {
 }  // namespace wv
 
 static ck::PhysIO g_io;
-static void body32() { ck::cassie_step_kernel<32>(g_io); }
-static void body40() { ck::cassie_step_kernel<40>(g_io); }
+static int g_force_runtime_topology = 0;
+static void body32s() { ck::cassie_step_kernel<32, ck::TopoCassie32>(g_io); }
+static void body40s() { ck::cassie_step_kernel<40, ck::TopoCassieTray38>(g_io); }
+static void body32() { ck::cassie_step_kernel<32, ck::TopoRuntime>(g_io); }
+static void body40() { ck::cassie_step_kernel<40, ck::TopoRuntime>(g_io); }
+extern "C" void emu_force_runtime_topology(int on) { g_force_runtime_topology = on; }
+static bool topo_matches(const cm_model_t *m, const unsigned long long *t, int nv) {
+    if (m->nv != nv) return false;
+    for (int k = 0; k < nv; ++k) if (m->dof_ancmask[k] != t[k]) return false;
+    return true;
+}
 
 extern "C" int emu_phys_run(const cm_model_t *model, int nenv, int nsub, int integrate, double *qpos, double *qvel,
                             double *qacc_warmstart, double *time, const double *ctrl, const double *qfrc_applied,
@@ -136,7 +145,9 @@ extern "C" int emu_phys_run(const cm_model_t *model, int nenv, int nsub, int int
     g_io.pd_ptarget = pd_ptarget; g_io.pd_kp = pd_kp; g_io.pd_kd = pd_kd;
     for (int e = 0; e < nenv; ++e) {
         g_env = e;
-        run_block(model->nv <= 32 ? body32 : body40);
+        if (!g_force_runtime_topology && topo_matches(model, ck::TopoCassie32::table, ck::TopoCassie32::nv)) run_block(body32s);
+        else if (!g_force_runtime_topology && topo_matches(model, ck::TopoCassieTray38::table, ck::TopoCassieTray38::nv)) run_block(body40s);
+        else run_block(model->nv <= 32 ? body32 : body40);
     }
     return 0;
 }

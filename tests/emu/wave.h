@@ -31,6 +31,7 @@ double readlane(double v, int src);
 unsigned long long ballot(bool p);
 double wave_sum(double v);
 inline long long clock() { return 0; }
+inline int opaque(int x) { return x; }
 inline int popc64(unsigned long long x) { return __builtin_popcountll(x); }
 }  // namespace wv
 #endif

@@ -123,3 +123,21 @@ def test_on_device_pd_mode(cassie):
         emu.step()
     assert np.max(np.abs(emu.qpos[0] - o.qpos)) < 1e-11
     assert o.qpos[2] > 0.8          # still standing-ish under PD after 60 ms
+
+
+def test_runtime_topology_instantiation_matches_static_one(cassie):
+    """The generic kernel (dof-tree masks read from the model at run time) must agree bitwise with the
+    compile-time-topology instantiation used for the in-scope models."""
+    import emu_py
+    pod = cassie.pod
+    a, b = EmuBatch(pod, 1), EmuBatch(pod, 1)
+    for x in (a, b):
+        x.qpos[:] = cassie.qpos_init()
+        x.ctrl[:] = [1.0, -2.0, 3.0, -4.0, 0.5, -1.0, 2.0, -3.0, 4.0, -0.5]
+    a.step(40)
+    emu_py.lib().emu_force_runtime_topology(1)
+    try:
+        b.step(40)
+    finally:
+        emu_py.lib().emu_force_runtime_topology(0)
+    assert np.array_equal(a.qpos, b.qpos) and np.array_equal(a.qvel, b.qvel)
