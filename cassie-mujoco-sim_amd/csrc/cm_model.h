@@ -66,7 +66,8 @@ typedef struct cm_model {
     unsigned flags;
     int hfield_geom;       /* index into geom_* of the hfield geom, -1 if none */
     int hfield_nrow, hfield_ncol;
-    int pad0;
+    int npair_simple;      /* pairs [0, npair_simple) give <= 2 contacts and are tested one per lane; the rest
+                            * (plane-box, box-box, hfield-*) are tested by the whole wave, one pair at a time */
     double timestep, tolerance, meaninertia;
     double gravity[3], magnetic[3];
     double hfield_size[4]; /* x half-size, y half-size, z top scale, z bottom */
@@ -111,7 +112,8 @@ typedef struct cm_model {
 
     /* candidate pairs after the static bitmask / same-body / parent-child filter;
      * geom1's type <= geom2's type (MuJoCo's narrow-phase convention) and the list
-     * is sorted by (body1, body2, geom1, geom2) so contact order is deterministic */
+     * is sorted by (body1, body2, geom1, geom2) within the simple and the wave-cooperative groups, so contact
+     * order is deterministic */
     int pair_geom1[CM_MAXPAIR], pair_geom2[CM_MAXPAIR];
 
     /* equality constraints (connect only) */

@@ -1124,6 +1124,13 @@ bool HostModel::compile(cm_model_t *o, std::string *err) const {
         if (x.b1 != y.b1) return x.b1 < y.b1;
         return x.b2 < y.b2;
     });
+    auto multi = [&](const P &x) {
+        int t1 = o->geom_type[x.g1], t2 = o->geom_type[x.g2];
+        return t1 == CM_GEOM_HFIELD || (t1 == CM_GEOM_PLANE && t2 == CM_GEOM_BOX) || (t1 == CM_GEOM_BOX && t2 == CM_GEOM_BOX);
+    };
+    std::stable_partition(pairs.begin(), pairs.end(), [&](const P &x) { return !multi(x); });
+    o->npair_simple = 0;
+    for (auto &x : pairs) if (!multi(x)) o->npair_simple++;
     if ((int)pairs.size() > CM_MAXPAIR) return fail("too many candidate collision pairs");
     o->npair = (int)pairs.size();
     for (int i = 0; i < o->npair; ++i) { o->pair_geom1[i] = pairs[i].g1; o->pair_geom2[i] = pairs[i].g2; }

@@ -233,6 +233,100 @@ WV_DEVICE void make_frame(double *frame) {
     cross3(frame + 6, frame, frame + 3);
 }
 
+
+/* ---- boxes (same definitions as oracle/cassie_oracle.c) ---- */
+WV_DEVICE double point_box(const double *q, const double *pb, const double *mb, const double *sb, double *nworld) {
+    double d[3] = {q[0] - pb[0], q[1] - pb[1], q[2] - pb[2]}, loc[3], cl[3];
+    mulmatTvec3(loc, mb, d);
+    bool inside = true;
+    for (int k = 0; k < 3; ++k) { cl[k] = clampd(loc[k], -sb[k], sb[k]); if (cl[k] != loc[k]) inside = false; }
+    double nl[3] = {0, 0, 0}, dist;
+    if (!inside) {
+        double dif[3] = {loc[0] - cl[0], loc[1] - cl[1], loc[2] - cl[2]};
+        dist = sqrt(dot3(dif, dif));
+        for (int k = 0; k < 3; ++k) nl[k] = dif[k] / dist;
+    } else {
+        const double d0 = sb[0] - fabs(loc[0]), d1 = sb[1] - fabs(loc[1]), d2 = sb[2] - fabs(loc[2]);
+        double best = d0;
+        int kb = 0;
+        if (d1 < best) { best = d1; kb = 1; }
+        if (d2 < best) { best = d2; kb = 2; }
+        const double sg = (kb == 0 ? loc[0] : (kb == 1 ? loc[1] : loc[2])) >= 0 ? 1.0 : -1.0;
+        nl[0] = kb == 0 ? sg : 0.0; nl[1] = kb == 1 ? sg : 0.0; nl[2] = kb == 2 ? sg : 0.0;
+        dist = -best;
+    }
+    mulmatvec3(nworld, mb, nl);
+    return dist;
+}
+WV_DEVICE int sphere_box(RawContact &c, const double *ps, double r, const double *pb, const double *mb, const double *sb, double margin) {
+    double nw[3];
+    const double dist = point_box(ps, pb, mb, sb, nw) - r;
+    if (dist > margin) return 0;
+    c.dist = dist;
+    for (int i = 0; i < 3; ++i) { c.normal[i] = -nw[i]; c.pos[i] = ps[i] - nw[i] * (r + 0.5 * dist); c.tangent[i] = 0; }
+    return 1;
+}
+WV_DEVICE int capsule_box(RawContact &c0, RawContact &c1, const double *pc, const double *mc, double rad, double h, const double *pb,
+                          const double *mb, const double *sb, double margin) {
+    const double ax[3] = {mc[2], mc[5], mc[8]}, gr = 0.6180339887498949;
+    double lo = -h, hi = h, nw[3];
+    double t1 = hi - gr * (hi - lo), t2 = lo + gr * (hi - lo);
+    double q1[3] = {pc[0] + ax[0] * t1, pc[1] + ax[1] * t1, pc[2] + ax[2] * t1}, q2[3] = {pc[0] + ax[0] * t2, pc[1] + ax[1] * t2, pc[2] + ax[2] * t2};
+    double f1 = point_box(q1, pb, mb, sb, nw), f2 = point_box(q2, pb, mb, sb, nw);
+    for (int it = 0; it < 32; ++it) {
+        if (f1 <= f2) { hi = t2; t2 = t1; f2 = f1; t1 = hi - gr * (hi - lo); for (int i = 0; i < 3; ++i) q1[i] = pc[i] + ax[i] * t1; f1 = point_box(q1, pb, mb, sb, nw); }
+        else { lo = t1; t1 = t2; f1 = f2; t2 = lo + gr * (hi - lo); for (int i = 0; i < 3; ++i) q2[i] = pc[i] + ax[i] * t2; f2 = point_box(q2, pb, mb, sb, nw); }
+    }
+    double ts = 0.5 * (lo + hi);
+    if (ts > h - 1e-9 * (1 + h)) ts = h;
+    if (ts < -h + 1e-9 * (1 + h)) ts = -h;
+    const double tf = ts >= 0 ? -h : h;
+    int n = 0;
+    double qa[3] = {pc[0] + ax[0] * ts, pc[1] + ax[1] * ts, pc[2] + ax[2] * ts};
+    if (sphere_box(c0, qa, rad, pb, mb, sb, margin)) { for (int i = 0; i < 3; ++i) c0.tangent[i] = ax[i]; n = 1; }
+    if (!(fabs(tf - ts) < 1e-6 + 1e-3 * h)) {
+        double qb[3] = {pc[0] + ax[0] * tf, pc[1] + ax[1] * tf, pc[2] + ax[2] * tf};
+        RawContact t;
+        if (sphere_box(t, qb, rad, pb, mb, sb, margin)) { for (int i = 0; i < 3; ++i) t.tangent[i] = ax[i]; if (n == 0) c0 = t; else c1 = t; ++n; }
+    }
+    return n;
+}
+
+/* stores one contact with its mixed parameters (priority wins, else max condim / max friction /
+ * solmix-weighted solref, solimp) into slot `slot` of the env's contact list */
+template <int NVP>
+WV_DEVICE void write_contact(EnvShared<NVP> &S, const cm_model_t *m, int slot, int g1, int g2, const RawContact &r, double includemargin) {
+    double fr[9];
+    for (int i = 0; i < 3; ++i) { fr[i] = r.normal[i]; fr[3 + i] = r.tangent[i]; fr[6 + i] = 0; }
+    make_frame(fr);
+    S.c_dist[slot] = r.dist;
+    for (int i = 0; i < 3; ++i) S.c_pos[slot][i] = r.pos[i];
+    for (int i = 0; i < 9; ++i) S.c_frame[slot][i] = fr[i];
+    S.c_g1[slot] = g1; S.c_g2[slot] = g2;
+    S.c_margin[slot] = includemargin;
+    const int pa = m->geom_priority[g1], pb = m->geom_priority[g2];
+    if (pa != pb) {
+        const int g = pa > pb ? g1 : g2;
+        S.c_dim[slot] = m->geom_condim[g];
+        for (int i = 0; i < 2; ++i) S.c_solref[slot][i] = m->geom_solref[g][i];
+        for (int i = 0; i < 5; ++i) S.c_solimp[slot][i] = m->geom_solimp[g][i];
+        for (int i = 0; i < 3; ++i) S.c_fri[slot][i] = m->geom_friction[g][i];
+    } else {
+        S.c_dim[slot] = m->geom_condim[g1] > m->geom_condim[g2] ? m->geom_condim[g1] : m->geom_condim[g2];
+        const double s1 = m->geom_solmix[g1], s2 = m->geom_solmix[g2];
+        double mix;
+        if (s1 >= CM_MINVAL && s2 >= CM_MINVAL) mix = s1 / (s1 + s2);
+        else if (s1 < CM_MINVAL && s2 < CM_MINVAL) mix = 0.5;
+        else mix = s1 < CM_MINVAL ? 0.0 : 1.0;
+        if (m->geom_solref[g1][0] > 0 && m->geom_solref[g2][0] > 0)
+            for (int i = 0; i < 2; ++i) S.c_solref[slot][i] = mix * m->geom_solref[g1][i] + (1 - mix) * m->geom_solref[g2][i];
+        else
+            for (int i = 0; i < 2; ++i) S.c_solref[slot][i] = fmin(m->geom_solref[g1][i], m->geom_solref[g2][i]);
+        for (int i = 0; i < 5; ++i) S.c_solimp[slot][i] = mix * m->geom_solimp[g1][i] + (1 - mix) * m->geom_solimp[g2][i];
+        for (int i = 0; i < 3; ++i) S.c_fri[slot][i] = fmax(m->geom_friction[g1][i], m->geom_friction[g2][i]);
+    }
+}
+
 WV_DEVICE double impedance(const double *solimp, double pos, double margin) {
     double dmin = solimp[0], dmax = solimp[1], width = solimp[2], mid = solimp[3], power = solimp[4];
     if (dmin == dmax || width <= CM_MINVAL) return 0.5 * (dmin + dmax);
@@ -586,15 +680,16 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
         }
         CK_STAMP(4);
 
-        /* ================= P4 collision: lane = candidate pair ================= */
+        /* ================= P4 collision ================= */
+        /* pass 1, lane = candidate pair (pair types that give at most two contacts) */
         int ncon = 0;
-        for (int p0 = 0; p0 < m->npair; p0 += WV_WAVE) {
+        for (int p0 = 0; p0 < m->npair_simple; p0 += WV_WAVE) {
             const int p = p0 + lane;
             int n = 0;
-            RawContact rc[2];
+            RawContact rc0, rc1;
             int g1 = 0, g2 = 0;
             double margin = 0, gap = 0;
-            if (p < m->npair) {
+            if (p < m->npair_simple) {
                 g1 = m->pair_geom1[p]; g2 = m->pair_geom2[p];
                 const int t1 = m->geom_type[g1], t2 = m->geom_type[g2];
                 margin = fmax(m->geom_margin[g1], m->geom_margin[g2]);
@@ -615,30 +710,36 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
                     const double s10 = m->geom_size[g1][0], s11 = m->geom_size[g1][1];
                     const double s20 = m->geom_size[g2][0], s21 = m->geom_size[g2][1];
                     if (t1 == CM_GEOM_PLANE && t2 == CM_GEOM_SPHERE) {
-                        n = plane_sphere(rc[0], p1, m1, p2, s20, margin);
+                        n = plane_sphere(rc0, p1, m1, p2, s20, margin);
                     } else if (t1 == CM_GEOM_PLANE && t2 == CM_GEOM_CAPSULE) {
                         double axis[3] = {m2[2], m2[5], m2[8]};
                         RawContact tmp;
                         double e0[3] = {p2[0] + s21 * axis[0], p2[1] + s21 * axis[1], p2[2] + s21 * axis[2]};
-                        if (plane_sphere(tmp, p1, m1, e0, s20, margin)) { rc[0] = tmp; n = 1; }
+                        if (plane_sphere(tmp, p1, m1, e0, s20, margin)) { rc0 = tmp; n = 1; }
                         double e1[3] = {p2[0] - s21 * axis[0], p2[1] - s21 * axis[1], p2[2] - s21 * axis[2]};
-                        if (plane_sphere(tmp, p1, m1, e1, s20, margin)) { if (n == 0) rc[0] = tmp; else rc[1] = tmp; ++n; }
-                        for (int i = 0; i < 3; ++i) { rc[0].tangent[i] = axis[i]; rc[1].tangent[i] = axis[i]; }
+                        if (plane_sphere(tmp, p1, m1, e1, s20, margin)) { if (n == 0) rc0 = tmp; else rc1 = tmp; ++n; }
+                        for (int i = 0; i < 3; ++i) { rc0.tangent[i] = axis[i]; rc1.tangent[i] = axis[i]; }
                     } else if (t1 == CM_GEOM_SPHERE && t2 == CM_GEOM_SPHERE) {
-                        n = sphere_sphere(rc[0], p1, s10, p2, s20, margin);
+                        n = sphere_sphere(rc0, p1, s10, p2, s20, margin);
                     } else if (t1 == CM_GEOM_SPHERE && t2 == CM_GEOM_CAPSULE) {
                         double a2[3] = {m2[2], m2[5], m2[8]};
                         double d12[3] = {-dif[0], -dif[1], -dif[2]};
                         double x = clampd(dot3(a2, d12), -s21, s21);
                         double q2[3] = {p2[0] + a2[0] * x, p2[1] + a2[1] * x, p2[2] + a2[2] * x};
-                        n = sphere_sphere(rc[0], p1, s10, q2, s20, margin);
+                        n = sphere_sphere(rc0, p1, s10, q2, s20, margin);
                     } else if (t1 == CM_GEOM_CAPSULE && t2 == CM_GEOM_CAPSULE) {
                         double a1[3] = {m1[2], m1[5], m1[8]}, a2[3] = {m2[2], m2[5], m2[8]};
                         double x1, x2;
                         segment_closest(p1, a1, s11, p2, a2, s21, x1, x2);
                         double q1[3] = {p1[0] + a1[0] * x1, p1[1] + a1[1] * x1, p1[2] + a1[2] * x1};
                         double q2[3] = {p2[0] + a2[0] * x2, p2[1] + a2[1] * x2, p2[2] + a2[2] * x2};
-                        n = sphere_sphere(rc[0], q1, s10, q2, s20, margin);
+                        n = sphere_sphere(rc0, q1, s10, q2, s20, margin);
+                    } else if (t1 == CM_GEOM_SPHERE && t2 == CM_GEOM_BOX) {
+                        double sb[3] = {m->geom_size[g2][0], m->geom_size[g2][1], m->geom_size[g2][2]};
+                        n = sphere_box(rc0, p1, s10, p2, m2, sb, margin);
+                    } else if (t1 == CM_GEOM_CAPSULE && t2 == CM_GEOM_BOX) {
+                        double sb[3] = {m->geom_size[g2][0], m->geom_size[g2][1], m->geom_size[g2][2]};
+                        n = capsule_box(rc0, rc1, p1, m1, s10, s11, p2, m2, sb, margin);
                     } else {
                         warn |= WARN_UNSUPPORTED_PAIR;
                     }
@@ -647,41 +748,70 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
             /* ballot-compact in pair order */
             const unsigned long long m1b = wv::ballot(n >= 1), m2b = wv::ballot(n >= 2);
             const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-            int slot = ncon + wv::popc64(m1b & below) + wv::popc64(m2b & below);
-            for (int c = 0; c < n; ++c, ++slot) {
-                if (slot >= CM_MAXCON) continue;
-                const RawContact &r = (c == 0) ? rc[0] : rc[1];
-                double fr[9];
-                for (int i = 0; i < 3; ++i) { fr[i] = r.normal[i]; fr[3 + i] = r.tangent[i]; fr[6 + i] = 0; }
-                make_frame(fr);
-                S.c_dist[slot] = r.dist;
-                for (int i = 0; i < 3; ++i) S.c_pos[slot][i] = r.pos[i];
-                for (int i = 0; i < 9; ++i) S.c_frame[slot][i] = fr[i];
-                S.c_g1[slot] = g1; S.c_g2[slot] = g2;
-                S.c_margin[slot] = margin - gap;
-                const int pa = m->geom_priority[g1], pb = m->geom_priority[g2];
-                if (pa != pb) {
-                    const int g = pa > pb ? g1 : g2;
-                    S.c_dim[slot] = m->geom_condim[g];
-                    for (int i = 0; i < 2; ++i) S.c_solref[slot][i] = m->geom_solref[g][i];
-                    for (int i = 0; i < 5; ++i) S.c_solimp[slot][i] = m->geom_solimp[g][i];
-                    for (int i = 0; i < 3; ++i) S.c_fri[slot][i] = m->geom_friction[g][i];
-                } else {
-                    S.c_dim[slot] = m->geom_condim[g1] > m->geom_condim[g2] ? m->geom_condim[g1] : m->geom_condim[g2];
-                    const double s1 = m->geom_solmix[g1], s2 = m->geom_solmix[g2];
-                    double mix;
-                    if (s1 >= CM_MINVAL && s2 >= CM_MINVAL) mix = s1 / (s1 + s2);
-                    else if (s1 < CM_MINVAL && s2 < CM_MINVAL) mix = 0.5;
-                    else mix = s1 < CM_MINVAL ? 0.0 : 1.0;
-                    if (m->geom_solref[g1][0] > 0 && m->geom_solref[g2][0] > 0)
-                        for (int i = 0; i < 2; ++i) S.c_solref[slot][i] = mix * m->geom_solref[g1][i] + (1 - mix) * m->geom_solref[g2][i];
-                    else
-                        for (int i = 0; i < 2; ++i) S.c_solref[slot][i] = fmin(m->geom_solref[g1][i], m->geom_solref[g2][i]);
-                    for (int i = 0; i < 5; ++i) S.c_solimp[slot][i] = mix * m->geom_solimp[g1][i] + (1 - mix) * m->geom_solimp[g2][i];
-                    for (int i = 0; i < 3; ++i) S.c_fri[slot][i] = fmax(m->geom_friction[g1][i], m->geom_friction[g2][i]);
-                }
-            }
+            const int slot = ncon + wv::popc64(m1b & below) + wv::popc64(m2b & below);
+            if (n >= 1 && slot < CM_MAXCON) write_contact<NVP>(S, m, slot, g1, g2, rc0, margin - gap);
+            if (n >= 2 && slot + 1 < CM_MAXCON) write_contact<NVP>(S, m, slot + 1, g1, g2, rc1, margin - gap);
             ncon += wv::popc64(m1b) + wv::popc64(m2b);
+        }
+        /* pass 2, one pair at a time with the whole wave: lane = feature (box corner / vertex), first four hits kept */
+        for (int p = m->npair_simple; p < m->npair; ++p) {
+            const int g1 = m->pair_geom1[p], g2 = m->pair_geom2[p];
+            const int t1 = m->geom_type[g1], t2 = m->geom_type[g2];
+            const double margin = fmax(m->geom_margin[g1], m->geom_margin[g2]), gap = fmax(m->geom_gap[g1], m->geom_gap[g2]);
+            const double *p1 = S.x.s.geom_xpos[g1], *p2 = S.x.s.geom_xpos[g2];
+            const double *m1 = S.x.s.geom_xmat[g1], *m2 = S.x.s.geom_xmat[g2];
+            const double rb1 = m->geom_rbound[g1], rb2 = m->geom_rbound[g2];
+            {
+                double dif[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
+                bool cull = false;
+                if (rb1 > 0 && rb2 > 0) { const double bound = rb1 + rb2 + margin; cull = dot3(dif, dif) > bound * bound; }
+                else if (t1 == CM_GEOM_PLANE && rb2 > 0) { double nn[3] = {m1[2], m1[5], m1[8]}; cull = dot3(dif, nn) > margin + rb2; }
+                if (cull) continue; /* wave-uniform: poses come from LDS broadcasts */
+            }
+            bool hit = false;
+            RawContact rc;
+            if (t1 == CM_GEOM_PLANE && t2 == CM_GEOM_BOX) {
+                if (lane < 8) {
+                    const double sb0 = m->geom_size[g2][0], sb1 = m->geom_size[g2][1], sb2 = m->geom_size[g2][2];
+                    double nrm[3] = {m1[2], m1[5], m1[8]}, dif[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
+                    const double dist = dot3(dif, nrm);
+                    double v[3] = {(lane & 1) ? sb0 : -sb0, (lane & 2) ? sb1 : -sb1, (lane & 4) ? sb2 : -sb2}, corner[3];
+                    mulmatvec3(corner, m2, v);
+                    const double ld = dot3(nrm, corner);
+                    if (!(dist + ld > margin || ld > 0)) {
+                        hit = true;
+                        rc.dist = dist + ld;
+                        for (int k = 0; k < 3; ++k) { rc.normal[k] = nrm[k]; rc.tangent[k] = 0; rc.pos[k] = corner[k] + p2[k] - nrm[k] * 0.5 * rc.dist; }
+                    }
+                }
+            } else if (t1 == CM_GEOM_BOX && t2 == CM_GEOM_BOX) {
+                if (lane < 16) {
+                    const bool second = lane >= 8;
+                    const int ga = second ? g2 : g1, gb = second ? g1 : g2;
+                    const double *pa = second ? p2 : p1, *ma = second ? m2 : m1, *pb = second ? p1 : p2, *mb = second ? m1 : m2;
+                    double sa[3] = {m->geom_size[ga][0], m->geom_size[ga][1], m->geom_size[ga][2]};
+                    double sb[3] = {m->geom_size[gb][0], m->geom_size[gb][1], m->geom_size[gb][2]};
+                    const int i = lane & 7;
+                    double v[3] = {(i & 1) ? sa[0] : -sa[0], (i & 2) ? sa[1] : -sa[1], (i & 4) ? sa[2] : -sa[2]}, w[3], nw[3];
+                    mulmatvec3(w, ma, v);
+                    for (int k = 0; k < 3; ++k) w[k] += pa[k];
+                    const double dist = point_box(w, pb, mb, sb, nw);
+                    if (!(dist > margin)) {
+                        hit = true;
+                        rc.dist = dist;
+                        const double sgn = second ? 1.0 : -1.0;
+                        for (int k = 0; k < 3; ++k) { rc.normal[k] = sgn * nw[k]; rc.tangent[k] = 0; rc.pos[k] = w[k] - nw[k] * 0.5 * dist; }
+                    }
+                }
+            } else {
+                warn |= WARN_UNSUPPORTED_PAIR;
+            }
+            const unsigned long long hb = wv::ballot(hit);
+            const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+            const int rank = wv::popc64(hb & below);
+            if (hit && rank < 4 && ncon + rank < CM_MAXCON) write_contact<NVP>(S, m, ncon + rank, g1, g2, rc, margin - gap);
+            const int nh = wv::popc64(hb);
+            ncon += nh < 4 ? nh : 4;
         }
         if (ncon > CM_MAXCON) { ncon = CM_MAXCON; warn |= WARN_CONTACT_FULL; }
         CK_STAMP(5);

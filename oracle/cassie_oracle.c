@@ -404,6 +404,104 @@ static int sphere_capsule(raw_contact_t *c, const double *p1, double r1, const d
     return sphere_sphere(c, p1, r1, q2, s2[0], margin);
 }
 
+
+/* ---- boxes (this repository's own definition of these pair types; MuJoCo's routines differ in detail) ---- */
+/* signed distance from point q to a box (centre pb, frame mb, half sizes sb); outward unit normal at the
+ * closest surface point, in world axes */
+static double point_box(const double *q, const double *pb, const double *mb, const double *sb, double *nworld) {
+    double d[3] = {q[0] - pb[0], q[1] - pb[1], q[2] - pb[2]}, loc[3], cl[3];
+    mulmatTvec3(loc, mb, d);
+    int inside = 1;
+    for (int k = 0; k < 3; ++k) { cl[k] = clampd(loc[k], -sb[k], sb[k]); if (cl[k] != loc[k]) inside = 0; }
+    double nl[3] = {0, 0, 0}, dist;
+    if (!inside) {
+        double dif[3] = {loc[0] - cl[0], loc[1] - cl[1], loc[2] - cl[2]};
+        dist = norm3(dif);
+        for (int k = 0; k < 3; ++k) nl[k] = dif[k] / dist;
+    } else {
+        int kb = 0;
+        double best = sb[0] - fabs(loc[0]);
+        for (int k = 1; k < 3; ++k) { double dk = sb[k] - fabs(loc[k]); if (dk < best) { best = dk; kb = k; } }
+        nl[kb] = loc[kb] >= 0 ? 1.0 : -1.0;
+        dist = -best;
+    }
+    mulmatvec3(nworld, mb, nl);
+    return dist;
+}
+static int sphere_box(raw_contact_t *c, const double *ps, double r, const double *pb, const double *mb, const double *sb, double margin) {
+    double nw[3];
+    double dist = point_box(ps, pb, mb, sb, nw) - r;
+    if (dist > margin) return 0;
+    c->dist = dist;
+    for (int i = 0; i < 3; ++i) { c->normal[i] = -nw[i]; c->pos[i] = ps[i] - nw[i] * (r + 0.5 * dist); c->tangent[i] = 0; }
+    return 1;
+}
+/* capsule vs box: the point of the capsule axis closest to the box (golden-section search on the convex
+ * distance function, fixed 32 iterations) and, if it also touches, the far end cap: at most 2 contacts */
+static int capsule_box(raw_contact_t *c, const double *pc, const double *mc, const double *sc, const double *pb, const double *mb,
+                       const double *sb, double margin) {
+    const double ax[3] = {mc[2], mc[5], mc[8]}, h = sc[1], gr = 0.6180339887498949;
+    double lo = -h, hi = h, nw[3];
+    double t1 = hi - gr * (hi - lo), t2 = lo + gr * (hi - lo);
+    double q1[3] = {pc[0] + ax[0] * t1, pc[1] + ax[1] * t1, pc[2] + ax[2] * t1}, q2[3] = {pc[0] + ax[0] * t2, pc[1] + ax[1] * t2, pc[2] + ax[2] * t2};
+    double f1 = point_box(q1, pb, mb, sb, nw), f2 = point_box(q2, pb, mb, sb, nw);
+    for (int it = 0; it < 32; ++it) {
+        if (f1 <= f2) { hi = t2; t2 = t1; f2 = f1; t1 = hi - gr * (hi - lo); for (int i = 0; i < 3; ++i) q1[i] = pc[i] + ax[i] * t1; f1 = point_box(q1, pb, mb, sb, nw); }
+        else { lo = t1; t1 = t2; f1 = f2; t2 = lo + gr * (hi - lo); for (int i = 0; i < 3; ++i) q2[i] = pc[i] + ax[i] * t2; f2 = point_box(q2, pb, mb, sb, nw); }
+    }
+    double ts = 0.5 * (lo + hi);
+    /* snap to an end cap when the minimum sits there */
+    if (ts > h - 1e-9 * (1 + h)) ts = h;
+    if (ts < -h + 1e-9 * (1 + h)) ts = -h;
+    double tt[2] = {ts, ts >= 0 ? -h : h};
+    int n = 0;
+    for (int k = 0; k < 2; ++k) {
+        if (k == 1 && fabs(tt[1] - tt[0]) < 1e-6 + 1e-3 * h) break;
+        double q[3] = {pc[0] + ax[0] * tt[k], pc[1] + ax[1] * tt[k], pc[2] + ax[2] * tt[k]};
+        if (sphere_box(c + n, q, sc[0], pb, mb, sb, margin)) { for (int i = 0; i < 3; ++i) c[n].tangent[i] = ax[i]; ++n; }
+    }
+    return n;
+}
+/* plane vs box: corners below the box centre, in corner order, at most 4 (same rule as MuJoCo's plane-box) */
+static int plane_box(raw_contact_t *c, const double *pp, const double *mp, const double *pb, const double *mb, const double *sb, double margin) {
+    double nrm[3] = {mp[2], mp[5], mp[8]}, dif[3] = {pb[0] - pp[0], pb[1] - pp[1], pb[2] - pp[2]};
+    double dist = dot3(dif, nrm);
+    int n = 0;
+    for (int i = 0; i < 8 && n < 4; ++i) {
+        double v[3] = {(i & 1) ? sb[0] : -sb[0], (i & 2) ? sb[1] : -sb[1], (i & 4) ? sb[2] : -sb[2]}, corner[3];
+        mulmatvec3(corner, mb, v);
+        double ld = dot3(nrm, corner);
+        if (dist + ld > margin || ld > 0) continue;
+        c[n].dist = dist + ld;
+        for (int k = 0; k < 3; ++k) { c[n].normal[k] = nrm[k]; c[n].tangent[k] = 0; c[n].pos[k] = corner[k] + pb[k] - nrm[k] * 0.5 * c[n].dist; }
+        ++n;
+    }
+    return n;
+}
+/* box vs box, vertex-in-box contacts only (edge-edge crossings are not generated -- documented limitation):
+ * the 8 vertices of box 1 inside box 2, then the 8 vertices of box 2 inside box 1, first 4 found */
+static int box_box(raw_contact_t *c, const double *p1, const double *m1, const double *s1, const double *p2, const double *m2, const double *s2,
+                   double margin) {
+    int n = 0;
+    for (int pass = 0; pass < 2 && n < 4; ++pass) {
+        const double *pa = pass ? p2 : p1, *ma = pass ? m2 : m1, *sa = pass ? s2 : s1; /* box whose vertices are tested */
+        const double *pb = pass ? p1 : p2, *mb = pass ? m1 : m2, *sb = pass ? s1 : s2; /* box they may be inside of */
+        for (int i = 0; i < 8 && n < 4; ++i) {
+            double v[3] = {(i & 1) ? sa[0] : -sa[0], (i & 2) ? sa[1] : -sa[1], (i & 4) ? sa[2] : -sa[2]}, w[3], nw[3];
+            mulmatvec3(w, ma, v);
+            for (int k = 0; k < 3; ++k) w[k] += pa[k];
+            double dist = point_box(w, pb, mb, sb, nw);
+            if (dist > margin) continue;
+            c[n].dist = dist;
+            /* nw points out of the containing box towards the intruding vertex; the contact normal goes from geom1 to geom2 */
+            double sgn = pass ? 1.0 : -1.0;
+            for (int k = 0; k < 3; ++k) { c[n].normal[k] = sgn * nw[k]; c[n].tangent[k] = 0; c[n].pos[k] = w[k] - nw[k] * 0.5 * dist; }
+            ++n;
+        }
+    }
+    return n;
+}
+
 /* completes a contact frame from its normal and an optional tangent hint */
 static void make_frame(double *frame) {
     normalize3(frame);
@@ -437,12 +535,17 @@ void co_collision(const cm_model_t *m, co_data_t *d) {
             if (dot3(dif, n) > margin + m->geom_rbound[g2]) continue;
         }
         raw_contact_t rc[8];
+        (void)mulmat3;
         int n = 0;
         if (t1 == CM_GEOM_PLANE && t2 == CM_GEOM_SPHERE) n = plane_sphere(rc, p1, m1, p2, m->geom_size[g2][0], margin);
         else if (t1 == CM_GEOM_PLANE && t2 == CM_GEOM_CAPSULE) n = plane_capsule(rc, p1, m1, p2, m2, m->geom_size[g2], margin);
         else if (t1 == CM_GEOM_SPHERE && t2 == CM_GEOM_SPHERE) n = sphere_sphere(rc, p1, m->geom_size[g1][0], p2, m->geom_size[g2][0], margin);
         else if (t1 == CM_GEOM_SPHERE && t2 == CM_GEOM_CAPSULE) n = sphere_capsule(rc, p1, m->geom_size[g1][0], p2, m2, m->geom_size[g2], margin);
         else if (t1 == CM_GEOM_CAPSULE && t2 == CM_GEOM_CAPSULE) n = capsule_capsule(rc, p1, m1, m->geom_size[g1], p2, m2, m->geom_size[g2], margin);
+        else if (t1 == CM_GEOM_SPHERE && t2 == CM_GEOM_BOX) n = sphere_box(rc, p1, m->geom_size[g1][0], p2, m2, m->geom_size[g2], margin);
+        else if (t1 == CM_GEOM_CAPSULE && t2 == CM_GEOM_BOX) n = capsule_box(rc, p1, m1, m->geom_size[g1], p2, m2, m->geom_size[g2], margin);
+        else if (t1 == CM_GEOM_PLANE && t2 == CM_GEOM_BOX) n = plane_box(rc, p1, m1, p2, m2, m->geom_size[g2], margin);
+        else if (t1 == CM_GEOM_BOX && t2 == CM_GEOM_BOX) n = box_box(rc, p1, m1, m->geom_size[g1], p2, m2, m->geom_size[g2], margin);
         else { d->warn_unsupported_pair = 1; continue; }
         for (int k = 0; k < n; ++k) {
             if (d->ncon >= CM_MAXCON) { d->warn_contact_full = 1; break; }

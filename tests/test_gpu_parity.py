@@ -123,3 +123,41 @@ def test_per_env_model_override(cassie):
     o.step(50)
     assert np.max(np.abs(q[1] - o.qpos)) < 1e-11
     b.close()
+
+
+def test_config5_tray_box_vs_oracle(built):
+    """BASELINE config 5 (cassie_tray_box.xml, nv = 38 kernel instantiation, box pair types): 8 envs x 400
+    free-running steps against the oracle, then the 4096-env size with property checks."""
+    from cassie_amd import Model
+    tray = Model("cassie_tray_box")
+    pod = tray.pod
+    rng = np.random.default_rng(21)
+    n = 8
+    q0 = tray.qpos_init()
+    b = Batch(tray, n)
+    b.set(P.F_QPOS, np.tile(q0, (n, 1)))
+    orcs = [Oracle(pod, q0) for _ in range(n)]
+    hi = np.array([pod.act_ctrlrange[u][1] for u in range(pod.nu)])
+    for s in range(0, 400, 50):
+        c = 0.4 * hi * rng.uniform(-1, 1, (n, pod.nu))
+        b.set(P.F_CTRL, c)
+        b.step(50)
+        for e, o in enumerate(orcs):
+            o.ctrl[:] = c[e]
+            o.step(50)
+    q = b.get(P.F_QPOS)
+    w, info = b.warnings()
+    assert not w.any()
+    for e, o in enumerate(orcs):
+        assert (info[e, 0], info[e, 1]) == (o.d.ncon, o.d.nefc)
+        assert np.max(np.abs(q[e] - o.qpos)) < 1e-8
+    b.close()
+    big = Batch(tray, 4096)
+    big.set(P.F_QPOS, np.tile(q0, (4096, 1)))
+    big.step(300)
+    qb = big.get(P.F_QPOS)
+    wb, _ = big.warnings()
+    assert not wb.any() and np.all(np.isfinite(qb))
+    assert np.all(qb[:, 37] > 0.9)             # every cube still on its tray after 0.15 s of zero-torque sag
+    assert np.array_equal(qb[0], qb[4095])
+    big.close()
