@@ -134,6 +134,11 @@ class Batch:
         if lib().phys_batch_forward(self._h, stream) != 0:
             raise RuntimeError("forward failed: " + (lib().phys_last_error() or b"").decode())
 
+    def set_hfield(self, data):
+        a = np.ascontiguousarray(data, dtype=np.float32)
+        if lib().phys_batch_set_hfield(self._h, a.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), a.size) != 0:
+            raise RuntimeError("set_hfield failed")
+
     def set_pd_mode(self, on=True):
         lib().phys_batch_set_pd_mode(self._h, 1 if on else 0)
 

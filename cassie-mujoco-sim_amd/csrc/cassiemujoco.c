@@ -57,6 +57,7 @@ struct cassie_sim {
     cassie_hostenv_t *host;   /* Agility block states, cassie_out, encoder filters, torque delay line */
     cassie_hostmodel_t hm;
     int left_foot_body, right_foot_body, left_heel, right_heel, left_toe, right_toe;
+    unsigned long long hfield_hash; /* of the samples last uploaded (callers write through cassie_sim_hfielddata) */
 };
 
 struct cassie_state {
@@ -141,9 +142,21 @@ static void sim_recompile(cassie_sim_t *c)
     }
 }
 
+static void sim_push_hfield(cassie_sim_t *c)
+{
+    const float *hf = phys_model_hfield_data(c->m);
+    if (!hf) return;
+    int n = phys_model_size(c->m, PHYS_NHFIELDDATA);
+    unsigned long long h = 1469598103934665603ull;
+    const unsigned *w = (const unsigned *)hf;
+    for (int i = 0; i < n; ++i) h = (h ^ w[i]) * 1099511628211ull;
+    if (h != c->hfield_hash) { phys_batch_set_hfield(c->b, hf, n); c->hfield_hash = h; }
+}
+
 static void sim_push(cassie_sim_t *c)
 {
     sim_recompile(c); /* the caller may have edited model arrays through the accessors */
+    sim_push_hfield(c);
     phys_batch_upload(c->b, PHYS_F_QPOS, c->d.qpos, 0, 1);
     phys_batch_upload(c->b, PHYS_F_QVEL, c->d.qvel, 0, 1);
     phys_batch_upload(c->b, PHYS_F_CTRL, c->d.ctrl, 0, 1);

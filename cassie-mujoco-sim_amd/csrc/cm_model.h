@@ -67,7 +67,7 @@ typedef struct cm_model {
     int hfield_geom;       /* index into geom_* of the hfield geom, -1 if none */
     int hfield_nrow, hfield_ncol;
     int npair_simple;      /* pairs [0, npair_simple) give <= 2 contacts and are tested one per lane; the rest
-                            * (plane-box, box-box, hfield-*) are tested by the whole wave, one pair at a time */
+                            * (plane-box, box-box) are tested by the whole wave, one pair at a time */
     double timestep, tolerance, meaninertia;
     double gravity[3], magnetic[3];
     double hfield_size[4]; /* x half-size, y half-size, z top scale, z bottom */

@@ -1126,7 +1126,7 @@ bool HostModel::compile(cm_model_t *o, std::string *err) const {
     });
     auto multi = [&](const P &x) {
         int t1 = o->geom_type[x.g1], t2 = o->geom_type[x.g2];
-        return t1 == CM_GEOM_HFIELD || (t1 == CM_GEOM_PLANE && t2 == CM_GEOM_BOX) || (t1 == CM_GEOM_BOX && t2 == CM_GEOM_BOX);
+        return (t1 == CM_GEOM_PLANE && t2 == CM_GEOM_BOX) || (t1 == CM_GEOM_BOX && t2 == CM_GEOM_BOX);
     };
     std::stable_partition(pairs.begin(), pairs.end(), [&](const P &x) { return !multi(x); });
     o->npair_simple = 0;

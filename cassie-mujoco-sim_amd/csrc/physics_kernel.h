@@ -292,6 +292,41 @@ WV_DEVICE int capsule_box(RawContact &c0, RawContact &c1, const double *pc, cons
     return n;
 }
 
+
+/* ---- height field: tangent plane of the grid triangle under the sample centre (same definition as the oracle) ---- */
+WV_DEVICE int hfield_sphere(RawContact &c, const cm_model_t *m, const float *data, const double *ph, const double *mh, const double *ps,
+                            double r, double margin) {
+    if (!data || m->hfield_nrow < 2 || m->hfield_ncol < 2) return 0;
+    const double sx = m->hfield_size[0], sy = m->hfield_size[1], sz = m->hfield_size[2];
+    double d[3] = {ps[0] - ph[0], ps[1] - ph[1], ps[2] - ph[2]}, p[3];
+    mulmatTvec3(p, mh, d);
+    if (fabs(p[0]) > sx || fabs(p[1]) > sy || p[2] - r > sz + margin) return 0;
+    const int nc = m->hfield_ncol, nr = m->hfield_nrow;
+    const double dx = 2 * sx / (nc - 1), dy = 2 * sy / (nr - 1);
+    const double u = (p[0] + sx) / dx, v = (p[1] + sy) / dy;
+    int j = (int)floor(u), i = (int)floor(v);
+    if (j > nc - 2) j = nc - 2;
+    if (i > nr - 2) i = nr - 2;
+    if (j < 0) j = 0;
+    if (i < 0) i = 0;
+    const double fu = u - j, fv = v - i;
+    const double z00 = sz * data[i * nc + j], z10 = sz * data[i * nc + j + 1], z01 = sz * data[(i + 1) * nc + j], z11 = sz * data[(i + 1) * nc + j + 1];
+    double gx, gy, z0;
+    const double x0 = -sx + j * dx, y0 = -sy + i * dy;
+    if (fu + fv <= 1.0) { gx = (z10 - z00) / dx; gy = (z01 - z00) / dy; z0 = z00; }
+    else { gx = (z11 - z01) / dx; gy = (z11 - z10) / dy; z0 = z11 - gx * dx - gy * dy; }
+    const double inv = 1.0 / sqrt(1.0 + gx * gx + gy * gy);
+    double nl[3] = {-gx * inv, -gy * inv, inv};
+    const double height = z0 + gx * (p[0] - x0) + gy * (p[1] - y0);
+    const double dist = (p[2] - height) * inv - r;
+    if (dist > margin) return 0;
+    double nw[3];
+    mulmatvec3(nw, mh, nl);
+    c.dist = dist;
+    for (int k = 0; k < 3; ++k) { c.normal[k] = nw[k]; c.pos[k] = ps[k] - nw[k] * (r + 0.5 * dist); c.tangent[k] = 0; }
+    return 1;
+}
+
 /* stores one contact with its mixed parameters (priority wins, else max condim / max friction /
  * solmix-weighted solref, solimp) into slot `slot` of the env's contact list */
 template <int NVP>
@@ -734,6 +769,16 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
                         double q1[3] = {p1[0] + a1[0] * x1, p1[1] + a1[1] * x1, p1[2] + a1[2] * x1};
                         double q2[3] = {p2[0] + a2[0] * x2, p2[1] + a2[1] * x2, p2[2] + a2[2] * x2};
                         n = sphere_sphere(rc0, q1, s10, q2, s20, margin);
+                    } else if (t1 == CM_GEOM_HFIELD && t2 == CM_GEOM_SPHERE) {
+                        n = hfield_sphere(rc0, m, io.hfield, p1, m1, p2, s20, margin);
+                    } else if (t1 == CM_GEOM_HFIELD && t2 == CM_GEOM_CAPSULE) {
+                        double axis[3] = {m2[2], m2[5], m2[8]};
+                        RawContact tmp;
+                        double e0[3] = {p2[0] + s21 * axis[0], p2[1] + s21 * axis[1], p2[2] + s21 * axis[2]};
+                        if (hfield_sphere(tmp, m, io.hfield, p1, m1, e0, s20, margin)) { rc0 = tmp; n = 1; }
+                        double e1[3] = {p2[0] - s21 * axis[0], p2[1] - s21 * axis[1], p2[2] - s21 * axis[2]};
+                        if (hfield_sphere(tmp, m, io.hfield, p1, m1, e1, s20, margin)) { if (n == 0) rc0 = tmp; else rc1 = tmp; ++n; }
+                        for (int i = 0; i < 3; ++i) { rc0.tangent[i] = axis[i]; rc1.tangent[i] = axis[i]; }
                     } else if (t1 == CM_GEOM_SPHERE && t2 == CM_GEOM_BOX) {
                         double sb[3] = {m->geom_size[g2][0], m->geom_size[g2][1], m->geom_size[g2][2]};
                         n = sphere_box(rc0, p1, s10, p2, m2, sb, margin);

@@ -502,6 +502,56 @@ static int box_box(raw_contact_t *c, const double *p1, const double *m1, const d
     return n;
 }
 
+
+/* ---- height field (this repository's definition; MuJoCo uses prism decomposition + a generic convex routine):
+ * a sample sphere touches the terrain through the tangent plane of the grid triangle that lies under its
+ * centre.  Grid layout as in MuJoCo: nrow x ncol samples, x <-> columns over [-sx, sx], y <-> rows over
+ * [-sy, sy], elevation = sample * size[2].  Each cell is split along the diagonal joining (col+1,row) and
+ * (col,row+1). ---- */
+static int hfield_sphere(raw_contact_t *c, const cm_model_t *m, const float *data, const double *ph, const double *mh, const double *ps,
+                         double r, double margin) {
+    if (!data || m->hfield_nrow < 2 || m->hfield_ncol < 2) return 0;
+    const double sx = m->hfield_size[0], sy = m->hfield_size[1], sz = m->hfield_size[2];
+    double d[3] = {ps[0] - ph[0], ps[1] - ph[1], ps[2] - ph[2]}, p[3];
+    mulmatTvec3(p, mh, d);
+    if (fabs(p[0]) > sx || fabs(p[1]) > sy || p[2] - r > sz + margin) return 0;
+    const int nc = m->hfield_ncol, nr = m->hfield_nrow;
+    const double dx = 2 * sx / (nc - 1), dy = 2 * sy / (nr - 1);
+    double u = (p[0] + sx) / dx, v = (p[1] + sy) / dy;
+    int j = (int)floor(u), i = (int)floor(v);
+    if (j > nc - 2) j = nc - 2;
+    if (i > nr - 2) i = nr - 2;
+    if (j < 0) j = 0;
+    if (i < 0) i = 0;
+    const double fu = u - j, fv = v - i;
+    const double z00 = sz * data[i * nc + j], z10 = sz * data[i * nc + j + 1], z01 = sz * data[(i + 1) * nc + j], z11 = sz * data[(i + 1) * nc + j + 1];
+    /* plane z = z0 + gx (x - x0) + gy (y - y0) of the triangle under the centre */
+    double gx, gy, z0, x0 = -sx + j * dx, y0 = -sy + i * dy;
+    if (fu + fv <= 1.0) { gx = (z10 - z00) / dx; gy = (z01 - z00) / dy; z0 = z00; }
+    else { gx = (z11 - z01) / dx; gy = (z11 - z10) / dy; z0 = z11 - gx * dx - gy * dy; }
+    const double inv = 1.0 / sqrt(1.0 + gx * gx + gy * gy);
+    double nl[3] = {-gx * inv, -gy * inv, inv};
+    const double height = z0 + gx * (p[0] - x0) + gy * (p[1] - y0);
+    const double dist = (p[2] - height) * inv - r;
+    if (dist > margin) return 0;
+    double nw[3];
+    mulmatvec3(nw, mh, nl);
+    c->dist = dist;
+    for (int k = 0; k < 3; ++k) { c->normal[k] = nw[k]; c->pos[k] = ps[k] - nw[k] * (r + 0.5 * dist); c->tangent[k] = 0; }
+    return 1;
+}
+static int hfield_capsule(raw_contact_t *c, const cm_model_t *m, const float *data, const double *ph, const double *mh, const double *pc,
+                          const double *mc, const double *sc, double margin) {
+    const double ax[3] = {mc[2], mc[5], mc[8]};
+    int n = 0;
+    for (int s = 0; s < 2; ++s) {
+        const double sg = s == 0 ? sc[1] : -sc[1];
+        double e[3] = {pc[0] + sg * ax[0], pc[1] + sg * ax[1], pc[2] + sg * ax[2]};
+        if (hfield_sphere(c + n, m, data, ph, mh, e, sc[0], margin)) { for (int k = 0; k < 3; ++k) c[n].tangent[k] = ax[k]; ++n; }
+    }
+    return n;
+}
+
 /* completes a contact frame from its normal and an optional tangent hint */
 static void make_frame(double *frame) {
     normalize3(frame);
@@ -542,6 +592,8 @@ void co_collision(const cm_model_t *m, co_data_t *d) {
         else if (t1 == CM_GEOM_SPHERE && t2 == CM_GEOM_SPHERE) n = sphere_sphere(rc, p1, m->geom_size[g1][0], p2, m->geom_size[g2][0], margin);
         else if (t1 == CM_GEOM_SPHERE && t2 == CM_GEOM_CAPSULE) n = sphere_capsule(rc, p1, m->geom_size[g1][0], p2, m2, m->geom_size[g2], margin);
         else if (t1 == CM_GEOM_CAPSULE && t2 == CM_GEOM_CAPSULE) n = capsule_capsule(rc, p1, m1, m->geom_size[g1], p2, m2, m->geom_size[g2], margin);
+        else if (t1 == CM_GEOM_HFIELD && t2 == CM_GEOM_SPHERE) n = hfield_sphere(rc, m, g_hfield, p1, m1, p2, m->geom_size[g2][0], margin);
+        else if (t1 == CM_GEOM_HFIELD && t2 == CM_GEOM_CAPSULE) n = hfield_capsule(rc, m, g_hfield, p1, m1, p2, m2, m->geom_size[g2], margin);
         else if (t1 == CM_GEOM_SPHERE && t2 == CM_GEOM_BOX) n = sphere_box(rc, p1, m->geom_size[g1][0], p2, m2, m->geom_size[g2], margin);
         else if (t1 == CM_GEOM_CAPSULE && t2 == CM_GEOM_BOX) n = capsule_box(rc, p1, m1, m->geom_size[g1], p2, m2, m->geom_size[g2], margin);
         else if (t1 == CM_GEOM_PLANE && t2 == CM_GEOM_BOX) n = plane_box(rc, p1, m1, p2, m2, m->geom_size[g2], margin);

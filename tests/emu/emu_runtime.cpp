@@ -133,7 +133,7 @@ extern "C" int emu_phys_run(const cm_model_t *model, int nenv, int nsub, int int
                             double *qacc_warmstart, double *time, const double *ctrl, const double *qfrc_applied,
                             const double *xfrc_applied, double *qacc, double *sensordata, double *actuator_velocity,
                             int *warn, int *info, double *xpos_out, double *xquat_out, const double *pd_ptarget,
-                            const double *pd_kp, const double *pd_kd) {
+                            const double *pd_kp, const double *pd_kd, const float *hfield) {
     memset(&g_io, 0, sizeof g_io);
     g_io.models = model; g_io.model_stride = 0;
     g_io.nenv = nenv; g_io.nsub = nsub; g_io.integrate = integrate;
@@ -142,6 +142,7 @@ extern "C" int emu_phys_run(const cm_model_t *model, int nenv, int nsub, int int
     g_io.ctrl = ctrl; g_io.qfrc_applied = qfrc_applied; g_io.xfrc_applied = xfrc_applied;
     g_io.qacc = qacc; g_io.sensordata = sensordata; g_io.actuator_velocity = actuator_velocity;
     g_io.warn = warn; g_io.info = info; g_io.xpos_out = xpos_out; g_io.xquat_out = xquat_out;
+    g_io.hfield = hfield;
     g_io.pd_ptarget = pd_ptarget; g_io.pd_kp = pd_kp; g_io.pd_kd = pd_kd;
     for (int e = 0; e < nenv; ++e) {
         g_env = e;

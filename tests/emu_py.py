@@ -13,7 +13,7 @@ def lib():
     global _lib
     if _lib is None:
         _lib = ctypes.CDLL(os.path.join(REPO_DIR, "tests", "emu", "libcassie_emu.so"))
-        _lib.emu_phys_run.argtypes = [ctypes.POINTER(CmModel)] + [ctypes.c_int] * 3 + [ctypes.c_void_p] * 17
+        _lib.emu_phys_run.argtypes = [ctypes.POINTER(CmModel)] + [ctypes.c_int] * 3 + [ctypes.c_void_p] * 18
     return _lib
 
 
@@ -34,6 +34,7 @@ class EmuBatch:
         self.xpos = z(pod.nbody * 3)
         self.xquat = z(pod.nbody * 4)
         self.pd_ptarget = self.pd_kp = self.pd_kd = None
+        self.hfield = None          # float32 [nrow * ncol] shared by all envs
 
     def _run(self, nsub, integrate):
         p = lambda a: None if a is None else a.ctypes.data
@@ -41,7 +42,7 @@ class EmuBatch:
                            p(self.qacc_warmstart), p(self.time), p(self.ctrl), p(self.qfrc_applied),
                            p(self.xfrc_applied), p(self.qacc), p(self.sensordata), p(self.actuator_velocity),
                            p(self.warn), p(self.info), p(self.xpos), p(self.xquat), p(self.pd_ptarget), p(self.pd_kp),
-                           p(self.pd_kd))
+                           p(self.pd_kd), p(self.hfield))
 
     def step(self, nsub=1):
         self._run(nsub, 1)

@@ -31,6 +31,8 @@ def lib():
         _lib.co_step_batch.argtypes = [ctypes.POINTER(CmModel), ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
         _lib.co_step_batch.restype = None
+        _lib.co_set_hfield.argtypes = [ctypes.c_void_p]
+        _lib.co_set_hfield.restype = None
     return _lib
 
 
@@ -38,6 +40,16 @@ def arr(cfield, *shape):
     """numpy view (no copy) of a ctypes array member."""
     a = np.ctypeslib.as_array(cfield)
     return a.reshape(shape) if shape else a
+
+
+_hfield_keepalive = None
+
+
+def set_hfield(data):
+    """Height-field samples (float32, nrow*ncol) used by every Oracle instance; None clears them."""
+    global _hfield_keepalive
+    _hfield_keepalive = None if data is None else np.ascontiguousarray(data, dtype=np.float32)
+    lib().co_set_hfield(None if data is None else _hfield_keepalive.ctypes.data)
 
 
 class Oracle:

@@ -161,3 +161,42 @@ def test_config5_tray_box_vs_oracle(built):
     assert np.all(qb[:, 37] > 0.9)             # every cube still on its tray after 0.15 s of zero-torque sag
     assert np.array_equal(qb[0], qb[4095])
     big.close()
+
+
+def test_config4_heightfield_vs_oracle(built):
+    """BASELINE config 4 (cassie_hfield.xml, terrain of reference example/test_hfield.py:39-41 shared by all envs)."""
+    import oracle_py
+    from cassie_amd import Model
+    hf = Model("cassie_hfield")
+    pod = hf.pod
+    h = np.random.default_rng(99).random((200, 200)).astype(np.float32)
+    h[95:105, 95:105] = 0
+    oracle_py.set_hfield(h)
+    try:
+        n = 4
+        q0 = np.tile(hf.qpos_init(), (n, 1))
+        q0[:, 0] = [0.0, 0.35, -0.3, 0.6]                         # on the flat patch, straddling its edge, on the rough part
+        b = Batch(hf, n)
+        b.set_hfield(h)
+        b.set(P.F_QPOS, q0)
+        orcs = [Oracle(pod, q0[e]) for e in range(n)]
+        b.step(400)
+        q = b.get(P.F_QPOS)
+        w, info = b.warnings()
+        assert not w.any()
+        for e, o in enumerate(orcs):
+            o.step(400)
+            assert (info[e, 0], info[e, 1]) == (o.d.ncon, o.d.nefc)
+            assert np.max(np.abs(q[e] - o.qpos)) < 1e-8
+        assert info[:, 0].max() >= 2                              # contacts with the terrain happened
+        b.close()
+        big = Batch(hf, 4096)
+        big.set_hfield(h)
+        big.set(P.F_QPOS, np.tile(hf.qpos_init(), (4096, 1)))
+        big.step(200)
+        qb = big.get(P.F_QPOS)
+        wb, _ = big.warnings()
+        assert not wb.any() and np.all(np.isfinite(qb)) and np.array_equal(qb[0], qb[-1])
+        big.close()
+    finally:
+        oracle_py.set_hfield(None)
