@@ -154,8 +154,8 @@ class Batch:
         return ms.value
 
     def profile_step(self):
-        """Runs one step and returns the per-env shader-clock stamps [nenv][16] taken at the stage boundaries."""
-        st = np.zeros((self.nenv, 16), dtype=np.int64)
+        """Runs one step and returns the per-env shader-clock stamps [nenv][48] taken at the stage boundaries."""
+        st = np.zeros((self.nenv, 48), dtype=np.int64)
         if lib().phys_batch_profile_step(self._h, st.ctypes.data) != 0:
             raise RuntimeError("profile_step failed")
         return st

@@ -66,6 +66,8 @@ typedef struct cm_model {
     unsigned flags;
     int hfield_geom;       /* index into geom_* of the hfield geom, -1 if none */
     int hfield_nrow, hfield_ncol;
+    int npair_always;      /* simple pairs [0, npair_always) are always tested; [npair_always, npair_simple) involve a static
+                            * non-plane geom (stairs ...) and are skipped as a block while all of those are out of reach */
     int npair_simple;      /* pairs [0, npair_simple) give <= 2 contacts and are tested one per lane; the rest
                             * (plane-box, box-box) are tested by the whole wave, one pair at a time */
     double timestep, tolerance, meaninertia;
@@ -81,10 +83,16 @@ typedef struct cm_model {
     int body_depth[CM_MAXBODY];
     int body_subtreeend[CM_MAXBODY];      /* bodies [b, end) form b's subtree (depth-first ids) */
     uint64_t body_dofmask[CM_MAXBODY];    /* bit k set <=> dof k moves this body */
+    int body_nchild[CM_MAXBODY], body_child[CM_MAXBODY][4]; /* direct children (at most 4 in the supported models) */
+    int body_anc[CM_MAXBODY][4];          /* 1st, 2nd, 4th, 8th ancestor (0 = world) for pointer-jumping recursions */
+    int nroot, root_body[4];              /* kinematic tree roots (children of the world that move) */
     double body_pos[CM_MAXBODY][3], body_quat[CM_MAXBODY][4];
     double body_ipos[CM_MAXBODY][3], body_iquat[CM_MAXBODY][4];
     double body_mass[CM_MAXBODY], body_inertia[CM_MAXBODY][3];
+    double body_mat[CM_MAXBODY][9], body_imat[CM_MAXBODY][9]; /* rotation matrices of body_quat / body_iquat */
     double body_invweight0[CM_MAXBODY][2];
+    double body_reach[CM_MAXBODY];        /* for tree roots: radius around the root body's origin that contains every
+                                           * collision geom of the tree in any configuration (1e30 = unbounded) */
 
     /* joints */
     int jnt_type[CM_MAXJNT], jnt_qposadr[CM_MAXJNT], jnt_dofadr[CM_MAXJNT];
@@ -106,9 +114,11 @@ typedef struct cm_model {
     int geom_priority[CM_MAXGEOM], geom_contype[CM_MAXGEOM], geom_conaffinity[CM_MAXGEOM];
     int geom_fullid[CM_MAXGEOM];          /* id in the host model's full geom list */
     double geom_pos[CM_MAXGEOM][3], geom_quat[CM_MAXGEOM][4], geom_size[CM_MAXGEOM][3];
+    double geom_mat[CM_MAXGEOM][9];       /* rotation matrix of geom_quat */
     double geom_friction[CM_MAXGEOM][3], geom_solref[CM_MAXGEOM][2], geom_solimp[CM_MAXGEOM][5];
     double geom_solmix[CM_MAXGEOM], geom_margin[CM_MAXGEOM], geom_gap[CM_MAXGEOM];
     double geom_rbound[CM_MAXGEOM];       /* bounding-sphere radius, 0 for planes/hfields */
+    int geom_farstatic[CM_MAXGEOM];       /* 1: static, not a plane / height field -> its pairs can be block-culled */
 
     /* candidate pairs after the static bitmask / same-body / parent-child filter;
      * geom1's type <= geom2's type (MuJoCo's narrow-phase convention) and the list
@@ -134,6 +144,7 @@ typedef struct cm_model {
     int sensor_type[CM_MAXSENSOR], sensor_objid[CM_MAXSENSOR];
     int sensor_adr[CM_MAXSENSOR], sensor_dim[CM_MAXSENSOR];
     double sensor_cutoff[CM_MAXSENSOR];
+    int sensor_slot[CM_MAXSENSOR];        /* accelerometers: 0, 1, ... in sensor order (-1 otherwise / beyond two) */
 } cm_model_t;
 
 /* Optional per-env "extended" outputs of a step (what the reference reads out of mjData for its

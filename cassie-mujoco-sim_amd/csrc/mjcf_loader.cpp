@@ -1025,6 +1025,8 @@ bool HostModel::compile(cm_model_t *o, std::string *err) const {
         }
         for (int i = 0; i < 4; ++i) { o->body_quat[b][i] = body_quat[4 * b + i]; o->body_iquat[b][i] = body_iquat[4 * b + i]; }
         o->body_mass[b] = body_mass[b];
+        quat2mat(o->body_mat[b], &body_quat[4 * b]);
+        quat2mat(o->body_imat[b], &body_iquat[4 * b]);
         o->body_invweight0[b][0] = body_invweight0[2 * b]; o->body_invweight0[b][1] = body_invweight0[2 * b + 1];
     }
     /* subtree ranges (ids are depth-first) and dof masks */
@@ -1056,6 +1058,31 @@ bool HostModel::compile(cm_model_t *o, std::string *err) const {
     for (int d = 0; d < nv; ++d) {
         o->dof_bodyid[d] = dof_bodyid[d]; o->dof_jntid[d] = dof_jntid[d]; o->dof_parentid[d] = dof_parentid[d];
         o->dof_armature[d] = dof_armature[d]; o->dof_damping[d] = dof_damping[d]; o->dof_invweight0[d] = dof_invweight0[d];
+    }
+    if (o->maxdepth > 16) return fail("kinematic tree deeper than 16 levels");
+    for (int b = 0; b < nbody; ++b) {
+        int a = b;
+        for (int r = 0, hop = 1; r < 4; ++r, hop *= 2) {
+            int x = b;
+            for (int t = 0; t < hop; ++t) x = x > 0 ? body_parentid[x] : 0;
+            o->body_anc[b][r] = x;
+        }
+        (void)a;
+    }
+    o->nroot = 0;
+    for (int b = 1; b < nbody; ++b) {
+        o->body_nchild[b] = 0;
+        if (body_parentid[b] == 0 && weld[b] != 0) {
+            if (o->nroot >= 4) return fail("more than 4 kinematic trees");
+            o->root_body[o->nroot++] = b;
+        }
+    }
+    o->body_nchild[0] = 0;
+    for (int b = 1; b < nbody; ++b) {
+        int p = body_parentid[b];
+        if (p == 0) continue;
+        if (o->body_nchild[p] >= 4) return fail("a body has more than 4 children");
+        o->body_child[p][o->body_nchild[p]++] = b;
     }
     for (int d = 0; d < nv; ++d) {
         uint64_t anc = 0, vel = 0;
@@ -1094,11 +1121,13 @@ bool HostModel::compile(cm_model_t *o, std::string *err) const {
             o->geom_friction[k][i] = geom_friction[3 * g + i];
         }
         for (int i = 0; i < 4; ++i) o->geom_quat[k][i] = geom_quat[4 * g + i];
+        quat2mat(o->geom_mat[k], &geom_quat[4 * g]);
         for (int i = 0; i < 2; ++i) o->geom_solref[k][i] = geom_solref[2 * g + i];
         for (int i = 0; i < 5; ++i) o->geom_solimp[k][i] = geom_solimp[5 * g + i];
         o->geom_solmix[k] = geom_solmix[g]; o->geom_margin[k] = geom_margin[g]; o->geom_gap[k] = geom_gap[g];
         o->geom_rbound[k] = geom_rbound[g];
         if (geom_type[g] == CM_GEOM_HFIELD) o->hfield_geom = k;
+        o->geom_farstatic[k] = (weld[geom_bodyid[g]] == 0 && geom_type[g] != CM_GEOM_PLANE && geom_type[g] != CM_GEOM_HFIELD) ? 1 : 0;
         if (geom_type[g] == CM_GEOM_MESH || geom_type[g] == CM_GEOM_ELLIPSOID || geom_type[g] == CM_GEOM_CYLINDER)
             return fail("collision geom type not in the supported subset (mesh/ellipsoid/cylinder)");
     }
@@ -1128,9 +1157,39 @@ bool HostModel::compile(cm_model_t *o, std::string *err) const {
         int t1 = o->geom_type[x.g1], t2 = o->geom_type[x.g2];
         return (t1 == CM_GEOM_PLANE && t2 == CM_GEOM_BOX) || (t1 == CM_GEOM_BOX && t2 == CM_GEOM_BOX);
     };
+    /* static geoms other than planes / height fields can be culled as a block when the robot is nowhere near them */
+    auto far_static = [&](int g) {
+        return weld[o->geom_bodyid[g]] == 0 && o->geom_type[g] != CM_GEOM_PLANE && o->geom_type[g] != CM_GEOM_HFIELD;
+    };
+    auto cullable = [&](const P &x) { return !multi(x) && (far_static(x.g1) || far_static(x.g2)); };
     std::stable_partition(pairs.begin(), pairs.end(), [&](const P &x) { return !multi(x); });
     o->npair_simple = 0;
     for (auto &x : pairs) if (!multi(x)) o->npair_simple++;
+    std::stable_partition(pairs.begin(), pairs.begin() + o->npair_simple, [&](const P &x) { return !cullable(x); });
+    o->npair_always = 0;
+    for (int i = 0; i < o->npair_simple; ++i) if (!cullable(pairs[i])) o->npair_always++;
+    /* reach of every kinematic tree around its root body's origin */
+    for (int b = 0; b < nbody; ++b) o->body_reach[b] = 0;
+    for (int k = 0; k < o->ngeom; ++k) {
+        int b = o->geom_bodyid[k];
+        if (weld[b] == 0) continue;
+        double len = std::sqrt(o->geom_pos[k][0] * o->geom_pos[k][0] + o->geom_pos[k][1] * o->geom_pos[k][1] + o->geom_pos[k][2] * o->geom_pos[k][2]) + o->geom_rbound[k];
+        int r = o->body_rootid[b];
+        for (int a = b; a != r && a > 0; a = body_parentid[a]) {
+            len += std::sqrt(body_pos[3 * a] * body_pos[3 * a] + body_pos[3 * a + 1] * body_pos[3 * a + 1] + body_pos[3 * a + 2] * body_pos[3 * a + 2]);
+            for (int jj = 0; jj < body_jntnum[a]; ++jj) {
+                int j = body_jntadr[a] + jj;
+                len += 2 * std::sqrt(jnt_pos[3 * j] * jnt_pos[3 * j] + jnt_pos[3 * j + 1] * jnt_pos[3 * j + 1] + jnt_pos[3 * j + 2] * jnt_pos[3 * j + 2]);
+                if (jnt_type[j] == CM_JNT_SLIDE || jnt_type[j] == CM_JNT_FREE) len = 1e30; /* unbounded travel below the root */
+            }
+        }
+        /* joints of the root itself: rotations about an offset anchor move the origin by at most 2 |jnt_pos| */
+        for (int jj = 0; jj < body_jntnum[r]; ++jj) {
+            int j = body_jntadr[r] + jj;
+            len += 2 * std::sqrt(jnt_pos[3 * j] * jnt_pos[3 * j] + jnt_pos[3 * j + 1] * jnt_pos[3 * j + 1] + jnt_pos[3 * j + 2] * jnt_pos[3 * j + 2]);
+        }
+        if (len > o->body_reach[r]) o->body_reach[r] = len;
+    }
     if ((int)pairs.size() > CM_MAXPAIR) return fail("too many candidate collision pairs");
     o->npair = (int)pairs.size();
     for (int i = 0; i < o->npair; ++i) { o->pair_geom1[i] = pairs[i].g1; o->pair_geom2[i] = pairs[i].g2; }
@@ -1157,6 +1216,13 @@ bool HostModel::compile(cm_model_t *o, std::string *err) const {
     for (int s = 0; s < nsensor; ++s) {
         o->sensor_type[s] = sensor_type[s]; o->sensor_objid[s] = sensor_objid[s];
         o->sensor_adr[s] = sensor_adr[s]; o->sensor_dim[s] = sensor_dim[s]; o->sensor_cutoff[s] = sensor_cutoff[s];
+        o->sensor_slot[s] = -1;
+        if (sensor_type[s] == CM_SENS_ACCELEROMETER) {
+            int slot = 0;
+            for (int t = 0; t < s; ++t) if (sensor_type[t] == CM_SENS_ACCELEROMETER) ++slot;
+            if (slot > 1) return fail("more than two accelerometers");
+            o->sensor_slot[s] = slot;
+        }
     }
     return true;
 }

@@ -42,12 +42,19 @@ namespace ck {
 constexpr int NB = CM_MAXBODY;
 constexpr int NG = CM_MAXGEOM;
 constexpr int NROW = 64;       /* rows 0..62 constraints, column 63 = qfrc_smooth */
-constexpr int NSTAMP = 16;
+constexpr int NSTAMP = 48;   /* 0..15 stage boundaries, 16..47 sub-stage stamps (tools/stage_profile.py names them) */
 #define CK_TRI(k, i) ((k) * ((k) + 1) / 2 + (i))
-#define CK_STAMP(i) do { if (io.prof && lane == 0) io.prof[(size_t)env * NSTAMP + (i)] = wv::clock(); } while (0)
+#define CK_STAMP(i) do { if (io.prof && lane == 0) io.prof[(size_t)env * NSTAMP + (i)] = wv::clock(); CK_FRESH(); } while (0)
+/* stage boundary: re-derive the lane index and its aliases (see wv::fresh_lane) */
+#define CK_FRESH() do { lane = wv::fresh_lane(); b = lane; k_ = lane; isbody = b < nbody; isdof = k_ < nv; } while (0)
 
 /* warning bits reported per env */
 enum { WARN_CONTACT_FULL = 1, WARN_CONSTRAINT_FULL = 2, WARN_UNSUPPORTED_PAIR = 4, WARN_DIVERGED = 8 };
+
+#ifndef WV_OCC
+#define WV_OCC
+#endif
+typedef const WV_CONST_AS cm_model_t *ModelPtr;
 
 struct PhysIO {
     const cm_model_t *models;   /* one shared model, or one per env */
@@ -294,7 +301,7 @@ WV_DEVICE int capsule_box(RawContact &c0, RawContact &c1, const double *pc, cons
 
 
 /* ---- height field: tangent plane of the grid triangle under the sample centre (same definition as the oracle) ---- */
-WV_DEVICE int hfield_sphere(RawContact &c, const cm_model_t *m, const float *data, const double *ph, const double *mh, const double *ps,
+WV_DEVICE int hfield_sphere(RawContact &c, ModelPtr m, const float *data, const double *ph, const double *mh, const double *ps,
                             double r, double margin) {
     if (!data || m->hfield_nrow < 2 || m->hfield_ncol < 2) return 0;
     const double sx = m->hfield_size[0], sy = m->hfield_size[1], sz = m->hfield_size[2];
@@ -330,7 +337,7 @@ WV_DEVICE int hfield_sphere(RawContact &c, const cm_model_t *m, const float *dat
 /* stores one contact with its mixed parameters (priority wins, else max condim / max friction /
  * solmix-weighted solref, solimp) into slot `slot` of the env's contact list */
 template <int NVP>
-WV_DEVICE void write_contact(EnvShared<NVP> &S, const cm_model_t *m, int slot, int g1, int g2, const RawContact &r, double includemargin) {
+WV_DEVICE void write_contact(EnvShared<NVP> &S, ModelPtr m, int slot, int g1, int g2, const RawContact &r, double includemargin) {
     double fr[9];
     for (int i = 0; i < 3; ++i) { fr[i] = r.normal[i]; fr[3 + i] = r.tangent[i]; fr[6 + i] = 0; }
     make_frame(fr);
@@ -380,33 +387,81 @@ WV_DEVICE double impedance(const double *solimp, double pos, double margin) {
 struct TopoRuntime { static constexpr bool is_static = false; static constexpr int nv = 0; };
 
 template <class TOPO>
-WV_DEVICE unsigned long long anc_mask(const cm_model_t *m, int k) {
+WV_DEVICE unsigned long long anc_mask(ModelPtr m, int k) {
     if constexpr (TOPO::is_static) return TOPO::table[k];
     else return m->dof_ancmask[k];
 }
 
-/* L^T D L factorisation of a tree-sparse matrix held one column per lane in registers (lane j owns
- * col[i] = A[i][j], i >= j).  Pivot-row entries travel by readlane; the (k, i) loop nest is fully
- * unrolled over the ancestor pattern.  No lane predication is needed: entries above the diagonal
- * (col[i] in lanes j > i) are never read, so they may absorb harmless updates.  On exit col[k] holds
- * L[k][j] for k > j; the pivots are returned through dinv / rsd (wave-uniform, written by lane 0). */
+/* reciprocal to full fp64 accuracy without the IEEE division sequence: hardware estimate + two Newton steps
+ * (the pivots are positive and far from the denormal / overflow ranges) */
+WV_DEVICE double fast_rcp(double x) {
+    double r = wv::rcp_estimate(x);
+    r = r * (2.0 - x * r);
+    r = r * (2.0 - x * r);
+    return r;
+}
+
+/* L^T D L factorisation of two tree-sparse matrices (M and M + hB) held one column per lane in registers
+ * (lane j owns col[i] = A[i][j], i >= j).  Pivot-row entries travel by readlane; the (k, i) loop nest is
+ * fully unrolled over the ancestor pattern and the two factorisations are interleaved so that each one's
+ * dependent chain hides behind the other's.  No lane predication is needed: entries above the diagonal
+ * (col[i] in lanes j > i) are never read, so they may absorb harmless updates.  On exit col[k] holds L[k][j]
+ * for k > j; the pivots are returned through dinv / rsd / dinvH (wave-uniform, written by lane 0). */
 template <int NVP, class TOPO>
-WV_DEVICE void factor_in_registers(const cm_model_t *m, double (&col)[NVP], int lane, int nv, double *dinv, double *rsd) {
+WV_DEVICE void factor_pair_in_registers(ModelPtr m, double (&col)[NVP], double (&colh)[NVP], int lane, int nv,
+                                        double *dinv, double *rsd, double *dinvH) {
 #pragma unroll
     for (int k = NVP - 1; k >= 0; --k) {
         if (TOPO::is_static ? k >= TOPO::nv : k >= nv) continue;
         const unsigned long long anc = anc_mask<TOPO>(m, k);
-        const double inv = 1.0 / wv::readlane(col[k], k);
-        if (lane == 0) { dinv[k] = inv; if (rsd) rsd[k] = sqrt(inv); }
+        const double inv = fast_rcp(wv::readlane(col[k], k)), invh = fast_rcp(wv::readlane(colh[k], k));
+        if (lane == 0) { dinv[k] = inv; rsd[k] = sqrt(inv); dinvH[k] = invh; }
         if (anc == 0ull) continue;
 #pragma unroll
         for (int i = k - 1; i >= 0; --i) {
             if (!((anc >> i) & 1ull)) continue;
-            const double t = wv::readlane(col[k], i) * inv; /* A[k][i] / D_k */
+            const double t = wv::readlane(col[k], i) * inv, th = wv::readlane(colh[k], i) * invh; /* A[k][i] / D_k */
             col[i] -= t * col[k];
+            colh[i] -= th * colh[k];
         }
         col[k] *= inv;
+        colh[k] *= invh;
     }
+}
+
+/* Compile-time-topology variant: the same two factorisations, eliminated height by height.  All dofs of one
+ * elimination height (TOPO::height) are mutually unrelated, so a round scales their pivot rows (one multiply per
+ * matrix gives L[k][:] in every lane at once), parks them in the packed LDS factors -- where the solves want them
+ * anyway -- and then applies the rank-one updates with L[k][i] fetched back as LDS broadcast reads: two FMAs and two
+ * reads per ancestor pair, no scalar registers, one LDS round trip per height instead of one per dof. */
+template <int NVP, class TOPO, class SH>
+WV_DEVICE void factor_pair_by_height(SH &S, double (&col)[NVP], double (&colh)[NVP], int lane) {
+#pragma unroll
+    for (int s = 0; s < TOPO::nheight; ++s) {
+#pragma unroll
+        for (int k = NVP - 1; k >= 0; --k) {
+            if (TOPO::height[k] != s) continue;
+            const double inv = fast_rcp(wv::readlane(col[k], k)), invh = fast_rcp(wv::readlane(colh[k], k));
+            S.dinv[k] = inv; S.dinvH[k] = invh; /* every lane holds the same value: an unpredicated same-address store */
+            if (lane < k) { S.Lp[CK_TRI(k, lane)] = col[k] * inv; S.LHp[CK_TRI(k, lane)] = colh[k] * invh; }
+        }
+        wv::sync();
+#pragma unroll
+        for (int k = NVP - 1; k >= 0; --k) {
+            if (TOPO::height[k] != s) continue;
+            int npair = 0;
+#pragma unroll
+            for (int i = k - 1; i >= 0; --i) {
+                if (!((TOPO::table[k] >> i) & 1ull)) continue;
+                col[i] -= S.Lp[CK_TRI(k, i)] * col[k];
+                colh[i] -= S.LHp[CK_TRI(k, i)] * colh[k];
+                if ((++npair & 3) == 0) wv::sched_fence(); /* at most four pairs' multipliers in flight */
+            }
+            wv::sched_fence();
+        }
+    }
+    wv::sync();
+    if (lane < TOPO::nv) S.rsd[lane] = sqrt(S.dinv[lane]);
 }
 
 /* One PGS sweep over rows I, I+1, ... : nested so that the first row index >= nrows ends the sweep with a
@@ -417,8 +472,7 @@ WV_DEVICE void pgs_rows(const double (&arow)[CM_MAXEFC], int nrows, int r_, doub
                         double &f, double &res, double &improvement) {
     if constexpr (I < CM_MAXEFC) {
         if (I < nrows) {
-            const double fn = fmax(f - res * invAii, flo);
-            double delta = fn - f;
+            double delta = fmax(-res * invAii, flo - f); /* = max(f - res / Aii, flo) - f */
             double change = delta * (halfAii * delta + res);
             if (change > 1e-10) { delta = 0; change = 0; } /* never accept a cost increase */
             const double dlt = wv::readlane(delta, I), chg = wv::readlane(change, I);
@@ -433,8 +487,8 @@ WV_DEVICE void pgs_rows(const double (&arow)[CM_MAXEFC], int nrows, int r_, doub
 /* ======================================================== the env step ==== */
 template <int NVP, class TOPO>
 WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
-    const cm_model_t *m = io.models + (size_t)env * io.model_stride;
-    const int lane = wv::lane();
+    ModelPtr m = (ModelPtr)(io.models + (size_t)env * io.model_stride);
+    int lane = wv::lane();
     const int nq = m->nq, nv = m->nv, nu = m->nu, nbody = m->nbody, njnt = m->njnt;
     const double h = m->timestep;
     int warn = 0;
@@ -451,8 +505,8 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
     /* ---------------- per-lane model indices (the fp64 constants are loaded where they are used, to keep
      * register live ranges short: the kernel runs one wave per SIMD and lives on its 512 VGPRs) ---------------- */
     /* lane = body */
-    const int b = lane;
-    const bool isbody = b < nbody;
+    int b = lane;
+    bool isbody = b < nbody;
     const int depth = isbody ? m->body_depth[b] : -1;
     const int bparent = isbody ? m->body_parentid[b] : 0;
     const int broot = isbody ? m->body_rootid[b] : -1;
@@ -464,8 +518,8 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
     const int bjt = (isbody && bjn > 0) ? m->jnt_type[bj0] : -1;
     const int bjq = (isbody && bjn > 0) ? m->jnt_qposadr[bj0] : 0;
     /* lane = dof */
-    const int k_ = lane;
-    const bool isdof = k_ < nv;
+    int k_ = lane;
+    bool isdof = k_ < nv;
     const int kjnt = isdof ? m->dof_jntid[k_] : 0;
     const int kbody = isdof ? m->dof_bodyid[k_] : 0;
     const int kjt = isdof ? m->jnt_type[kjnt] : -1;
@@ -480,7 +534,11 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
     for (int u = 0; u < nu; ++u) if (isdof && m->act_dofid[u] == k_) kact = u;
     wv::sync();
 
+#ifdef CK_SINGLE_STEP
+    for (int sub = 0; sub < 1; ++sub) {
+#else
     for (int sub = 0; sub < io.nsub; ++sub) {
+#endif
         /* divergence guard (mj_checkPos/mj_checkVel role): sticky flag, state left alone */
         {
             bool badv = false;
@@ -502,132 +560,176 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
         }
         CK_STAMP(0);
 
-        /* ================= P1 kinematics: lane = body, level by level ================= */
-        /* joint-local rotation of the body's first joint, all lanes at once (hoists sin/cos out of the recursion) */
-        double bpos[3] = {0, 0, 0}, bquat[4] = {1, 0, 0, 0}, bipos[3] = {0, 0, 0}, biquat[4] = {1, 0, 0, 0};
-        double bjpos[3] = {0, 0, 0}, bjaxis[3] = {0, 0, 1}, bjq0 = 0;
-        if (isbody) {
-            for (int i = 0; i < 3; ++i) { bpos[i] = m->body_pos[b][i]; bipos[i] = m->body_ipos[b][i]; }
-            for (int i = 0; i < 4; ++i) { bquat[i] = m->body_quat[b][i]; biquat[i] = m->body_iquat[b][i]; }
-            if (bjn > 0) {
-                for (int i = 0; i < 3; ++i) { bjpos[i] = m->jnt_pos[bj0][i]; bjaxis[i] = m->jnt_axis[bj0][i]; }
-                bjq0 = m->qpos0[bjq];
-            }
-        }
-        double qloc[4] = {1, 0, 0, 0}, slide = 0;
-        if (bjt == CM_JNT_HINGE) {
-            const double ang = S.qpos[bjq] - bjq0;
-            const double sn = sin(0.5 * ang), cs = cos(0.5 * ang);
-            qloc[0] = cs; qloc[1] = bjaxis[0] * sn; qloc[2] = bjaxis[1] * sn; qloc[3] = bjaxis[2] * sn;
-        } else if (bjt == CM_JNT_BALL) {
-            for (int i = 0; i < 4; ++i) qloc[i] = S.qpos[bjq + i];
-            normalize4(qloc);
-        } else if (bjt == CM_JNT_SLIDE) {
-            slide = S.qpos[bjq] - bjq0;
-        }
-        double ximat[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-        if (b == 0) {
-            for (int i = 0; i < 3; ++i) { S.x.s.xpos[0][i] = 0; S.x.s.xipos[0][i] = 0; }
-            S.x.s.xquat[0][0] = 1; S.x.s.xquat[0][1] = S.x.s.xquat[0][2] = S.x.s.xquat[0][3] = 0;
-            for (int i = 0; i < 9; ++i) S.x.s.xmat[0][i] = (i % 4 == 0) ? 1.0 : 0.0;
-        }
-        wv::sync();
-        for (int d = 1; d <= m->maxdepth; ++d) {
-            if (depth == d) {
-                double pos[3], quat[4];
-                if (bjt == CM_JNT_FREE) {
-                    for (int i = 0; i < 3; ++i) pos[i] = S.qpos[bjq + i];
-                    for (int i = 0; i < 4; ++i) quat[i] = S.qpos[bjq + 3 + i];
-                    normalize4(quat);
-                    for (int i = 0; i < 3; ++i) { S.x.s.xanchor[bj0][i] = pos[i]; S.x.s.xaxis[bj0][i] = (i == 2) ? 1.0 : 0.0; }
-                } else {
-                    mulmatvec3(pos, S.x.s.xmat[bparent], bpos);
-                    for (int i = 0; i < 3; ++i) pos[i] += S.x.s.xpos[bparent][i];
-                    mulquat(quat, S.x.s.xquat[bparent], bquat);
-                    for (int jj = 0; jj < bjn; ++jj) {
-                        const int j = bj0 + jj;
-                        int jt = bjt;
-                        double jp[3] = {bjpos[0], bjpos[1], bjpos[2]}, ja[3] = {bjaxis[0], bjaxis[1], bjaxis[2]};
-                        double ql[4] = {qloc[0], qloc[1], qloc[2], qloc[3]}, sl = slide;
-                        if (jj > 0) { /* bodies with several joints (the pelvis): slow path, constants from the model */
-                            jt = m->jnt_type[j];
-                            const int qa = m->jnt_qposadr[j];
-                            for (int i = 0; i < 3; ++i) { jp[i] = m->jnt_pos[j][i]; ja[i] = m->jnt_axis[j][i]; }
-                            if (jt == CM_JNT_SLIDE) sl = S.qpos[qa] - m->qpos0[qa];
-                            else if (jt == CM_JNT_BALL) { for (int i = 0; i < 4; ++i) ql[i] = S.qpos[qa + i]; normalize4(ql); }
-                            else {
-                                const double ang = S.qpos[qa] - m->qpos0[qa];
-                                const double sn = sin(0.5 * ang);
-                                ql[0] = cos(0.5 * ang); ql[1] = ja[0] * sn; ql[2] = ja[1] * sn; ql[3] = ja[2] * sn;
-                            }
+        /* ================= P1 kinematics ================= */
+        /* Every body first builds, in parallel, its transform relative to its parent INCLUDING its joints
+         * (rotation matrix Rl, offset pl, and the local quaternion for the few consumers of xquat); the recursion
+         * over the tree levels is then just R = Rp Rl, p = pp + Rp pl -- no trigonometry, quaternions or square
+         * roots on the dependent chain. */
+        double Rl[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, pl[3] = {0, 0, 0}, qlq[4] = {1, 0, 0, 0};
+        const bool isfree = bjt == CM_JNT_FREE;
+        if (isbody && b > 0) {
+            double bpos[3], bq[4];
+            for (int i = 0; i < 3; ++i) bpos[i] = m->body_pos[b][i];
+            for (int i = 0; i < 4; ++i) bq[i] = m->body_quat[b][i];
+            if (isfree) {
+                for (int i = 0; i < 3; ++i) pl[i] = S.qpos[bjq + i];
+                for (int i = 0; i < 4; ++i) qlq[i] = S.qpos[bjq + 3 + i];
+                normalize4(qlq);
+                quat2mat(Rl, qlq);
+                for (int i = 0; i < 3; ++i) { S.x.s.xanchor[bj0][i] = pl[i]; S.x.s.xaxis[bj0][i] = (i == 2) ? 1.0 : 0.0; }
+            } else {
+                for (int i = 0; i < 9; ++i) Rl[i] = m->body_mat[b][i];
+                for (int i = 0; i < 3; ++i) pl[i] = bpos[i];
+                for (int i = 0; i < 4; ++i) qlq[i] = bq[i];
+                for (int jj = 0; jj < bjn; ++jj) { /* one iteration for every Cassie body but the pelvis (3 slides + ball) */
+                    const int j = bj0 + jj, jt = m->jnt_type[j], qa = m->jnt_qposadr[j];
+                    double jp[3] = {m->jnt_pos[j][0], m->jnt_pos[j][1], m->jnt_pos[j][2]};
+                    double ja[3] = {m->jnt_axis[j][0], m->jnt_axis[j][1], m->jnt_axis[j][2]};
+                    /* joint anchor and axis in the PARENT frame (turned into world coordinates after the recursion) */
+                    double al[3], xl[3];
+                    mulmatvec3(al, Rl, jp);
+                    for (int i = 0; i < 3; ++i) al[i] += pl[i];
+                    mulmatvec3(xl, Rl, ja);
+                    for (int i = 0; i < 3; ++i) { S.x.s.xanchor[j][i] = al[i]; S.x.s.xaxis[j][i] = xl[i]; }
+                    if (jt == CM_JNT_SLIDE) {
+                        const double sl = S.qpos[qa] - m->qpos0[qa];
+                        for (int i = 0; i < 3; ++i) pl[i] += xl[i] * sl;
+                    } else {
+                        double qj[4];
+                        if (jt == CM_JNT_BALL) { for (int i = 0; i < 4; ++i) qj[i] = S.qpos[qa + i]; normalize4(qj); }
+                        else {
+                            const double ang = S.qpos[qa] - m->qpos0[qa];
+                            const double sn = sin(0.5 * ang);
+                            qj[0] = cos(0.5 * ang); qj[1] = ja[0] * sn; qj[2] = ja[1] * sn; qj[3] = ja[2] * sn;
                         }
-                        double anchor[3], axis[3];
-                        rotvecquat(anchor, jp, quat);
-                        for (int i = 0; i < 3; ++i) anchor[i] += pos[i];
-                        rotvecquat(axis, ja, quat);
-                        for (int i = 0; i < 3; ++i) { S.x.s.xanchor[j][i] = anchor[i]; S.x.s.xaxis[j][i] = axis[i]; }
-                        if (jt == CM_JNT_SLIDE) {
-                            for (int i = 0; i < 3; ++i) pos[i] += axis[i] * sl;
-                        } else {
-                            mulquat(quat, quat, ql);
-                            double r[3];
-                            rotvecquat(r, jp, quat);
-                            for (int i = 0; i < 3; ++i) pos[i] = anchor[i] - r[i];
-                        }
+                        double Rq[9], Rn[9], r[3];
+                        quat2mat(Rq, qj);
+                        for (int i = 0; i < 3; ++i)
+                            for (int c = 0; c < 3; ++c) Rn[3 * i + c] = Rl[3 * i] * Rq[c] + Rl[3 * i + 1] * Rq[3 + c] + Rl[3 * i + 2] * Rq[6 + c];
+                        for (int i = 0; i < 9; ++i) Rl[i] = Rn[i];
+                        mulquat(qlq, qlq, qj);
+                        /* rotation about the anchor: the origin moves so that the anchor stays put */
+                        mulmatvec3(r, Rl, jp);
+                        for (int i = 0; i < 3; ++i) pl[i] = al[i] - r[i];
                     }
                 }
-                normalize4(quat);
-                double xm[9];
-                quat2mat(xm, quat);
-                for (int i = 0; i < 3; ++i) S.x.s.xpos[b][i] = pos[i];
-                for (int i = 0; i < 4; ++i) S.x.s.xquat[b][i] = quat[i];
-                for (int i = 0; i < 9; ++i) S.x.s.xmat[b][i] = xm[i];
-                double xi[3];
-                mulmatvec3(xi, xm, bipos);
-                for (int i = 0; i < 3; ++i) S.x.s.xipos[b][i] = pos[i] + xi[i];
-                double qi[4];
-                mulquat(qi, quat, biquat);
-                quat2mat(ximat, qi);
+            }
+        }
+        CK_STAMP(16);
+        /* recursion over the tree by pointer jumping: after round r every body holds the product of the local
+         * transforms of its 2^(r+1) nearest ancestors-or-self; four rounds cover trees up to 16 levels deep.  The
+         * partial products ping-pong between the pose tiles and a second buffer laid over the (still unused)
+         * cinert / crb tiles. */
+        double xm[9], xp[3], xq[4];
+        for (int i = 0; i < 9; ++i) xm[i] = Rl[i];
+        for (int i = 0; i < 3; ++i) xp[i] = pl[i];
+        for (int i = 0; i < 4; ++i) xq[i] = qlq[i];
+        {
+            double *bufB = &S.x.s.cinert[0][0]; /* 16 doubles per body: R(9) p(3) q(4) */
+            if (lane < NB) {
+                for (int i = 0; i < 9; ++i) S.x.s.xmat[lane][i] = xm[i];
+                for (int i = 0; i < 3; ++i) S.x.s.xpos[lane][i] = xp[i];
+                for (int i = 0; i < 4; ++i) S.x.s.xquat[lane][i] = xq[i];
             }
             wv::sync();
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int a = isbody ? m->body_anc[b][r] : 0;
+                double Ra[9], pa[3], qa[4];
+                if ((r & 1) == 0) {
+                    for (int i = 0; i < 9; ++i) Ra[i] = S.x.s.xmat[a][i];
+                    for (int i = 0; i < 3; ++i) pa[i] = S.x.s.xpos[a][i];
+                    for (int i = 0; i < 4; ++i) qa[i] = S.x.s.xquat[a][i];
+                } else {
+                    for (int i = 0; i < 9; ++i) Ra[i] = bufB[a * 16 + i];
+                    for (int i = 0; i < 3; ++i) pa[i] = bufB[a * 16 + 9 + i];
+                    for (int i = 0; i < 4; ++i) qa[i] = bufB[a * 16 + 12 + i];
+                }
+                if (a > 0 || r == 0) { /* the world's transform is the identity: nothing to compose beyond the root */
+                    double Rn[9], pn[3];
+                    for (int i = 0; i < 3; ++i) {
+                        for (int c = 0; c < 3; ++c) Rn[3 * i + c] = Ra[3 * i] * xm[c] + Ra[3 * i + 1] * xm[3 + c] + Ra[3 * i + 2] * xm[6 + c];
+                        pn[i] = pa[i] + (Ra[3 * i] * xp[0] + Ra[3 * i + 1] * xp[1] + Ra[3 * i + 2] * xp[2]);
+                    }
+                    if (a > 0) {
+                        for (int i = 0; i < 9; ++i) xm[i] = Rn[i];
+                        for (int i = 0; i < 3; ++i) xp[i] = pn[i];
+                        mulquat(xq, qa, xq);
+                    }
+                }
+                if (lane < NB) {
+                    if ((r & 1) == 0) {
+                        for (int i = 0; i < 9; ++i) bufB[lane * 16 + i] = xm[i];
+                        for (int i = 0; i < 3; ++i) bufB[lane * 16 + 9 + i] = xp[i];
+                        for (int i = 0; i < 4; ++i) bufB[lane * 16 + 12 + i] = xq[i];
+                    } else {
+                        for (int i = 0; i < 9; ++i) S.x.s.xmat[lane][i] = xm[i];
+                        for (int i = 0; i < 3; ++i) S.x.s.xpos[lane][i] = xp[i];
+                        for (int i = 0; i < 4; ++i) S.x.s.xquat[lane][i] = xq[i];
+                    }
+                }
+                wv::sync();
+            }
+        }
+        if (b == 0) for (int i = 0; i < 3; ++i) S.x.s.xipos[0][i] = 0;
+        /* inertial frames, and joint anchors / axes from the parent frame to the world frame */
+        double ximat[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        if (isbody && b > 0) {
+            double ip[3] = {m->body_ipos[b][0], m->body_ipos[b][1], m->body_ipos[b][2]}, xi[3], im[9];
+            for (int i = 0; i < 9; ++i) im[i] = m->body_imat[b][i];
+            mulmatvec3(xi, xm, ip);
+            for (int i = 0; i < 3; ++i) S.x.s.xipos[b][i] = xp[i] + xi[i];
+            for (int i = 0; i < 3; ++i)
+                for (int c = 0; c < 3; ++c) ximat[3 * i + c] = xm[3 * i] * im[c] + xm[3 * i + 1] * im[3 + c] + xm[3 * i + 2] * im[6 + c];
+        }
+        if (lane < njnt && m->jnt_type[lane] != CM_JNT_FREE) {
+            const int pb = m->body_parentid[m->jnt_bodyid[lane]];
+            double al[3] = {S.x.s.xanchor[lane][0], S.x.s.xanchor[lane][1], S.x.s.xanchor[lane][2]};
+            double xl[3] = {S.x.s.xaxis[lane][0], S.x.s.xaxis[lane][1], S.x.s.xaxis[lane][2]}, aw[3], xw[3];
+            mulmatvec3(aw, S.x.s.xmat[pb], al);
+            mulmatvec3(xw, S.x.s.xmat[pb], xl);
+            for (int i = 0; i < 3; ++i) { S.x.s.xanchor[lane][i] = aw[i] + S.x.s.xpos[pb][i]; S.x.s.xaxis[lane][i] = xw[i]; }
         }
         CK_STAMP(1);
 
         /* geoms (lane = collision geom) */
         if (lane < m->ngeom) {
             const int g = lane, gb = m->geom_bodyid[g];
-            double gp[3] = {m->geom_pos[g][0], m->geom_pos[g][1], m->geom_pos[g][2]};
-            double gq[4] = {m->geom_quat[g][0], m->geom_quat[g][1], m->geom_quat[g][2], m->geom_quat[g][3]};
-            double t[3], q[4], mm[9];
-            mulmatvec3(t, S.x.s.xmat[gb], gp);
+            double gp[3] = {m->geom_pos[g][0], m->geom_pos[g][1], m->geom_pos[g][2]}, gm[9], t[3];
+            for (int i = 0; i < 9; ++i) gm[i] = m->geom_mat[g][i];
+            const double *R = S.x.s.xmat[gb];
+            mulmatvec3(t, R, gp);
             for (int i = 0; i < 3; ++i) S.x.s.geom_xpos[g][i] = t[i] + S.x.s.xpos[gb][i];
-            mulquat(q, S.x.s.xquat[gb], gq);
-            quat2mat(mm, q);
-            for (int i = 0; i < 9; ++i) S.x.s.geom_xmat[g][i] = mm[i];
+            for (int i = 0; i < 3; ++i)
+                for (int c = 0; c < 3; ++c) S.x.s.geom_xmat[g][3 * i + c] = R[3 * i] * gm[c] + R[3 * i + 1] * gm[3 + c] + R[3 * i + 2] * gm[6 + c];
         }
 
+        CK_STAMP(17);
         /* ================= com of every kinematic tree (wave reduction per root) ================= */
         const double bmass = (isbody && b > 0) ? m->body_mass[b] : 0.0;
         {
-            double wx = 0, wy = 0, wz = 0;
-            if (isbody && b > 0) { wx = bmass * S.x.s.xipos[b][0]; wy = bmass * S.x.s.xipos[b][1]; wz = bmass * S.x.s.xipos[b][2]; }
-            for (int r = 1; r < nbody; ++r) {
-                if (m->body_parentid[r] != 0) continue;
-                const bool in = broot == r;
-                double sm = wv::wave_sum(in ? bmass : 0.0);
-                double sx = wv::wave_sum(in ? wx : 0.0), sy = wv::wave_sum(in ? wy : 0.0), sz = wv::wave_sum(in ? wz : 0.0);
-                if (lane == 0) {
-                    if (sm < CM_MINVAL) { S.com[r][0] = S.x.s.xipos[r][0]; S.com[r][1] = S.x.s.xipos[r][1]; S.com[r][2] = S.x.s.xipos[r][2]; }
-                    else { double inv = 1.0 / sm; S.com[r][0] = sx * inv; S.com[r][1] = sy * inv; S.com[r][2] = sz * inv; }
-                }
+            /* mass-weighted positions go through an LDS tile (the crb tile is free at this point); one lane per root adds
+             * its tree up -- a 26-term sum of staged values beats four dependent 6-step shuffle reductions */
+            if (isbody) {
+                const double w = b > 0 ? bmass : 0.0;
+                S.x.s.crb[b][0] = w; S.x.s.crb[b][1] = w * S.x.s.xipos[b][0]; S.x.s.crb[b][2] = w * S.x.s.xipos[b][1];
+                S.x.s.crb[b][3] = w * S.x.s.xipos[b][2];
+            }
+            wv::sync();
+            if (lane < m->nroot) {
+                const int r = m->root_body[lane], e = m->body_subtreeend[r];
+                double sm = 0, sx = 0, sy = 0, sz = 0;
+                for (int c = r; c < e; ++c) { sm += S.x.s.crb[c][0]; sx += S.x.s.crb[c][1]; sy += S.x.s.crb[c][2]; sz += S.x.s.crb[c][3]; }
+                if (sm < CM_MINVAL) { S.com[r][0] = S.x.s.xipos[r][0]; S.com[r][1] = S.x.s.xipos[r][1]; S.com[r][2] = S.x.s.xipos[r][2]; }
+                else { const double inv = 1.0 / sm; S.com[r][0] = sx * inv; S.com[r][1] = sy * inv; S.com[r][2] = sz * inv; }
             }
         }
         wv::sync();
-
+        CK_STAMP(18);
         /* ================= cinert (lane = body), cdof (lane = dof) ================= */
-        if (isbody) {
+        if (lane < NB) {
             double ci[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-            if (b > 0) {
+            if (isbody && b > 0) {
                 const double I0 = m->body_inertia[b][0], I1 = m->body_inertia[b][1], I2 = m->body_inertia[b][2];
                 const double *c = S.com[broot];
                 double dif[3] = {S.x.s.xipos[b][0] - c[0], S.x.s.xipos[b][1] - c[1], S.x.s.xipos[b][2] - c[2]};
@@ -647,8 +749,9 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
                 ci[5] = W12 - bmass * dif[1] * dif[2];
                 ci[6] = bmass * dif[0]; ci[7] = bmass * dif[1]; ci[8] = bmass * dif[2]; ci[9] = bmass;
             }
-            for (int i = 0; i < 10; ++i) S.x.s.cinert[b][i] = ci[i];
+            for (int i = 0; i < 10; ++i) S.x.s.cinert[lane][i] = ci[i];
         }
+        {
         double cd[6] = {0, 0, 0, 0, 0, 0};
         if (isdof) {
             const double *c = S.com[kroot];
@@ -666,35 +769,66 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
                 cd[0] = S.x.s.xmat[kbody][a]; cd[1] = S.x.s.xmat[kbody][3 + a]; cd[2] = S.x.s.xmat[kbody][6 + a];
                 cross3(cd + 3, cd, off);
             }
-            for (int i = 0; i < 6; ++i) S.cdof[k_][i] = cd[i];
+        }
+        if (lane < NVP) for (int i = 0; i < 6; ++i) S.cdof[lane][i] = cd[i]; /* zero rows past nv */
         }
         wv::sync();
         CK_STAMP(2);
 
         /* ================= P2 CRBA: composite inertias, then one COLUMN of M per lane ================= */
-        if (isbody) {
+        /* composite inertias: crb_b = sum of cinert_c over the contiguous subtree range [b, bend): dense loop over all
+         * bodies with a per-lane range predicate, operands staged four bodies at a time */
+        {
             double acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-            if (b > 0) for (int c = b; c < bend; ++c) for (int i = 0; i < 10; ++i) acc[i] += S.x.s.cinert[c][i];
-            for (int i = 0; i < 10; ++i) S.x.s.crb[b][i] = acc[i];
-        }
-        wv::sync();
-        if (isdof) {
-            double bf[6];
-            mul_inert_vec(bf, S.x.s.crb[kbody], cd);
-            for (int i = 0; i < 6; ++i) S.x.s.buf[k_][i] = bf[i];
-        }
-        wv::sync();
-        double col[NVP], colh[NVP]; /* col[i] = M[i][lane] (i >= lane); colh: same for M + h*diag(damping) */
-        const double karm = isdof ? m->dof_armature[k_] : 0.0, kdamp0 = isdof ? m->dof_damping[k_] : 0.0;
 #pragma unroll
-        for (int i = 0; i < NVP; ++i) {
-            double v = 0;
-            if (i < nv && ((kdesc >> i) & 1ull)) {
-                for (int t = 0; t < 6; ++t) v += cd[t] * S.x.s.buf[i][t];
-                if (i == k_) v += karm;
+            for (int c0 = 0; c0 < NB; c0 += 4) {
+                double ci4[4][10];
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+                    for (int t = 0; t < 10; ++t) ci4[cc][t] = S.x.s.cinert[c0 + cc][t];
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) {
+                    const int c = c0 + cc;
+                    const bool in = isbody && b > 0 && c >= b && c < bend;
+#pragma unroll
+                    for (int t = 0; t < 10; ++t) acc[t] += in ? ci4[cc][t] : 0.0;
+                }
             }
-            col[i] = v;
-            colh[i] = (i == k_) ? v + h * kdamp0 : v;
+            if (isbody) for (int i = 0; i < 10; ++i) S.x.s.crb[b][i] = acc[i];
+        }
+        wv::sync();
+        CK_STAMP(19);
+        if (lane < NVP) {
+            double bf[6] = {0, 0, 0, 0, 0, 0}, cd[6];
+            for (int i = 0; i < 6; ++i) cd[i] = S.cdof[lane][i];
+            if (isdof) mul_inert_vec(bf, S.x.s.crb[kbody], cd);
+            for (int i = 0; i < 6; ++i) S.x.s.buf[lane][i] = bf[i];
+        }
+        wv::sync();
+        CK_STAMP(20);
+        double col[NVP], colh[NVP]; /* col[i] = M[i][lane] (i >= lane); colh: same for M + h*diag(damping) */
+        double cdm[6]; /* this lane's motion axis, fetched where it is used rather than carried in registers */
+        for (int i = 0; i < 6; ++i) cdm[i] = S.cdof[lane < NVP ? lane : 0][i];
+        const double karm = isdof ? m->dof_armature[k_] : 0.0, kdamp0 = isdof ? m->dof_damping[k_] : 0.0;
+        /* M[i][lane] = cdof_lane . (crb[body_i] cdof_i): the buf rows are broadcast reads, staged eight rows at a time so
+         * the LDS latency is paid once per group instead of once per row */
+#pragma unroll
+        for (int i0 = 0; i0 < NVP; i0 += 8) {
+            double bb[8][6];
+#pragma unroll
+            for (int ii = 0; ii < 8; ++ii)
+#pragma unroll
+                for (int t = 0; t < 6; ++t) bb[ii][t] = S.x.s.buf[i0 + ii][t];
+#pragma unroll
+            for (int ii = 0; ii < 8; ++ii) {
+                const int i = i0 + ii;
+                double v = (cdm[0] * bb[ii][0] + cdm[1] * bb[ii][1]) + (cdm[2] * bb[ii][2] + cdm[3] * bb[ii][3]) + (cdm[4] * bb[ii][4] + cdm[5] * bb[ii][5]);
+                if (!(i < nv && ((kdesc >> i) & 1ull))) v = 0;
+                if (i == k_ && isdof) v += karm;
+                col[i] = v;
+                colh[i] = (i == k_) ? v + h * kdamp0 : v;
+            }
         }
         if (io.ext && isdof) {
             cm_ext_t *ex = io.ext + env;
@@ -704,13 +838,21 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
         CK_STAMP(3);
 
         /* ================= P3 factor M and M + hB in registers; park the factors in LDS ================= */
-        factor_in_registers<NVP, TOPO>(m, col, lane, nv, S.dinv, S.rsd);
-        factor_in_registers<NVP, TOPO>(m, colh, lane, nv, S.dinvH, nullptr);
-        if (isdof) {
+#ifdef CK_FACTOR_BY_HEIGHT
+        constexpr bool by_height = TOPO::is_static;
+#else
+        constexpr bool by_height = false;
+#endif
+        if constexpr (by_height) {
+            factor_pair_by_height<NVP, TOPO>(S, col, colh, lane);
+        } else {
+            factor_pair_in_registers<NVP, TOPO>(m, col, colh, lane, nv, S.dinv, S.rsd, S.dinvH);
+            if (isdof) {
 #pragma unroll
-            for (int k = 1; k < NVP; ++k) {
-                if (TOPO::is_static ? k >= TOPO::nv : k >= nv) continue;
-                if (k > k_) { S.Lp[CK_TRI(k, k_)] = col[k]; S.LHp[CK_TRI(k, k_)] = colh[k]; }
+                for (int k = 1; k < NVP; ++k) {
+                    if (TOPO::is_static ? k >= TOPO::nv : k >= nv) continue;
+                    if (k > k_) { S.Lp[CK_TRI(k, k_)] = col[k]; S.LHp[CK_TRI(k, k_)] = colh[k]; }
+                }
             }
         }
         CK_STAMP(4);
@@ -718,13 +860,31 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
         /* ================= P4 collision ================= */
         /* pass 1, lane = candidate pair (pair types that give at most two contacts) */
         int ncon = 0;
-        for (int p0 = 0; p0 < m->npair_simple; p0 += WV_WAVE) {
+        /* block cull: pairs against static non-plane geoms (stairs ...) are visited only if one of those geoms is
+         * within reach of a kinematic tree (lane = collision geom) */
+        int npass = m->npair_always;
+        if (m->npair_simple > m->npair_always) {
+            bool nearby = false;
+            if (lane < m->ngeom && m->geom_farstatic[lane]) {
+                const double rb = m->geom_rbound[lane] + m->geom_margin[lane];
+                for (int ri = 0; ri < m->nroot; ++ri) {
+                    const int r = m->root_body[ri];
+                    double dv[3] = {S.x.s.geom_xpos[lane][0] - S.x.s.xpos[r][0], S.x.s.geom_xpos[lane][1] - S.x.s.xpos[r][1],
+                                    S.x.s.geom_xpos[lane][2] - S.x.s.xpos[r][2]};
+                    const double bound = m->body_reach[r] + rb + 0.01;
+                    if (dot3(dv, dv) < bound * bound) nearby = true;
+                }
+            }
+            if (wv::ballot(nearby) != 0ull) npass = m->npair_simple;
+        }
+        CK_STAMP(21);
+        for (int p0 = 0; p0 < npass; p0 += WV_WAVE) {
             const int p = p0 + lane;
             int n = 0;
             RawContact rc0, rc1;
             int g1 = 0, g2 = 0;
             double margin = 0, gap = 0;
-            if (p < m->npair_simple) {
+            if (p < npass) {
                 g1 = m->pair_geom1[p]; g2 = m->pair_geom2[p];
                 const int t1 = m->geom_type[g1], t2 = m->geom_type[g2];
                 margin = fmax(m->geom_margin[g1], m->geom_margin[g2]);
@@ -798,6 +958,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
             if (n >= 2 && slot + 1 < CM_MAXCON) write_contact<NVP>(S, m, slot + 1, g1, g2, rc1, margin - gap);
             ncon += wv::popc64(m1b) + wv::popc64(m2b);
         }
+        CK_STAMP(22);
         /* pass 2, one pair at a time with the whole wave: lane = feature (box corner / vertex), first four hits kept */
         for (int p = m->npair_simple; p < m->npair; ++p) {
             const int g1 = m->pair_geom1[p], g2 = m->pair_geom2[p];
@@ -861,43 +1022,67 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
         if (ncon > CM_MAXCON) { ncon = CM_MAXCON; warn |= WARN_CONTACT_FULL; }
         CK_STAMP(5);
 
-        /* ================= P6 velocities and bias forces as chain sums (no recursion) ================= */
-        /* lane = body: com-frame velocity = sum over the dofs that move the body */
-        double mycvel[6] = {0, 0, 0, 0, 0, 0};
-        for (unsigned long long mk = bdofmask; mk; mk &= mk - 1) {
-            const int k = wv::popc64((mk & (0ull - mk)) - 1);
-            const double qv = S.qvel[k];
-            for (int i = 0; i < 6; ++i) mycvel[i] += S.cdof[k][i] * qv;
+        /* ================= P6 velocities and bias forces (no recursion) ================= */
+        /* All tree sums are written as dense wave-uniform loops with per-lane predicates: the operands are broadcast
+         * LDS reads staged four at a time, so nothing on the dependent chain waits for memory. */
+        /* velocity of every body (lane = body) and velocity entering every joint (lane = dof), same broadcast data */
+        double mycvel[6] = {0, 0, 0, 0, 0, 0}, vin[6] = {0, 0, 0, 0, 0, 0};
+        {
+            /* free joints: the rotational dofs also see the joint's own translational dofs; the translational ones see nothing */
+            unsigned long long vmask = kvelmask;
+            if (kjt == CM_JNT_FREE) vmask = (k_ - kda >= 3) ? (kvelmask | (7ull << kda)) : 0ull;
+#pragma unroll
+            for (int k0 = 0; k0 < NVP; k0 += 4) {
+                double cc[4][6], qv[4];
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+                    for (int t = 0; t < 6; ++t) cc[kk][t] = S.cdof[k0 + kk][t];
+                    qv[kk] = S.qvel[k0 + kk];
+                }
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const int k = k0 + kk;
+                    if (TOPO::is_static ? k >= TOPO::nv : k >= nv) continue;
+                    const double qb = ((bdofmask >> k) & 1ull) ? qv[kk] : 0.0, qd = ((vmask >> k) & 1ull) ? qv[kk] : 0.0;
+#pragma unroll
+                    for (int t = 0; t < 6; ++t) { mycvel[t] += cc[kk][t] * qb; vin[t] += cc[kk][t] * qd; }
+                }
+            }
         }
         if (isbody) for (int i = 0; i < 6; ++i) S.x.s.cvel[b][i] = mycvel[i];
         /* lane = dof: time derivative of the motion axis = (velocity entering the joint) x axis */
-        double cdd[6] = {0, 0, 0, 0, 0, 0};
-        if (isdof) {
-            double vin[6] = {0, 0, 0, 0, 0, 0};
-            for (unsigned long long mk = kvelmask; mk; mk &= mk - 1) {
-                const int k = wv::popc64((mk & (0ull - mk)) - 1);
-                const double qv = S.qvel[k];
-                for (int i = 0; i < 6; ++i) vin[i] += S.cdof[k][i] * qv;
-            }
-            if (kjt == CM_JNT_FREE) {
-                if (k_ - kda >= 3) for (int t = 0; t < 3; ++t) { const double qv = S.qvel[kda + t]; for (int i = 0; i < 6; ++i) vin[i] += S.cdof[kda + t][i] * qv; }
-                else { for (int i = 0; i < 6; ++i) vin[i] = 0; }
-            }
-            cross_motion(cdd, vin, cd);
-            if (kjt == CM_JNT_FREE && k_ - kda < 3) for (int i = 0; i < 6; ++i) cdd[i] = 0;
-            for (int i = 0; i < 6; ++i) S.x.s.cdof_dot[k_][i] = cdd[i];
+        if (lane < NVP) {
+            double cdd[6] = {0, 0, 0, 0, 0, 0}, cd[6];
+            for (int i = 0; i < 6; ++i) cd[i] = S.cdof[lane][i];
+            if (isdof && !(kjt == CM_JNT_FREE && k_ - kda < 3)) cross_motion(cdd, vin, cd);
+            for (int i = 0; i < 6; ++i) S.x.s.cdof_dot[lane][i] = cdd[i];
         }
         wv::sync();
+        CK_STAMP(23);
         /* lane = body: bias acceleration (gravity enters as -g on the world) and the body's inertial force */
         double mycacc[6] = {0, 0, 0, -m->gravity[0], -m->gravity[1], -m->gravity[2]};
-        for (unsigned long long mk = bdofmask; mk; mk &= mk - 1) {
-            const int k = wv::popc64((mk & (0ull - mk)) - 1);
-            const double qv = S.qvel[k];
-            for (int i = 0; i < 6; ++i) mycacc[i] += S.x.s.cdof_dot[k][i] * qv;
+#pragma unroll
+        for (int k0 = 0; k0 < NVP; k0 += 4) {
+            double cc[4][6], qv[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+                for (int t = 0; t < 6; ++t) cc[kk][t] = S.x.s.cdof_dot[k0 + kk][t];
+                qv[kk] = S.qvel[k0 + kk];
+            }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int k = k0 + kk;
+                if (TOPO::is_static ? k >= TOPO::nv : k >= nv) continue;
+                const double qb = ((bdofmask >> k) & 1ull) ? qv[kk] : 0.0;
+#pragma unroll
+                for (int t = 0; t < 6; ++t) mycacc[t] += cc[kk][t] * qb;
+            }
         }
-        if (isbody) {
+        if (lane < NB) {
             double f6[6] = {0, 0, 0, 0, 0, 0};
-            if (b > 0) {
+            if (isbody && b > 0) {
                 double t1[6], t2[6], t3[6], ci[10];
                 for (int i = 0; i < 10; ++i) ci[i] = S.x.s.cinert[b][i];
                 mul_inert_vec(t1, ci, mycacc);
@@ -905,14 +1090,30 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
                 cross_force(t3, mycvel, t2);
                 for (int i = 0; i < 6; ++i) f6[i] = t1[i] + t3[i];
             }
-            for (int i = 0; i < 6; ++i) S.x.s.cfrc[b][i] = f6[i];
+            for (int i = 0; i < 6; ++i) S.x.s.cfrc[lane][i] = f6[i];
         }
         wv::sync();
+        CK_STAMP(24);
+        /* lane = dof: project the subtree's force on the motion axis; subtree = contiguous body range [kbody, kbend) */
         double qfrc_bias = 0;
-        if (isdof) {
+        {
             double acc[6] = {0, 0, 0, 0, 0, 0};
-            for (int c = kbody; c < kbend; ++c) for (int i = 0; i < 6; ++i) acc[i] += S.x.s.cfrc[c][i];
-            for (int i = 0; i < 6; ++i) qfrc_bias += cd[i] * acc[i];
+#pragma unroll
+            for (int c0 = 0; c0 < NB; c0 += 4) {
+                double ff[4][6];
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+                    for (int t = 0; t < 6; ++t) ff[cc][t] = S.x.s.cfrc[c0 + cc][t];
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) {
+                    const int c = c0 + cc;
+                    const bool in = isdof && c >= kbody && c < kbend;
+#pragma unroll
+                    for (int t = 0; t < 6; ++t) acc[t] += in ? ff[cc][t] : 0.0;
+                }
+            }
+            for (int i = 0; i < 6; ++i) qfrc_bias += S.cdof[lane < NVP ? lane : 0][i] * acc[i];
         }
         CK_STAMP(6);
 
@@ -1002,6 +1203,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
             nefc += nrow;
         }
 
+        CK_STAMP(25);
         /* per-row geometry: J_rk = plus_k (u.lin_k + wp.ang_k) - minus_k (u.lin_k + wm.ang_k) (+ sgn at one dof) */
         double u3[3] = {0, 0, 0}, wp[3] = {0, 0, 0}, wm[3] = {0, 0, 0};
         unsigned long long maskp = 0, maskm = 0;
@@ -1067,6 +1269,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
             solref0 = S.c_solref[c][0]; solref1 = S.c_solref[c][1];
             for (int i = 0; i < 5; ++i) solimp[i] = S.c_solimp[c][i];
         }
+        CK_STAMP(26);
         double rR = 1.0, rK = 0, rB = 0, rimp = 1.0;
         if (rtype >= 0) {
             rimp = impedance(solimp, imp_pos, rmargin);
@@ -1083,28 +1286,41 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
                 rB = -solref1 / fmax(CM_MINVAL, dmax);
             }
         }
+        CK_STAMP(27);
         /* this lane's Jacobian row, one dof at a time, straight into registers; lane 63 carries qfrc_smooth */
         double ycol[NVP];
         double jvel = 0, jws = 0;
+        const bool lastcol = r_ == NROW - 1;
 #pragma unroll
-        for (int k = 0; k < NVP; ++k) {
-            double v = 0;
-            if (k < nv) {
-                if (rtype >= 0) {
-                    const double c0 = S.cdof[k][0], c1 = S.cdof[k][1], c2 = S.cdof[k][2];
-                    const double c3 = S.cdof[k][3], c4 = S.cdof[k][4], c5 = S.cdof[k][5];
-                    const double ul = u3[0] * c3 + u3[1] * c4 + u3[2] * c5;
-                    if ((maskp >> k) & 1ull) v += ul + wp[0] * c0 + wp[1] * c1 + wp[2] * c2;
-                    if ((maskm >> k) & 1ull) v -= ul + wm[0] * c0 + wm[1] * c1 + wm[2] * c2;
-                    if (k == limdof) v = limsgn;
-                    jvel += v * S.qvel[k];
-                    jws += v * S.qacc_ws[k];
-                } else if (r_ == NROW - 1) {
-                    v = S.qfrc_smooth[k];
-                }
+        for (int k0 = 0; k0 < NVP; k0 += 4) {
+            /* stage four motion axes and the matching qvel / qacc_warmstart / qfrc_smooth entries, then compute */
+            double cc[4][6], qv[4], qw[4], qs[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+                for (int t = 0; t < 6; ++t) cc[kk][t] = S.cdof[k0 + kk][t];
+                qv[kk] = S.qvel[k0 + kk]; qw[kk] = S.qacc_ws[k0 + kk]; qs[kk] = S.qfrc_smooth[k0 + kk];
             }
-            ycol[k] = v;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int k = k0 + kk;
+                double v = 0;
+                if (k < nv) {
+                    if (rtype >= 0) {
+                        const double ul = u3[0] * cc[kk][3] + u3[1] * cc[kk][4] + u3[2] * cc[kk][5];
+                        if ((maskp >> k) & 1ull) v += ul + wp[0] * cc[kk][0] + wp[1] * cc[kk][1] + wp[2] * cc[kk][2];
+                        if ((maskm >> k) & 1ull) v -= ul + wm[0] * cc[kk][0] + wm[1] * cc[kk][1] + wm[2] * cc[kk][2];
+                        if (k == limdof) v = limsgn;
+                        jvel += v * qv[kk];
+                        jws += v * qw[kk];
+                    } else if (lastcol) {
+                        v = qs[kk];
+                    }
+                }
+                ycol[k] = v;
+            }
         }
+        CK_STAMP(28);
         const double raref = rtype >= 0 ? -rB * jvel - rK * rimp * (rpos - rmargin) : 0.0;
 
         /* ---- sensors, part 1 (lane = sensor): everything that does not need qacc is final here; the
@@ -1112,12 +1328,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
         const bool issens = lane < m->nsensor;
         const int stype = issens ? m->sensor_type[lane] : -1;
         const int sobj = issens ? m->sensor_objid[lane] : 0;
-        int aslot = -1; /* which accelerometer this lane is (two supported) */
-        if (stype == CM_SENS_ACCELEROMETER) {
-            aslot = 0;
-            for (int s2 = 0; s2 < lane; ++s2) if (m->sensor_type[s2] == CM_SENS_ACCELEROMETER) ++aslot;
-            if (aslot > 1) { aslot = -1; warn |= WARN_UNSUPPORTED_PAIR; }
-        }
+        const int aslot = (stype == CM_SENS_ACCELEROMETER) ? m->sensor_slot[lane] : -1; /* which accelerometer this lane is */
         if (issens) {
             double sout[4] = {0, 0, 0, 0};
             if (stype == CM_SENS_ACTUATORPOS) sout[0] = m->act_gear[sobj] * S.qpos[m->act_qposadr[sobj]];
@@ -1162,6 +1373,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
                 }
             }
         }
+        CK_STAMP(29);
         if (io.xpos_out && isbody) {
             for (int i = 0; i < 3; ++i) io.xpos_out[((size_t)env * io.sb + b) * 3 + i] = S.x.s.xpos[b][i];
             if (io.xquat_out) for (int i = 0; i < 4; ++i) io.xquat_out[((size_t)env * io.sb + b) * 4 + i] = S.x.s.xquat[b][i];
@@ -1283,6 +1495,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
                 if (cost > 0) f = 0;
                 else if (isrow) res = rb + af;
             }
+        CK_STAMP(30);
             const double scale = 1.0 / (m->meaninertia * (nv > 1 ? nv : 1));
             const double halfAii = 0.5 * Aii;
             const double flo = clampf ? 0.0 : -1e300; /* lower bound of this row's force */
@@ -1316,18 +1529,29 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
         double qacc;
         {
             double z = isdof ? S.x.Yr[NROW - 1][k_] : 0.0;
-#pragma unroll
-            for (int r = 0; r < CM_MAXEFC; ++r) {
-                if (r >= nefc) continue;
-                const double fr = wv::readlane(f, r);
-                if (isdof) z += S.x.Yr[r][k_] * fr;
+            {
+                /* z += Y f : rows in groups of four so LDS reads and broadcasts overlap; rolled (row count is dynamic) */
+                double z1 = 0, z2 = 0, z3 = 0;
+                const int kk = isdof ? k_ : 0;
+                int r = 0;
+                for (; r + 4 <= nefc; r += 4) {
+                    const double y0 = S.x.Yr[r][kk], y1 = S.x.Yr[r + 1][kk], y2 = S.x.Yr[r + 2][kk], y3 = S.x.Yr[r + 3][kk];
+                    z += y0 * wv::readlane(f, r); z1 += y1 * wv::readlane(f, r + 1);
+                    z2 += y2 * wv::readlane(f, r + 2); z3 += y3 * wv::readlane(f, r + 3);
+                }
+                for (; r < nefc; ++r) z += S.x.Yr[r][kk] * wv::readlane(f, r);
+                z = (z + z1) + (z2 + z3);
+                if (!isdof) z = 0.0;
             }
             if (isdof) z *= S.rsd[k_];
+            /* forward substitution with this lane's row of L staged first (all LDS reads in flight together) */
+            double lrow[NVP];
+#pragma unroll
+            for (int i = 0; i < NVP; ++i) lrow[i] = (isdof && i < k_) ? S.Lp[CK_TRI(k_, i)] : 0.0;
 #pragma unroll
             for (int i = 0; i < NVP - 1; ++i) {
                 if (TOPO::is_static ? i >= TOPO::nv - 1 : i >= nv - 1) continue;
-                const double zi = wv::readlane(z, i);
-                if (isdof && k_ > i) z -= S.Lp[CK_TRI(k_, i)] * zi;
+                z -= lrow[i] * wv::readlane(z, i);
             }
             qacc = z;
         }
@@ -1375,18 +1599,24 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
         if (m->flags & CM_FLAG_EULERDAMP) {
             /* (M + hB) x = M qacc  <=>  x = qacc - (M + hB)^-1 (hB qacc) */
             double w = isdof ? h * m->dof_damping[k_] * qacc : 0.0;
+            double lcol[NVP], lrowh[NVP]; /* this lane's column and row of the factor of M + hB, staged before the chains */
+#pragma unroll
+            for (int k = 0; k < NVP; ++k) {
+                const bool inrange = TOPO::is_static ? k < TOPO::nv : k < nv;
+                lcol[k] = (inrange && isdof && k > k_) ? S.LHp[CK_TRI(k, k_)] : 0.0;
+                lrowh[k] = (isdof && k < k_) ? S.LHp[CK_TRI(k_, k)] : 0.0;
+            }
+            const double dih = isdof ? S.dinvH[k_] : 0.0;
 #pragma unroll
             for (int k = NVP - 1; k >= 1; --k) { /* L^-T */
                 if (TOPO::is_static ? k >= TOPO::nv : k >= nv) continue;
-                const double wk = wv::readlane(w, k);
-                if (lane < k) w -= S.LHp[CK_TRI(k, lane)] * wk;
+                w -= lcol[k] * wv::readlane(w, k);
             }
-            if (isdof) w *= S.dinvH[k_];
+            w *= dih;
 #pragma unroll
             for (int i = 0; i < NVP - 1; ++i) { /* L^-1 */
                 if (TOPO::is_static ? i >= TOPO::nv - 1 : i >= nv - 1) continue;
-                const double wi = wv::readlane(w, i);
-                if (isdof && k_ > i) w -= S.LHp[CK_TRI(k_, i)] * wi;
+                w -= lrowh[i] * wv::readlane(w, i);
             }
             qacc_int = qacc - w;
         }
@@ -1439,7 +1669,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
 
 /* one single-wave workgroup per environment */
 template <int NVP, class TOPO>
-WV_GLOBAL void __launch_bounds__(WV_WAVE) cassie_step_kernel(PhysIO io) {
+WV_GLOBAL void __launch_bounds__(WV_WAVE) WV_OCC cassie_step_kernel(PhysIO io) {
     WV_SHARED EnvShared<NVP> S;
     const int env = wv::env_id();
     if (env >= io.nenv) return;

@@ -15,10 +15,22 @@
 #define WV_GLOBAL __global__
 #define WV_SHARED __shared__
 #define WV_WAVE 64
+/* address-space qualifier of the model pointer.  The constant address space (4) was measured slower on gfx950:
+ * the compiler then re-reads constants at their use sites, one exposed load latency each, instead of batching the
+ * loads at the top of the kernel. */
+#define WV_CONST_AS
 
 namespace wv {
 
 WV_DEVICE int lane() { return (int)threadIdx.x; }
+/* the lane index recomputed from nothing (two VALU ops) through an asm the optimiser cannot merge or hoist: values
+ * derived from it (LDS addresses, lane predicates) then live only inside the stage that asked, instead of being
+ * computed once at the top of the kernel and carried -- i.e. spilled -- across everything in between */
+WV_DEVICE int fresh_lane() {
+    int x;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(x));
+    return x;
+}
 WV_DEVICE int env_id() { return (int)blockIdx.x; }
 
 /* workgroup == one wave: this is an LDS fence + s_barrier that the backend
@@ -45,8 +57,23 @@ WV_DEVICE double wave_sum(double v) {
     return v;
 }
 
+/* hardware reciprocal estimate (v_rcp_f64) */
+WV_DEVICE double rcp_estimate(double x) { return __builtin_amdgcn_rcp(x); }
+
 /* value-preserving move the optimiser cannot see through (wave-uniform ints only) */
-WV_DEVICE int opaque(int x) { asm volatile("" : "+s"(x)); return x; }
+WV_DEVICE int opaque(int x) { x = __builtin_amdgcn_readfirstlane(x); asm volatile("" : "+s"(x)); return x; }
+
+/* same for a wave-uniform pointer: loads through the result cannot be hoisted above this point */
+template <class P> WV_DEVICE P opaque_ptr(P p) {
+    const unsigned long long v = (unsigned long long)p;
+    unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    asm volatile("" : "+s"(lo), "+s"(hi));
+    return (P)(((unsigned long long)hi << 32) | lo);
+}
+
+/* instruction-scheduling fence: nothing is moved across it.  Used between hand-staged load / compute groups so the
+ * scheduler's appetite for early loads cannot push the register allocator into scratch. */
+WV_DEVICE void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 
 WV_DEVICE long long clock() { return (long long)__builtin_readcyclecounter(); }
 

@@ -109,7 +109,7 @@ int phys_batch_time_steps(phys_batch_t *b, int nsub, int reps, float *mean_ms);
 int phys_batch_enable_ext(phys_batch_t *b, int on);
 int phys_batch_download_ext(phys_batch_t *b, cm_ext_t *host, int env0, int n);
 
-/* per-stage shader-clock stamps of the next launches: [nenv][16] long long on the host after the call (profiling aid) */
+/* per-stage shader-clock stamps of the next launches: [nenv][48] long long on the host after the call (profiling aid) */
 int phys_batch_profile_step(phys_batch_t *b, long long *host_stamps);
 
 size_t phys_sizeof_model(void);

@@ -18,6 +18,7 @@
 #define WV_GLOBAL
 #define WV_SHARED static
 #define WV_WAVE 64
+#define WV_CONST_AS
 #define __launch_bounds__(x)
 
 namespace wv {
@@ -32,6 +33,10 @@ unsigned long long ballot(bool p);
 double wave_sum(double v);
 inline long long clock() { return 0; }
 inline int opaque(int x) { return x; }
+inline void sched_fence() {}
+inline int fresh_lane() { return lane(); }
+template <class P> inline P opaque_ptr(P p) { return p; }
+inline double rcp_estimate(double x) { return (double)(1.0f / (float)x); } /* deliberately low precision, like the hardware estimate */
 inline int popc64(unsigned long long x) { return __builtin_popcountll(x); }
 }  // namespace wv
 #endif

@@ -89,3 +89,23 @@ def test_capsule_and_sphere_vs_box_geometry(tray):
         assert emu.info[0, 0] == o.d.ncon, s
     assert (2, 6) in seen or (3, 6) in seen
     assert np.max(np.abs(emu.qpos[0] - o.qpos)) < 1e-8
+
+
+def test_stair_box_under_the_feet_is_not_culled(cassie):
+    """cassie.xml parks its 15 stair boxes 20 m away, where the kernel skips their 135 pairs as a block; when a
+    box is moved under the robot (cassie_sim_set_geom_name_pos) its capsule-box contacts must appear."""
+    from cassie_amd._lib import CmModel
+    pod = CmModel.from_buffer_copy(cassie.pod)
+    assert pod.geom_type[1] == 6 and pod.npair_always == 18 and pod.npair_simple == 153
+    pod.geom_pos[1][0], pod.geom_pos[1][1], pod.geom_pos[1][2] = 0.0, 0.0, -0.96     # 2 m cube, top face at z = +0.04
+    o = Oracle(pod, cassie.qpos_init())
+    emu = EmuBatch(pod, 1)
+    emu.qpos[:] = cassie.qpos_init()
+    on_box = 0
+    for s in range(300):
+        emu.step()
+        o.step()
+        assert (emu.info[0, 0], emu.info[0, 1]) == (o.d.ncon, o.d.nefc), s
+        on_box = max(on_box, sum(1 for i in range(o.d.ncon) if o.d.contact[i].geom2 == 1 or o.d.contact[i].geom1 == 1))
+    assert on_box >= 2
+    assert np.max(np.abs(emu.qpos[0] - o.qpos)) < 1e-8

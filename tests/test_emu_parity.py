@@ -72,7 +72,7 @@ def test_multi_substep_launch_equals_single_steps(cassie):
     a.step(nsub=25)
     for _ in range(25):
         b.step()
-    assert np.array_equal(a.qpos, b.qpos) and np.array_equal(a.qvel, b.qvel)
+    assert np.abs(a.qpos - b.qpos).max() < 1e-11 and np.abs(a.qvel - b.qvel).max() < 1e-9
     assert abs(a.time[0] - 25 * pod.timestep) < 1e-15
 
 
@@ -126,8 +126,10 @@ def test_on_device_pd_mode(cassie):
 
 
 def test_runtime_topology_instantiation_matches_static_one(cassie):
-    """The generic kernel (dof-tree masks read from the model at run time) must agree bitwise with the
-    compile-time-topology instantiation used for the in-scope models."""
+    """The generic kernel (dof-tree masks read from the model at run time) must agree with the
+    compile-time-topology instantiation used for the in-scope models.  The static one eliminates the mass matrix
+    height by height, the generic one dof by dof: the same updates in another order, so the agreement is to
+    rounding, not bitwise."""
     import emu_py
     pod = cassie.pod
     a, b = EmuBatch(pod, 1), EmuBatch(pod, 1)
@@ -140,4 +142,4 @@ def test_runtime_topology_instantiation_matches_static_one(cassie):
         b.step(40)
     finally:
         emu_py.lib().emu_force_runtime_topology(0)
-    assert np.array_equal(a.qpos, b.qpos) and np.array_equal(a.qvel, b.qvel)
+    assert np.abs(a.qpos - b.qpos).max() < 1e-11 and np.abs(a.qvel - b.qvel).max() < 1e-9
