@@ -464,22 +464,55 @@ WV_DEVICE void factor_pair_by_height(SH &S, double (&col)[NVP], double (&colh)[N
     if (lane < TOPO::nv) S.rsd[lane] = sqrt(S.dinv[lane]);
 }
 
-/* One PGS sweep over rows I, I+1, ... : nested so that the first row index >= nrows ends the sweep with a
- * single branch (rows are contiguous).  Every lane evaluates its own candidate update; only row I's is
- * consumed, through readlane. */
+/* Projected Gauss-Seidel sweeps, one constraint row per lane.  The per-row state is the SCALED residual
+ * s_j = -res_j / A_jj, so a row's unclamped step is s itself and the serial chain per row is max, readlane, FMA:
+ *     delta_I = max(s_I, lo_I);   s_j += B_jI * delta_I  for every j,   B_jI = -A_jI / A_jj  (brow, per lane).
+ * Every lane evaluates its own candidate each row; only lane I's is consumed, through readlane.
+ *
+ * pgs_rows: the guarded sweep (MuJoCo's rule `never accept a cost increase`, evaluated row by row).  Nested so that
+ * the first row index >= nrows ends the sweep with one wave-uniform branch. */
 template <int I>
-WV_DEVICE void pgs_rows(const double (&arow)[CM_MAXEFC], int nrows, int r_, double invAii, double halfAii, double flo,
-                        double &f, double &res, double &improvement) {
+WV_DEVICE void pgs_rows(const double (&brow)[CM_MAXEFC], int nrows, int r_, double Aii, double halfAii, double flo, double &f,
+                        double &sres, double &improvement) {
     if constexpr (I < CM_MAXEFC) {
         if (I < nrows) {
-            double delta = fmax(-res * invAii, flo - f); /* = max(f - res / Aii, flo) - f */
-            double change = delta * (halfAii * delta + res);
+            double delta = fmax(sres, flo - f); /* = max(f - res / Aii, flo) - f */
+            double change = delta * (halfAii * delta - Aii * sres);
             if (change > 1e-10) { delta = 0; change = 0; } /* never accept a cost increase */
             const double dlt = wv::readlane(delta, I), chg = wv::readlane(change, I);
             if (r_ == I) f += dlt;
             improvement -= chg;
-            res += arow[I] * dlt;
-            pgs_rows<I + 1>(arow, nrows, r_, invAii, halfAii, flo, f, res, improvement);
+            sres += brow[I] * dlt;
+            pgs_rows<I + 1>(brow, nrows, r_, Aii, halfAii, flo, f, sres, improvement);
+        }
+    }
+}
+
+/* The same sweep with the guard off the dependent chain: the row's own lane keeps its step (v_writelane) and the
+ * residual it started from, so every row's cost change -- hence the guard and the sweep's improvement -- can be
+ * evaluated once, after the sweep.  The caller re-runs the sweep through pgs_rows when a guard would have fired. */
+template <int I>
+WV_DEVICE void pgs_row_fast(const double (&brow)[CM_MAXEFC], int r_, double lo_f, double &sres, double &mydelta, double &mys) {
+    if constexpr (I < CM_MAXEFC) {
+        const double delta = fmax(sres, lo_f);
+        if (r_ == I) mys = sres;
+        const double dlt = wv::readlane(delta, I);
+        mydelta = wv::writelane<I>(mydelta, dlt);
+        sres += brow[I] * dlt;
+    }
+}
+/* rows go four to a (wave-uniform) branch: rows past the last one are inert -- their column of A is zero in every
+ * lane and their own lane's step is finite -- so running up to three of them costs less than three more branches */
+template <int I>
+WV_DEVICE void pgs_rows_fast(const double (&brow)[CM_MAXEFC], int nrows, int r_, double lo_f, double &sres, double &mydelta,
+                             double &mys) {
+    if constexpr (I < CM_MAXEFC) {
+        if (I < nrows) {
+            pgs_row_fast<I>(brow, r_, lo_f, sres, mydelta, mys);
+            pgs_row_fast<I + 1>(brow, r_, lo_f, sres, mydelta, mys);
+            pgs_row_fast<I + 2>(brow, r_, lo_f, sres, mydelta, mys);
+            pgs_row_fast<I + 3>(brow, r_, lo_f, sres, mydelta, mys);
+            pgs_rows_fast<I + 4>(brow, nrows, r_, lo_f, sres, mydelta, mys);
         }
     }
 }
@@ -1499,10 +1532,35 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
             const double scale = 1.0 / (m->meaninertia * (nv > 1 ? nv : 1));
             const double halfAii = 0.5 * Aii;
             const double flo = clampf ? 0.0 : -1e300; /* lower bound of this row's force */
+            /* to the scaled domain (see pgs_rows): arow becomes B in place */
+            const double ninvAii = -invAii;
+            double sres = res * ninvAii;
+#pragma unroll
+            for (int t = 0; t < CM_MAXEFC; ++t) arow[t] *= ninvAii;
             while (iters < m->iterations) {
                 const int nrows = wv::opaque(nefc); /* keeps the row-bound tests out of loop-invariant hoisting */
                 double improvement = 0;
-                pgs_rows<0>(arow, nrows, r_, invAii, halfAii, flo, f, res, improvement);
+                {
+                    const double f0 = f, s0 = sres;
+                    double mydelta = 0, mys = 0;
+                    pgs_rows_fast<0>(arow, nrows, r_, flo - f, sres, mydelta, mys);
+                    const double change = (r_ < nrows) ? mydelta * (halfAii * mydelta - Aii * mys) : 0.0;
+                    if (wv::ballot(change > 1e-10) != 0ull || wv::debug_force_guarded()) { /* some row would have raised the cost: redo guarded */
+                        f = f0; sres = s0;
+                        pgs_rows<0>(arow, nrows, r_, Aii, halfAii, flo, f, sres, improvement);
+                    } else {
+                        if (r_ < nrows) f += mydelta;
+                        /* The guarded sweep adds the rows' cost changes in row order.  The sum only feeds the convergence
+                         * test, so a tree sum decides it unless it lands within a factor two of the tolerance -- far
+                         * outside what the order of summation can move -- and only then is the ordered sum formed. */
+                        improvement = -wv::wave_sum(change);
+                        const double tol = m->tolerance, est = improvement * scale;
+                        if (est > 0.5 * tol && est < 2.0 * tol) {
+                            improvement = 0;
+                            for (int t = 0; t < nrows; ++t) improvement -= wv::readlane(change, t);
+                        }
+                    }
+                }
                 improvement *= scale;
                 ++iters;
                 if (improvement < m->tolerance) break;

@@ -49,12 +49,35 @@ WV_DEVICE double readlane(double v, int src) {
     return __hiloint2double(hi, lo);
 }
 
+/* write the wave-uniform value s into lane DST of v: two v_writelane_b32 (no builtin in this compiler) */
+template <int DST> WV_DEVICE double writelane(double v, double s) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    const int slo = __builtin_amdgcn_readfirstlane(__double2loint(s)), shi = __builtin_amdgcn_readfirstlane(__double2hiint(s));
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(lo) : "s"(slo), "n"(DST));
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(hi) : "s"(shi), "n"(DST));
+    return __hiloint2double(hi, lo);
+}
+
 WV_DEVICE unsigned long long ballot(bool p) { return __ballot(p); }
 
+/* v taken from another lane through a DPP control (quad_perm / row_mirror / row_bcast), 0.0 where the control or the
+ * row mask selects nothing */
+template <int CTRL, int ROW_MASK> WV_DEVICE double dpp_take(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+/* sum over the 64 lanes, returned wave-uniform: butterfly inside each row of 16 (quad permutes and mirrors), then the
+ * row totals chained through lane 15 -> next row and lane 31 -> upper half; no LDS crossbar traffic */
 WV_DEVICE double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += shfl_xor(v, o);
-    return v;
+    v += dpp_take<0xB1, 0xf>(v);  /* quad_perm [1,0,3,2] */
+    v += dpp_take<0x4E, 0xf>(v);  /* quad_perm [2,3,0,1] */
+    v += dpp_take<0x141, 0xf>(v); /* row_half_mirror */
+    v += dpp_take<0x140, 0xf>(v); /* row_mirror: every lane of a row now holds the row total */
+    v += dpp_take<0x142, 0xa>(v); /* row_bcast15 into rows 1 and 3 */
+    v += dpp_take<0x143, 0xc>(v); /* row_bcast31 into rows 2 and 3 */
+    return readlane(v, 63);
 }
 
 /* hardware reciprocal estimate (v_rcp_f64) */
@@ -74,6 +97,9 @@ template <class P> WV_DEVICE P opaque_ptr(P p) {
 /* instruction-scheduling fence: nothing is moved across it.  Used between hand-staged load / compute groups so the
  * scheduler's appetite for early loads cannot push the register allocator into scratch. */
 WV_DEVICE void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+
+/* test hook of the CPU emulator (always false on the device): take the guarded PGS sweep every time */
+WV_DEVICE constexpr bool debug_force_guarded() { return false; }
 
 WV_DEVICE long long clock() { return (long long)__builtin_readcyclecounter(); }
 

@@ -110,13 +110,21 @@ unsigned long long ballot(bool p) {
     rendezvous();
     return m;
 }
-double wave_sum(double v) {
-    for (int o = 32; o > 0; o >>= 1) v += shfl_xor(v, o);
-    return v;
+int g_force_guarded = 0;
+double wave_sum(double v) { /* same association order as the device's DPP reduction (csrc/wave.h) */
+    const int l = lane(), row = l >> 4;
+    v += shfl(v, l ^ 1);
+    v += shfl(v, l ^ 2);
+    v += shfl(v, (l & ~7) | (7 - (l & 7)));
+    v += shfl(v, (l & ~15) | (15 - (l & 15)));
+    { const double t = shfl(v, ((row > 0 ? row - 1 : 0) << 4) | 15); if (row & 1) v += t; }
+    { const double t = shfl(v, 31); if (row >= 2) v += t; }
+    return shfl(v, 63);
 }
 }  // namespace wv
 
 static ck::PhysIO g_io;
+extern "C" void emu_force_guarded_pgs(int on) { wv::g_force_guarded = on; }
 static int g_force_runtime_topology = 0;
 static void body32s() { ck::cassie_step_kernel<32, ck::TopoCassie32>(g_io); }
 static void body40s() { ck::cassie_step_kernel<40, ck::TopoCassieTray38>(g_io); }

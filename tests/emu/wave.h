@@ -29,11 +29,15 @@ double shfl(double v, int src_lane);
 double shfl_xor(double v, int mask);
 int shfl_i(int v, int src_lane);
 double readlane(double v, int src);
+int lane();
+template <int DST> inline double writelane(double v, double s) { return lane() == DST ? s : v; } /* s is the same in every lane */
 unsigned long long ballot(bool p);
 double wave_sum(double v);
 inline long long clock() { return 0; }
 inline int opaque(int x) { return x; }
 inline void sched_fence() {}
+extern int g_force_guarded;
+inline bool debug_force_guarded() { return g_force_guarded != 0; }
 inline int fresh_lane() { return lane(); }
 template <class P> inline P opaque_ptr(P p) { return p; }
 inline double rcp_estimate(double x) { return (double)(1.0f / (float)x); } /* deliberately low precision, like the hardware estimate */

@@ -143,3 +143,22 @@ def test_runtime_topology_instantiation_matches_static_one(cassie):
     finally:
         emu_py.lib().emu_force_runtime_topology(0)
     assert np.abs(a.qpos - b.qpos).max() < 1e-11 and np.abs(a.qvel - b.qvel).max() < 1e-9
+
+
+def test_guarded_pgs_sweep_agrees_with_the_speculative_one(cassie):
+    """The kernel runs PGS sweeps with the cost guard evaluated after the sweep and falls back to the row-by-row
+    guarded sweep only when a guard would have fired (rare).  Forcing the fallback on every sweep must give the same
+    trajectory to rounding."""
+    import emu_py
+    pod = cassie.pod
+    a, b = EmuBatch(pod, 1), EmuBatch(pod, 1)
+    for x in (a, b):
+        x.qpos[:] = cassie.qpos_init()
+        x.ctrl[:] = [1.0, -2.0, 3.0, -4.0, 0.5, -1.0, 2.0, -3.0, 4.0, -0.5]
+    a.step(60)
+    emu_py.lib().emu_force_guarded_pgs(1)
+    try:
+        b.step(60)
+    finally:
+        emu_py.lib().emu_force_guarded_pgs(0)
+    assert np.abs(a.qpos - b.qpos).max() < 1e-11 and np.abs(a.qvel - b.qvel).max() < 1e-9
