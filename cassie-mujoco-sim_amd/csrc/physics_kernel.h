@@ -443,7 +443,10 @@ WV_DEVICE void factor_pair_by_height(SH &S, double (&col)[NVP], double (&colh)[N
             if (TOPO::height[k] != s) continue;
             const double inv = fast_rcp(wv::readlane(col[k], k)), invh = fast_rcp(wv::readlane(colh[k], k));
             S.dinv[k] = inv; S.dinvH[k] = invh; /* every lane holds the same value: an unpredicated same-address store */
-            if (lane < k) { S.Lp[CK_TRI(k, lane)] = col[k] * inv; S.LHp[CK_TRI(k, lane)] = colh[k] * invh; }
+            /* lanes at or past the diagonal all land on the (unused) diagonal slot: an unpredicated store */
+            const int at = CK_TRI(k, 0) + (lane < k ? lane : k);
+            S.Lp[at] = col[k] * inv;
+            S.LHp[at] = colh[k] * invh;
         }
         wv::sync();
 #pragma unroll
@@ -871,7 +874,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
         CK_STAMP(3);
 
         /* ================= P3 factor M and M + hB in registers; park the factors in LDS ================= */
-#ifdef CK_FACTOR_BY_HEIGHT
+#ifndef CK_FACTOR_IN_REGISTERS
         constexpr bool by_height = TOPO::is_static;
 #else
         constexpr bool by_height = false;
