@@ -125,6 +125,16 @@ typedef struct cm_model {
      * is sorted by (body1, body2, geom1, geom2) within the simple and the wave-cooperative groups, so contact
      * order is deterministic */
     int pair_geom1[CM_MAXPAIR], pair_geom2[CM_MAXPAIR];
+    /* everything about a pair that does not depend on the state, denormalised so the collision pass reads it with
+     * one level of (lane-coalesced) loads instead of chasing pair -> geom -> parameter arrays; the contact
+     * parameters are already mixed the way mj_contactParam does (priority, else solmix / max condim / max friction) */
+    int pair_type[CM_MAXPAIR];            /* geom1 type | geom2 type << 8 */
+    int pair_condim[CM_MAXPAIR];
+    double pair_margin[CM_MAXPAIR];       /* max of the two margins */
+    double pair_includemargin[CM_MAXPAIR];/* margin - max of the two gaps */
+    double pair_rbound[CM_MAXPAIR][2];
+    double pair_size[CM_MAXPAIR][6];      /* geom1 size, geom2 size */
+    double pair_solref[CM_MAXPAIR][2], pair_solimp[CM_MAXPAIR][5], pair_friction[CM_MAXPAIR][3];
 
     /* equality constraints (connect only) */
     int eq_body1[CM_MAXEQ], eq_body2[CM_MAXEQ], eq_active[CM_MAXEQ];

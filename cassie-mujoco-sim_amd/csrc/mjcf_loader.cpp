@@ -1192,7 +1192,38 @@ bool HostModel::compile(cm_model_t *o, std::string *err) const {
     }
     if ((int)pairs.size() > CM_MAXPAIR) return fail("too many candidate collision pairs");
     o->npair = (int)pairs.size();
-    for (int i = 0; i < o->npair; ++i) { o->pair_geom1[i] = pairs[i].g1; o->pair_geom2[i] = pairs[i].g2; }
+    for (int i = 0; i < o->npair; ++i) {
+        const int g1 = pairs[i].g1, g2 = pairs[i].g2;
+        o->pair_geom1[i] = g1; o->pair_geom2[i] = g2;
+        o->pair_type[i] = o->geom_type[g1] | (o->geom_type[g2] << 8);
+        o->pair_margin[i] = std::max(o->geom_margin[g1], o->geom_margin[g2]);
+        o->pair_includemargin[i] = o->pair_margin[i] - std::max(o->geom_gap[g1], o->geom_gap[g2]);
+        o->pair_rbound[i][0] = o->geom_rbound[g1]; o->pair_rbound[i][1] = o->geom_rbound[g2];
+        for (int k = 0; k < 3; ++k) { o->pair_size[i][k] = o->geom_size[g1][k]; o->pair_size[i][3 + k] = o->geom_size[g2][k]; }
+        /* contact parameter mixing (MuJoCo mj_contactParam): the geom with the higher priority wins outright; at equal
+         * priority condim and friction take the maximum and solref / solimp are blended by solmix */
+        const int pa = o->geom_priority[g1], pb = o->geom_priority[g2];
+        if (pa != pb) {
+            const int g = pa > pb ? g1 : g2;
+            o->pair_condim[i] = o->geom_condim[g];
+            for (int k = 0; k < 2; ++k) o->pair_solref[i][k] = o->geom_solref[g][k];
+            for (int k = 0; k < 5; ++k) o->pair_solimp[i][k] = o->geom_solimp[g][k];
+            for (int k = 0; k < 3; ++k) o->pair_friction[i][k] = o->geom_friction[g][k];
+        } else {
+            o->pair_condim[i] = std::max(o->geom_condim[g1], o->geom_condim[g2]);
+            const double s1 = o->geom_solmix[g1], s2 = o->geom_solmix[g2];
+            double mix;
+            if (s1 >= CM_MINVAL && s2 >= CM_MINVAL) mix = s1 / (s1 + s2);
+            else if (s1 < CM_MINVAL && s2 < CM_MINVAL) mix = 0.5;
+            else mix = s1 < CM_MINVAL ? 0.0 : 1.0;
+            if (o->geom_solref[g1][0] > 0 && o->geom_solref[g2][0] > 0)
+                for (int k = 0; k < 2; ++k) o->pair_solref[i][k] = mix * o->geom_solref[g1][k] + (1 - mix) * o->geom_solref[g2][k];
+            else
+                for (int k = 0; k < 2; ++k) o->pair_solref[i][k] = std::min(o->geom_solref[g1][k], o->geom_solref[g2][k]);
+            for (int k = 0; k < 5; ++k) o->pair_solimp[i][k] = mix * o->geom_solimp[g1][k] + (1 - mix) * o->geom_solimp[g2][k];
+            for (int k = 0; k < 3; ++k) o->pair_friction[i][k] = std::max(o->geom_friction[g1][k], o->geom_friction[g2][k]);
+        }
+    }
 
     for (int e = 0; e < neq; ++e) {
         o->eq_body1[e] = eq_body1[e]; o->eq_body2[e] = eq_body2[e]; o->eq_active[e] = eq_active[e];

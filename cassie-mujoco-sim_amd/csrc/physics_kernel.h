@@ -46,7 +46,11 @@ constexpr int NSTAMP = 48;   /* 0..15 stage boundaries, 16..47 sub-stage stamps 
 #define CK_TRI(k, i) ((k) * ((k) + 1) / 2 + (i))
 #define CK_STAMP(i) do { if (io.prof && lane == 0) io.prof[(size_t)env * NSTAMP + (i)] = wv::clock(); CK_FRESH(); } while (0)
 /* stage boundary: re-derive the lane index and its aliases (see wv::fresh_lane) */
+#ifdef CK_FRESH_MODEL
+#define CK_FRESH() do { lane = wv::fresh_lane(); b = lane; k_ = lane; isbody = b < nbody; isdof = k_ < nv; m = wv::opaque_ptr(m_launch); } while (0)
+#else
 #define CK_FRESH() do { lane = wv::fresh_lane(); b = lane; k_ = lane; isbody = b < nbody; isdof = k_ < nv; } while (0)
+#endif
 
 /* warning bits reported per env */
 enum { WARN_CONTACT_FULL = 1, WARN_CONSTRAINT_FULL = 2, WARN_UNSUPPORTED_PAIR = 4, WARN_DIVERGED = 8 };
@@ -105,7 +109,7 @@ struct EnvShared {
     /* contacts */
     double c_dist[CM_MAXCON], c_pos[CM_MAXCON][3], c_frame[CM_MAXCON][9], c_fri[CM_MAXCON][3];
     double c_solref[CM_MAXCON][2], c_solimp[CM_MAXCON][5], c_margin[CM_MAXCON];
-    int c_dim[CM_MAXCON], c_g1[CM_MAXCON], c_g2[CM_MAXCON];
+    int c_dim[CM_MAXCON], c_g1[CM_MAXCON], c_g2[CM_MAXCON], c_pair[CM_MAXCON];
 };
 
 /* ------------------------------------------------------------ small math --- */
@@ -334,38 +338,31 @@ WV_DEVICE int hfield_sphere(RawContact &c, ModelPtr m, const float *data, const 
     return 1;
 }
 
-/* stores one contact with its mixed parameters (priority wins, else max condim / max friction /
- * solmix-weighted solref, solimp) into slot `slot` of the env's contact list */
+/* parks one detected contact (geometry only) in the contact list; finish_contacts completes the entries */
 template <int NVP>
-WV_DEVICE void write_contact(EnvShared<NVP> &S, ModelPtr m, int slot, int g1, int g2, const RawContact &r, double includemargin) {
-    double fr[9];
-    for (int i = 0; i < 3; ++i) { fr[i] = r.normal[i]; fr[3 + i] = r.tangent[i]; fr[6 + i] = 0; }
-    make_frame(fr);
+WV_DEVICE void write_raw_contact(EnvShared<NVP> &S, int slot, int pair, const RawContact &r) {
     S.c_dist[slot] = r.dist;
-    for (int i = 0; i < 3; ++i) S.c_pos[slot][i] = r.pos[i];
-    for (int i = 0; i < 9; ++i) S.c_frame[slot][i] = fr[i];
-    S.c_g1[slot] = g1; S.c_g2[slot] = g2;
-    S.c_margin[slot] = includemargin;
-    const int pa = m->geom_priority[g1], pb = m->geom_priority[g2];
-    if (pa != pb) {
-        const int g = pa > pb ? g1 : g2;
-        S.c_dim[slot] = m->geom_condim[g];
-        for (int i = 0; i < 2; ++i) S.c_solref[slot][i] = m->geom_solref[g][i];
-        for (int i = 0; i < 5; ++i) S.c_solimp[slot][i] = m->geom_solimp[g][i];
-        for (int i = 0; i < 3; ++i) S.c_fri[slot][i] = m->geom_friction[g][i];
-    } else {
-        S.c_dim[slot] = m->geom_condim[g1] > m->geom_condim[g2] ? m->geom_condim[g1] : m->geom_condim[g2];
-        const double s1 = m->geom_solmix[g1], s2 = m->geom_solmix[g2];
-        double mix;
-        if (s1 >= CM_MINVAL && s2 >= CM_MINVAL) mix = s1 / (s1 + s2);
-        else if (s1 < CM_MINVAL && s2 < CM_MINVAL) mix = 0.5;
-        else mix = s1 < CM_MINVAL ? 0.0 : 1.0;
-        if (m->geom_solref[g1][0] > 0 && m->geom_solref[g2][0] > 0)
-            for (int i = 0; i < 2; ++i) S.c_solref[slot][i] = mix * m->geom_solref[g1][i] + (1 - mix) * m->geom_solref[g2][i];
-        else
-            for (int i = 0; i < 2; ++i) S.c_solref[slot][i] = fmin(m->geom_solref[g1][i], m->geom_solref[g2][i]);
-        for (int i = 0; i < 5; ++i) S.c_solimp[slot][i] = mix * m->geom_solimp[g1][i] + (1 - mix) * m->geom_solimp[g2][i];
-        for (int i = 0; i < 3; ++i) S.c_fri[slot][i] = fmax(m->geom_friction[g1][i], m->geom_friction[g2][i]);
+    S.c_pair[slot] = pair;
+    for (int i = 0; i < 3; ++i) { S.c_pos[slot][i] = r.pos[i]; S.c_frame[slot][i] = r.normal[i]; S.c_frame[slot][3 + i] = r.tangent[i]; }
+}
+
+/* lane = contact: contact frame from (normal, tangent hint) and the pair's pre-mixed parameters (model compile
+ * time, cm_model_t::pair_*), once per contact and outside the divergent pair loops */
+template <int NVP>
+WV_DEVICE void finish_contacts(EnvShared<NVP> &S, ModelPtr m, int lane, int ncon) {
+    if (lane < ncon) {
+        const int p = S.c_pair[lane];
+        double fr[9];
+        for (int i = 0; i < 6; ++i) fr[i] = S.c_frame[lane][i];
+        fr[6] = fr[7] = fr[8] = 0;
+        make_frame(fr);
+        for (int i = 0; i < 9; ++i) S.c_frame[lane][i] = fr[i];
+        S.c_g1[lane] = m->pair_geom1[p]; S.c_g2[lane] = m->pair_geom2[p];
+        S.c_margin[lane] = m->pair_includemargin[p];
+        S.c_dim[lane] = m->pair_condim[p];
+        for (int i = 0; i < 2; ++i) S.c_solref[lane][i] = m->pair_solref[p][i];
+        for (int i = 0; i < 5; ++i) S.c_solimp[lane][i] = m->pair_solimp[p][i];
+        for (int i = 0; i < 3; ++i) S.c_fri[lane][i] = m->pair_friction[p][i];
     }
 }
 
@@ -523,7 +520,8 @@ WV_DEVICE void pgs_rows_fast(const double (&brow)[CM_MAXEFC], int nrows, int r_,
 /* ======================================================== the env step ==== */
 template <int NVP, class TOPO>
 WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
-    ModelPtr m = (ModelPtr)(io.models + (size_t)env * io.model_stride);
+    const ModelPtr m_launch = (ModelPtr)(io.models + (size_t)env * io.model_stride);
+    ModelPtr m = m_launch;
     int lane = wv::lane();
     const int nq = m->nq, nv = m->nv, nu = m->nu, nbody = m->nbody, njnt = m->njnt;
     const double h = m->timestep;
@@ -918,17 +916,15 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
             const int p = p0 + lane;
             int n = 0;
             RawContact rc0, rc1;
-            int g1 = 0, g2 = 0;
-            double margin = 0, gap = 0;
             if (p < npass) {
-                g1 = m->pair_geom1[p]; g2 = m->pair_geom2[p];
-                const int t1 = m->geom_type[g1], t2 = m->geom_type[g2];
-                margin = fmax(m->geom_margin[g1], m->geom_margin[g2]);
-                gap = fmax(m->geom_gap[g1], m->geom_gap[g2]);
+                const int g1 = m->pair_geom1[p], g2 = m->pair_geom2[p], tt = m->pair_type[p];
+                const int t1 = tt & 255, t2 = tt >> 8;
+                const double margin = m->pair_margin[p];
                 const double *p1 = S.x.s.geom_xpos[g1], *p2 = S.x.s.geom_xpos[g2];
                 const double *m1 = S.x.s.geom_xmat[g1], *m2 = S.x.s.geom_xmat[g2];
-                const double rb1 = m->geom_rbound[g1], rb2 = m->geom_rbound[g2];
+                const double rb1 = m->pair_rbound[p][0], rb2 = m->pair_rbound[p][1];
                 double dif[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
+                CK_STAMP(31);
                 bool cull = false;
                 if (rb1 > 0 && rb2 > 0) {
                     double bound = rb1 + rb2 + margin;
@@ -938,8 +934,8 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
                     cull = dot3(dif, nn) > margin + rb2;
                 }
                 if (!cull) {
-                    const double s10 = m->geom_size[g1][0], s11 = m->geom_size[g1][1];
-                    const double s20 = m->geom_size[g2][0], s21 = m->geom_size[g2][1];
+                    const double s10 = m->pair_size[p][0], s11 = m->pair_size[p][1];
+                    const double s20 = m->pair_size[p][3], s21 = m->pair_size[p][4];
                     if (t1 == CM_GEOM_PLANE && t2 == CM_GEOM_SPHERE) {
                         n = plane_sphere(rc0, p1, m1, p2, s20, margin);
                     } else if (t1 == CM_GEOM_PLANE && t2 == CM_GEOM_CAPSULE) {
@@ -976,33 +972,34 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
                         if (hfield_sphere(tmp, m, io.hfield, p1, m1, e1, s20, margin)) { if (n == 0) rc0 = tmp; else rc1 = tmp; ++n; }
                         for (int i = 0; i < 3; ++i) { rc0.tangent[i] = axis[i]; rc1.tangent[i] = axis[i]; }
                     } else if (t1 == CM_GEOM_SPHERE && t2 == CM_GEOM_BOX) {
-                        double sb[3] = {m->geom_size[g2][0], m->geom_size[g2][1], m->geom_size[g2][2]};
+                        double sb[3] = {s20, s21, m->pair_size[p][5]};
                         n = sphere_box(rc0, p1, s10, p2, m2, sb, margin);
                     } else if (t1 == CM_GEOM_CAPSULE && t2 == CM_GEOM_BOX) {
-                        double sb[3] = {m->geom_size[g2][0], m->geom_size[g2][1], m->geom_size[g2][2]};
+                        double sb[3] = {s20, s21, m->pair_size[p][5]};
                         n = capsule_box(rc0, rc1, p1, m1, s10, s11, p2, m2, sb, margin);
                     } else {
                         warn |= WARN_UNSUPPORTED_PAIR;
                     }
                 }
             }
+            CK_STAMP(32);
             /* ballot-compact in pair order */
             const unsigned long long m1b = wv::ballot(n >= 1), m2b = wv::ballot(n >= 2);
             const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
             const int slot = ncon + wv::popc64(m1b & below) + wv::popc64(m2b & below);
-            if (n >= 1 && slot < CM_MAXCON) write_contact<NVP>(S, m, slot, g1, g2, rc0, margin - gap);
-            if (n >= 2 && slot + 1 < CM_MAXCON) write_contact<NVP>(S, m, slot + 1, g1, g2, rc1, margin - gap);
+            if (n >= 1 && slot < CM_MAXCON) write_raw_contact<NVP>(S, slot, p, rc0);
+            if (n >= 2 && slot + 1 < CM_MAXCON) write_raw_contact<NVP>(S, slot + 1, p, rc1);
             ncon += wv::popc64(m1b) + wv::popc64(m2b);
         }
         CK_STAMP(22);
         /* pass 2, one pair at a time with the whole wave: lane = feature (box corner / vertex), first four hits kept */
         for (int p = m->npair_simple; p < m->npair; ++p) {
-            const int g1 = m->pair_geom1[p], g2 = m->pair_geom2[p];
-            const int t1 = m->geom_type[g1], t2 = m->geom_type[g2];
-            const double margin = fmax(m->geom_margin[g1], m->geom_margin[g2]), gap = fmax(m->geom_gap[g1], m->geom_gap[g2]);
+            const int g1 = m->pair_geom1[p], g2 = m->pair_geom2[p], tt = m->pair_type[p];
+            const int t1 = tt & 255, t2 = tt >> 8;
+            const double margin = m->pair_margin[p];
             const double *p1 = S.x.s.geom_xpos[g1], *p2 = S.x.s.geom_xpos[g2];
             const double *m1 = S.x.s.geom_xmat[g1], *m2 = S.x.s.geom_xmat[g2];
-            const double rb1 = m->geom_rbound[g1], rb2 = m->geom_rbound[g2];
+            const double rb1 = m->pair_rbound[p][0], rb2 = m->pair_rbound[p][1];
             {
                 double dif[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
                 bool cull = false;
@@ -1014,7 +1011,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
             RawContact rc;
             if (t1 == CM_GEOM_PLANE && t2 == CM_GEOM_BOX) {
                 if (lane < 8) {
-                    const double sb0 = m->geom_size[g2][0], sb1 = m->geom_size[g2][1], sb2 = m->geom_size[g2][2];
+                    const double sb0 = m->pair_size[p][3], sb1 = m->pair_size[p][4], sb2 = m->pair_size[p][5];
                     double nrm[3] = {m1[2], m1[5], m1[8]}, dif[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
                     const double dist = dot3(dif, nrm);
                     double v[3] = {(lane & 1) ? sb0 : -sb0, (lane & 2) ? sb1 : -sb1, (lane & 4) ? sb2 : -sb2}, corner[3];
@@ -1029,10 +1026,10 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
             } else if (t1 == CM_GEOM_BOX && t2 == CM_GEOM_BOX) {
                 if (lane < 16) {
                     const bool second = lane >= 8;
-                    const int ga = second ? g2 : g1, gb = second ? g1 : g2;
                     const double *pa = second ? p2 : p1, *ma = second ? m2 : m1, *pb = second ? p1 : p2, *mb = second ? m1 : m2;
-                    double sa[3] = {m->geom_size[ga][0], m->geom_size[ga][1], m->geom_size[ga][2]};
-                    double sb[3] = {m->geom_size[gb][0], m->geom_size[gb][1], m->geom_size[gb][2]};
+                    const int oa = second ? 3 : 0, ob = second ? 0 : 3;
+                    double sa[3] = {m->pair_size[p][oa], m->pair_size[p][oa + 1], m->pair_size[p][oa + 2]};
+                    double sb[3] = {m->pair_size[p][ob], m->pair_size[p][ob + 1], m->pair_size[p][ob + 2]};
                     const int i = lane & 7;
                     double v[3] = {(i & 1) ? sa[0] : -sa[0], (i & 2) ? sa[1] : -sa[1], (i & 4) ? sa[2] : -sa[2]}, w[3], nw[3];
                     mulmatvec3(w, ma, v);
@@ -1051,11 +1048,13 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
             const unsigned long long hb = wv::ballot(hit);
             const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
             const int rank = wv::popc64(hb & below);
-            if (hit && rank < 4 && ncon + rank < CM_MAXCON) write_contact<NVP>(S, m, ncon + rank, g1, g2, rc, margin - gap);
+            if (hit && rank < 4 && ncon + rank < CM_MAXCON) write_raw_contact<NVP>(S, ncon + rank, p, rc);
             const int nh = wv::popc64(hb);
             ncon += nh < 4 ? nh : 4;
         }
         if (ncon > CM_MAXCON) { ncon = CM_MAXCON; warn |= WARN_CONTACT_FULL; }
+        wv::sync();
+        finish_contacts<NVP>(S, m, lane, ncon);
         CK_STAMP(5);
 
         /* ================= P6 velocities and bias forces (no recursion) ================= */

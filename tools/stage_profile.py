@@ -31,7 +31,7 @@ for n in (int(a) for a in (sys.argv[1:] or ["512", "4096"])):
         print("  %-24s %9.0f cycles  %5.1f%%" % (nm, d[:, i].mean(), 100 * d[:, i].mean() / tot.mean()))
     # sub-stage stamps: (label, from stamp, to stamp)
     sub = [("kin: joint locals", 0, 16), ("kin: level loop", 16, 1), ("geoms", 1, 17), ("com reduce", 17, 18), ("cinert+cdof", 18, 2),
-           ("crb subtree sums", 2, 19), ("buf", 19, 20), ("M columns", 20, 3), ("coll: block cull", 4, 21), ("coll: lane pass", 21, 22),
+           ("crb subtree sums", 2, 19), ("buf", 19, 20), ("M columns", 20, 3), ("coll: block cull", 4, 21), ("coll: lane pass", 21, 22), ("  pair loads", 21, 31), ("  narrow phase", 31, 32), ("  compact+write", 32, 22),
            ("coll: wave pass", 22, 5), ("vel: cvel+cdof_dot", 5, 23), ("vel: cacc+cfrc", 23, 24), ("vel: bias proj", 24, 6),
            ("rows: descriptors", 7, 25), ("rows: geometry", 25, 26), ("rows: impedance", 26, 27), ("rows: J loop", 27, 28),
            ("rows: sensors1", 28, 29), ("rows: dumps+sync", 29, 8), ("pgs: warm start", 10, 30), ("pgs: sweeps", 30, 11)]
