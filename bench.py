@@ -65,6 +65,22 @@ def gather_observations(obs, world, out=None):
     return out
 
 
+def pmc_traffic(env_steps_per_launch):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (tools/gpu_pmc.sh: FETCH_SIZE and WRITE_SIZE in
+    separate --pmc runs, corrected as MI355X_MICROARCH.md prescribes), scaled to this run's env-steps per launch.
+    The counters cannot be collected from inside the timed process, so this is the last measured figure, or None."""
+    import glob
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "round*", "*pmc_summary.json")))
+    for path in reversed(files):
+        try:
+            d = json.load(open(path))["derived"]
+            per_env_step = (d["hbm_read_bytes_per_launch"] + d["hbm_write_bytes_per_launch"]) / d["env_steps_per_launch"]
+            return per_env_step * env_steps_per_launch, os.path.relpath(path, REPO)
+        except (KeyError, ValueError, OSError):
+            continue
+    return None, None
+
+
 def cpu_baseline(model, budget_s=12.0):
     """Times the CPU oracle on a bounded sample of the same workload, all host cores (OpenMP over envs)."""
     import oracle_py
@@ -236,6 +252,7 @@ def main():
         steps_per_launch = args.steps / timed_launches
         achieved = ALGO_BYTES_PER_ENV_STEP * n * steps_per_launch / (kern_ms * 1e-3) / 1e9
         value = world * n * args.steps / elapsed
+        traffic, traffic_src = pmc_traffic(n * steps_per_launch)
         out = {
             "metric": "env-steps/sec (whole node) at N envs", "value": value, "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
@@ -247,7 +264,7 @@ def main():
                        "obs_allgather_every_steps": HOLD if world > 1 else None,
                        "substeps_per_launch": steps_per_launch, "launches_timed": timed_launches},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "cassie_step_kernel<32>", "kernel_ms": kern_ms, "env_steps_per_launch": n * steps_per_launch,
                          "note": "latency/fp64-VALU bound by design: 1976 algorithmic bytes vs ~0.22 MFLOP per env-step"},
             "envs_with_warnings": nwarn,

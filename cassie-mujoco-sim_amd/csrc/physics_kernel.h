@@ -488,31 +488,28 @@ WV_DEVICE void pgs_rows(const double (&brow)[CM_MAXEFC], int nrows, int r_, doub
     }
 }
 
-/* The same sweep with the guard off the dependent chain: the row's own lane keeps its step (v_writelane) and the
- * residual it started from, so every row's cost change -- hence the guard and the sweep's improvement -- can be
+/* The same sweep with the guard off the dependent chain: the row's own lane keeps the residual it started from
+ * (its step follows from it), so every row's cost change -- hence the guard and the sweep's improvement -- can be
  * evaluated once, after the sweep.  The caller re-runs the sweep through pgs_rows when a guard would have fired. */
 template <int I>
-WV_DEVICE void pgs_row_fast(const double (&brow)[CM_MAXEFC], int r_, double lo_f, double &sres, double &mydelta, double &mys) {
+WV_DEVICE void pgs_row_fast(const double (&brow)[CM_MAXEFC], int r_, double lo_f, double &sres, double &mys) {
     if constexpr (I < CM_MAXEFC) {
         const double delta = fmax(sres, lo_f);
-        if (r_ == I) mys = sres;
-        const double dlt = wv::readlane(delta, I);
-        mydelta = wv::writelane<I>(mydelta, dlt);
-        sres += brow[I] * dlt;
+        if (r_ == I) mys = sres; /* the residual this row started from: its step is recomputed from it after the sweep */
+        sres += brow[I] * wv::readlane(delta, I);
     }
 }
 /* rows go four to a (wave-uniform) branch: rows past the last one are inert -- their column of A is zero in every
  * lane and their own lane's step is finite -- so running up to three of them costs less than three more branches */
 template <int I>
-WV_DEVICE void pgs_rows_fast(const double (&brow)[CM_MAXEFC], int nrows, int r_, double lo_f, double &sres, double &mydelta,
-                             double &mys) {
+WV_DEVICE void pgs_rows_fast(const double (&brow)[CM_MAXEFC], int nrows, int r_, double lo_f, double &sres, double &mys) {
     if constexpr (I < CM_MAXEFC) {
         if (I < nrows) {
-            pgs_row_fast<I>(brow, r_, lo_f, sres, mydelta, mys);
-            pgs_row_fast<I + 1>(brow, r_, lo_f, sres, mydelta, mys);
-            pgs_row_fast<I + 2>(brow, r_, lo_f, sres, mydelta, mys);
-            pgs_row_fast<I + 3>(brow, r_, lo_f, sres, mydelta, mys);
-            pgs_rows_fast<I + 4>(brow, nrows, r_, lo_f, sres, mydelta, mys);
+            pgs_row_fast<I>(brow, r_, lo_f, sres, mys);
+            pgs_row_fast<I + 1>(brow, r_, lo_f, sres, mys);
+            pgs_row_fast<I + 2>(brow, r_, lo_f, sres, mys);
+            pgs_row_fast<I + 3>(brow, r_, lo_f, sres, mys);
+            pgs_rows_fast<I + 4>(brow, nrows, r_, lo_f, sres, mys);
         }
     }
 }
@@ -1544,8 +1541,10 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
                 double improvement = 0;
                 {
                     const double f0 = f, s0 = sres;
-                    double mydelta = 0, mys = 0;
-                    pgs_rows_fast<0>(arow, nrows, r_, flo - f, sres, mydelta, mys);
+                    double mys = 0;
+                    const double lo_f = flo - f;
+                    pgs_rows_fast<0>(arow, nrows, r_, lo_f, sres, mys);
+                    const double mydelta = fmax(mys, lo_f);
                     const double change = (r_ < nrows) ? mydelta * (halfAii * mydelta - Aii * mys) : 0.0;
                     if (wv::ballot(change > 1e-10) != 0ull || wv::debug_force_guarded()) { /* some row would have raised the cost: redo guarded */
                         f = f0; sres = s0;
