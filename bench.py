@@ -268,7 +268,7 @@ def main():
                          "kernel": "cassie_step_kernel<32>", "kernel_ms": kern_ms, "env_steps_per_launch": n * steps_per_launch,
                          "note": "latency/fp64-VALU bound by design: 1976 algorithmic bytes vs ~0.22 MFLOP per env-step"},
             "envs_with_warnings": nwarn,
-            "mean_constraint_rows": float(info[:, 1].mean()), "mean_pgs_iterations": float(info[:, 2].mean()),
+            "mean_constraint_rows": float(info[:, 1].mean()), "mean_pgs_iterations": float(info[:, 2].mean()), "mean_pgs_guarded_sweeps": float(info[:, 3].mean()),
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model)

@@ -1511,7 +1511,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
         if (!isrow) Aii = 1.0;
         const double invAii = 1.0 / Aii;
         double f = 0, res = isrow ? rb : 0.0;
-        int iters = 0;
+        int iters = 0, nguarded = 0; /* sweeps taken, and how many of them through the guarded fallback */
         if (nefc > 0) {
             if (m->flags & CM_FLAG_WARMSTART) {
                 if (isrow) {
@@ -1547,7 +1547,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
                     const double mydelta = fmax(mys, lo_f);
                     const double change = (r_ < nrows) ? mydelta * (halfAii * mydelta - Aii * mys) : 0.0;
                     if (wv::ballot(change > 1e-10) != 0ull || wv::debug_force_guarded()) { /* some row would have raised the cost: redo guarded */
-                        f = f0; sres = s0;
+                        f = f0; sres = s0; ++nguarded;
                         pgs_rows<0>(arow, nrows, r_, Aii, halfAii, flo, f, sres, improvement);
                     } else {
                         if (r_ < nrows) f += mydelta;
@@ -1647,7 +1647,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
         if (lane < nu) io.actuator_velocity[(size_t)env * io.su + lane] = m->act_gear[lane] * S.qvel[m->act_dofid[lane]];
         if (io.info && lane == 0) {
             io.info[(size_t)env * 4 + 0] = ncon; io.info[(size_t)env * 4 + 1] = nefc;
-            io.info[(size_t)env * 4 + 2] = iters; io.info[(size_t)env * 4 + 3] = 0;
+            io.info[(size_t)env * 4 + 2] = iters; io.info[(size_t)env * 4 + 3] = nguarded;
         }
         if (isdof) io.qacc[(size_t)env * io.sv + k_] = qacc;
         if (!io.integrate) break;

@@ -23,8 +23,8 @@ for n in (int(a) for a in (sys.argv[1:] or ["512", "4096"])):
     w, info = b.warnings()
     d = np.diff(st[:, :15], axis=1).astype(float)
     tot = (st[:, 14] - st[:, 0]).astype(float)
-    print("nenv %d: %.3f ms/step launch; per-env kernel cycles mean %.0f (min %.0f max %.0f); nefc mean %.1f iters mean %.1f"
-          % (n, ms, tot.mean(), tot.min(), tot.max(), info[:, 1].mean(), info[:, 2].mean()))
+    print("nenv %d: %.3f ms/step launch; per-env kernel cycles mean %.0f (min %.0f max %.0f); nefc mean %.1f iters mean %.1f (guarded %.2f)"
+          % (n, ms, tot.mean(), tot.min(), tot.max(), info[:, 1].mean(), info[:, 2].mean(), info[:, 3].mean()))
     span = st[:, 14].max() - st[:, 0].min()
     print("  whole-launch span in clock ticks: %d" % span)
     for i, nm in enumerate(names):
