@@ -739,20 +739,17 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
         /* ================= com of every kinematic tree (wave reduction per root) ================= */
         const double bmass = (isbody && b > 0) ? m->body_mass[b] : 0.0;
         {
-            /* mass-weighted positions go through an LDS tile (the crb tile is free at this point); one lane per root adds
-             * its tree up -- a 26-term sum of staged values beats four dependent 6-step shuffle reductions */
-            if (isbody) {
-                const double w = b > 0 ? bmass : 0.0;
-                S.x.s.crb[b][0] = w; S.x.s.crb[b][1] = w * S.x.s.xipos[b][0]; S.x.s.crb[b][2] = w * S.x.s.xipos[b][1];
-                S.x.s.crb[b][3] = w * S.x.s.xipos[b][2];
-            }
-            wv::sync();
-            if (lane < m->nroot) {
-                const int r = m->root_body[lane], e = m->body_subtreeend[r];
-                double sm = 0, sx = 0, sy = 0, sz = 0;
-                for (int c = r; c < e; ++c) { sm += S.x.s.crb[c][0]; sx += S.x.s.crb[c][1]; sy += S.x.s.crb[c][2]; sz += S.x.s.crb[c][3]; }
-                if (sm < CM_MINVAL) { S.com[r][0] = S.x.s.xipos[r][0]; S.com[r][1] = S.x.s.xipos[r][1]; S.com[r][2] = S.x.s.xipos[r][2]; }
-                else { const double inv = 1.0 / sm; S.com[r][0] = sx * inv; S.com[r][1] = sy * inv; S.com[r][2] = sz * inv; }
+            /* one masked DPP tree reduction per kinematic tree (wave_sum returns the total in every lane) */
+            const double px = isbody ? S.x.s.xipos[b < NB ? b : 0][0] : 0.0, py = isbody ? S.x.s.xipos[b < NB ? b : 0][1] : 0.0,
+                         pz = isbody ? S.x.s.xipos[b < NB ? b : 0][2] : 0.0;
+            for (int ri = 0; ri < m->nroot; ++ri) {
+                const int r = m->root_body[ri], e = m->body_subtreeend[r];
+                const double w = (isbody && b >= r && b < e) ? bmass : 0.0;
+                const double sm = wv::wave_sum(w), sx = wv::wave_sum(w * px), sy = wv::wave_sum(w * py), sz = wv::wave_sum(w * pz);
+                if (lane == 0) {
+                    if (sm < CM_MINVAL) { S.com[r][0] = S.x.s.xipos[r][0]; S.com[r][1] = S.x.s.xipos[r][1]; S.com[r][2] = S.x.s.xipos[r][2]; }
+                    else { const double inv = 1.0 / sm; S.com[r][0] = sx * inv; S.com[r][1] = sy * inv; S.com[r][2] = sz * inv; }
+                }
             }
         }
         wv::sync();
@@ -1054,35 +1051,64 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
         finish_contacts<NVP>(S, m, lane, ncon);
         CK_STAMP(5);
 
-        /* ================= P6 velocities and bias forces (no recursion) ================= */
-        /* All tree sums are written as dense wave-uniform loops with per-lane predicates: the operands are broadcast
-         * LDS reads staged four at a time, so nothing on the dependent chain waits for memory. */
-        /* velocity of every body (lane = body) and velocity entering every joint (lane = dof), same broadcast data */
-        double mycvel[6] = {0, 0, 0, 0, 0, 0}, vin[6] = {0, 0, 0, 0, 0, 0};
+        /* ================= P6 velocities and bias forces ================= */
+        /* Spatial vectors are all taken about the tree's centre of mass, so a body's velocity is the plain sum of
+         * cdof_k * qvel_k over the dofs on its chain to the root.  Lane = dof forms the terms, lane = body adds its own
+         * (contiguous, at most six) dofs and the chain sum is a pointer-jumping prefix over the 1st/2nd/4th/8th ancestors
+         * (four rounds, ping-pong between two LDS tiles) -- ~30 LDS round trips instead of a 32-dof dense loop. */
+        double mycvel[6], vin[6];
+        const int bd0 = isbody ? m->body_dofadr[b] : 0, bdn = isbody ? m->body_dofnum[b] : 0;
+        int anc[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) anc[r] = isbody ? m->body_anc[b][r] : 0;
         {
-            /* free joints: the rotational dofs also see the joint's own translational dofs; the translational ones see nothing */
+            if (lane < NVP) {
+                const double qd = isdof ? S.qvel[lane] : 0.0;
+                for (int t = 0; t < 6; ++t) S.x.s.buf[lane][t] = S.cdof[lane][t] * qd;
+            }
+            wv::sync();
+            double own[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const bool on = i < bdn;
+                const int k = on ? bd0 + i : 0;
+#pragma unroll
+                for (int t = 0; t < 6; ++t) { const double v = S.x.s.buf[k][t]; own[t] += on ? v : 0.0; }
+            }
+            /* prefix over the ancestor chain; tiles: cvel (even rounds read it) and cfrc */
+            for (int t = 0; t < 6; ++t) mycvel[t] = own[t];
+            if (lane < NB) for (int t = 0; t < 6; ++t) S.x.s.cvel[lane][t] = mycvel[t];
+            wv::sync();
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double up[6];
+                if ((r & 1) == 0) { for (int t = 0; t < 6; ++t) up[t] = S.x.s.cvel[anc[r]][t]; }
+                else { for (int t = 0; t < 6; ++t) up[t] = S.x.s.cfrc[anc[r]][t]; }
+                if (anc[r] > 0) for (int t = 0; t < 6; ++t) mycvel[t] += up[t];
+                if (lane < NB) {
+                    if ((r & 1) == 0) { for (int t = 0; t < 6; ++t) S.x.s.cfrc[lane][t] = mycvel[t]; }
+                    else { for (int t = 0; t < 6; ++t) S.x.s.cvel[lane][t] = mycvel[t]; }
+                }
+                wv::sync();
+            }
+            /* four rounds: the result sits in the cvel tile */
+            /* lane = dof: velocity entering the joint = parent body's velocity + the earlier dofs of the same body that
+             * MuJoCo has already added (dof_velmask); free joints: the rotational dofs also see the joint's own
+             * translational dofs, the translational ones see nothing */
             unsigned long long vmask = kvelmask;
             if (kjt == CM_JNT_FREE) vmask = (k_ - kda >= 3) ? (kvelmask | (7ull << kda)) : 0ull;
+            const int kparent = isdof ? m->body_parentid[kbody] : 0, kd0 = isdof ? m->body_dofadr[kbody] : 0;
+            const bool sees_parent = isdof && !(kjt == CM_JNT_FREE && k_ - kda < 3);
+            for (int t = 0; t < 6; ++t) vin[t] = sees_parent ? S.x.s.cvel[kparent][t] : 0.0;
 #pragma unroll
-            for (int k0 = 0; k0 < NVP; k0 += 4) {
-                double cc[4][6], qv[4];
+            for (int i = 0; i < 6; ++i) {
+                const int k = kd0 + i;
+                const bool on = isdof && k < nv && ((vmask >> k) & 1ull) && k >= kd0;
+                const int kk = on ? k : 0;
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-#pragma unroll
-                    for (int t = 0; t < 6; ++t) cc[kk][t] = S.cdof[k0 + kk][t];
-                    qv[kk] = S.qvel[k0 + kk];
-                }
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    const int k = k0 + kk;
-                    if (TOPO::is_static ? k >= TOPO::nv : k >= nv) continue;
-                    const double qb = ((bdofmask >> k) & 1ull) ? qv[kk] : 0.0, qd = ((vmask >> k) & 1ull) ? qv[kk] : 0.0;
-#pragma unroll
-                    for (int t = 0; t < 6; ++t) { mycvel[t] += cc[kk][t] * qb; vin[t] += cc[kk][t] * qd; }
-                }
+                for (int t = 0; t < 6; ++t) { const double v = S.x.s.buf[kk][t]; vin[t] += on ? v : 0.0; }
             }
         }
-        if (isbody) for (int i = 0; i < 6; ++i) S.x.s.cvel[b][i] = mycvel[i];
         /* lane = dof: time derivative of the motion axis = (velocity entering the joint) x axis */
         if (lane < NVP) {
             double cdd[6] = {0, 0, 0, 0, 0, 0}, cd[6];
@@ -1092,25 +1118,42 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
         }
         wv::sync();
         CK_STAMP(23);
-        /* lane = body: bias acceleration (gravity enters as -g on the world) and the body's inertial force */
-        double mycacc[6] = {0, 0, 0, -m->gravity[0], -m->gravity[1], -m->gravity[2]};
-#pragma unroll
-        for (int k0 = 0; k0 < NVP; k0 += 4) {
-            double cc[4][6], qv[4];
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-#pragma unroll
-                for (int t = 0; t < 6; ++t) cc[kk][t] = S.x.s.cdof_dot[k0 + kk][t];
-                qv[kk] = S.qvel[k0 + kk];
+        /* lane = body: bias acceleration = -g on the world + the same chain sum of cdof_dot_k * qvel_k; tiles: xfrc (free
+         * until the applied forces are loaded) and cfrc */
+        double mycacc[6];
+        {
+            if (lane < NVP) {
+                const double qd = isdof ? S.qvel[lane] : 0.0;
+                for (int t = 0; t < 6; ++t) S.x.s.buf[lane][t] = S.x.s.cdof_dot[lane][t] * qd;
             }
+            wv::sync();
+            double own[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const int k = k0 + kk;
-                if (TOPO::is_static ? k >= TOPO::nv : k >= nv) continue;
-                const double qb = ((bdofmask >> k) & 1ull) ? qv[kk] : 0.0;
+            for (int i = 0; i < 6; ++i) {
+                const bool on = i < bdn;
+                const int k = on ? bd0 + i : 0;
 #pragma unroll
-                for (int t = 0; t < 6; ++t) mycacc[t] += cc[kk][t] * qb;
+                for (int t = 0; t < 6; ++t) { const double v = S.x.s.buf[k][t]; own[t] += on ? v : 0.0; }
             }
+            for (int t = 0; t < 6; ++t) mycacc[t] = own[t];
+            if (lane < NB) for (int t = 0; t < 6; ++t) S.x.s.xfrc[lane][t] = mycacc[t];
+            wv::sync();
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double up[6];
+                if ((r & 1) == 0) { for (int t = 0; t < 6; ++t) up[t] = S.x.s.xfrc[anc[r]][t]; }
+                else { for (int t = 0; t < 6; ++t) up[t] = S.x.s.cfrc[anc[r]][t]; }
+                if (anc[r] > 0) for (int t = 0; t < 6; ++t) mycacc[t] += up[t];
+                if (r < 3) {
+                    if (lane < NB) {
+                        if ((r & 1) == 0) { for (int t = 0; t < 6; ++t) S.x.s.cfrc[lane][t] = mycacc[t]; }
+                        else { for (int t = 0; t < 6; ++t) S.x.s.xfrc[lane][t] = mycacc[t]; }
+                    }
+                    wv::sync();
+                }
+            }
+            mycacc[3] -= m->gravity[0]; mycacc[4] -= m->gravity[1]; mycacc[5] -= m->gravity[2];
+            wv::sync(); /* every lane has read the last round's tile before cfrc is overwritten below */
         }
         if (lane < NB) {
             double f6[6] = {0, 0, 0, 0, 0, 0};
