@@ -389,6 +389,10 @@ WV_DEVICE unsigned long long anc_mask(ModelPtr m, int k) {
     else return m->dof_ancmask[k];
 }
 
+/* bit `c` of a per-lane mask as 0.0 / 1.0: predicates of the dense tree loops are applied by multiplication (two VALU
+ * ops, no compare -> scalar mask -> select round trip, which costs ~30 clocks per use on this hardware) */
+WV_DEVICE double bitf(unsigned long long mask, int c) { return (double)(unsigned)((mask >> c) & 1ull); }
+
 /* reciprocal to full fp64 accuracy without the IEEE division sequence: hardware estimate + two Newton steps
  * (the pivots are positive and far from the denormal / overflow ranges) */
 WV_DEVICE double fast_rcp(double x) {
@@ -808,6 +812,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
          * bodies with a per-lane range predicate, operands staged four bodies at a time */
         {
             double acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            const unsigned bsub = (isbody && b > 0) ? (unsigned)(((1ull << bend) - 1ull) ^ ((1ull << b) - 1ull)) : 0u; /* bodies [b, bend) */
 #pragma unroll
             for (int c0 = 0; c0 < NB; c0 += 4) {
                 double ci4[4][10];
@@ -817,10 +822,9 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
                     for (int t = 0; t < 10; ++t) ci4[cc][t] = S.x.s.cinert[c0 + cc][t];
 #pragma unroll
                 for (int cc = 0; cc < 4; ++cc) {
-                    const int c = c0 + cc;
-                    const bool in = isbody && b > 0 && c >= b && c < bend;
+                    const double w = bitf(bsub, c0 + cc);
 #pragma unroll
-                    for (int t = 0; t < 10; ++t) acc[t] += in ? ci4[cc][t] : 0.0;
+                    for (int t = 0; t < 10; ++t) acc[t] = fma(w, ci4[cc][t], acc[t]);
                 }
             }
             if (isbody) for (int i = 0; i < 10; ++i) S.x.s.crb[b][i] = acc[i];
@@ -1173,6 +1177,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
         double qfrc_bias = 0;
         {
             double acc[6] = {0, 0, 0, 0, 0, 0};
+            const unsigned ksub = isdof ? (unsigned)(((1ull << kbend) - 1ull) ^ ((1ull << kbody) - 1ull)) : 0u; /* bodies [kbody, kbend) */
 #pragma unroll
             for (int c0 = 0; c0 < NB; c0 += 4) {
                 double ff[4][6];
@@ -1182,10 +1187,9 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
                     for (int t = 0; t < 6; ++t) ff[cc][t] = S.x.s.cfrc[c0 + cc][t];
 #pragma unroll
                 for (int cc = 0; cc < 4; ++cc) {
-                    const int c = c0 + cc;
-                    const bool in = isdof && c >= kbody && c < kbend;
+                    const double w = bitf(ksub, c0 + cc);
 #pragma unroll
-                    for (int t = 0; t < 6; ++t) acc[t] += in ? ff[cc][t] : 0.0;
+                    for (int t = 0; t < 6; ++t) acc[t] = fma(w, ff[cc][t], acc[t]);
                 }
             }
             for (int i = 0; i < 6; ++i) qfrc_bias += S.cdof[lane < NVP ? lane : 0][i] * acc[i];
