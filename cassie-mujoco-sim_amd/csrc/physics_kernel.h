@@ -1157,6 +1157,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
                 }
             }
             mycacc[3] -= m->gravity[0]; mycacc[4] -= m->gravity[1]; mycacc[5] -= m->gravity[2];
+            if (lane < NB) for (int t = 0; t < 6; ++t) S.x.s.buf[lane][t] = mycacc[t]; /* kept for the accelerometers */
             wv::sync(); /* every lane has read the last round's tile before cfrc is overwritten below */
         }
         if (lane < NB) {
@@ -1426,12 +1427,9 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
                     mulmatTvec3(sout, sxmat, mg);
                 } else if (aslot >= 0) {
                     /* accelerometer: velocity-product part of the body's com-frame acceleration (incl. -gravity) */
-                    double acc_lin[3] = {-m->gravity[0], -m->gravity[1], -m->gravity[2]}, acc_ang[3] = {0, 0, 0};
-                    for (unsigned long long mk = m->body_dofmask[sb]; mk; mk &= mk - 1) {
-                        const int k = wv::popc64((mk & (0ull - mk)) - 1);
-                        const double qv = S.qvel[k];
-                        for (int i = 0; i < 3; ++i) { acc_ang[i] += S.x.s.cdof_dot[k][i] * qv; acc_lin[i] += S.x.s.cdof_dot[k][3 + i] * qv; }
-                    }
+                    /* = the body's bias acceleration, which the velocity stage left in the buf tile */
+                    double acc_ang[3] = {S.x.s.buf[sb][0], S.x.s.buf[sb][1], S.x.s.buf[sb][2]};
+                    double acc_lin[3] = {S.x.s.buf[sb][3], S.x.s.buf[sb][4], S.x.s.buf[sb][5]};
                     double sp[3] = {m->site_pos[sobj][0], m->site_pos[sobj][1], m->site_pos[sobj][2]}, t[3];
                     mulmatvec3(t, S.x.s.xmat[sb], sp);
                     const double *c = S.com[m->body_rootid[sb]];
