@@ -153,10 +153,11 @@ class Batch:
             raise RuntimeError("timing failed: " + (lib().phys_last_error() or b"").decode())
         return ms.value
 
-    def profile_step(self):
-        """Runs one step and returns the per-env shader-clock stamps [nenv][48] taken at the stage boundaries."""
+    def profile_step(self, nsub=1):
+        """Runs one launch of `nsub` fused substeps and returns the per-env shader-clock stamps [nenv][48] taken at the
+        stage boundaries of the last substep."""
         st = np.zeros((self.nenv, 48), dtype=np.int64)
-        if lib().phys_batch_profile_step(self._h, st.ctypes.data) != 0:
+        if lib().phys_batch_profile_substeps(self._h, int(nsub), st.ctypes.data) != 0:
             raise RuntimeError("profile_step failed")
         return st
 

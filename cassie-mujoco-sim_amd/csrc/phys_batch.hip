@@ -313,13 +313,15 @@ int phys_batch_download_ext(phys_batch_t *b, cm_ext_t *host, int env0, int n) {
                ? 0 : -1;
 }
 
-int phys_batch_profile_step(phys_batch_t *b, long long *host_stamps) {
-    if (!b || !host_stamps) return -1;
+int phys_batch_profile_step(phys_batch_t *b, long long *host_stamps) { return phys_batch_profile_substeps(b, 1, host_stamps); }
+
+int phys_batch_profile_substeps(phys_batch_t *b, int nsub, long long *host_stamps) {
+    if (!b || !host_stamps || nsub < 1) return -1;
     (void)hipSetDevice(b->device);
     const size_t bytes = sizeof(long long) * ck::NSTAMP * (size_t)b->nenv;
     if (!hip_ok(hipMalloc((void **)&b->d_prof, bytes), "hipMalloc(prof)")) return -1;
     (void)hipMemsetAsync(b->d_prof, 0, bytes, b->stream);
-    int rc = launch(b, 1, 1, b->stream);
+    int rc = launch(b, nsub, 1, b->stream);
     bool ok = rc == 0 && hip_ok(hipStreamSynchronize(b->stream), "sync") &&
               hip_ok(hipMemcpy(host_stamps, b->d_prof, bytes, hipMemcpyDeviceToHost), "prof download");
     (void)hipFree(b->d_prof);

@@ -111,6 +111,8 @@ int phys_batch_download_ext(phys_batch_t *b, cm_ext_t *host, int env0, int n);
 
 /* per-stage shader-clock stamps of the next launches: [nenv][48] long long on the host after the call (profiling aid) */
 int phys_batch_profile_step(phys_batch_t *b, long long *host_stamps);
+/* same for one launch of nsub fused substeps: the stamps are those of the last substep */
+int phys_batch_profile_substeps(phys_batch_t *b, int nsub, long long *host_stamps);
 
 size_t phys_sizeof_model(void);
 const char *phys_last_error(void);

@@ -9,6 +9,7 @@ from cassie_amd import phys as P
 names = ["kinematics", "geoms+com+cinert+cdof", "crba", "factor", "collision", "velocity+rne", "qfrc_smooth",
          "rows+J", "halfsolve", "A", "pgs", "qacc", "sensors", "euler"]
 m = Model("cassie")
+NSUB = int(os.environ.get("NSUB", "1"))   # substeps fused per launch (the bench uses 50)
 for n in (int(a) for a in (sys.argv[1:] or ["512", "4096"])):
     b = Batch(m, n)
     b.set(P.F_QPOS, np.tile(m.qpos_init(), (n, 1)))
@@ -18,13 +19,13 @@ for n in (int(a) for a in (sys.argv[1:] or ["512", "4096"])):
     b.set(P.F_PD_KD, np.tile([7, 7, 8, 8, 5] * 2, (n, 1)))
     b.set_pd_mode(True)
     b.step(300); b.sync()
-    ms = b.time_steps(1, 50)
-    st = b.profile_step()
+    ms = b.time_steps(NSUB, 50 if NSUB == 1 else 4) / NSUB
+    st = b.profile_step(NSUB)
     w, info = b.warnings()
     d = np.diff(st[:, :15], axis=1).astype(float)
     tot = (st[:, 14] - st[:, 0]).astype(float)
-    print("nenv %d: %.3f ms/step launch; per-env kernel cycles mean %.0f (min %.0f max %.0f); nefc mean %.1f iters mean %.1f (guarded %.2f)"
-          % (n, ms, tot.mean(), tot.min(), tot.max(), info[:, 1].mean(), info[:, 2].mean(), info[:, 3].mean()))
+    print("nenv %d, %d substeps per launch: %.3f ms/step; per-env kernel cycles mean %.0f (min %.0f max %.0f); nefc mean %.1f iters mean %.1f (guarded %.2f)"
+          % (n, NSUB, ms, tot.mean(), tot.min(), tot.max(), info[:, 1].mean(), info[:, 2].mean(), info[:, 3].mean()))
     span = st[:, 14].max() - st[:, 0].min()
     print("  whole-launch span in clock ticks: %d" % span)
     for i, nm in enumerate(names):
