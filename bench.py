@@ -70,7 +70,12 @@ def pmc_traffic(env_steps_per_launch):
     separate --pmc runs, corrected as MI355X_MICROARCH.md prescribes), scaled to this run's env-steps per launch.
     The counters cannot be collected from inside the timed process, so this is the last measured figure, or None."""
     import glob
-    files = sorted(glob.glob(os.path.join(REPO, "profiles", "round*", "*pmc_summary.json")))
+    import re
+
+    def version(path):   # profiles/roundR/vN_pmc_summary.json -> (R, N)
+        m = re.search(r"round(\d+).*?v(\d+)_pmc_summary", path)
+        return (int(m.group(1)), int(m.group(2))) if m else (0, 0)
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "round*", "*pmc_summary.json")), key=version)
     for path in reversed(files):
         try:
             d = json.load(open(path))["derived"]
