@@ -1583,7 +1583,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
             for (int t = 0; t < CM_MAXEFC; ++t) arow[t] *= ninvAii;
             while (iters < m->iterations) {
                 const int nrows = wv::opaque(nefc); /* keeps the row-bound tests out of loop-invariant hoisting */
-                double improvement = 0;
+                bool converged;
                 {
                     const double f0 = f, s0 = sres;
                     double mys = 0;
@@ -1591,25 +1591,29 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
                     pgs_rows_fast<0>(arow, nrows, r_, lo_f, sres, mys);
                     const double mydelta = fmax(mys, lo_f);
                     const double change = (r_ < nrows) ? mydelta * (halfAii * mydelta - Aii * mys) : 0.0;
+                    /* The guarded sweep adds the rows' cost changes in row order, and the sum only feeds the convergence test.
+                     * A single-precision tree sum (issued before the guard ballot, so the two latencies overlap) decides it
+                     * unless it lands within a factor two of the tolerance -- far outside what precision or the order of
+                     * summation can move -- and only then is the ordered double-precision sum formed. */
+                    const float est = -wv::wave_sum_f32((float)change) * (float)scale, tol = (float)m->tolerance;
                     if (wv::ballot(change > 1e-10) != 0ull || wv::debug_force_guarded()) { /* some row would have raised the cost: redo guarded */
+                        double improvement = 0;
                         f = f0; sres = s0; ++nguarded;
                         pgs_rows<0>(arow, nrows, r_, Aii, halfAii, flo, f, sres, improvement);
+                        converged = improvement * scale < m->tolerance;
                     } else {
                         if (r_ < nrows) f += mydelta;
-                        /* The guarded sweep adds the rows' cost changes in row order.  The sum only feeds the convergence
-                         * test, so a tree sum decides it unless it lands within a factor two of the tolerance -- far
-                         * outside what the order of summation can move -- and only then is the ordered sum formed. */
-                        improvement = -wv::wave_sum(change);
-                        const double tol = m->tolerance, est = improvement * scale;
-                        if (est > 0.5 * tol && est < 2.0 * tol) {
-                            improvement = 0;
+                        if (est < 0.5f * tol) converged = true;
+                        else if (est > 2.0f * tol) converged = false;
+                        else {
+                            double improvement = 0;
                             for (int t = 0; t < nrows; ++t) improvement -= wv::readlane(change, t);
+                            converged = improvement * scale < m->tolerance;
                         }
                     }
                 }
-                improvement *= scale;
                 ++iters;
-                if (improvement < m->tolerance) break;
+                if (converged) break;
             }
         }
         CK_STAMP(11);

@@ -59,6 +59,20 @@ template <int DST> WV_DEVICE double writelane(double v, double s) {
     return __hiloint2double(hi, lo);
 }
 
+/* single-precision sum over the 64 lanes (same tree as wave_sum; the DPP moves fold into the adds): for estimates */
+template <int CTRL, int ROW_MASK> WV_DEVICE float dpp_take_f32(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+WV_DEVICE float wave_sum_f32(float v) {
+    v += dpp_take_f32<0xB1, 0xf>(v);
+    v += dpp_take_f32<0x4E, 0xf>(v);
+    v += dpp_take_f32<0x141, 0xf>(v);
+    v += dpp_take_f32<0x140, 0xf>(v);
+    v += dpp_take_f32<0x142, 0xa>(v);
+    v += dpp_take_f32<0x143, 0xc>(v);
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
 WV_DEVICE unsigned long long ballot(bool p) { return __ballot(p); }
 
 /* v taken from another lane through a DPP control (quad_perm / row_mirror / row_bcast), 0.0 where the control or the

@@ -121,6 +121,16 @@ double wave_sum(double v) { /* same association order as the device's DPP reduct
     { const double t = shfl(v, 31); if (row >= 2) v += t; }
     return shfl(v, 63);
 }
+float wave_sum_f32(float v) { /* same tree in single precision */
+    const int l = lane(), row = l >> 4;
+    v += (float)shfl((double)v, l ^ 1);
+    v += (float)shfl((double)v, l ^ 2);
+    v += (float)shfl((double)v, (l & ~7) | (7 - (l & 7)));
+    v += (float)shfl((double)v, (l & ~15) | (15 - (l & 15)));
+    { const float t = (float)shfl((double)v, ((row > 0 ? row - 1 : 0) << 4) | 15); if (row & 1) v += t; }
+    { const float t = (float)shfl((double)v, 31); if (row >= 2) v += t; }
+    return (float)shfl((double)v, 63);
+}
 }  // namespace wv
 
 static ck::PhysIO g_io;

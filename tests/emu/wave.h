@@ -33,6 +33,7 @@ int lane();
 template <int DST> inline double writelane(double v, double s) { return lane() == DST ? s : v; } /* s is the same in every lane */
 unsigned long long ballot(bool p);
 double wave_sum(double v);
+float wave_sum_f32(float v);
 inline long long clock() { return 0; }
 inline int opaque(int x) { return x; }
 inline void sched_fence() {}
