@@ -409,13 +409,14 @@ WV_DEVICE double fast_rcp(double x) {
  * (col[i] in lanes j > i) are never read, so they may absorb harmless updates.  On exit col[k] holds L[k][j]
  * for k > j; the pivots are returned through dinv / rsd / dinvH (wave-uniform, written by lane 0). */
 template <int NVP, class TOPO>
-WV_DEVICE void factor_pair_in_registers(ModelPtr m, double (&col)[NVP], double (&colh)[NVP], int lane, int nv,
+WV_DEVICE void factor_pair_in_registers(ModelPtr m, double h, double (&col)[NVP], double (&colh)[NVP], int lane, int nv,
                                         double *dinv, double *rsd, double *dinvH) {
 #pragma unroll
     for (int k = NVP - 1; k >= 0; --k) {
         if (TOPO::is_static ? k >= TOPO::nv : k >= nv) continue;
         const unsigned long long anc = anc_mask<TOPO>(m, k);
-        const double inv = fast_rcp(wv::readlane(col[k], k)), invh = fast_rcp(wv::readlane(colh[k], k));
+        const double arm = m->dof_armature[k]; /* diagonal terms, see the mass-matrix stage */
+        const double inv = fast_rcp(wv::readlane(col[k], k) + arm), invh = fast_rcp(wv::readlane(colh[k], k) + (arm + h * m->dof_damping[k]));
         if (lane == 0) { dinv[k] = inv; rsd[k] = sqrt(inv); dinvH[k] = invh; }
         if (anc == 0ull) continue;
 #pragma unroll
@@ -436,13 +437,14 @@ WV_DEVICE void factor_pair_in_registers(ModelPtr m, double (&col)[NVP], double (
  * anyway -- and then applies the rank-one updates with L[k][i] fetched back as LDS broadcast reads: two FMAs and two
  * reads per ancestor pair, no scalar registers, one LDS round trip per height instead of one per dof. */
 template <int NVP, class TOPO, class SH>
-WV_DEVICE void factor_pair_by_height(SH &S, double (&col)[NVP], double (&colh)[NVP], int lane) {
+WV_DEVICE void factor_pair_by_height(ModelPtr m, double h, SH &S, double (&col)[NVP], double (&colh)[NVP], int lane) {
 #pragma unroll
     for (int s = 0; s < TOPO::nheight; ++s) {
 #pragma unroll
         for (int k = NVP - 1; k >= 0; --k) {
             if (TOPO::height[k] != s) continue;
-            const double inv = fast_rcp(wv::readlane(col[k], k)), invh = fast_rcp(wv::readlane(colh[k], k));
+            const double arm = m->dof_armature[k]; /* diagonal terms, see the mass-matrix stage */
+            const double inv = fast_rcp(wv::readlane(col[k], k) + arm), invh = fast_rcp(wv::readlane(colh[k], k) + (arm + h * m->dof_damping[k]));
             S.dinv[k] = inv; S.dinvH[k] = invh; /* every lane holds the same value: an unpredicated same-address store */
             /* lanes at or past the diagonal all land on the (unused) diagonal slot: an unpredicated store */
             const int at = CK_TRI(k, 0) + (lane < k ? lane : k);
@@ -453,13 +455,21 @@ WV_DEVICE void factor_pair_by_height(SH &S, double (&col)[NVP], double (&colh)[N
 #pragma unroll
         for (int k = NVP - 1; k >= 0; --k) {
             if (TOPO::height[k] != s) continue;
-            int npair = 0;
+            /* all of this dof's multipliers are fetched before the first update (the fences keep the scheduler from
+             * pairing every LDS read with its own wait): one LDS latency per dof instead of one per ancestor pair */
+            double t[NVP], th[NVP];
 #pragma unroll
             for (int i = k - 1; i >= 0; --i) {
                 if (!((TOPO::table[k] >> i) & 1ull)) continue;
-                col[i] -= S.Lp[CK_TRI(k, i)] * col[k];
-                colh[i] -= S.LHp[CK_TRI(k, i)] * colh[k];
-                if ((++npair & 3) == 0) wv::sched_fence(); /* at most four pairs' multipliers in flight */
+                t[i] = S.Lp[CK_TRI(k, i)];
+                th[i] = S.LHp[CK_TRI(k, i)];
+            }
+            wv::sched_fence();
+#pragma unroll
+            for (int i = k - 1; i >= 0; --i) {
+                if (!((TOPO::table[k] >> i) & 1ull)) continue;
+                col[i] -= t[i] * col[k];
+                colh[i] -= th[i] * colh[k];
             }
             wv::sched_fence();
         }
@@ -842,7 +852,8 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
         double col[NVP], colh[NVP]; /* col[i] = M[i][lane] (i >= lane); colh: same for M + h*diag(damping) */
         double cdm[6]; /* this lane's motion axis, fetched where it is used rather than carried in registers */
         for (int i = 0; i < 6; ++i) cdm[i] = S.cdof[lane < NVP ? lane : 0][i];
-        const double karm = isdof ? m->dof_armature[k_] : 0.0, kdamp0 = isdof ? m->dof_damping[k_] : 0.0;
+        /* armature and h * damping sit on the diagonal only: they are added where the pivots are read (wave-uniform
+         * scalars there) instead of being selected into one lane-dependent entry of each column here */
         /* M[i][lane] = cdof_lane . (crb[body_i] cdof_i): the buf rows are broadcast reads, staged eight rows at a time so
          * the LDS latency is paid once per group instead of once per row */
 #pragma unroll
@@ -857,15 +868,14 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
                 const int i = i0 + ii;
                 double v = (cdm[0] * bb[ii][0] + cdm[1] * bb[ii][1]) + (cdm[2] * bb[ii][2] + cdm[3] * bb[ii][3]) + (cdm[4] * bb[ii][4] + cdm[5] * bb[ii][5]);
                 if (!(i < nv && ((kdesc >> i) & 1ull))) v = 0;
-                if (i == k_ && isdof) v += karm;
                 col[i] = v;
-                colh[i] = (i == k_) ? v + h * kdamp0 : v;
+                colh[i] = v;
             }
         }
         if (io.ext && isdof) {
             cm_ext_t *ex = io.ext + env;
 #pragma unroll
-            for (int i = 0; i < NVP; ++i) if (i < nv && i >= k_) { ex->qM[i][k_] = col[i]; ex->qM[k_][i] = col[i]; }
+            for (int i = 0; i < NVP; ++i) if (i < nv && i >= k_) { const double v = (i == k_) ? col[i] + m->dof_armature[k_] : col[i]; ex->qM[i][k_] = v; ex->qM[k_][i] = v; }
         }
         CK_STAMP(3);
 
@@ -876,9 +886,9 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
         constexpr bool by_height = false;
 #endif
         if constexpr (by_height) {
-            factor_pair_by_height<NVP, TOPO>(S, col, colh, lane);
+            factor_pair_by_height<NVP, TOPO>(m, h, S, col, colh, lane);
         } else {
-            factor_pair_in_registers<NVP, TOPO>(m, col, colh, lane, nv, S.dinv, S.rsd, S.dinvH);
+            factor_pair_in_registers<NVP, TOPO>(m, h, col, colh, lane, nv, S.dinv, S.rsd, S.dinvH);
             if (isdof) {
 #pragma unroll
                 for (int k = 1; k < NVP; ++k) {
