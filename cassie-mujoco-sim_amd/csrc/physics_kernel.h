@@ -1511,17 +1511,41 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
         CK_STAMP(8);
 
         /* ================= half solve in registers: Y = D^-1/2 L^-T [J^T | qfrc_smooth], lane = column ================= */
+        if constexpr (TOPO::is_static) {
+            /* The multipliers do not depend on the solve, so dof k - 1's row of L is fetched (LDS broadcast reads) while
+             * dof k's updates run; the fences keep the scheduler from re-pairing every read with its own wait. */
+            double ta[NVP], tb[NVP], ra = 0, rb = 0;
+            auto fetch = [&](int k, double (&t)[NVP], double &rs) {
 #pragma unroll
-        for (int k = NVP - 1; k >= 0; --k) {
-            if (TOPO::is_static ? k >= TOPO::nv : k >= nv) continue;
-            const unsigned long long anc = anc_mask<TOPO>(m, k);
-            const double xk = ycol[k];
+                for (int i = k - 1; i >= 0; --i) if ((TOPO::table[k] >> i) & 1ull) t[i] = S.Lp[CK_TRI(k, i)];
+                rs = S.rsd[k];
+            };
+            fetch(TOPO::nv - 1, ((TOPO::nv - 1) & 1) ? ta : tb, ((TOPO::nv - 1) & 1) ? ra : rb);
 #pragma unroll
-            for (int i = k - 1; i >= 0; --i) {
-                if (!((anc >> i) & 1ull)) continue;
-                ycol[i] -= S.Lp[CK_TRI(k, i)] * xk;
+            for (int k = NVP - 1; k >= 0; --k) {
+                if (k >= TOPO::nv) continue;
+                if (k > 0) fetch(k - 1, ((k - 1) & 1) ? ta : tb, ((k - 1) & 1) ? ra : rb);
+                wv::sched_fence();
+                const double (&t)[NVP] = (k & 1) ? ta : tb;
+                const double xk = ycol[k];
+#pragma unroll
+                for (int i = k - 1; i >= 0; --i) if ((TOPO::table[k] >> i) & 1ull) ycol[i] -= t[i] * xk;
+                ycol[k] = xk * ((k & 1) ? ra : rb);
+                wv::sched_fence();
             }
-            ycol[k] = xk * S.rsd[k];
+        } else {
+#pragma unroll
+            for (int k = NVP - 1; k >= 0; --k) {
+                if (k >= nv) continue;
+                const unsigned long long anc = m->dof_ancmask[k];
+                const double xk = ycol[k];
+#pragma unroll
+                for (int i = k - 1; i >= 0; --i) {
+                    if (!((anc >> i) & 1ull)) continue;
+                    ycol[i] -= S.Lp[CK_TRI(k, i)] * xk;
+                }
+                ycol[k] = xk * S.rsd[k];
+            }
         }
 #pragma unroll
         for (int k = 0; k < NVP; ++k) S.x.Yr[r_][k] = ycol[k];
@@ -1540,6 +1564,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
                 double yr[NVP];
 #pragma unroll
                 for (int k = 0; k < NVP; ++k) yr[k] = S.x.Yr[r][k];
+                wv::sched_fence(); /* keep the reads together: without it every read gets its own wait */
                 double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
 #pragma unroll
                 for (int k = 0; k < NVP; k += 4) {
