@@ -863,6 +863,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
             for (int ii = 0; ii < 8; ++ii)
 #pragma unroll
                 for (int t = 0; t < 6; ++t) bb[ii][t] = S.x.s.buf[i0 + ii][t];
+            wv::sched_fence();
 #pragma unroll
             for (int ii = 0; ii < 8; ++ii) {
                 const int i = i0 + ii;
@@ -1196,6 +1197,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
                 for (int cc = 0; cc < 4; ++cc)
 #pragma unroll
                     for (int t = 0; t < 6; ++t) ff[cc][t] = S.x.s.cfrc[c0 + cc][t];
+                wv::sched_fence();
 #pragma unroll
                 for (int cc = 0; cc < 4; ++cc) {
                     const double w = bitf(ksub, c0 + cc);
@@ -1391,6 +1393,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
                 for (int t = 0; t < 6; ++t) cc[kk][t] = S.cdof[k0 + kk][t];
                 qv[kk] = S.qvel[k0 + kk]; qw[kk] = S.qacc_ws[k0 + kk]; qs[kk] = S.qfrc_smooth[k0 + kk];
             }
+            wv::sched_fence();
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 const int k = k0 + kk;
