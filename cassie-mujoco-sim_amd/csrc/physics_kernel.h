@@ -611,6 +611,9 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
          * over the tree levels is then just R = Rp Rl, p = pp + Rp pl -- no trigonometry, quaternions or square
          * roots on the dependent chain. */
         double Rl[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, pl[3] = {0, 0, 0}, qlq[4] = {1, 0, 0, 0};
+        int kanc[4]; /* the four jump ancestors in one 16-byte read, issued with the stage's other model reads */
+#pragma unroll
+        for (int r = 0; r < 4; ++r) kanc[r] = isbody ? m->body_anc[b][r] : 0;
         const bool isfree = bjt == CM_JNT_FREE;
         if (isbody && b > 0) {
             double bpos[3], bq[4];
@@ -670,7 +673,8 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
         for (int i = 0; i < 3; ++i) xp[i] = pl[i];
         for (int i = 0; i < 4; ++i) xq[i] = qlq[i];
         {
-            double *bufB = &S.x.s.cinert[0][0]; /* 16 doubles per body: R(9) p(3) q(4) */
+            double *bufB = &S.x.s.cinert[0][0]; /* 16 doubles per body, R(9) p(3) q(4), at a stride of 17: a 128-byte stride
+                                                   would put all lanes on two LDS banks */
             if (lane < NB) {
                 for (int i = 0; i < 9; ++i) S.x.s.xmat[lane][i] = xm[i];
                 for (int i = 0; i < 3; ++i) S.x.s.xpos[lane][i] = xp[i];
@@ -679,16 +683,16 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
             wv::sync();
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int a = isbody ? m->body_anc[b][r] : 0;
+                const int a = kanc[r];
                 double Ra[9], pa[3], qa[4];
                 if ((r & 1) == 0) {
                     for (int i = 0; i < 9; ++i) Ra[i] = S.x.s.xmat[a][i];
                     for (int i = 0; i < 3; ++i) pa[i] = S.x.s.xpos[a][i];
                     for (int i = 0; i < 4; ++i) qa[i] = S.x.s.xquat[a][i];
                 } else {
-                    for (int i = 0; i < 9; ++i) Ra[i] = bufB[a * 16 + i];
-                    for (int i = 0; i < 3; ++i) pa[i] = bufB[a * 16 + 9 + i];
-                    for (int i = 0; i < 4; ++i) qa[i] = bufB[a * 16 + 12 + i];
+                    for (int i = 0; i < 9; ++i) Ra[i] = bufB[a * 17 + i];
+                    for (int i = 0; i < 3; ++i) pa[i] = bufB[a * 17 + 9 + i];
+                    for (int i = 0; i < 4; ++i) qa[i] = bufB[a * 17 + 12 + i];
                 }
                 if (a > 0 || r == 0) { /* the world's transform is the identity: nothing to compose beyond the root */
                     double Rn[9], pn[3];
@@ -704,9 +708,9 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
                 }
                 if (lane < NB) {
                     if ((r & 1) == 0) {
-                        for (int i = 0; i < 9; ++i) bufB[lane * 16 + i] = xm[i];
-                        for (int i = 0; i < 3; ++i) bufB[lane * 16 + 9 + i] = xp[i];
-                        for (int i = 0; i < 4; ++i) bufB[lane * 16 + 12 + i] = xq[i];
+                        for (int i = 0; i < 9; ++i) bufB[lane * 17 + i] = xm[i];
+                        for (int i = 0; i < 3; ++i) bufB[lane * 17 + 9 + i] = xp[i];
+                        for (int i = 0; i < 4; ++i) bufB[lane * 17 + 12 + i] = xq[i];
                     } else {
                         for (int i = 0; i < 9; ++i) S.x.s.xmat[lane][i] = xm[i];
                         for (int i = 0; i < 3; ++i) S.x.s.xpos[lane][i] = xp[i];
@@ -727,8 +731,9 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
             for (int i = 0; i < 3; ++i)
                 for (int c = 0; c < 3; ++c) ximat[3 * i + c] = xm[3 * i] * im[c] + xm[3 * i + 1] * im[3 + c] + xm[3 * i + 2] * im[6 + c];
         }
-        if (lane < njnt && m->jnt_type[lane] != CM_JNT_FREE) {
-            const int pb = m->body_parentid[m->jnt_bodyid[lane]];
+        const int jpb = lane < njnt ? m->jnt_parentbody[lane] : -1;
+        if (jpb >= 0) {
+            const int pb = jpb;
             double al[3] = {S.x.s.xanchor[lane][0], S.x.s.xanchor[lane][1], S.x.s.xanchor[lane][2]};
             double xl[3] = {S.x.s.xaxis[lane][0], S.x.s.xaxis[lane][1], S.x.s.xaxis[lane][2]}, aw[3], xw[3];
             mulmatvec3(aw, S.x.s.xmat[pb], al);
