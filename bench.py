@@ -159,6 +159,8 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=4096)
     ap.add_argument("--substeps-per-launch", type=int, default=HOLD,
                     help="physics steps fused into one kernel launch (at most up to the next PD-target re-draw)")
+    ap.add_argument("--model", default="cassie", choices=["cassie", "cassie_hfield", "cassie_tray_box"],
+                    help="cassie = BASELINE configs[1] (the headline); the other two are configs[3] / configs[4], for the record")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -181,7 +183,7 @@ def main():
     from cassie_amd import Batch, Model
     from cassie_amd import phys as P
 
-    model = Model("cassie")
+    model = Model(args.model)
     pod = model.pod
     n = args.envs_per_gpu
     env_ids = shard_env_ids(rank, world, n)
@@ -189,6 +191,10 @@ def main():
     npolicy = (total_steps + HOLD - 1) // HOLD + 1
 
     b = Batch(model, n, device=local_rank)
+    if args.model == "cassie_hfield":   # terrain of reference example/test_hfield.py:39-41, shared by all envs
+        hf = np.random.default_rng(99).random((200, 200)).astype(np.float32)
+        hf[95:105, 95:105] = 0
+        b.set_hfield(hf)
     dev = torch.device("cuda", local_rank)
     # state and inputs live in HBM before the timed region starts (torch owns the observation fields)
     qpos = torch.from_numpy(np.tile(model.qpos_init(), (n, 1))).to(dev)
@@ -255,27 +261,30 @@ def main():
         # dominant-kernel duration: HIP events on the launch stream around the K timed launches
         kern_ms = launch_ms_stream
         steps_per_launch = args.steps / timed_launches
-        achieved = ALGO_BYTES_PER_ENV_STEP * n * steps_per_launch / (kern_ms * 1e-3) / 1e9
+        # read qpos+qvel+qacc_warmstart+ctrl, write qpos+qvel+qacc+sensordata+actuator_velocity (1976 B for cassie)
+        algo_bytes = 8 * ((pod.nq + 2 * pod.nv + pod.nu) + (pod.nq + 2 * pod.nv + pod.nsensordata + pod.nu))
+        assert args.model != "cassie" or algo_bytes == ALGO_BYTES_PER_ENV_STEP
+        achieved = algo_bytes * n * steps_per_launch / (kern_ms * 1e-3) / 1e9
         value = world * n * args.steps / elapsed
         traffic, traffic_src = pmc_traffic(n * steps_per_launch)
         out = {
             "metric": "env-steps/sec (whole node) at N envs", "value": value, "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%d envs/GPU, cassie.xml, random joint-PD targets re-drawn every %d steps, "
+            "config": {"workload": "%d envs/GPU, %s.xml, random joint-PD targets re-drawn every %d steps, "
                                    "PD + motor limit + physics on device (cassie_sim_step_pd motor-PD semantics, "
-                                   "Agility host blocks not in the timed region)" % (n, HOLD),
+                                   "Agility host blocks not in the timed region)" % (n, args.model, HOLD),
                        "envs_total": world * n, "parallelism": "env-sharded x%d" % world,
                        "obs_allgather_every_steps": HOLD if world > 1 else None,
                        "substeps_per_launch": steps_per_launch, "launches_timed": timed_launches},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "cassie_step_kernel<32>", "kernel_ms": kern_ms, "env_steps_per_launch": n * steps_per_launch,
-                         "note": "latency/fp64-VALU bound by design: 1976 algorithmic bytes vs ~0.22 MFLOP per env-step"},
+                         "kernel": "cassie_step_kernel<%d>" % (32 if pod.nv <= 32 else 40), "kernel_ms": kern_ms, "algorithmic_bytes_per_env_step": algo_bytes, "env_steps_per_launch": n * steps_per_launch,
+                         "note": "latency-bound by design: ~2 KB of state vs ~0.22 MFLOP of serially dependent fp64 per env-step"},
             "envs_with_warnings": nwarn,
             "mean_constraint_rows": float(info[:, 1].mean()), "mean_pgs_iterations": float(info[:, 2].mean()), "mean_pgs_guarded_sweeps": float(info[:, 3].mean()),
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.model == "cassie":
             out["cpu_baseline"] = cpu_baseline(model)
             b.close()
             out["step_pd_host_api"] = step_pd_host_api(n)
