@@ -34,9 +34,15 @@ WV_DEVICE int fresh_lane() {
 }
 WV_DEVICE int env_id() { return (int)blockIdx.x; }
 
-/* workgroup == one wave: this is an LDS fence + s_barrier that the backend
- * reduces to a wave barrier; it orders LDS traffic between lanes */
-WV_DEVICE void sync() { __syncthreads(); }
+/* Orders LDS traffic between the lanes of the wave.  The workgroup IS one wave, whose LDS instructions are issued and
+ * executed in program order, so a later read already sees an earlier write of any lane: all that is needed is that
+ * the compiler keeps the order (a wavefront-scope fence, no instructions).  __syncthreads() would add
+ * `s_waitcnt vmcnt(0) lgkmcnt(0)` -- a full drain of LDS and vector memory -- at each of the ~40 stage boundaries. */
+WV_DEVICE void sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 WV_DEVICE double shfl(double v, int src_lane) { return __shfl(v, src_lane, WV_WAVE); }
 WV_DEVICE double shfl_xor(double v, int mask) { return __shfl_xor(v, mask, WV_WAVE); }
