@@ -108,6 +108,10 @@ typedef struct cm_model {
     double dof_armature[CM_MAXV], dof_damping[CM_MAXV], dof_invweight0[CM_MAXV];
     uint64_t dof_ancmask[CM_MAXV];        /* proper ancestors of dof k in the dof tree (M's row pattern) */
     uint64_t dof_descmask[CM_MAXV];       /* dofs that have k as ancestor, plus k itself (M's column pattern) */
+    int dof_anc[CM_MAXV][5];              /* 1st, 2nd, 4th, 8th, 16th ancestor dof (-1 = none) for pointer-jumping prefix sums */
+    int dof_vinsrc[CM_MAXV];              /* dof whose chain sum is the velocity entering dof k's joint (-1 = none): the nearest
+                                             ancestor of another joint; for the rotational dofs of a free joint its last translational dof */
+    int body_lastdof[CM_MAXBODY];         /* last dof on the body's chain to the root (-1 = none) */
     uint64_t dof_velmask[CM_MAXV];        /* ancestors of k that belong to other joints (velocity seen by joint k) */
 
     /* collision geoms (contype|conaffinity != 0) */

@@ -1095,6 +1095,26 @@ bool HostModel::compile(cm_model_t *o, std::string *err) const {
         o->dof_velmask[d] = vel;
     }
     for (int d = 0; d < nv; ++d) {
+        int depth = 0;
+        for (int a = dof_parentid[d]; a >= 0; a = dof_parentid[a]) ++depth;
+        if (depth >= 32) return fail("dof chain deeper than 32");
+        for (int r = 0, hop = 1; r < 5; ++r, hop *= 2) {
+            int a = d;
+            for (int t = 0; t < hop && a >= 0; ++t) a = dof_parentid[a];
+            o->dof_anc[d][r] = a;
+        }
+        int src = dof_parentid[d];
+        while (src >= 0 && dof_jntid[src] == dof_jntid[d]) src = dof_parentid[src];
+        const int j = dof_jntid[d];
+        if (jnt_type[j] == CM_JNT_FREE) src = (d - jnt_dofadr[j] >= 3) ? jnt_dofadr[j] + 2 : -1;
+        o->dof_vinsrc[d] = src;
+    }
+    for (int b = 0; b < nbody; ++b) {
+        int a = b;
+        while (a > 0 && body_dofnum[a] == 0) a = body_parentid[a];
+        o->body_lastdof[b] = a > 0 ? body_dofadr[a] + body_dofnum[a] - 1 : -1;
+    }
+    for (int d = 0; d < nv; ++d) {
         uint64_t desc = 1ull << d;
         for (int k = 0; k < nv; ++k)
             if ((o->dof_ancmask[k] >> d) & 1ull) desc |= 1ull << k;

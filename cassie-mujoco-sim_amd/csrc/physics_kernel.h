@@ -1072,109 +1072,60 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
         CK_STAMP(5);
 
         /* ================= P6 velocities and bias forces ================= */
-        /* Spatial vectors are all taken about the tree's centre of mass, so a body's velocity is the plain sum of
-         * cdof_k * qvel_k over the dofs on its chain to the root.  Lane = dof forms the terms, lane = body adds its own
-         * (contiguous, at most six) dofs and the chain sum is a pointer-jumping prefix over the 1st/2nd/4th/8th ancestors
-         * (four rounds, ping-pong between two LDS tiles) -- ~30 LDS round trips instead of a 32-dof dense loop. */
-        double mycvel[6], vin[6];
-        const int bd0 = isbody ? m->body_dofadr[b] : 0, bdn = isbody ? m->body_dofnum[b] : 0;
-        int anc[4];
+        /* Spatial vectors are all taken about the tree's centre of mass, so the velocity at the end of dof k's chain is
+         * the plain sum of cdof_a * qvel_a over k and its ancestor dofs.  Lane = dof: the terms go to an LDS tile and
+         * the chain sums are a pointer-jumping prefix over the 1st/2nd/4th/8th/16th ancestor dofs, in place (one wave:
+         * every lane's read of a round is issued before any lane's write).  A body's velocity is the sum at its last
+         * dof; the velocity entering a joint is the sum at dof_vinsrc. */
+        double mycvel[6], mycacc[6];
+        int danc[5];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) anc[r] = isbody ? m->body_anc[b][r] : 0;
-        {
-            if (lane < NVP) {
-                const double qd = isdof ? S.qvel[lane] : 0.0;
-                for (int t = 0; t < 6; ++t) S.x.s.buf[lane][t] = S.cdof[lane][t] * qd;
-            }
-            wv::sync();
-            double own[6] = {0, 0, 0, 0, 0, 0};
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                const bool on = i < bdn;
-                const int k = on ? bd0 + i : 0;
-#pragma unroll
-                for (int t = 0; t < 6; ++t) { const double v = S.x.s.buf[k][t]; own[t] += on ? v : 0.0; }
-            }
-            /* prefix over the ancestor chain; tiles: cvel (even rounds read it) and cfrc */
-            for (int t = 0; t < 6; ++t) mycvel[t] = own[t];
-            if (lane < NB) for (int t = 0; t < 6; ++t) S.x.s.cvel[lane][t] = mycvel[t];
+        for (int r = 0; r < 5; ++r) danc[r] = isdof ? m->dof_anc[k_][r] : -1;
+        const int blast = isbody ? m->body_lastdof[b] : -1;
+        const int kvin = isdof ? m->dof_vinsrc[k_] : -1;
+        auto chain_sums = [&](double (&acc)[6]) { /* acc: this dof's term in, its chain sum out; tile: buf */
+            if (lane < NVP) for (int t = 0; t < 6; ++t) S.x.s.buf[lane][t] = acc[t];
             wv::sync();
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
+            for (int r = 0; r < 5; ++r) {
                 double up[6];
-                if ((r & 1) == 0) { for (int t = 0; t < 6; ++t) up[t] = S.x.s.cvel[anc[r]][t]; }
-                else { for (int t = 0; t < 6; ++t) up[t] = S.x.s.cfrc[anc[r]][t]; }
-                if (anc[r] > 0) for (int t = 0; t < 6; ++t) mycvel[t] += up[t];
-                if (lane < NB) {
-                    if ((r & 1) == 0) { for (int t = 0; t < 6; ++t) S.x.s.cfrc[lane][t] = mycvel[t]; }
-                    else { for (int t = 0; t < 6; ++t) S.x.s.cvel[lane][t] = mycvel[t]; }
-                }
+                const int a = danc[r] >= 0 ? danc[r] : 0;
+                for (int t = 0; t < 6; ++t) up[t] = S.x.s.buf[a][t];
+                wv::sync();
+                if (danc[r] >= 0) for (int t = 0; t < 6; ++t) acc[t] += up[t];
+                if (lane < NVP) for (int t = 0; t < 6; ++t) S.x.s.buf[lane][t] = acc[t];
                 wv::sync();
             }
-            /* four rounds: the result sits in the cvel tile */
-            /* lane = dof: velocity entering the joint = parent body's velocity + the earlier dofs of the same body that
-             * MuJoCo has already added (dof_velmask); free joints: the rotational dofs also see the joint's own
-             * translational dofs, the translational ones see nothing */
-            unsigned long long vmask = kvelmask;
-            if (kjt == CM_JNT_FREE) vmask = (k_ - kda >= 3) ? (kvelmask | (7ull << kda)) : 0ull;
-            const int kparent = isdof ? m->body_parentid[kbody] : 0, kd0 = isdof ? m->body_dofadr[kbody] : 0;
-            const bool sees_parent = isdof && !(kjt == CM_JNT_FREE && k_ - kda < 3);
-            for (int t = 0; t < 6; ++t) vin[t] = sees_parent ? S.x.s.cvel[kparent][t] : 0.0;
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                const int k = kd0 + i;
-                const bool on = isdof && k < nv && ((vmask >> k) & 1ull) && k >= kd0;
-                const int kk = on ? k : 0;
-#pragma unroll
-                for (int t = 0; t < 6; ++t) { const double v = S.x.s.buf[kk][t]; vin[t] += on ? v : 0.0; }
-            }
-        }
-        /* lane = dof: time derivative of the motion axis = (velocity entering the joint) x axis */
-        if (lane < NVP) {
-            double cdd[6] = {0, 0, 0, 0, 0, 0}, cd[6];
-            for (int i = 0; i < 6; ++i) cd[i] = S.cdof[lane][i];
-            if (isdof && !(kjt == CM_JNT_FREE && k_ - kda < 3)) cross_motion(cdd, vin, cd);
-            for (int i = 0; i < 6; ++i) S.x.s.cdof_dot[lane][i] = cdd[i];
-        }
-        wv::sync();
-        CK_STAMP(23);
-        /* lane = body: bias acceleration = -g on the world + the same chain sum of cdof_dot_k * qvel_k; tiles: xfrc (free
-         * until the applied forces are loaded) and cfrc */
-        double mycacc[6];
+        };
         {
+            double term[6];
+            const double qd = isdof ? S.qvel[lane < NVP ? lane : 0] : 0.0;
+            for (int t = 0; t < 6; ++t) term[t] = (lane < NVP ? S.cdof[lane < NVP ? lane : 0][t] : 0.0) * qd;
+            chain_sums(term);
+            for (int t = 0; t < 6; ++t) mycvel[t] = blast >= 0 ? S.x.s.buf[blast >= 0 ? blast : 0][t] : 0.0;
+            double vin[6];
+            for (int t = 0; t < 6; ++t) vin[t] = kvin >= 0 ? S.x.s.buf[kvin >= 0 ? kvin : 0][t] : 0.0;
+            if (lane < NB) for (int t = 0; t < 6; ++t) S.x.s.cvel[lane][t] = mycvel[t];
+            /* lane = dof: time derivative of the motion axis = (velocity entering the joint) x axis; zero for the
+             * translational dofs of a free joint */
             if (lane < NVP) {
-                const double qd = isdof ? S.qvel[lane] : 0.0;
-                for (int t = 0; t < 6; ++t) S.x.s.buf[lane][t] = S.x.s.cdof_dot[lane][t] * qd;
+                double cdd[6] = {0, 0, 0, 0, 0, 0}, cd[6];
+                for (int i = 0; i < 6; ++i) cd[i] = S.cdof[lane][i];
+                if (isdof && !(kjt == CM_JNT_FREE && k_ - kda < 3)) cross_motion(cdd, vin, cd);
+                for (int i = 0; i < 6; ++i) S.x.s.cdof_dot[lane][i] = cdd[i];
+                /* next: the chain sums of cdof_dot * qvel give the bias accelerations */
+                for (int t = 0; t < 6; ++t) term[t] = cdd[t] * qd;
+            } else {
+                for (int t = 0; t < 6; ++t) term[t] = 0;
             }
             wv::sync();
-            double own[6] = {0, 0, 0, 0, 0, 0};
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                const bool on = i < bdn;
-                const int k = on ? bd0 + i : 0;
-#pragma unroll
-                for (int t = 0; t < 6; ++t) { const double v = S.x.s.buf[k][t]; own[t] += on ? v : 0.0; }
-            }
-            for (int t = 0; t < 6; ++t) mycacc[t] = own[t];
-            if (lane < NB) for (int t = 0; t < 6; ++t) S.x.s.xfrc[lane][t] = mycacc[t];
+            CK_STAMP(23);
+            chain_sums(term);
+            for (int t = 0; t < 6; ++t) mycacc[t] = blast >= 0 ? S.x.s.buf[blast >= 0 ? blast : 0][t] : 0.0;
+            mycacc[3] -= m->gravity[0]; mycacc[4] -= m->gravity[1]; mycacc[5] -= m->gravity[2]; /* -g on the world */
             wv::sync();
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                double up[6];
-                if ((r & 1) == 0) { for (int t = 0; t < 6; ++t) up[t] = S.x.s.xfrc[anc[r]][t]; }
-                else { for (int t = 0; t < 6; ++t) up[t] = S.x.s.cfrc[anc[r]][t]; }
-                if (anc[r] > 0) for (int t = 0; t < 6; ++t) mycacc[t] += up[t];
-                if (r < 3) {
-                    if (lane < NB) {
-                        if ((r & 1) == 0) { for (int t = 0; t < 6; ++t) S.x.s.cfrc[lane][t] = mycacc[t]; }
-                        else { for (int t = 0; t < 6; ++t) S.x.s.xfrc[lane][t] = mycacc[t]; }
-                    }
-                    wv::sync();
-                }
-            }
-            mycacc[3] -= m->gravity[0]; mycacc[4] -= m->gravity[1]; mycacc[5] -= m->gravity[2];
             if (lane < NB) for (int t = 0; t < 6; ++t) S.x.s.buf[lane][t] = mycacc[t]; /* kept for the accelerometers */
-            wv::sync(); /* every lane has read the last round's tile before cfrc is overwritten below */
+            wv::sync();
         }
         if (lane < NB) {
             double f6[6] = {0, 0, 0, 0, 0, 0};
