@@ -1515,25 +1515,38 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
         double arow[CM_MAXEFC];
         double Aii = 1.0;
 #pragma unroll
-        for (int r = 0; r < CM_MAXEFC; ++r) {
-            double acc = 0;
+        for (int r = 0; r < CM_MAXEFC; r += 2) {
+            /* rows in pairs: both broadcast rows are requested before the first product, so the second row's LDS latency
+             * hides behind the first row's FMAs (rows past the last constraint hold zeros and cost one wasted row at most) */
+            double acc0 = 0, acc1 = 0;
             if (r < nefc) {
-                /* stage the whole broadcast row first (all LDS reads in flight together), then four independent
-                 * partial sums: one wave per SIMD has nothing else to hide LDS or fp64 latency behind */
-                double yr[NVP];
+                double ya[NVP], yb[NVP];
 #pragma unroll
-                for (int k = 0; k < NVP; ++k) yr[k] = S.x.Yr[r][k];
-                wv::sched_fence(); /* keep the reads together: without it every read gets its own wait */
+                for (int k = 0; k < NVP; ++k) ya[k] = S.x.Yr[r][k];
+#pragma unroll
+                for (int k = 0; k < NVP; ++k) yb[k] = S.x.Yr[r + 1 < CM_MAXEFC ? r + 1 : r][k];
+                wv::sched_fence();
                 double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
 #pragma unroll
                 for (int k = 0; k < NVP; k += 4) {
-                    a0 += yr[k] * ycol[k]; a1 += yr[k + 1] * ycol[k + 1];
-                    a2 += yr[k + 2] * ycol[k + 2]; a3 += yr[k + 3] * ycol[k + 3];
+                    a0 += ya[k] * ycol[k]; a1 += ya[k + 1] * ycol[k + 1];
+                    a2 += ya[k + 2] * ycol[k + 2]; a3 += ya[k + 3] * ycol[k + 3];
                 }
-                acc = (a0 + a1) + (a2 + a3);
-                if (r == r_) { acc += rR; Aii = acc; }
+                acc0 = (a0 + a1) + (a2 + a3);
+                if (r == r_) { acc0 += rR; Aii = acc0; }
+                if (r + 1 < CM_MAXEFC) {
+                    double b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+#pragma unroll
+                    for (int k = 0; k < NVP; k += 4) {
+                        b0 += yb[k] * ycol[k]; b1 += yb[k + 1] * ycol[k + 1];
+                        b2 += yb[k + 2] * ycol[k + 2]; b3 += yb[k + 3] * ycol[k + 3];
+                    }
+                    acc1 = (b0 + b1) + (b2 + b3);
+                    if (r + 1 == r_) { acc1 += rR; Aii = acc1; }
+                }
             }
-            arow[r] = acc;
+            arow[r] = acc0;
+            if (r + 1 < CM_MAXEFC) arow[r + 1] = acc1;
         }
         double rb = 0;
         {
