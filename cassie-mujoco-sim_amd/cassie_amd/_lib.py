@@ -74,6 +74,7 @@ def _declare(L):
     L.phys_batch_forward.argtypes = [vp, vp]
     L.phys_batch_sync.argtypes = [vp]
     L.phys_batch_set_pd_mode.argtypes = [vp, c.c_int]
+    L.phys_batch_set_generic_kernel.argtypes = [vp, ctypes.c_int]
     L.phys_batch_profile_step.argtypes = [vp, vp]
     L.phys_batch_profile_substeps.argtypes = [vp, ctypes.c_int, vp]
     L.phys_batch_time_steps.argtypes = [vp, c.c_int, c.c_int, c.POINTER(c.c_float)]

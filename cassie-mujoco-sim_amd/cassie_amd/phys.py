@@ -153,6 +153,10 @@ class Batch:
             raise RuntimeError("timing failed: " + (lib().phys_last_error() or b"").decode())
         return ms.value
 
+    def set_generic_kernel(self, on=True):
+        """Validation aid: use the run-time-topology instantiation of the step kernel."""
+        lib().phys_batch_set_generic_kernel(self._h, 1 if on else 0)
+
     def profile_step(self, nsub=1):
         """Runs one launch of `nsub` fused substeps and returns the per-env shader-clock stamps [nenv][48] taken at the
         stage boundaries of the last substep."""

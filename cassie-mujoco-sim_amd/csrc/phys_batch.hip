@@ -26,6 +26,7 @@ struct phys_batch {
     cm_model_t host_model;          /* copy of the shared model (sizes) */
     cm_model_t *d_models = nullptr; /* 1 or nenv models in HBM */
     int model_stride = 0;
+    bool generic_kernel = false;   /* validation aid: never pick a compile-time-topology instantiation */
     int dim[PHYS_F_COUNT];
     double *d_field[PHYS_F_COUNT];
     bool owned[PHYS_F_COUNT];
@@ -79,7 +80,7 @@ static int launch(phys_batch *b, int nsub, int integrate, hipStream_t s) {
     /* the compile-time-topology instantiations are used only when the model's dof tree is exactly theirs */
     const cm_model_t &hm = b->host_model;
     auto matches = [&](const unsigned long long *table, int nv) {
-        if (hm.nv != nv) return false;
+        if (b->generic_kernel || hm.nv != nv) return false;
         for (int k = 0; k < nv; ++k) if (hm.dof_ancmask[k] != table[k]) return false;
         return true;
     };
@@ -311,6 +312,12 @@ int phys_batch_download_ext(phys_batch_t *b, cm_ext_t *host, int env0, int n) {
     return hip_ok(hipMemcpyAsync(host, b->d_ext + env0, sizeof(cm_ext_t) * (size_t)n, hipMemcpyDeviceToHost, b->stream), "ext download") &&
                    hip_ok(hipStreamSynchronize(b->stream), "ext sync")
                ? 0 : -1;
+}
+
+int phys_batch_set_generic_kernel(phys_batch_t *b, int on) {
+    if (!b) return -1;
+    b->generic_kernel = on != 0;
+    return 0;
 }
 
 int phys_batch_profile_step(phys_batch_t *b, long long *host_stamps) { return phys_batch_profile_substeps(b, 1, host_stamps); }

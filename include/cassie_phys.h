@@ -109,6 +109,10 @@ int phys_batch_time_steps(phys_batch_t *b, int nsub, int reps, float *mean_ms);
 int phys_batch_enable_ext(phys_batch_t *b, int on);
 int phys_batch_download_ext(phys_batch_t *b, cm_ext_t *host, int env0, int n);
 
+/* validation aid: run the generic instantiation of the step kernel (dof-tree topology read from the model at run
+ * time) even when the model matches one of the compile-time-topology instantiations */
+int phys_batch_set_generic_kernel(phys_batch_t *b, int on);
+
 /* per-stage shader-clock stamps of the next launches: [nenv][48] long long on the host after the call (profiling aid) */
 int phys_batch_profile_step(phys_batch_t *b, long long *host_stamps);
 /* same for one launch of nsub fused substeps: the stamps are those of the last substep */

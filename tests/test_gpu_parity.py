@@ -200,3 +200,28 @@ def test_config4_heightfield_vs_oracle(built):
         big.close()
     finally:
         oracle_py.set_hfield(None)
+
+
+@pytest.mark.gpu
+def test_generic_kernel_agrees_with_the_compile_time_topology_one(cassie, built):
+    """The launcher uses a compile-time-topology instantiation for the in-scope models and a generic one (dof tree read
+    from the model) for anything else.  Both must give the same trajectories to rounding (they eliminate the mass matrix
+    in different orders), for the 32-dof and the 40-dof padded sizes."""
+    from cassie_amd import Model
+    for model in (cassie, Model("cassie_tray_box")):
+        pod = model.pod
+        n = 16
+        rng = np.random.default_rng(5)
+        q0 = np.tile(model.qpos_init(), (n, 1))
+        ctrl = rng.uniform(-3, 3, (n, pod.nu))
+        out = []
+        for generic in (False, True):
+            b = Batch(model, n)
+            b.set_generic_kernel(generic)
+            b.set(P.F_QPOS, q0)
+            b.set(P.F_CTRL, ctrl)
+            b.step(150)
+            out.append((b.get(P.F_QPOS), b.get(P.F_QVEL)))
+            b.close()
+        assert np.abs(out[0][0] - out[1][0]).max() < 1e-9
+        assert np.abs(out[0][1] - out[1][1]).max() < 1e-7
