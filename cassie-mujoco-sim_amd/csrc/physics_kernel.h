@@ -873,7 +873,8 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
             for (int ii = 0; ii < 8; ++ii) {
                 const int i = i0 + ii;
                 double v = (cdm[0] * bb[ii][0] + cdm[1] * bb[ii][1]) + (cdm[2] * bb[ii][2] + cdm[3] * bb[ii][3]) + (cdm[4] * bb[ii][4] + cdm[5] * bb[ii][5]);
-                if (!(i < nv && ((kdesc >> i) & 1ull))) v = 0;
+                /* kdesc holds no bit at or past nv; with a compile-time topology the bound is a constant, not a branch */
+                if (TOPO::is_static ? (i >= TOPO::nv || !((kdesc >> i) & 1ull)) : !(i < nv && ((kdesc >> i) & 1ull))) v = 0;
                 col[i] = v;
                 colh[i] = v;
             }
@@ -1354,7 +1355,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
             for (int kk = 0; kk < 4; ++kk) {
                 const int k = k0 + kk;
                 double v = 0;
-                if (k < nv) {
+                if (TOPO::is_static ? k < TOPO::nv : k < nv) {
                     if (rtype >= 0) {
                         const double ul = u3[0] * cc[kk][3] + u3[1] * cc[kk][4] + u3[2] * cc[kk][5];
                         if ((maskp >> k) & 1ull) v += ul + wp[0] * cc[kk][0] + wp[1] * cc[kk][1] + wp[2] * cc[kk][2];
