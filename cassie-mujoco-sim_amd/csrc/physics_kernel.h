@@ -1571,11 +1571,19 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
                     f = -(jws - raref) / rR;
                     if (clampf && f < 0) f = 0;
                 }
-                double af = 0;
+                /* A f, rows four to a wave-uniform branch and four partial sums (rows past the last one contribute
+                 * nothing: their column of A is zero and f is zero in lanes that are not rows) */
+                double af0 = 0, af1 = 0, af2 = 0, af3 = 0;
 #pragma unroll
-                for (int t = 0; t < CM_MAXEFC; ++t) {
-                    if (t < nefc) af += arow[t] * wv::readlane(f, t);
+                for (int t = 0; t < CM_MAXEFC; t += 4) {
+                    if (t < nefc) {
+                        af0 += arow[t] * wv::readlane(f, t);
+                        if (t + 1 < CM_MAXEFC) af1 += arow[t + 1] * wv::readlane(f, t + 1);
+                        if (t + 2 < CM_MAXEFC) af2 += arow[t + 2] * wv::readlane(f, t + 2);
+                        if (t + 3 < CM_MAXEFC) af3 += arow[t + 3] * wv::readlane(f, t + 3);
+                    }
                 }
+                const double af = (af0 + af1) + (af2 + af3);
                 double cost = wv::wave_sum(isrow ? f * (rb + 0.5 * af) : 0.0);
                 if (cost > 0) f = 0;
                 else if (isrow) res = rb + af;
