@@ -1514,7 +1514,6 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
 
         /* ================= P9: this lane's row of A = Y^T Y + diag(R), b = Y^T y63 - aref ================= */
         double arow[CM_MAXEFC];
-        double Aii = 1.0;
 #pragma unroll
         for (int r = 0; r < CM_MAXEFC; r += 2) {
             /* rows in pairs: both broadcast rows are requested before the first product, so the second row's LDS latency
@@ -1534,7 +1533,6 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
                     a2 += ya[k + 2] * ycol[k + 2]; a3 += ya[k + 3] * ycol[k + 3];
                 }
                 acc0 = (a0 + a1) + (a2 + a3);
-                if (r == r_) { acc0 += rR; Aii = acc0; }
                 if (r + 1 < CM_MAXEFC) {
                     double b0 = 0, b1 = 0, b2 = 0, b3 = 0;
 #pragma unroll
@@ -1543,7 +1541,6 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
                         b2 += yb[k + 2] * ycol[k + 2]; b3 += yb[k + 3] * ycol[k + 3];
                     }
                     acc1 = (b0 + b1) + (b2 + b3);
-                    if (r + 1 == r_) { acc1 += rR; Aii = acc1; }
                 }
             }
             arow[r] = acc0;
@@ -1561,7 +1558,20 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
         /* ================= P10: warm start + projected Gauss-Seidel, one row per lane ================= */
         const bool isrow = rtype >= 0;
         const bool clampf = isrow && rtype != CM_CNSTR_EQUALITY;
-        if (!isrow) Aii = 1.0;
+        /* The diagonal of A: the lane's own row of Y with itself, plus the regulariser.  arow holds Y Y^T only -- selecting
+         * R into the one lane-dependent entry of every row would cost a compare and four selects per row; instead the
+         * R part of a row's action on its own residual is applied once per sweep (cdiag below): a row's residual is not
+         * read again between its own turn and the end of the sweep. */
+        double Aii = 1.0;
+        if (isrow) {
+            double d0 = 0, d1 = 0, d2 = 0, d3 = 0;
+#pragma unroll
+            for (int k = 0; k < NVP; k += 4) {
+                d0 += ycol[k] * ycol[k]; d1 += ycol[k + 1] * ycol[k + 1];
+                d2 += ycol[k + 2] * ycol[k + 2]; d3 += ycol[k + 3] * ycol[k + 3];
+            }
+            Aii = ((d0 + d1) + (d2 + d3)) + rR;
+        }
         const double invAii = 1.0 / Aii;
         double f = 0, res = isrow ? rb : 0.0;
         int iters = 0, nguarded = 0; /* sweeps taken, and how many of them through the guarded fallback */
@@ -1583,7 +1593,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
                         if (t + 3 < CM_MAXEFC) af3 += arow[t + 3] * wv::readlane(f, t + 3);
                     }
                 }
-                const double af = (af0 + af1) + (af2 + af3);
+                const double af = ((af0 + af1) + (af2 + af3)) + (isrow ? rR * f : 0.0); /* + the diagonal's R */
                 double cost = wv::wave_sum(isrow ? f * (rb + 0.5 * af) : 0.0);
                 if (cost > 0) f = 0;
                 else if (isrow) res = rb + af;
@@ -1597,6 +1607,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
             double sres = res * ninvAii;
 #pragma unroll
             for (int t = 0; t < CM_MAXEFC; ++t) arow[t] *= ninvAii;
+            const double cdiag = isrow ? rR * ninvAii : 0.0; /* the R part of B_jj = -(Y Y^T + R)_jj / A_jj, see above */
             while (iters < m->iterations) {
                 const int nrows = wv::opaque(nefc); /* keeps the row-bound tests out of loop-invariant hoisting */
                 bool converged;
@@ -1616,9 +1627,10 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
                         double improvement = 0;
                         f = f0; sres = s0; ++nguarded;
                         pgs_rows<0>(arow, nrows, r_, Aii, halfAii, flo, f, sres, improvement);
+                        sres = fma(cdiag, f - f0, sres);
                         converged = improvement * scale < m->tolerance;
                     } else {
-                        if (r_ < nrows) f += mydelta;
+                        if (r_ < nrows) { f += mydelta; sres = fma(cdiag, mydelta, sres); }
                         if (est < 0.5f * tol) converged = true;
                         else if (est > 2.0f * tol) converged = false;
                         else {
