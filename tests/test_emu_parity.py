@@ -162,3 +162,45 @@ def test_guarded_pgs_sweep_agrees_with_the_speculative_one(cassie):
     finally:
         emu_py.lib().emu_force_guarded_pgs(0)
     assert np.abs(a.qpos - b.qpos).max() < 1e-11 and np.abs(a.qvel - b.qvel).max() < 1e-9
+
+
+def test_joint_limit_rows_and_deep_penetration_from_qpos0(cassie):
+    """qpos0 is not a rest pose: four limit rows are active and the feet start below the floor, so
+    the first steps exercise limit rows, many simultaneous contacts and large corrective forces."""
+    pod = cassie.pod
+    q0 = np.array([pod.qpos0[i] for i in range(pod.nq)])
+    o = Oracle(pod, q0)
+    emu = EmuBatch(pod, 1)
+    emu.qpos[:] = q0
+    saw_limits = False
+    for s in range(60):
+        emu.step()
+        o.step()
+        assert (emu.info[0, 0], emu.info[0, 1], emu.info[0, 2]) == (o.d.ncon, o.d.nefc, o.d.solver_iter), s
+        saw_limits |= o.d.nefc > 12 + 4 * o.d.ncon
+        assert np.max(np.abs(emu.qpos[0] - o.qpos)) < 1e-9 and np.max(np.abs(emu.qvel[0] - o.qvel)) < 1e-6, s
+    assert saw_limits
+
+
+def test_contact_and_row_caps_drop_the_same_rows_as_the_oracle(cassie):
+    """Sunk into the floor, every collision geom touches it: more contacts than the 16-contact cap and more rows than
+    the 63-row cap.  Oracle and kernel must raise the same warning bits and keep the same (first) contacts and rows;
+    a second pose (on its back, 13 contacts) overflows the rows only."""
+    pod = cassie.pod
+    for z, quat, want_bits in ((0.0, [1.0, 0.0, 0.0, 0.0], 3), (-0.2, [np.cos(np.pi / 4), 0.0, np.sin(np.pi / 4), 0.0], 2)):
+        q0 = cassie.qpos_init().copy()
+        q0[2] = z
+        q0[3:7] = quat
+        o = Oracle(pod, q0)
+        emu = EmuBatch(pod, 1)
+        emu.qpos[:] = q0
+        seen = 0
+        for s in range(12):
+            emu.step()
+            o.step()
+            assert (emu.info[0, 0], emu.info[0, 1], emu.info[0, 2]) == (o.d.ncon, o.d.nefc, o.d.solver_iter), s
+            want = (1 if o.d.warn_contact_full else 0) | (2 if o.d.warn_constraint_full else 0) | (4 if o.d.warn_unsupported_pair else 0)
+            assert int(emu.warn[0]) & 7 == want, (s, int(emu.warn[0]), want)
+            seen |= want
+            assert np.max(np.abs(emu.qpos[0] - o.qpos)) < 1e-8, s
+        assert seen & want_bits == want_bits

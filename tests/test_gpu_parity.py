@@ -225,3 +225,29 @@ def test_generic_kernel_agrees_with_the_compile_time_topology_one(cassie, built)
             b.close()
         assert np.abs(out[0][0] - out[1][0]).max() < 1e-9
         assert np.abs(out[0][1] - out[1][1]).max() < 1e-7
+
+
+@pytest.mark.gpu
+def test_contact_and_row_caps_on_the_gpu(cassie):
+    """Poses that overflow the 16-contact and 63-row caps (tests/test_emu_parity.py has the emulator twin): same warning
+    bits, counts and trajectory as the oracle."""
+    pod = cassie.pod
+    poses = ((0.0, [1.0, 0.0, 0.0, 0.0]), (-0.2, [np.cos(np.pi / 4), 0.0, np.sin(np.pi / 4), 0.0]), (-0.5, [np.cos(np.pi / 4), np.sin(np.pi / 4), 0.0, 0.0]))
+    q0 = np.tile(cassie.qpos_init(), (len(poses), 1))
+    for e, (z, quat) in enumerate(poses):
+        q0[e, 2] = z
+        q0[e, 3:7] = quat
+    b = Batch(cassie, len(poses))
+    b.set(P.F_QPOS, q0)
+    orcs = [Oracle(pod, q0[e]) for e in range(len(poses))]
+    for s in range(12):
+        b.step(1)
+        q = b.get(P.F_QPOS)
+        w, info = b.warnings()
+        for e, o in enumerate(orcs):
+            o.step()
+            assert (info[e, 0], info[e, 1], info[e, 2]) == (o.d.ncon, o.d.nefc, o.d.solver_iter), (s, e)
+            want = (1 if o.d.warn_contact_full else 0) | (2 if o.d.warn_constraint_full else 0)
+            assert int(w[e]) & 3 == want, (s, e)
+            assert np.max(np.abs(q[e] - o.qpos)) < 1e-8, (s, e)
+    b.close()
