@@ -97,6 +97,7 @@ typedef struct cm_model {
     /* joints */
     int jnt_type[CM_MAXJNT], jnt_qposadr[CM_MAXJNT], jnt_dofadr[CM_MAXJNT];
     int jnt_bodyid[CM_MAXJNT], jnt_limited[CM_MAXJNT];
+    double jnt_ref[CM_MAXJNT];            /* qpos0 at the joint's qposadr (hinge / slide reference), so kinematics reads it in one level */
     int jnt_parentbody[CM_MAXJNT];        /* parent of the joint's body, -1 for free joints (their anchor is already in world coordinates) */
     double jnt_pos[CM_MAXJNT][3], jnt_axis[CM_MAXJNT][3], jnt_range[CM_MAXJNT][2];
     double jnt_stiffness[CM_MAXJNT], jnt_margin[CM_MAXJNT];

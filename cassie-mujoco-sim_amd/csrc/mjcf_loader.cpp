@@ -1050,6 +1050,7 @@ bool HostModel::compile(cm_model_t *o, std::string *err) const {
         o->jnt_type[j] = jnt_type[j]; o->jnt_qposadr[j] = jnt_qposadr[j]; o->jnt_dofadr[j] = jnt_dofadr[j];
         o->jnt_bodyid[j] = jnt_bodyid[j]; o->jnt_limited[j] = jnt_limited[j];
         o->jnt_parentbody[j] = jnt_type[j] == CM_JNT_FREE ? -1 : body_parentid[jnt_bodyid[j]];
+        o->jnt_ref[j] = qpos0[jnt_qposadr[j]];
         for (int i = 0; i < 3; ++i) { o->jnt_pos[j][i] = jnt_pos[3 * j + i]; o->jnt_axis[j][i] = jnt_axis[3 * j + i]; }
         for (int i = 0; i < 2; ++i) { o->jnt_range[j][i] = jnt_range[2 * j + i]; o->jnt_solref[j][i] = jnt_solref[2 * j + i]; }
         for (int i = 0; i < 5; ++i) o->jnt_solimp[j][i] = jnt_solimp[5 * j + i];

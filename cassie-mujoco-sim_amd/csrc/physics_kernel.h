@@ -629,10 +629,23 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
                 for (int i = 0; i < 9; ++i) Rl[i] = m->body_mat[b][i];
                 for (int i = 0; i < 3; ++i) pl[i] = bpos[i];
                 for (int i = 0; i < 4; ++i) qlq[i] = bq[i];
-                for (int jj = 0; jj < bjn; ++jj) { /* one iteration for every Cassie body but the pelvis (3 slides + ball) */
-                    const int j = bj0 + jj, jt = m->jnt_type[j], qa = m->jnt_qposadr[j];
-                    double jp[3] = {m->jnt_pos[j][0], m->jnt_pos[j][1], m->jnt_pos[j][2]};
-                    double ja[3] = {m->jnt_axis[j][0], m->jnt_axis[j][1], m->jnt_axis[j][2]};
+                /* one iteration for every Cassie body but the pelvis (3 slides + ball).  A joint's constants are one level
+                 * of model reads, and the next joint's are requested before this one is processed, so the extra
+                 * iterations (where a single lane is active) do not each wait out a memory round trip */
+                int jt_n = 0, qa_n = 0;
+                double jp_n[3] = {0, 0, 0}, ja_n[3] = {0, 0, 0}, ref_n = 0;
+                if (bjn > 0) {
+                    jt_n = m->jnt_type[bj0]; qa_n = m->jnt_qposadr[bj0]; ref_n = m->jnt_ref[bj0];
+                    for (int i = 0; i < 3; ++i) { jp_n[i] = m->jnt_pos[bj0][i]; ja_n[i] = m->jnt_axis[bj0][i]; }
+                }
+                for (int jj = 0; jj < bjn; ++jj) {
+                    const int j = bj0 + jj, jt = jt_n, qa = qa_n;
+                    const double jref = ref_n;
+                    double jp[3] = {jp_n[0], jp_n[1], jp_n[2]}, ja[3] = {ja_n[0], ja_n[1], ja_n[2]};
+                    if (jj + 1 < bjn) {
+                        jt_n = m->jnt_type[j + 1]; qa_n = m->jnt_qposadr[j + 1]; ref_n = m->jnt_ref[j + 1];
+                        for (int i = 0; i < 3; ++i) { jp_n[i] = m->jnt_pos[j + 1][i]; ja_n[i] = m->jnt_axis[j + 1][i]; }
+                    }
                     /* joint anchor and axis in the PARENT frame (turned into world coordinates after the recursion) */
                     double al[3], xl[3];
                     mulmatvec3(al, Rl, jp);
@@ -640,13 +653,13 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
                     mulmatvec3(xl, Rl, ja);
                     for (int i = 0; i < 3; ++i) { S.x.s.xanchor[j][i] = al[i]; S.x.s.xaxis[j][i] = xl[i]; }
                     if (jt == CM_JNT_SLIDE) {
-                        const double sl = S.qpos[qa] - m->qpos0[qa];
+                        const double sl = S.qpos[qa] - jref;
                         for (int i = 0; i < 3; ++i) pl[i] += xl[i] * sl;
                     } else {
                         double qj[4];
                         if (jt == CM_JNT_BALL) { for (int i = 0; i < 4; ++i) qj[i] = S.qpos[qa + i]; normalize4(qj); }
                         else {
-                            const double ang = S.qpos[qa] - m->qpos0[qa];
+                            const double ang = S.qpos[qa] - jref;
                             const double sn = sin(0.5 * ang);
                             qj[0] = cos(0.5 * ang); qj[1] = ja[0] * sn; qj[2] = ja[1] * sn; qj[3] = ja[2] * sn;
                         }
