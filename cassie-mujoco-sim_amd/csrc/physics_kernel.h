@@ -8,22 +8,30 @@
  * list SURVEY.md 8a P1..P12, semantics SURVEY.md App. B) -- redesigned for a
  * CDNA4 wave instead of a CPU thread:
  *
- *   lanes = bodies   kinematics level by level; velocities / bias accelerations as
- *                    sums over the dof chain of each body (no recursion)
- *   lanes = dofs     motion axes, one COLUMN of the mass matrix per lane kept in
- *                    VGPRs; the tree-sparse L^T D L factorisation of M and of
- *                    M + h*B runs entirely in registers, pivots travel by v_readlane
- *   lanes = pairs    narrow-phase collision, ballot-compacted contact list
+ *   lanes = bodies   every body builds its joint-inclusive local transform; the tree
+ *                    recursion is pointer jumping (4 rounds over the 1st/2nd/4th/8th
+ *                    ancestors); composite inertias and bias-force projections are dense
+ *                    loops over bodies with the subtree predicate applied by multiplication
+ *   lanes = dofs     motion axes; body velocities / bias accelerations as in-place
+ *                    pointer-jumping prefix sums over the dof tree; one COLUMN of the mass
+ *                    matrix per lane in VGPRs; the tree-sparse L^T D L factorisations of M
+ *                    and M + h*B go height by height through LDS broadcasts (compile-time
+ *                    topology) or by v_readlane pivots (run-time topology)
+ *   lanes = pairs    narrow-phase collision from denormalised pair records, ballot-compacted
+ *                    contact list, contacts finished one per lane
  *   lanes = rows     one constraint row per lane: its Jacobian row, its column of
- *                    Y = D^-1/2 L^-T [J^T | qfrc_smooth] and its row of A = Y^T Y + R
- *                    all live in VGPRs; L and Y are broadcast from LDS; PGS keeps the
- *                    residual one row per lane and broadcasts each force update with
- *                    v_readlane
+ *                    Y = D^-1/2 L^-T [J^T | qfrc_smooth] and its row of A = Y^T Y all live
+ *                    in registers; L and Y are broadcast from LDS; PGS keeps the scaled
+ *                    residual one row per lane, broadcasts each step with v_readlane and
+ *                    evaluates the cost guard once per sweep
  *
- * Loops over dofs / rows are fully unrolled with wave-uniform skips taken from the
- * model's sparsity bitmasks, so register arrays are statically indexed and LDS
- * offsets are immediates.  The batched qpos/qvel/ctrl/sensordata arrays are
- * env-major in HBM so a wave's loads and stores are contiguous.
+ * Loops over dofs / rows are fully unrolled over compile-time sparsity tables
+ * (topo_static.h) where the model matches one, so register arrays are statically
+ * indexed and LDS offsets are immediates; LDS reads are staged ahead of their use behind
+ * scheduling fences (the compiler otherwise pairs every read with its own wait).  The
+ * workgroup is one wave: "sync" is a compiler fence, not a barrier.  The batched
+ * qpos/qvel/ctrl/sensordata arrays are env-major in HBM so a wave's loads and stores are
+ * contiguous; nsub steps per launch keep the state in LDS.
  *
  * Numerically this follows the same algorithm as oracle/cassie_oracle.c but with
  * its own operation order (half solves, reciprocal multiplies, wave reductions,
