@@ -64,6 +64,7 @@ def _declare(L):
     L.phys_batch_field_dim.argtypes = [vp, c.c_int]
     L.phys_batch_set_model.argtypes = [vp, c.POINTER(CmModel), c.c_int]
     L.phys_batch_set_hfield.argtypes = [vp, c.POINTER(c.c_float), c.c_int]
+    L.phys_batch_set_hfield_env.argtypes = [vp, c.c_int, c.POINTER(c.c_float), c.c_int]
     L.phys_batch_upload.argtypes = [vp, c.c_int, vp, c.c_int, c.c_int]
     L.phys_batch_download.argtypes = [vp, c.c_int, vp, c.c_int, c.c_int]
     L.phys_batch_download_warn.argtypes = [vp, vp, vp]

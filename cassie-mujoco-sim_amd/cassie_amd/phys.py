@@ -134,9 +134,12 @@ class Batch:
         if lib().phys_batch_forward(self._h, stream) != 0:
             raise RuntimeError("forward failed: " + (lib().phys_last_error() or b"").decode())
 
-    def set_hfield(self, data):
+    def set_hfield(self, data, env=None):
+        """Height-field samples for all envs (env=None, one shared grid) or for one env only (per-env terrain)."""
         a = np.ascontiguousarray(data, dtype=np.float32)
-        if lib().phys_batch_set_hfield(self._h, a.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), a.size) != 0:
+        ptr = a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+        rc = lib().phys_batch_set_hfield(self._h, ptr, a.size) if env is None else lib().phys_batch_set_hfield_env(self._h, int(env), ptr, a.size)
+        if rc != 0:
             raise RuntimeError("set_hfield failed")
 
     def set_pd_mode(self, on=True):

@@ -32,6 +32,7 @@ struct phys_batch {
     bool owned[PHYS_F_COUNT];
     int *d_warn = nullptr, *d_info = nullptr;
     float *d_hfield = nullptr;
+    size_t hfield_stride = 0, hfield_floats = 0; /* stride 0: one grid shared by all envs; else one grid of hfield_floats per env */
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool use_applied = false;       /* qfrc_applied / xfrc_applied are passed only once uploaded */
@@ -66,6 +67,7 @@ static ck::PhysIO make_io(phys_batch *b, int nsub, int integrate) {
     io.warn = b->d_warn; io.info = b->d_info;
     io.xpos_out = b->d_field[PHYS_F_XPOS]; io.xquat_out = b->d_field[PHYS_F_XQUAT];
     io.hfield = b->d_hfield;
+    io.hfield_stride = b->hfield_stride;
     if (b->pd_mode) {
         io.pd_ptarget = b->d_field[PHYS_F_PD_PTARGET]; io.pd_kp = b->d_field[PHYS_F_PD_KP]; io.pd_kd = b->d_field[PHYS_F_PD_KD];
     }
@@ -195,8 +197,34 @@ int phys_batch_set_model(phys_batch_t *b, const cm_model_t *model, int env) {
 int phys_batch_set_hfield(phys_batch_t *b, const float *data, int n) {
     if (!b || !data || n <= 0) return -1;
     (void)hipSetDevice(b->device);
+    if (b->d_hfield && (b->hfield_stride != 0 || b->hfield_floats != (size_t)n)) { /* back to one shared grid */
+        (void)hipFree(b->d_hfield);
+        b->d_hfield = nullptr;
+    }
     if (!b->d_hfield && !hip_ok(hipMalloc((void **)&b->d_hfield, sizeof(float) * (size_t)n), "hipMalloc(hfield)")) return -1;
+    b->hfield_stride = 0;
+    b->hfield_floats = (size_t)n;
     return hip_ok(hipMemcpy(b->d_hfield, data, sizeof(float) * (size_t)n, hipMemcpyHostToDevice), "hipMemcpy(hfield)") ? 0 : -1;
+}
+
+int phys_batch_set_hfield_env(phys_batch_t *b, int env, const float *data, int n) {
+    if (!b || !data || n <= 0 || env < 0 || env >= b->nenv) return -1;
+    (void)hipSetDevice(b->device);
+    if (b->hfield_stride == 0 || b->hfield_floats != (size_t)n) {
+        /* first per-env grid: expand to one grid per env, every env starting from the shared grid (or from zeros) */
+        float *all = nullptr;
+        const size_t bytes = sizeof(float) * (size_t)n;
+        if (!hip_ok(hipMalloc((void **)&all, bytes * (size_t)b->nenv), "hipMalloc(hfield per env)")) return -1;
+        const bool seed = b->d_hfield && b->hfield_stride == 0 && b->hfield_floats == (size_t)n;
+        if (!seed && !hip_ok(hipMemset(all, 0, bytes * (size_t)b->nenv), "hipMemset(hfield)")) { (void)hipFree(all); return -1; }
+        for (int e = 0; seed && e < b->nenv; ++e)
+            if (!hip_ok(hipMemcpy(all + (size_t)e * n, b->d_hfield, bytes, hipMemcpyDeviceToDevice), "hipMemcpy(hfield)")) { (void)hipFree(all); return -1; }
+        if (b->d_hfield) (void)hipFree(b->d_hfield);
+        b->d_hfield = all;
+        b->hfield_stride = (size_t)n;
+        b->hfield_floats = (size_t)n;
+    }
+    return hip_ok(hipMemcpy(b->d_hfield + (size_t)env * n, data, sizeof(float) * (size_t)n, hipMemcpyHostToDevice), "hipMemcpy(hfield)") ? 0 : -1;
 }
 
 int phys_batch_upload(phys_batch_t *b, int field, const double *host, int env0, int n) {

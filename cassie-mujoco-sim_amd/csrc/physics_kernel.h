@@ -81,7 +81,8 @@ struct PhysIO {
     int *info;                  /* [nenv][4]: ncon, nefc, solver iterations, reserved (may be null) */
     double *xpos_out;           /* optional [nenv][nbody][3] (may be null) */
     double *xquat_out;          /* optional [nenv][nbody][4] (may be null) */
-    const float *hfield;        /* shared heightfield samples (may be null) */
+    const float *hfield;        /* heightfield samples (may be null): one grid shared by all envs, or one per env */
+    size_t hfield_stride;       /* floats between consecutive envs' grids (0 = shared) */
     /* optional on-device joint PD (all three null = torque mode): every substep
      * ctrl_u = motor-side torque of  kp (ptarget - q) - kd qdot  after the motor's
      * speed-torque limit -- the motor law of pd_input_step followed by
@@ -930,6 +931,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
         /* ================= P4 collision ================= */
         /* pass 1, lane = candidate pair (pair types that give at most two contacts) */
         int ncon = 0;
+        const float *const env_hfield = io.hfield ? io.hfield + (size_t)env * io.hfield_stride : nullptr;
         /* block cull: pairs against static non-plane geoms (stairs ...) are visited only if one of those geoms is
          * within reach of a kinematic tree (lane = collision geom) */
         int npass = m->npair_always;
@@ -998,14 +1000,14 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
                         double q2[3] = {p2[0] + a2[0] * x2, p2[1] + a2[1] * x2, p2[2] + a2[2] * x2};
                         n = sphere_sphere(rc0, q1, s10, q2, s20, margin);
                     } else if (t1 == CM_GEOM_HFIELD && t2 == CM_GEOM_SPHERE) {
-                        n = hfield_sphere(rc0, m, io.hfield, p1, m1, p2, s20, margin);
+                        n = hfield_sphere(rc0, m, env_hfield, p1, m1, p2, s20, margin);
                     } else if (t1 == CM_GEOM_HFIELD && t2 == CM_GEOM_CAPSULE) {
                         double axis[3] = {m2[2], m2[5], m2[8]};
                         RawContact tmp;
                         double e0[3] = {p2[0] + s21 * axis[0], p2[1] + s21 * axis[1], p2[2] + s21 * axis[2]};
-                        if (hfield_sphere(tmp, m, io.hfield, p1, m1, e0, s20, margin)) { rc0 = tmp; n = 1; }
+                        if (hfield_sphere(tmp, m, env_hfield, p1, m1, e0, s20, margin)) { rc0 = tmp; n = 1; }
                         double e1[3] = {p2[0] - s21 * axis[0], p2[1] - s21 * axis[1], p2[2] - s21 * axis[2]};
-                        if (hfield_sphere(tmp, m, io.hfield, p1, m1, e1, s20, margin)) { if (n == 0) rc0 = tmp; else rc1 = tmp; ++n; }
+                        if (hfield_sphere(tmp, m, env_hfield, p1, m1, e1, s20, margin)) { if (n == 0) rc0 = tmp; else rc1 = tmp; ++n; }
                         for (int i = 0; i < 3; ++i) { rc0.tangent[i] = axis[i]; rc1.tangent[i] = axis[i]; }
                     } else if (t1 == CM_GEOM_SPHERE && t2 == CM_GEOM_BOX) {
                         double sb[3] = {s20, s21, m->pair_size[p][5]};

@@ -77,7 +77,10 @@ int phys_batch_nenv(const phys_batch_t *b);
 int phys_batch_field_dim(const phys_batch_t *b, int field);            /* doubles per env */
 /* replace the model of one env (env >= 0) or of all envs (env = -1): per-env domain randomisation */
 int phys_batch_set_model(phys_batch_t *b, const cm_model_t *model, int env);
+/* height-field samples (nrow * ncol floats, MuJoCo's normalised 0..1 elevations): one grid shared by all envs, or --
+ * per-env terrain randomisation -- a grid of its own for one env (the others keep what they had) */
 int phys_batch_set_hfield(phys_batch_t *b, const float *data, int n);
+int phys_batch_set_hfield_env(phys_batch_t *b, int env, const float *data, int n);
 /* host <-> HBM copies of whole fields or of a row range [env0, env0 + n) */
 int phys_batch_upload(phys_batch_t *b, int field, const double *host, int env0, int n);
 int phys_batch_download(phys_batch_t *b, int field, double *host, int env0, int n);

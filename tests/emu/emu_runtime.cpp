@@ -161,6 +161,7 @@ extern "C" int emu_phys_run(const cm_model_t *model, int nenv, int nsub, int int
     g_io.qacc = qacc; g_io.sensordata = sensordata; g_io.actuator_velocity = actuator_velocity;
     g_io.warn = warn; g_io.info = info; g_io.xpos_out = xpos_out; g_io.xquat_out = xquat_out;
     g_io.hfield = hfield;
+    g_io.hfield_stride = 0;
     g_io.pd_ptarget = pd_ptarget; g_io.pd_kp = pd_kp; g_io.pd_kd = pd_kd;
     for (int e = 0; e < nenv; ++e) {
         g_env = e;

@@ -251,3 +251,37 @@ def test_contact_and_row_caps_on_the_gpu(cassie):
             assert int(w[e]) & 3 == want, (s, e)
             assert np.max(np.abs(q[e] - o.qpos)) < 1e-8, (s, e)
     b.close()
+
+
+@pytest.mark.gpu
+def test_per_env_heightfields(built):
+    """Per-env terrain: env 1 gets its own grid, env 0 and 2 keep the shared one; every env must
+    follow the oracle run on its own terrain."""
+    import oracle_py
+    from cassie_amd import Model
+    hf = Model("cassie_hfield")
+    pod = hf.pod
+    shared = np.random.default_rng(99).random((200, 200)).astype(np.float32)
+    shared[95:105, 95:105] = 0
+    own = (0.5 * np.random.default_rng(7).random((200, 200))).astype(np.float32)
+    n = 3
+    q0 = np.tile(hf.qpos_init(), (n, 1))
+    q0[:, 0] = [0.6, 0.6, -0.3]
+    b = Batch(hf, n)
+    b.set_hfield(shared)
+    b.set_hfield(own, env=1)
+    b.set(P.F_QPOS, q0)
+    b.step(120)
+    q = b.get(P.F_QPOS)
+    w, info = b.warnings()
+    b.close()
+    assert not w.any()
+    try:
+        for e in range(n):
+            oracle_py.set_hfield(own if e == 1 else shared)
+            o = Oracle(pod, q0[e])
+            o.step(120)
+            assert np.max(np.abs(q[e] - o.qpos)) < 1e-8, e
+        assert np.max(np.abs(q[0] - q[1])) > 1e-6      # the two terrains really differ under the robot
+    finally:
+        oracle_py.set_hfield(None)
