@@ -14,7 +14,7 @@ from ._lib import CmModel, MODEL_DIR, lib
 
 # field ids (enum in cassie_phys.h)
 (F_QPOS, F_QVEL, F_QACC_WARMSTART, F_TIME, F_CTRL, F_QFRC_APPLIED, F_XFRC_APPLIED, F_QACC, F_SENSORDATA,
- F_ACTUATOR_VELOCITY, F_XPOS, F_XQUAT, F_PD_PTARGET, F_PD_KP, F_PD_KD) = range(15)
+ F_ACTUATOR_VELOCITY, F_XPOS, F_XQUAT, F_PD_PTARGET, F_PD_KP, F_PD_KD, F_BODY_CFRC) = range(16)
 
 WARN_CONTACT_FULL, WARN_CONSTRAINT_FULL, WARN_UNSUPPORTED_PAIR, WARN_DIVERGED = 1, 2, 4, 8
 

@@ -252,6 +252,25 @@ int cassie_batch_step_ethercat(cassie_batch_t *b, const cassie_in_t *u, cassie_o
     return rc;
 }
 
+int cassie_batch_foot_forces(cassie_batch_t *b, double *cfrc)
+{
+    if (!b || !cfrc) return -1;
+    const int nb = b->pod.nbody;
+    const int feet[2] = {phys_model_name2id(b->m, 1 /* mjOBJ_BODY */, "left-foot"), phys_model_name2id(b->m, 1, "right-foot")};
+    if (feet[0] < 0 || feet[1] < 0 || feet[0] >= nb || feet[1] >= nb) return -1;
+    double *all = malloc(sizeof(double) * (size_t)b->nenv * nb * 3);
+    if (!all) return -1;
+    int rc = phys_batch_download(b->pb, PHYS_F_BODY_CFRC, all, 0, b->nenv);
+    for (int e = 0; rc == 0 && e < b->nenv; ++e) {
+        double *out = cfrc + (size_t)e * 12;
+        memset(out, 0, 12 * sizeof(double));
+        for (int side = 0; side < 2; ++side)
+            for (int j = 0; j < 3; ++j) out[6 * side + j] = all[((size_t)e * nb + feet[side]) * 3 + j];
+    }
+    free(all);
+    return rc;
+}
+
 int cassie_batch_full_reset(cassie_batch_t *b, const unsigned char *mask)
 {
     if (!b) return -1;

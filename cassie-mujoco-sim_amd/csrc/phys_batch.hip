@@ -66,6 +66,7 @@ static ck::PhysIO make_io(phys_batch *b, int nsub, int integrate) {
     io.actuator_velocity = b->d_field[PHYS_F_ACTUATOR_VELOCITY];
     io.warn = b->d_warn; io.info = b->d_info;
     io.xpos_out = b->d_field[PHYS_F_XPOS]; io.xquat_out = b->d_field[PHYS_F_XQUAT];
+    io.body_cfrc = b->d_field[PHYS_F_BODY_CFRC];
     io.hfield = b->d_hfield;
     io.hfield_stride = b->hfield_stride;
     if (b->pd_mode) {
@@ -115,7 +116,7 @@ phys_batch_t *phys_batch_create(const cm_model_t *model, int nenv, int device) {
     b->host_model = *model;
     const int d[PHYS_F_COUNT] = {model->nq, model->nv, model->nv, 1, model->nu, model->nv, model->nbody * 6,
                                  model->nv, model->nsensordata, model->nu, model->nbody * 3, model->nbody * 4,
-                                 model->nu, model->nu, model->nu};
+                                 model->nu, model->nu, model->nu, model->nbody * 3};
     bool ok = true;
     for (int f = 0; f < PHYS_F_COUNT; ++f) {
         b->dim[f] = d[f]; b->d_field[f] = nullptr; b->owned[f] = true;

@@ -81,6 +81,7 @@ struct PhysIO {
     int *info;                  /* [nenv][4]: ncon, nefc, solver iterations, reserved (may be null) */
     double *xpos_out;           /* optional [nenv][nbody][3] (may be null) */
     double *xquat_out;          /* optional [nenv][nbody][4] (may be null) */
+    double *body_cfrc;          /* optional [nenv][nbody][3] net contact force per body (world frame), last substep only */
     const float *hfield;        /* heightfield samples (may be null): one grid shared by all envs, or one per env */
     size_t hfield_stride;       /* floats between consecutive envs' grids (0 = shared) */
     /* optional on-device joint PD (all three null = torque mode): every substep
@@ -1668,20 +1669,42 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
             }
         }
         CK_STAMP(11);
-        if (io.ext) {
+        const bool want_cfrc = io.body_cfrc && (sub == io.nsub - 1 || !io.integrate);
+        if (io.ext || want_cfrc) {
             /* decode the pyramid: normal = sum of the edge forces, tangents = mu (f+ - f-) */
-            cm_ext_t *ex = io.ext + env;
             const int a0 = caddr >= 0 ? caddr : 0;
             const double f0 = wv::shfl(f, a0), f1 = wv::shfl(f, (a0 + 1) & 63), f2 = wv::shfl(f, (a0 + 2) & 63), f3 = wv::shfl(f, (a0 + 3) & 63);
-            if (lane < ncon) {
-                double fn = 0, ft1 = 0, ft2 = 0;
-                if (caddr >= 0) {
-                    if (S.c_dim[lane] == 1) fn = f0;
-                    else { const double mu = S.c_fri[lane][0]; fn = f0 + f1 + f2 + f3; ft1 = mu * (f0 - f1); ft2 = mu * (f2 - f3); }
-                }
-                ex->con_force[lane][0] = fn; ex->con_force[lane][1] = ft1; ex->con_force[lane][2] = ft2;
+            double fn = 0, ft1 = 0, ft2 = 0;
+            if (lane < ncon && caddr >= 0) {
+                if (S.c_dim[lane] == 1) fn = f0;
+                else { const double mu = S.c_fri[lane][0]; fn = f0 + f1 + f2 + f3; ft1 = mu * (f0 - f1); ft2 = mu * (f2 - f3); }
             }
-            if (lane == 0) { ex->ncon = ncon; ex->nefc = nefc; ex->solver_iter = iters; }
+            if (io.ext) {
+                cm_ext_t *ex = io.ext + env;
+                if (lane < ncon) { ex->con_force[lane][0] = fn; ex->con_force[lane][1] = ft1; ex->con_force[lane][2] = ft2; }
+                if (lane == 0) { ex->ncon = ncon; ex->nefc = nefc; ex->solver_iter = iters; }
+            }
+            if (want_cfrc) {
+                /* world-frame force of every contact parked over its (no longer needed) position, then lane = body adds
+                 * up the contacts it takes part in: + on geom2's body, - on geom1's */
+                if (lane < ncon) {
+                    const double *fr = S.c_frame[lane];
+                    double fw[3];
+                    for (int j = 0; j < 3; ++j) fw[j] = fr[j] * fn + fr[3 + j] * ft1 + fr[6 + j] * ft2;
+                    for (int j = 0; j < 3; ++j) S.c_pos[lane][j] = fw[j];
+                }
+                wv::sync();
+                if (isbody) {
+                    double acc[3] = {0, 0, 0};
+                    for (int c = 0; c < ncon; ++c) {
+                        const int b1 = m->geom_bodyid[S.c_g1[c]], b2 = m->geom_bodyid[S.c_g2[c]];
+                        const double sg = (b2 == b ? 1.0 : 0.0) - (b1 == b ? 1.0 : 0.0);
+                        for (int j = 0; j < 3; ++j) acc[j] += sg * S.c_pos[c][j];
+                    }
+                    for (int j = 0; j < 3; ++j) io.body_cfrc[((size_t)env * io.sb + b) * 3 + j] = acc[j];
+                }
+                wv::sync();
+            }
         }
 
         /* ================= qacc = L^-1 D^-1/2 (y63 + Y f)  (lane = dof) ================= */

@@ -76,6 +76,9 @@ int cassie_batch_step_pd(cassie_batch_t *b, const pd_in_t *u, state_out_t *y);
 /* one cassie_sim_step / cassie_sim_step_ethercat for every env */
 int cassie_batch_step(cassie_batch_t *b, const cassie_user_in_t *u, cassie_out_t *y);
 int cassie_batch_step_ethercat(cassie_batch_t *b, const cassie_in_t *u, cassie_out_t *y);
+/* cassie_sim_foot_forces for every env: cfrc is [nenv][12] (left force xyz at 0..2, right force xyz at 6..8, the
+ * other entries zero like the single-env getter), from the per-body contact forces the last step left in HBM */
+int cassie_batch_foot_forces(cassie_batch_t *b, double *cfrc);
 /* cassie_sim_full_reset for the envs whose mask byte is non-zero (mask NULL = all) */
 int cassie_batch_full_reset(cassie_batch_t *b, const unsigned char *mask);
 

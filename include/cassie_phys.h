@@ -67,6 +67,8 @@ typedef struct phys_batch phys_batch_t; /* N envs resident in HBM: the mjData ro
 enum { PHYS_F_QPOS, PHYS_F_QVEL, PHYS_F_QACC_WARMSTART, PHYS_F_TIME, PHYS_F_CTRL, PHYS_F_QFRC_APPLIED,
        PHYS_F_XFRC_APPLIED, PHYS_F_QACC, PHYS_F_SENSORDATA, PHYS_F_ACTUATOR_VELOCITY, PHYS_F_XPOS, PHYS_F_XQUAT,
        PHYS_F_PD_PTARGET, PHYS_F_PD_KP, PHYS_F_PD_KD, /* on-device joint PD, see phys_batch_set_pd_mode */
+       PHYS_F_BODY_CFRC, /* [nbody][3]: net contact force on every body, world frame (reaction on geom2's body, minus it on
+                            geom1's; the foot rows are cassie_sim_foot_forces), of the last substep of a launch */
        PHYS_F_COUNT };
 
 /* mj_makeData (reference :441-447) for nenv environments on HIP device `device`;

@@ -45,6 +45,7 @@ def L(built):
     L.cassie_batch_create.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
     L.cassie_batch_free.argtypes = [VP]
     L.cassie_batch_step_pd.argtypes = [VP, VP, VP]
+    L.cassie_batch_foot_forces.argtypes = [VP, VP]
     L.cassie_batch_phys.restype = VP
     L.cassie_batch_phys.argtypes = [VP]
     L.cassie_hostenv_alloc.restype = VP
@@ -181,6 +182,15 @@ def test_batch_step_pd_equals_independent_simulators(L):
             y = T.state_out_t()
             L.cassie_sim_step_pd(sims[e], ctypes.byref(y), ctypes.byref(U[e]))
             assert bytes(y) == bytes(Y[e]), (k, e)
+        if k % 100 == 99:
+            # batched derived getter: the per-body contact forces left in HBM give every env's foot forces
+            ffb = np.zeros((n, 12))
+            assert L.cassie_batch_foot_forces(b, ffb.ctypes.data) == 0
+            for e in range(n):
+                ff = np.zeros(12)
+                L.cassie_sim_foot_forces(sims[e], ff.ctypes.data)
+                assert np.allclose(ffb[e], ff, rtol=1e-12, atol=1e-9), (k, e)
+            assert np.abs(ffb).max() > 1.0          # somebody is standing on something
     for s in sims:
         L.cassie_sim_free(s)
     L.cassie_batch_free(b)
