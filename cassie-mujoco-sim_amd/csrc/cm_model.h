@@ -160,6 +160,11 @@ typedef struct cm_model {
     int sensor_type[CM_MAXSENSOR], sensor_objid[CM_MAXSENSOR];
     int sensor_adr[CM_MAXSENSOR], sensor_dim[CM_MAXSENSOR];
     double sensor_cutoff[CM_MAXSENSOR];
+    /* denormalised per-sensor records, so the sensor stage reads its constants in one level */
+    int sensor_qadr[CM_MAXSENSOR];        /* actuatorpos / jointpos: qpos address; -1 otherwise */
+    double sensor_gain[CM_MAXSENSOR];     /* actuatorpos: gear; jointpos: 1 */
+    int sensor_body[CM_MAXSENSOR], sensor_root[CM_MAXSENSOR]; /* frame sensors: body of the site and that body's root */
+    double sensor_squat[CM_MAXSENSOR][4], sensor_spos[CM_MAXSENSOR][3]; /* frame sensors: site frame in its body */
     int sensor_slot[CM_MAXSENSOR];        /* accelerometers: 0, 1, ... in sensor order (-1 otherwise / beyond two) */
 } cm_model_t;
 

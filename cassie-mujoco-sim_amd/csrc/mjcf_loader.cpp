@@ -1269,6 +1269,18 @@ bool HostModel::compile(cm_model_t *o, std::string *err) const {
     for (int s = 0; s < nsensor; ++s) {
         o->sensor_type[s] = sensor_type[s]; o->sensor_objid[s] = sensor_objid[s];
         o->sensor_adr[s] = sensor_adr[s]; o->sensor_dim[s] = sensor_dim[s]; o->sensor_cutoff[s] = sensor_cutoff[s];
+        o->sensor_qadr[s] = -1; o->sensor_gain[s] = 1.0; o->sensor_body[s] = 0; o->sensor_root[s] = 0;
+        for (int i = 0; i < 4; ++i) o->sensor_squat[s][i] = i == 0 ? 1.0 : 0.0;
+        for (int i = 0; i < 3; ++i) o->sensor_spos[s][i] = 0.0;
+        if (sensor_type[s] == CM_SENS_ACTUATORPOS) { o->sensor_qadr[s] = o->act_qposadr[sensor_objid[s]]; o->sensor_gain[s] = o->act_gear[sensor_objid[s]]; }
+        else if (sensor_type[s] == CM_SENS_JOINTPOS) o->sensor_qadr[s] = jnt_qposadr[sensor_objid[s]];
+        else if (sensor_type[s] >= CM_SENS_FRAMEQUAT && sensor_type[s] <= CM_SENS_MAGNETOMETER) {
+            const int site = sensor_objid[s];
+            o->sensor_body[s] = site_bodyid[site];
+            o->sensor_root[s] = o->body_rootid[site_bodyid[site]];
+            for (int i = 0; i < 4; ++i) o->sensor_squat[s][i] = site_quat[4 * site + i];
+            for (int i = 0; i < 3; ++i) o->sensor_spos[s][i] = site_pos[3 * site + i];
+        }
         o->sensor_slot[s] = -1;
         if (sensor_type[s] == CM_SENS_ACCELEROMETER) {
             int slot = 0;

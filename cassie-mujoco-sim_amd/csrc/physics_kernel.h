@@ -1400,16 +1400,16 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
         /* ---- sensors, part 1 (lane = sensor): everything that does not need qacc is final here; the
          *      accelerometer parks its partial results in LDS because the body tiles are about to be recycled ---- */
         const bool issens = lane < m->nsensor;
-        const int stype = issens ? m->sensor_type[lane] : -1;
-        const int sobj = issens ? m->sensor_objid[lane] : 0;
-        const int aslot = (stype == CM_SENS_ACCELEROMETER) ? m->sensor_slot[lane] : -1; /* which accelerometer this lane is */
+        const int ls = issens ? lane : 0; /* every constant of the lane's sensor in one level of (unconditional) reads */
+        const int stype = issens ? m->sensor_type[ls] : -1;
+        const int aslot = (stype == CM_SENS_ACCELEROMETER) ? m->sensor_slot[ls] : -1; /* which accelerometer this lane is */
+        const int sqadr = m->sensor_qadr[ls], sb = m->sensor_body[ls], sroot = m->sensor_root[ls];
+        const double sgain = m->sensor_gain[ls];
         if (issens) {
             double sout[4] = {0, 0, 0, 0};
-            if (stype == CM_SENS_ACTUATORPOS) sout[0] = m->act_gear[sobj] * S.qpos[m->act_qposadr[sobj]];
-            else if (stype == CM_SENS_JOINTPOS) sout[0] = S.qpos[m->jnt_qposadr[sobj]];
+            if (sqadr >= 0) sout[0] = sgain * S.qpos[sqadr]; /* actuatorpos (gear * q) and jointpos */
             else if (stype >= CM_SENS_FRAMEQUAT && stype <= CM_SENS_MAGNETOMETER) {
-                const int sb = m->site_bodyid[sobj];
-                double sq[4] = {m->site_quat[sobj][0], m->site_quat[sobj][1], m->site_quat[sobj][2], m->site_quat[sobj][3]};
+                double sq[4] = {m->sensor_squat[ls][0], m->sensor_squat[ls][1], m->sensor_squat[ls][2], m->sensor_squat[ls][3]};
                 double q[4], sxmat[9], scvel[6];
                 mulquat(q, S.x.s.xquat[sb], sq);
                 quat2mat(sxmat, q);
@@ -1420,13 +1420,13 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
                     double mg[3] = {m->magnetic[0], m->magnetic[1], m->magnetic[2]};
                     mulmatTvec3(sout, sxmat, mg);
                 } else if (aslot >= 0) {
-                    /* accelerometer: velocity-product part of the body's com-frame acceleration (incl. -gravity) */
-                    /* = the body's bias acceleration, which the velocity stage left in the buf tile */
+                    /* accelerometer: velocity-product part of the body's com-frame acceleration (incl. -gravity)
+                     * = the body's bias acceleration, which the velocity stage left in the buf tile */
                     double acc_ang[3] = {S.x.s.buf[sb][0], S.x.s.buf[sb][1], S.x.s.buf[sb][2]};
                     double acc_lin[3] = {S.x.s.buf[sb][3], S.x.s.buf[sb][4], S.x.s.buf[sb][5]};
-                    double sp[3] = {m->site_pos[sobj][0], m->site_pos[sobj][1], m->site_pos[sobj][2]}, t[3];
+                    double sp[3] = {m->sensor_spos[ls][0], m->sensor_spos[ls][1], m->sensor_spos[ls][2]}, t[3];
                     mulmatvec3(t, S.x.s.xmat[sb], sp);
-                    const double *c = S.com[m->body_rootid[sb]];
+                    const double *c = S.com[sroot];
                     double *pa = S.accel[aslot];
                     for (int i = 0; i < 3; ++i) { pa[i] = acc_ang[i]; pa[3 + i] = acc_lin[i]; pa[6 + i] = t[i] + S.x.s.xpos[sb][i] - c[i]; }
                     for (int i = 0; i < 9; ++i) pa[9 + i] = sxmat[i];
@@ -1747,7 +1747,6 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
 
         /* ---- sensors, part 2: the accelerometer needs qacc ---- */
         if (aslot >= 0) {
-            const int sb = m->site_bodyid[sobj];
             const double *pa = S.accel[aslot];
             double acc_ang[3] = {pa[0], pa[1], pa[2]}, acc_lin[3] = {pa[3], pa[4], pa[5]}, acc_dif[3] = {pa[6], pa[7], pa[8]};
             for (unsigned long long mk = m->body_dofmask[sb]; mk; mk &= mk - 1) {
