@@ -109,6 +109,10 @@ typedef struct cm_model {
     double dof_armature[CM_MAXV], dof_damping[CM_MAXV], dof_invweight0[CM_MAXV];
     uint64_t dof_ancmask[CM_MAXV];        /* proper ancestors of dof k in the dof tree (M's row pattern) */
     uint64_t dof_descmask[CM_MAXV];       /* dofs that have k as ancestor, plus k itself (M's column pattern) */
+    /* denormalised per-dof records of the passive / actuation stage (one level of reads, no branches): spring of the
+     * dof's hinge / slide joint (stiffness 0 otherwise), and the actuator on the dof (gear 0, actuator 0 if none) */
+    double dof_stiffness[CM_MAXV], dof_springref[CM_MAXV], dof_gear[CM_MAXV], dof_ctrl_lo[CM_MAXV], dof_ctrl_hi[CM_MAXV];
+    int dof_qadr[CM_MAXV], dof_act[CM_MAXV];
     int dof_anc[CM_MAXV][5];              /* 1st, 2nd, 4th, 8th, 16th ancestor dof (-1 = none) for pointer-jumping prefix sums */
     int dof_vinsrc[CM_MAXV];              /* dof whose chain sum is the velocity entering dof k's joint (-1 = none): the nearest
                                              ancestor of another joint; for the rotational dofs of a free joint its last translational dof */

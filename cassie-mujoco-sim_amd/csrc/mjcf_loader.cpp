@@ -1261,6 +1261,19 @@ bool HostModel::compile(cm_model_t *o, std::string *err) const {
         o->act_maxrpm[u] = nuser_actuator > 0 ? act_user[(size_t)nuser_actuator * u] : 0.0;
         o->act_ctrlrange[u][0] = act_ctrlrange[2 * u]; o->act_ctrlrange[u][1] = act_ctrlrange[2 * u + 1];
     }
+    for (int d = 0; d < nv; ++d) {
+        const int j = dof_jntid[d];
+        const bool scalar = jnt_type[j] == CM_JNT_HINGE || jnt_type[j] == CM_JNT_SLIDE;
+        o->dof_qadr[d] = jnt_qposadr[j];
+        o->dof_stiffness[d] = scalar ? jnt_stiffness[j] : 0.0;
+        o->dof_springref[d] = scalar ? qpos_spring[jnt_qposadr[j]] : 0.0;
+        o->dof_act[d] = 0; o->dof_gear[d] = 0.0; o->dof_ctrl_lo[d] = -1e300; o->dof_ctrl_hi[d] = 1e300;
+        for (int u = 0; u < nu; ++u) {
+            if (o->act_dofid[u] != d) continue;
+            o->dof_act[d] = u; o->dof_gear[d] = o->act_gear[u];
+            if (o->act_ctrllimited[u]) { o->dof_ctrl_lo[d] = o->act_ctrlrange[u][0]; o->dof_ctrl_hi[d] = o->act_ctrlrange[u][1]; }
+        }
+    }
     for (int s = 0; s < nsite; ++s) {
         o->site_bodyid[s] = site_bodyid[s];
         for (int i = 0; i < 3; ++i) o->site_pos[s][i] = site_pos[3 * s + i];

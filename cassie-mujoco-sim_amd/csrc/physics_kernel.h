@@ -1191,20 +1191,21 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
         CK_STAMP(6);
 
         /* ================= P6/P7/P8 passive + actuation -> qfrc_smooth (lane = dof) ================= */
-        if (isdof) {
-            double f = -m->dof_damping[k_] * S.qvel[k_];
-            if (kjt == CM_JNT_HINGE || kjt == CM_JNT_SLIDE) {
-                const double kstiff = m->jnt_stiffness[kjnt];
-                if (kstiff != 0) f += -kstiff * (S.qpos[kqa] - m->qpos_spring[kqa]);
+        {
+            /* per-dof records (cm_model_t::dof_*): damping, the joint's spring, the actuator on the dof -- one level of
+             * unconditional reads; dofs without a spring / actuator carry zero stiffness / gear */
+            const int kd = isdof ? k_ : 0;
+            const double kdamp = m->dof_damping[kd], kstiff = m->dof_stiffness[kd], kref = m->dof_springref[kd];
+            const double kgear = m->dof_gear[kd], klo = m->dof_ctrl_lo[kd], khi = m->dof_ctrl_hi[kd];
+            const int kq = m->dof_qadr[kd], ka = m->dof_act[kd];
+            if (isdof) {
+                double f = -kdamp * S.qvel[k_];
+                f -= kstiff * (S.qpos[kq] - kref);
+                f -= qfrc_bias;
+                if (io.qfrc_applied) f += io.qfrc_applied[(size_t)env * io.sv + k_];
+                f += kgear * clampd(S.ctrl[ka], klo, khi);
+                S.qfrc_smooth[k_] = f;
             }
-            f -= qfrc_bias;
-            if (io.qfrc_applied) f += io.qfrc_applied[(size_t)env * io.sv + k_];
-            if (kact >= 0) {
-                double c = S.ctrl[kact];
-                if (m->act_ctrllimited[kact]) c = clampd(c, m->act_ctrlrange[kact][0], m->act_ctrlrange[kact][1]);
-                f += m->act_gear[kact] * c;
-            }
-            S.qfrc_smooth[k_] = f;
         }
         if (io.xfrc_applied) {
             /* Cartesian perturbations: [force, torque] at the body's inertial origin */
