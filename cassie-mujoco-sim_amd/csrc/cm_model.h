@@ -97,6 +97,7 @@ typedef struct cm_model {
     /* joints */
     int jnt_type[CM_MAXJNT], jnt_qposadr[CM_MAXJNT], jnt_dofadr[CM_MAXJNT];
     int jnt_bodyid[CM_MAXJNT], jnt_limited[CM_MAXJNT];
+    double jnt_liminvweight[CM_MAXJNT];   /* dof_invweight0 of the joint's (first) dof: diagonal approximation of a limit row */
     double jnt_ref[CM_MAXJNT];            /* qpos0 at the joint's qposadr (hinge / slide reference), so kinematics reads it in one level */
     int jnt_parentbody[CM_MAXJNT];        /* parent of the joint's body, -1 for free joints (their anchor is already in world coordinates) */
     double jnt_pos[CM_MAXJNT][3], jnt_axis[CM_MAXJNT][3], jnt_range[CM_MAXJNT][2];
@@ -145,11 +146,18 @@ typedef struct cm_model {
     double pair_rbound[CM_MAXPAIR][2];
     double pair_size[CM_MAXPAIR][6];      /* geom1 size, geom2 size */
     double pair_solref[CM_MAXPAIR][2], pair_solimp[CM_MAXPAIR][5], pair_friction[CM_MAXPAIR][3];
+    /* what a contact row needs about the two bodies: tree roots, dof chains, translational inverse weights summed */
+    int pair_root[CM_MAXPAIR][2];
+    uint64_t pair_dofmask[CM_MAXPAIR][2];
+    double pair_invweight[CM_MAXPAIR];
 
     /* equality constraints (connect only) */
     int eq_body1[CM_MAXEQ], eq_body2[CM_MAXEQ], eq_active[CM_MAXEQ];
     double eq_data[CM_MAXEQ][6];          /* anchor in body1 frame, anchor in body2 frame */
     double eq_solref[CM_MAXEQ][2], eq_solimp[CM_MAXEQ][5];
+    int eq_root[CM_MAXEQ][2];             /* same for the two bodies of an equality constraint */
+    uint64_t eq_dofmask[CM_MAXEQ][2];
+    double eq_invweight[CM_MAXEQ];
 
     /* actuators (motor on a hinge joint) */
     int act_dofid[CM_MAXU], act_qposadr[CM_MAXU], act_ctrllimited[CM_MAXU];

@@ -1051,6 +1051,7 @@ bool HostModel::compile(cm_model_t *o, std::string *err) const {
         o->jnt_bodyid[j] = jnt_bodyid[j]; o->jnt_limited[j] = jnt_limited[j];
         o->jnt_parentbody[j] = jnt_type[j] == CM_JNT_FREE ? -1 : body_parentid[jnt_bodyid[j]];
         o->jnt_ref[j] = qpos0[jnt_qposadr[j]];
+        o->jnt_liminvweight[j] = dof_invweight0[jnt_dofadr[j]];
         for (int i = 0; i < 3; ++i) { o->jnt_pos[j][i] = jnt_pos[3 * j + i]; o->jnt_axis[j][i] = jnt_axis[3 * j + i]; }
         for (int i = 0; i < 2; ++i) { o->jnt_range[j][i] = jnt_range[2 * j + i]; o->jnt_solref[j][i] = jnt_solref[2 * j + i]; }
         for (int i = 0; i < 5; ++i) o->jnt_solimp[j][i] = jnt_solimp[5 * j + i];
@@ -1222,6 +1223,15 @@ bool HostModel::compile(cm_model_t *o, std::string *err) const {
         o->pair_includemargin[i] = o->pair_margin[i] - std::max(o->geom_gap[g1], o->geom_gap[g2]);
         o->pair_rbound[i][0] = o->geom_rbound[g1]; o->pair_rbound[i][1] = o->geom_rbound[g2];
         for (int k = 0; k < 3; ++k) { o->pair_size[i][k] = o->geom_size[g1][k]; o->pair_size[i][3 + k] = o->geom_size[g2][k]; }
+        {
+            const int bb[2] = {o->geom_bodyid[g1], o->geom_bodyid[g2]};
+            o->pair_invweight[i] = 0;
+            for (int k = 0; k < 2; ++k) {
+                o->pair_root[i][k] = o->body_rootid[bb[k]];
+                o->pair_dofmask[i][k] = bb[k] > 0 ? o->body_dofmask[bb[k]] : 0ull;
+                o->pair_invweight[i] += o->body_invweight0[bb[k]][0];
+            }
+        }
         /* contact parameter mixing (MuJoCo mj_contactParam): the geom with the higher priority wins outright; at equal
          * priority condim and friction take the maximum and solref / solimp are blended by solmix */
         const int pa = o->geom_priority[g1], pb = o->geom_priority[g2];
@@ -1252,6 +1262,15 @@ bool HostModel::compile(cm_model_t *o, std::string *err) const {
         for (int i = 0; i < 6; ++i) o->eq_data[e][i] = eq_data[6 * e + i];
         for (int i = 0; i < 2; ++i) o->eq_solref[e][i] = eq_solref[2 * e + i];
         for (int i = 0; i < 5; ++i) o->eq_solimp[e][i] = eq_solimp[5 * e + i];
+        {
+            const int bb[2] = {eq_body1[e], eq_body2[e]};
+            o->eq_invweight[e] = 0;
+            for (int k = 0; k < 2; ++k) {
+                o->eq_root[e][k] = o->body_rootid[bb[k]];
+                o->eq_dofmask[e][k] = o->body_dofmask[bb[k]];
+                o->eq_invweight[e] += o->body_invweight0[bb[k]][0];
+            }
+        }
     }
     for (int u = 0; u < nu; ++u) {
         int j = act_jntid[u];

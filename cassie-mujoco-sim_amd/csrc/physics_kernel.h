@@ -120,6 +120,9 @@ struct EnvShared {
     double c_dist[CM_MAXCON], c_pos[CM_MAXCON][3], c_frame[CM_MAXCON][9], c_fri[CM_MAXCON][3];
     double c_solref[CM_MAXCON][2], c_solimp[CM_MAXCON][5], c_margin[CM_MAXCON];
     int c_dim[CM_MAXCON], c_g1[CM_MAXCON], c_g2[CM_MAXCON], c_pair[CM_MAXCON];
+    int c_root[CM_MAXCON][2];               /* tree roots of the two bodies, their dof chains, summed inverse weights */
+    unsigned long long c_dofmask[CM_MAXCON][2];
+    double c_tran[CM_MAXCON];
 };
 
 /* ------------------------------------------------------------ small math --- */
@@ -373,6 +376,8 @@ WV_DEVICE void finish_contacts(EnvShared<NVP> &S, ModelPtr m, int lane, int ncon
         for (int i = 0; i < 2; ++i) S.c_solref[lane][i] = m->pair_solref[p][i];
         for (int i = 0; i < 5; ++i) S.c_solimp[lane][i] = m->pair_solimp[p][i];
         for (int i = 0; i < 3; ++i) S.c_fri[lane][i] = m->pair_friction[p][i];
+        for (int k = 0; k < 2; ++k) { S.c_root[lane][k] = m->pair_root[p][k]; S.c_dofmask[lane][k] = m->pair_dofmask[p][k]; }
+        S.c_tran[lane] = m->pair_invweight[p];
     }
 }
 
@@ -1293,16 +1298,16 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
             mulmatvec3(a2, S.x.s.xmat[b2], l2);
             for (int i = 0; i < 3; ++i) { a1[i] += S.x.s.xpos[b1][i]; a2[i] += S.x.s.xpos[b2][i]; }
             u3[0] = rsub == 0 ? 1.0 : 0.0; u3[1] = rsub == 1 ? 1.0 : 0.0; u3[2] = rsub == 2 ? 1.0 : 0.0;
-            const double *c1 = S.com[m->body_rootid[b1]], *c2 = S.com[m->body_rootid[b2]];
+            const double *c1 = S.com[m->eq_root[rid][0]], *c2 = S.com[m->eq_root[rid][1]];
             double o1[3] = {a1[0] - c1[0], a1[1] - c1[1], a1[2] - c1[2]};
             double o2[3] = {a2[0] - c2[0], a2[1] - c2[1], a2[2] - c2[2]};
             cross3(wp, o1, u3);
             cross3(wm, o2, u3);
-            maskp = m->body_dofmask[b1]; maskm = m->body_dofmask[b2];
+            maskp = m->eq_dofmask[rid][0]; maskm = m->eq_dofmask[rid][1];
             double res[3] = {a1[0] - a2[0], a1[1] - a2[1], a1[2] - a2[2]};
             rpos = rsub == 0 ? res[0] : (rsub == 1 ? res[1] : res[2]); rmargin = 0;
             imp_pos = sqrt(dot3(res, res));
-            rdiag = m->body_invweight0[b1][0] + m->body_invweight0[b2][0];
+            rdiag = m->eq_invweight[rid];
             solref0 = m->eq_solref[rid][0]; solref1 = m->eq_solref[rid][1];
             for (int i = 0; i < 5; ++i) solimp[i] = m->eq_solimp[rid][i];
         } else if (rtype == CM_CNSTR_LIMIT_JOINT) {
@@ -1312,12 +1317,11 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
             imp_pos = rpos;
             limdof = m->jnt_dofadr[rid];
             limsgn = rsub == 0 ? 1.0 : -1.0;
-            rdiag = m->dof_invweight0[limdof];
+            rdiag = m->jnt_liminvweight[rid];
             solref0 = m->jnt_solref[rid][0]; solref1 = m->jnt_solref[rid][1];
             for (int i = 0; i < 5; ++i) solimp[i] = m->jnt_solimp[rid][i];
         } else if (rtype >= 0) {
             const int c = rid;
-            const int b1 = m->geom_bodyid[S.c_g1[c]], b2 = m->geom_bodyid[S.c_g2[c]];
             const double *fr = S.c_frame[c];
             if (rtype == CM_CNSTR_CONTACT_PYRAMIDAL) {
                 const int a = 1 + rsub / 2;
@@ -1329,15 +1333,15 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
             } else {
                 for (int i = 0; i < 3; ++i) u3[i] = fr[i];
             }
-            const double *c1 = S.com[m->body_rootid[b1]], *c2 = S.com[m->body_rootid[b2]];
+            const double *c1 = S.com[S.c_root[c][0]], *c2 = S.com[S.c_root[c][1]];
             double o1[3] = {S.c_pos[c][0] - c1[0], S.c_pos[c][1] - c1[1], S.c_pos[c][2] - c1[2]};
             double o2[3] = {S.c_pos[c][0] - c2[0], S.c_pos[c][1] - c2[1], S.c_pos[c][2] - c2[2]};
             cross3(wp, o2, u3);
             cross3(wm, o1, u3);
-            maskp = b2 > 0 ? m->body_dofmask[b2] : 0ull;
-            maskm = b1 > 0 ? m->body_dofmask[b1] : 0ull;
+            maskp = S.c_dofmask[c][1];
+            maskm = S.c_dofmask[c][0];
             rpos = S.c_dist[c]; rmargin = S.c_margin[c]; imp_pos = rpos;
-            const double tran = m->body_invweight0[b1][0] + m->body_invweight0[b2][0];
+            const double tran = S.c_tran[c];
             const double mu_first = S.c_fri[c][0];
             rdiag = rtype == CM_CNSTR_CONTACT_PYRAMIDAL ? tran + mu_first * mu_first * tran : tran;
             solref0 = S.c_solref[c][0]; solref1 = S.c_solref[c][1];
