@@ -543,6 +543,57 @@ WV_DEVICE void pgs_rows_fast(const double (&brow)[CM_MAXEFC], int nrows, int r_,
     }
 }
 
+/* x := L^-1 x (forward) and x := L^-T x (backward) by substitution, lane = dof: lrow / lcol hold the lane's row /
+ * column of the unit-triangular factor (zeros outside its ancestors / descendants) and every hop is a v_readlane round
+ * trip (~40 clocks).  With a compile-time topology the two mutually independent dof ranges [trunk, split) and
+ * [split, nv) -- Cassie's legs -- run as two interleaved chains in separate accumulators, which halves the number of
+ * dependent hops; lanes outside a range carry zeros in its coefficients, so the other chain never touches them. */
+template <int NVP, class TOPO>
+WV_DEVICE double solve_forward(double z, const double (&lrow)[NVP], int lane, int nv) {
+    if constexpr (TOPO::is_static) {
+        constexpr int T = TOPO::trunk, SP = TOPO::split, NV = TOPO::nv;
+#pragma unroll
+        for (int i = 0; i < T; ++i) z -= lrow[i] * wv::readlane(z, i);
+        double za = z, zb = z;
+#pragma unroll
+        for (int t = 0; t < NVP; ++t) {
+            if (T + t < SP) za -= lrow[T + t] * wv::readlane(za, T + t);
+            if (SP + t < NV - 1) zb -= lrow[SP + t] * wv::readlane(zb, SP + t);
+        }
+        return lane >= SP ? zb : za;
+    } else {
+#pragma unroll
+        for (int i = 0; i < NVP - 1; ++i) {
+            if (i >= nv - 1) continue;
+            z -= lrow[i] * wv::readlane(z, i);
+        }
+        return z;
+    }
+}
+template <int NVP, class TOPO>
+WV_DEVICE double solve_backward(double w, const double (&lcol)[NVP], int lane, int nv) {
+    if constexpr (TOPO::is_static) {
+        constexpr int T = TOPO::trunk, SP = TOPO::split, NV = TOPO::nv;
+        double wa = w, wb = lane >= SP ? w : 0.0; /* lanes below the split collect the second range's terms from zero */
+#pragma unroll
+        for (int t = 0; t < NVP; ++t) {
+            if (SP - 1 - t >= T) wa -= lcol[SP - 1 - t] * wv::readlane(wa, SP - 1 - t);
+            if (NV - 1 - t >= SP) wb -= lcol[NV - 1 - t] * wv::readlane(wb, NV - 1 - t);
+        }
+        w = lane >= SP ? wb : wa + wb;
+#pragma unroll
+        for (int k = T - 1; k >= 1; --k) w -= lcol[k] * wv::readlane(w, k);
+        return w;
+    } else {
+#pragma unroll
+        for (int k = NVP - 1; k >= 1; --k) {
+            if (k >= nv) continue;
+            w -= lcol[k] * wv::readlane(w, k);
+        }
+        return w;
+    }
+}
+
 /* ======================================================== the env step ==== */
 template <int NVP, class TOPO>
 WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
@@ -1735,12 +1786,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
             double lrow[NVP];
 #pragma unroll
             for (int i = 0; i < NVP; ++i) lrow[i] = (isdof && i < k_) ? S.Lp[CK_TRI(k_, i)] : 0.0;
-#pragma unroll
-            for (int i = 0; i < NVP - 1; ++i) {
-                if (TOPO::is_static ? i >= TOPO::nv - 1 : i >= nv - 1) continue;
-                z -= lrow[i] * wv::readlane(z, i);
-            }
-            qacc = z;
+            qacc = solve_forward<NVP, TOPO>(z, lrow, lane, nv);
         }
         {
             const bool badv = isdof && (!(qacc == qacc) || fabs(qacc) > 1e10);
@@ -1793,17 +1839,9 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
                 lrowh[k] = (isdof && k < k_) ? S.LHp[CK_TRI(k_, k)] : 0.0;
             }
             const double dih = isdof ? S.dinvH[k_] : 0.0;
-#pragma unroll
-            for (int k = NVP - 1; k >= 1; --k) { /* L^-T */
-                if (TOPO::is_static ? k >= TOPO::nv : k >= nv) continue;
-                w -= lcol[k] * wv::readlane(w, k);
-            }
+            w = solve_backward<NVP, TOPO>(w, lcol, lane, nv); /* L^-T */
             w *= dih;
-#pragma unroll
-            for (int i = 0; i < NVP - 1; ++i) { /* L^-1 */
-                if (TOPO::is_static ? i >= TOPO::nv - 1 : i >= nv - 1) continue;
-                w -= lrowh[i] * wv::readlane(w, i);
-            }
+            w = solve_forward<NVP, TOPO>(w, lrowh, lane, nv);  /* L^-1 */
             qacc_int = qacc - w;
         }
         if (isdof) {
