@@ -71,6 +71,8 @@ def _declare(L):
     L.phys_batch_device_ptr.restype = vp
     L.phys_batch_device_ptr.argtypes = [vp, c.c_int]
     L.phys_batch_bind.argtypes = [vp, c.c_int, vp]
+    L.phys_batch_bind_strided.argtypes = [vp, c.c_int, vp, c.c_int]
+    L.phys_batch_clear_warn.argtypes = [vp, c.c_int, c.c_int]
     L.phys_batch_step.argtypes = [vp, c.c_int, vp]
     L.phys_batch_forward.argtypes = [vp, vp]
     L.phys_batch_sync.argtypes = [vp]

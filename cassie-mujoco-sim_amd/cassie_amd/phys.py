@@ -118,9 +118,17 @@ class Batch:
     def device_ptr(self, field):
         return lib().phys_batch_device_ptr(self._h, field)
 
-    def bind(self, field, device_ptr):
-        if lib().phys_batch_bind(self._h, field, device_ptr) != 0:
-            raise RuntimeError("bind failed")
+    def bind(self, field, device_ptr, row_stride=None):
+        """Aliases a field to caller-owned HBM; `row_stride` (doubles, qpos / qvel / sensordata only) lets the field be a
+        column block of a wider tensor, e.g. one [nenv][nq + nv + nsensordata] observation block."""
+        rc = (lib().phys_batch_bind(self._h, field, device_ptr) if row_stride is None
+              else lib().phys_batch_bind_strided(self._h, field, device_ptr, int(row_stride)))
+        if rc != 0:
+            raise RuntimeError("bind failed: " + (lib().phys_last_error() or b"").decode())
+
+    def clear_warnings(self, env0=0, n=None):
+        if lib().phys_batch_clear_warn(self._h, env0, self.nenv - env0 if n is None else n) != 0:
+            raise RuntimeError("clear_warn failed")
 
     def set_model(self, pod, env=-1):
         if lib().phys_batch_set_model(self._h, ctypes.byref(pod), env) != 0:

@@ -13,8 +13,11 @@
  * cassie_sim_t driven with the same inputs.
  */
 #define _GNU_SOURCE
+#include <linux/futex.h>
+#include <math.h>
 #include <pthread.h>
 #include <sched.h>
+#include <sys/syscall.h>
 #include <stdatomic.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -55,19 +58,27 @@ int cassie_host_cpu_count(void)
 
 typedef void (*job_fn)(struct cassie_batch *b, int e0, int e1);
 
+/* Workers wait for the next job by spinning for a short while (the pre / post phases of one step and consecutive steps
+ * of a tight loop follow each other within tens of microseconds) and then SLEEP on the generation counter (futex), so
+ * an idle batch -- policy inference, a long fused launch -- does not burn nthreads - 1 host cores. */
+#define POOL_SPINS 20000
+static void futex_wait(atomic_int *addr, int expected) { syscall(SYS_futex, (int *)addr, FUTEX_WAIT_PRIVATE, expected, NULL, NULL, 0); }
+static void futex_wake_all(atomic_int *addr) { syscall(SYS_futex, (int *)addr, FUTEX_WAKE_PRIVATE, 0x7fffffff, NULL, NULL, 0); }
+
 struct cassie_batch {
     phys_model_t *m;
     cm_model_t pod;
     cassie_hostmodel_t hm;
     phys_batch_t *pb;
     int nenv, nthreads, nsd, nu;
+    int mjsteps;                        /* physics steps per control step: round(5e-4 / timestep), reference :1128-1131 */
     cassie_hostenv_t **env;
     double *sensordata, *actvel, *ctrl; /* pinned host mirrors [nenv][dim] */
     cassie_out_t *ytmp;
     /* fork-join pool */
     pthread_t *threads;
     int *tid_arg;
-    atomic_int generation, done, quit;
+    atomic_int generation, done, quit, sleepers;
     job_fn job;
     /* per-call arguments */
     const pd_in_t *u_pd;
@@ -94,7 +105,15 @@ static void *worker(void *arg)
         int spins = 0;
         while (atomic_load_explicit(&b->generation, memory_order_acquire) == seen) {
             if (atomic_load_explicit(&b->quit, memory_order_relaxed)) return NULL;
-            if (++spins > 4000) { sched_yield(); spins = 0; }
+            if (++spins > POOL_SPINS) {
+                atomic_fetch_add_explicit(&b->sleepers, 1, memory_order_seq_cst);
+                if (atomic_load_explicit(&b->generation, memory_order_seq_cst) == seen && !atomic_load_explicit(&b->quit, memory_order_seq_cst))
+                    futex_wait(&b->generation, seen);
+                atomic_fetch_sub_explicit(&b->sleepers, 1, memory_order_seq_cst);
+                spins = 0;
+            } else {
+                __builtin_ia32_pause();
+            }
         }
         seen = atomic_load_explicit(&b->generation, memory_order_acquire);
         int e0, e1;
@@ -108,7 +127,8 @@ static void run_parallel(struct cassie_batch *b, job_fn fn)
 {
     b->job = fn;
     atomic_store_explicit(&b->done, 0, memory_order_relaxed);
-    atomic_fetch_add_explicit(&b->generation, 1, memory_order_release);
+    atomic_fetch_add_explicit(&b->generation, 1, memory_order_seq_cst);
+    if (atomic_load_explicit(&b->sleepers, memory_order_seq_cst) > 0) futex_wake_all(&b->generation);
     int e0, e1;
     slice(b, 0, &e0, &e1);
     fn(b, e0, e1);
@@ -144,7 +164,7 @@ static void job_ethercat(struct cassie_batch *b, int e0, int e1)
 static int launch_physics(struct cassie_batch *b)
 {
     int rc = phys_batch_upload_async(b->pb, PHYS_F_CTRL, b->ctrl, 0, b->nenv);
-    rc |= phys_batch_step(b->pb, 1, NULL);
+    rc |= phys_batch_step(b->pb, b->mjsteps, NULL);
     rc |= phys_batch_download_async(b->pb, PHYS_F_SENSORDATA, b->sensordata, 0, b->nenv);
     rc |= phys_batch_download_async(b->pb, PHYS_F_ACTUATOR_VELOCITY, b->actvel, 0, b->nenv);
     return rc;
@@ -164,6 +184,8 @@ cassie_batch_t *cassie_batch_create(const char *modelfile, int nenv, int device,
         return NULL;
     }
     b->nenv = nenv; b->nsd = b->pod.nsensordata; b->nu = b->pod.nu;
+    b->mjsteps = (int)round(5e-4 / b->pod.timestep);
+    if (b->mjsteps < 1) b->mjsteps = 1;
     b->pb = phys_batch_create(&b->pod, nenv, device);
     if (!b->pb) { fprintf(stderr, "cassie_batch_create: %s\n", phys_last_error()); cassie_batch_free(b); return NULL; }
     b->sensordata = phys_host_alloc(sizeof(double) * (size_t)nenv * b->nsd);
@@ -187,7 +209,13 @@ cassie_batch_t *cassie_batch_create(const char *modelfile, int nenv, int device,
     phys_batch_download(b->pb, PHYS_F_SENSORDATA, b->sensordata, 0, nenv);
     phys_batch_download(b->pb, PHYS_F_ACTUATOR_VELOCITY, b->actvel, 0, nenv);
 
-    if (nthreads <= 0) nthreads = cassie_host_cpu_count();
+    if (nthreads <= 0) {
+        /* all usable cores, shared fairly between the ranks of a one-process-per-GPU job on this node */
+        const char *lws = getenv("LOCAL_WORLD_SIZE");
+        int ranks = lws ? atoi(lws) : 1;
+        nthreads = cassie_host_cpu_count() / (ranks > 0 ? ranks : 1);
+        if (nthreads < 1) nthreads = 1;
+    }
     if (nthreads > nenv) nthreads = nenv;
     b->nthreads = nthreads;
     b->threads = calloc((size_t)nthreads, sizeof(pthread_t));
@@ -204,6 +232,7 @@ void cassie_batch_free(cassie_batch_t *b)
     if (!b) return;
     if (b->threads) {
         atomic_store(&b->quit, 1);
+        futex_wake_all(&b->generation);
         for (int t = 1; t < b->nthreads; ++t) pthread_join(b->threads[t], NULL);
         free(b->threads);
     }
@@ -273,9 +302,12 @@ int cassie_batch_foot_forces(cassie_batch_t *b, double *cfrc)
 
 int cassie_batch_full_reset(cassie_batch_t *b, const unsigned char *mask)
 {
+    /* cassie_sim_full_reset per env (reference :2008-2033): pose, velocities, controls, perturbations, torque delay,
+     * estimator; plus the sticky device-side warning bits of the envs that are reset (mj_resetData clears
+     * mjData.warning).  Time, filters and the solver warm start are left alone like the single-env version. */
     if (!b) return -1;
-    const int nq = b->pod.nq, nv = b->pod.nv;
-    double *q = malloc(sizeof(double) * nq), *z = calloc((size_t)(nv > 6 * b->pod.nbody ? nv : 6 * b->pod.nbody), sizeof(double));
+    const int nq = b->pod.nq, nv = b->pod.nv, nz = nv > 6 * b->pod.nbody ? nv : 6 * b->pod.nbody;
+    double *q = malloc(sizeof(double) * nq), *z = calloc((size_t)nz, sizeof(double));
     if (!q || !z) { free(q); free(z); return -1; }
     memcpy(q, b->pod.qpos0, sizeof(double) * nq);
     q[0] = 0; q[1] = 0; q[2] = 1.01; q[3] = 1; q[4] = q[5] = q[6] = 0; /* reference :2010 */
@@ -286,6 +318,13 @@ int cassie_batch_full_reset(cassie_batch_t *b, const unsigned char *mask)
         rc |= phys_batch_upload(b->pb, PHYS_F_QPOS, q, e, 1);
         rc |= phys_batch_upload(b->pb, PHYS_F_QVEL, z, e, 1);
         rc |= phys_batch_upload(b->pb, PHYS_F_CTRL, z, e, 1);
+        rc |= phys_batch_upload(b->pb, PHYS_F_QACC, z, e, 1);
+        if (phys_batch_uses_applied(b->pb)) { /* perturbations exist on the device only once somebody uploaded some */
+            rc |= phys_batch_upload(b->pb, PHYS_F_QFRC_APPLIED, z, e, 1);
+            rc |= phys_batch_upload(b->pb, PHYS_F_XFRC_APPLIED, z, e, 1);
+        }
+        rc |= phys_batch_clear_warn(b->pb, e, 1);
+        memset(b->ctrl + (size_t)e * b->nu, 0, sizeof(double) * b->nu);
         cassie_hostenv_reset(b->env[e]);
     }
     free(q); free(z);

@@ -310,6 +310,23 @@ void cassie_sim_free(cassie_sim_t *c)
 }
 
 /* ---------------------------------------------------------------- stepping --- */
+/* The encoder / motor constants are re-read from the model before every step because callers may edit gear, ctrlrange
+ * or the user data through the exposed pointers.  If the edited model is no longer usable (e.g. an actuator's gear no
+ * longer matches its drive encoder's) the previous constants are kept and the problem is reported once, instead of
+ * stepping with a half-written or zero table (division by zero -> NaN ctrl on the GPU). */
+static bool refresh_hostmodel(cassie_sim_t *c)
+{
+    cassie_hostmodel_t hm;
+    if (cassie_hostmodel_from_model(c->m, &hm) == 0) { c->hm = hm; return true; }
+    static bool told = false;
+    if (!told) {
+        fprintf(stderr, "cassiemujoco: the edited model no longer yields valid encoder / motor constants "
+                        "(actuator gear vs sensor objid, nuser_sensor / nuser_actuator); keeping the previous ones\n");
+        told = true;
+    }
+    return false;
+}
+
 static void step_physics_after_host(cassie_sim_t *c)
 {
     const double dt = *phys_model_array(c->m, PHYS_M_TIMESTEP);
@@ -321,14 +338,14 @@ void cassie_sim_step_ethercat(cassie_sim_t *c, cassie_out_t *y, const cassie_in_
 {
     /* motor model (new torque enters the delay line, oldest goes to ctrl), then the measurement of the
      * current state before the control acts, then the physics */
-    cassie_hostmodel_from_model(c->m, &c->hm);
+    refresh_hostmodel(c);
     cassie_hostenv_ethercat(c->host, &c->hm, u, c->d.sensordata, c->d.actuator_velocity, c->d.ctrl, y);
     step_physics_after_host(c);
 }
 
 void cassie_sim_step(cassie_sim_t *c, cassie_out_t *y, const cassie_user_in_t *u)
 {
-    cassie_hostmodel_from_model(c->m, &c->hm);
+    refresh_hostmodel(c);
     cassie_hostenv_step(c->host, &c->hm, u, c->d.sensordata, c->d.actuator_velocity, c->d.ctrl, y);
     step_physics_after_host(c);
 }
@@ -336,7 +353,7 @@ void cassie_sim_step(cassie_sim_t *c, cassie_out_t *y, const cassie_user_in_t *u
 void cassie_sim_step_pd(cassie_sim_t *c, state_out_t *y, const pd_in_t *u)
 {
     cassie_out_t cassie_out;
-    cassie_hostmodel_from_model(c->m, &c->hm);
+    refresh_hostmodel(c);
     cassie_hostenv_step_pd_pre(c->host, &c->hm, u, c->d.sensordata, c->d.actuator_velocity, c->d.ctrl, &cassie_out);
     step_physics_after_host(c);
     cassie_hostenv_step_pd_post(c->host, &cassie_out, y);
@@ -345,7 +362,7 @@ void cassie_sim_step_pd(cassie_sim_t *c, state_out_t *y, const pd_in_t *u)
 void cassie_sim_step_pd_no2khz(cassie_sim_t *c, state_out_t *y, const pd_in_t *u)
 {
     cassie_out_t cassie_out;
-    cassie_hostmodel_from_model(c->m, &c->hm);
+    refresh_hostmodel(c);
     cassie_hostenv_step_pd_pre(c->host, &c->hm, u, c->d.sensordata, c->d.actuator_velocity, c->d.ctrl, &cassie_out);
     physics_step(c, 1); /* exactly one physics step whatever the timestep (reference :1175) */
     cassie_hostenv_step_pd_post(c->host, &cassie_out, y);
@@ -1001,7 +1018,7 @@ void reset_state_est(cassie_sim_t *c, state_out_t *y)
     memset(&cassie_out, 0, sizeof cassie_out); /* uninitialised in the reference (:2039-2047) */
     cassie_out_t measured;
     (void)cassie_user_in; (void)cassie_in;
-    cassie_hostmodel_from_model(c->m, &c->hm);
+    refresh_hostmodel(c);
     cassie_hostenv_step_pd_pre(c->host, &c->hm, &u, c->d.sensordata, c->d.actuator_velocity, c->d.ctrl, &measured);
     state_output_step(cassie_hostenv_estimator(c->host), &cassie_out, y);
 }

@@ -28,12 +28,14 @@ struct phys_batch {
     int model_stride = 0;
     bool generic_kernel = false;   /* validation aid: never pick a compile-time-topology instantiation */
     int dim[PHYS_F_COUNT];
+    int stride[PHYS_F_COUNT];       /* doubles between consecutive envs' rows (= dim unless bound with a stride) */
     double *d_field[PHYS_F_COUNT];
     bool owned[PHYS_F_COUNT];
     int *d_warn = nullptr, *d_info = nullptr;
     float *d_hfield = nullptr;
     size_t hfield_stride = 0, hfield_floats = 0; /* stride 0: one grid shared by all envs; else one grid of hfield_floats per env */
     hipStream_t stream = nullptr;
+    hipStream_t last_stream = nullptr; /* the stream of the most recent launch (callers may pass their own) */
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool use_applied = false;       /* qfrc_applied / xfrc_applied are passed only once uploaded */
     bool pd_mode = false;
@@ -55,8 +57,8 @@ static ck::PhysIO make_io(phys_batch *b, int nsub, int integrate) {
     io.models = b->d_models;
     io.model_stride = b->model_stride;
     io.nenv = b->nenv; io.nsub = nsub; io.integrate = integrate;
-    io.sq = b->host_model.nq; io.sv = b->host_model.nv; io.su = b->host_model.nu;
-    io.ssd = b->host_model.nsensordata; io.sb = b->host_model.nbody;
+    io.sq = b->stride[PHYS_F_QPOS]; io.sqv = b->stride[PHYS_F_QVEL]; io.sv = b->host_model.nv; io.su = b->host_model.nu;
+    io.ssd = b->stride[PHYS_F_SENSORDATA]; io.sb = b->host_model.nbody;
     io.qpos = b->d_field[PHYS_F_QPOS]; io.qvel = b->d_field[PHYS_F_QVEL];
     io.qacc_warmstart = b->d_field[PHYS_F_QACC_WARMSTART]; io.time = b->d_field[PHYS_F_TIME];
     io.ctrl = b->d_field[PHYS_F_CTRL];
@@ -77,8 +79,17 @@ static ck::PhysIO make_io(phys_batch *b, int nsub, int integrate) {
     return io;
 }
 
+/* Model, terrain and ext-buffer updates are blocking copies that must not overtake (or be overtaken by) a kernel that
+ * is still in flight on the batch's stream or on the caller's: wait for both first. */
+static bool quiesce(phys_batch *b) {
+    bool ok = hip_ok(hipStreamSynchronize(b->stream), "hipStreamSynchronize");
+    if (b->last_stream && b->last_stream != b->stream) ok = hip_ok(hipStreamSynchronize(b->last_stream), "hipStreamSynchronize(caller stream)") && ok;
+    return ok;
+}
+
 static int launch(phys_batch *b, int nsub, int integrate, hipStream_t s) {
     ck::PhysIO io = make_io(b, nsub, integrate);
+    b->last_stream = s;
     const dim3 grid(b->nenv), block(WV_WAVE);
     /* the compile-time-topology instantiations are used only when the model's dof tree is exactly theirs */
     const cm_model_t &hm = b->host_model;
@@ -96,6 +107,19 @@ static int launch(phys_batch *b, int nsub, int integrate, hipStream_t s) {
     else
         hipLaunchKernelGGL((ck::cassie_step_kernel<40, ck::TopoRuntime>), grid, block, 0, s, io);
     return hip_ok(hipGetLastError(), "cassie_step_kernel launch") ? 0 : -1;
+}
+
+/* rows [env0, env0 + n) of a field between a dense host array and HBM (dense, or strided when the field is a column
+ * block of a caller-owned tensor), asynchronously on the batch's stream */
+static bool copy_rows(phys_batch *b, int field, void *host, int env0, int n, bool to_device, const char *what) {
+    const size_t row = (size_t)b->dim[field], st = (size_t)b->stride[field];
+    double *dev = b->d_field[field] + st * env0;
+    if (n == 0) return true;
+    if (st == row)
+        return hip_ok(to_device ? hipMemcpyAsync(dev, host, sizeof(double) * row * n, hipMemcpyHostToDevice, b->stream)
+                                : hipMemcpyAsync(host, dev, sizeof(double) * row * n, hipMemcpyDeviceToHost, b->stream), what);
+    return hip_ok(to_device ? hipMemcpy2DAsync(dev, sizeof(double) * st, host, sizeof(double) * row, sizeof(double) * row, n, hipMemcpyHostToDevice, b->stream)
+                            : hipMemcpy2DAsync(host, sizeof(double) * row, dev, sizeof(double) * st, sizeof(double) * row, n, hipMemcpyDeviceToHost, b->stream), what);
 }
 
 extern "C" {
@@ -119,7 +143,7 @@ phys_batch_t *phys_batch_create(const cm_model_t *model, int nenv, int device) {
                                  model->nu, model->nu, model->nu, model->nbody * 3};
     bool ok = true;
     for (int f = 0; f < PHYS_F_COUNT; ++f) {
-        b->dim[f] = d[f]; b->d_field[f] = nullptr; b->owned[f] = true;
+        b->dim[f] = d[f]; b->stride[f] = d[f]; b->d_field[f] = nullptr; b->owned[f] = true;
         size_t bytes = sizeof(double) * (size_t)nenv * (d[f] > 0 ? d[f] : 1);
         ok = ok && hip_ok(hipMalloc((void **)&b->d_field[f], bytes), "hipMalloc(field)");
         if (ok) ok = hip_ok(hipMemset(b->d_field[f], 0, bytes), "hipMemset(field)");
@@ -172,6 +196,7 @@ int phys_batch_set_model(phys_batch_t *b, const cm_model_t *model, int env) {
         return -1;
     }
     (void)hipSetDevice(b->device);
+    if (!quiesce(b)) return -1;
     if (env < 0) {
         if (b->model_stride == 1) { /* back to one shared model */
             (void)hipFree(b->d_models);
@@ -198,6 +223,7 @@ int phys_batch_set_model(phys_batch_t *b, const cm_model_t *model, int env) {
 int phys_batch_set_hfield(phys_batch_t *b, const float *data, int n) {
     if (!b || !data || n <= 0) return -1;
     (void)hipSetDevice(b->device);
+    if (!quiesce(b)) return -1;
     if (b->d_hfield && (b->hfield_stride != 0 || b->hfield_floats != (size_t)n)) { /* back to one shared grid */
         (void)hipFree(b->d_hfield);
         b->d_hfield = nullptr;
@@ -211,6 +237,7 @@ int phys_batch_set_hfield(phys_batch_t *b, const float *data, int n) {
 int phys_batch_set_hfield_env(phys_batch_t *b, int env, const float *data, int n) {
     if (!b || !data || n <= 0 || env < 0 || env >= b->nenv) return -1;
     (void)hipSetDevice(b->device);
+    if (!quiesce(b)) return -1;
     if (b->hfield_stride == 0 || b->hfield_floats != (size_t)n) {
         /* first per-env grid: expand to one grid per env, every env starting from the shared grid (or from zeros) */
         float *all = nullptr;
@@ -232,38 +259,26 @@ int phys_batch_upload(phys_batch_t *b, int field, const double *host, int env0, 
     if (!b || !host || field < 0 || field >= PHYS_F_COUNT || env0 < 0 || n < 0 || env0 + n > b->nenv) return -1;
     (void)hipSetDevice(b->device);
     if (field == PHYS_F_QFRC_APPLIED || field == PHYS_F_XFRC_APPLIED) b->use_applied = true;
-    const size_t row = (size_t)b->dim[field];
-    return hip_ok(hipMemcpyAsync(b->d_field[field] + row * env0, host, sizeof(double) * row * n, hipMemcpyHostToDevice,
-                                 b->stream), "upload") &&
-                   hip_ok(hipStreamSynchronize(b->stream), "upload sync")
-               ? 0 : -1;
+    return copy_rows(b, field, (void *)host, env0, n, true, "upload") && hip_ok(hipStreamSynchronize(b->stream), "upload sync") ? 0 : -1;
 }
 
 int phys_batch_download(phys_batch_t *b, int field, double *host, int env0, int n) {
     if (!b || !host || field < 0 || field >= PHYS_F_COUNT || env0 < 0 || n < 0 || env0 + n > b->nenv) return -1;
     (void)hipSetDevice(b->device);
-    const size_t row = (size_t)b->dim[field];
-    return hip_ok(hipMemcpyAsync(host, b->d_field[field] + row * env0, sizeof(double) * row * n, hipMemcpyDeviceToHost,
-                                 b->stream), "download") &&
-                   hip_ok(hipStreamSynchronize(b->stream), "download sync")
-               ? 0 : -1;
+    return copy_rows(b, field, host, env0, n, false, "download") && hip_ok(hipStreamSynchronize(b->stream), "download sync") ? 0 : -1;
 }
 
 int phys_batch_upload_async(phys_batch_t *b, int field, const double *host, int env0, int n) {
     if (!b || !host || field < 0 || field >= PHYS_F_COUNT || env0 < 0 || n < 0 || env0 + n > b->nenv) return -1;
     (void)hipSetDevice(b->device);
     if (field == PHYS_F_QFRC_APPLIED || field == PHYS_F_XFRC_APPLIED) b->use_applied = true;
-    const size_t row = (size_t)b->dim[field];
-    return hip_ok(hipMemcpyAsync(b->d_field[field] + row * env0, host, sizeof(double) * row * n, hipMemcpyHostToDevice,
-                                 b->stream), "upload_async") ? 0 : -1;
+    return copy_rows(b, field, (void *)host, env0, n, true, "upload_async") ? 0 : -1;
 }
 
 int phys_batch_download_async(phys_batch_t *b, int field, double *host, int env0, int n) {
     if (!b || !host || field < 0 || field >= PHYS_F_COUNT || env0 < 0 || n < 0 || env0 + n > b->nenv) return -1;
     (void)hipSetDevice(b->device);
-    const size_t row = (size_t)b->dim[field];
-    return hip_ok(hipMemcpyAsync(host, b->d_field[field] + row * env0, sizeof(double) * row * n, hipMemcpyDeviceToHost,
-                                 b->stream), "download_async") ? 0 : -1;
+    return copy_rows(b, field, host, env0, n, false, "download_async") ? 0 : -1;
 }
 
 void *phys_host_alloc(size_t bytes) {
@@ -283,15 +298,39 @@ int phys_batch_download_warn(phys_batch_t *b, int *host_warn, int *host_info) {
     return ok ? 0 : -1;
 }
 
+int phys_batch_uses_applied(const phys_batch_t *b) { return (b && b->use_applied) ? 1 : 0; }
+
+int phys_batch_clear_warn(phys_batch_t *b, int env0, int n) {
+    if (!b || env0 < 0 || n < 0 || env0 + n > b->nenv) return -1;
+    (void)hipSetDevice(b->device);
+    if (!quiesce(b)) return -1;
+    return hip_ok(hipMemsetAsync(b->d_warn + env0, 0, sizeof(int) * (size_t)n, b->stream), "hipMemset(warn)") &&
+                   hip_ok(hipStreamSynchronize(b->stream), "warn sync") ? 0 : -1;
+}
+
 void *phys_batch_device_ptr(phys_batch_t *b, int field) {
     return (b && field >= 0 && field < PHYS_F_COUNT) ? (void *)b->d_field[field] : nullptr;
 }
 
 int phys_batch_bind(phys_batch_t *b, int field, void *device_ptr) {
+    return phys_batch_bind_strided(b, field, device_ptr, (b && field >= 0 && field < PHYS_F_COUNT) ? b->dim[field] : 0);
+}
+
+int phys_batch_bind_strided(phys_batch_t *b, int field, void *device_ptr, int row_stride) {
     if (!b || !device_ptr || field < 0 || field >= PHYS_F_COUNT) return -1;
+    if (row_stride != b->dim[field]) {
+        const bool may = field == PHYS_F_QPOS || field == PHYS_F_QVEL || field == PHYS_F_SENSORDATA;
+        if (!may || row_stride < b->dim[field]) {
+            phys_set_last_error("phys_batch_bind_strided: only qpos / qvel / sensordata take a row stride, and it must be >= the field's dim");
+            return -1;
+        }
+    }
     (void)hipSetDevice(b->device);
+    /* no stream synchronisation: launches already queued keep the pointers they were given, and hipFree of the
+     * replaced buffer waits for the device by itself */
     if (b->owned[field] && b->d_field[field]) (void)hipFree(b->d_field[field]);
     b->d_field[field] = (double *)device_ptr;
+    b->stride[field] = row_stride;
     b->owned[field] = false;
     if (field == PHYS_F_QFRC_APPLIED || field == PHYS_F_XFRC_APPLIED) b->use_applied = true;
     return 0;
@@ -324,11 +363,12 @@ int phys_batch_sync(phys_batch_t *b) {
 int phys_batch_enable_ext(phys_batch_t *b, int on) {
     if (!b) return -1;
     (void)hipSetDevice(b->device);
+    if (!quiesce(b)) return -1;
     if (on && !b->d_ext) {
         if (!hip_ok(hipMalloc((void **)&b->d_ext, sizeof(cm_ext_t) * (size_t)b->nenv), "hipMalloc(ext)")) return -1;
-        (void)hipMemset(b->d_ext, 0, sizeof(cm_ext_t) * (size_t)b->nenv);
+        if (!hip_ok(hipMemsetAsync(b->d_ext, 0, sizeof(cm_ext_t) * (size_t)b->nenv, b->stream), "hipMemset(ext)") ||
+            !hip_ok(hipStreamSynchronize(b->stream), "ext sync")) return -1;
     } else if (!on && b->d_ext) {
-        (void)hipStreamSynchronize(b->stream);
         (void)hipFree(b->d_ext);
         b->d_ext = nullptr;
     }

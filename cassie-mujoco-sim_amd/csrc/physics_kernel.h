@@ -73,7 +73,9 @@ struct PhysIO {
     int model_stride;           /* 0 = shared, 1 = per-env */
     int nenv, nsub;             /* nsub physics steps per launch (ctrl / PD targets held) */
     int integrate;              /* 1 = step (Euler), 0 = forward only (mj_forward role) */
-    int sq, sv, su, ssd, sb;    /* row strides: nq, nv, nu, nsensordata, nbody */
+    int sq, sqv, sv, su, ssd, sb; /* row strides in doubles: qpos, qvel, the other nv-sized fields, nu-sized fields, sensordata;
+                                     sb = nbody.  qpos / qvel / sensordata have strides of their own so that the three can be
+                                     columns of one caller-owned [nenv][nq + nv + nsensordata] observation block */
     double *qpos, *qvel, *qacc_warmstart, *time;
     const double *ctrl, *qfrc_applied, *xfrc_applied; /* the last two may be null */
     double *qacc, *sensordata, *actuator_velocity;
@@ -607,7 +609,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
     /* ---------------- load state (coalesced, env-major) ---------------- */
     if (lane < nq) S.qpos[lane] = io.qpos[(size_t)env * io.sq + lane];
     if (lane < nv) {
-        S.qvel[lane] = io.qvel[(size_t)env * io.sv + lane];
+        S.qvel[lane] = io.qvel[(size_t)env * io.sqv + lane];
         S.qacc_ws[lane] = io.qacc_warmstart[(size_t)env * io.sv + lane];
     }
     if (lane < nu) S.ctrl[lane] = io.ctrl[(size_t)env * io.su + lane];
@@ -1878,7 +1880,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
     if (io.integrate) {
         if (lane < nq) io.qpos[(size_t)env * io.sq + lane] = S.qpos[lane];
         if (lane < nv) {
-            io.qvel[(size_t)env * io.sv + lane] = S.qvel[lane];
+            io.qvel[(size_t)env * io.sqv + lane] = S.qvel[lane];
             io.qacc_warmstart[(size_t)env * io.sv + lane] = S.qacc_ws[lane];
         }
         if (lane == 0) io.time[env] = time;

@@ -96,6 +96,15 @@ int phys_batch_download_warn(phys_batch_t *b, int *host_warn, int *host_info /* 
 /* raw device pointer of a field (for torch / RCCL interop); bind replaces it with caller-owned HBM */
 void *phys_batch_device_ptr(phys_batch_t *b, int field);
 int phys_batch_bind(phys_batch_t *b, int field, void *device_ptr);
+/* same with a row stride in doubles (>= the field's dim) for PHYS_F_QPOS / QVEL / SENSORDATA, so that the three can be
+ * column blocks of ONE caller-owned [nenv][nq + nv + nsensordata] observation tensor -- the buffer an RCCL all-gather
+ * sends as is; uploads / downloads of a strided field are 2-D copies */
+int phys_batch_bind_strided(phys_batch_t *b, int field, void *device_ptr, int row_stride);
+/* clears the sticky warning bits of envs [env0, env0 + n) (the batched cassie_sim_full_reset does this for the envs it
+ * resets; mj_resetData clears mjData.warning the same way) */
+int phys_batch_clear_warn(phys_batch_t *b, int env0, int n);
+/* non-zero once PHYS_F_QFRC_APPLIED / PHYS_F_XFRC_APPLIED have been uploaded or bound (until then the kernel skips them) */
+int phys_batch_uses_applied(const phys_batch_t *b);
 /* mj_step1 + mj_step2, nsub times with ctrl held (reference :1130-1134), on `stream`
  * (a hipStream_t passed as void*, NULL = the batch's own stream); asynchronous */
 int phys_batch_step(phys_batch_t *b, int nsub, void *stream);

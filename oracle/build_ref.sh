@@ -22,3 +22,12 @@ mkdir -p "$HERE/_ref"
 gcc -O2 -std=gnu11 -fPIC -shared -I"$HERE/../include" -I"$HERE/_ref" "$HERE/ref_hostpath_harness.c" \
     -Wl,--whole-archive "$REF/src/libagilitycassie.a" -Wl,--no-whole-archive -lm -o "$HERE/_ref/libref_hostpath.so"
 echo "built $HERE/_ref/libref_hostpath.so"
+# The reference's own Python wrapper and MJCF files, staged (not committed: oracle/_ref/ is git-ignored, but it travels
+# to the GPU box with the snapshot) so that the -m gpu suite can run the UNMODIFIED example/cassiemujoco.py against the
+# product library (tests/test_dropin_gpu.py) and so that tests/mujoco_ref.py has the XML a genuine MuJoCo would load.
+mkdir -p "$HERE/_ref/example" "$HERE/_ref/model"
+cp "$REF/example/cassiemujoco.py" "$REF/example/cassiemujoco_ctypes.py" "$HERE/_ref/example/"
+cp "$REF/model/cassie.xml" "$REF/model/cassie_hfield.xml" "$REF/model/cassie_tray_box.xml" "$HERE/_ref/model/"
+cp -r "$REF/model/cassie-stl-meshes" "$HERE/_ref/model/"
+[ -d "$REF/model/terrains" ] && cp -r "$REF/model/terrains" "$HERE/_ref/model/" || true
+echo "staged $HERE/_ref/example and $HERE/_ref/model"

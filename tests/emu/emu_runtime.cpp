@@ -155,7 +155,7 @@ extern "C" int emu_phys_run(const cm_model_t *model, int nenv, int nsub, int int
     memset(&g_io, 0, sizeof g_io);
     g_io.models = model; g_io.model_stride = 0;
     g_io.nenv = nenv; g_io.nsub = nsub; g_io.integrate = integrate;
-    g_io.sq = model->nq; g_io.sv = model->nv; g_io.su = model->nu; g_io.ssd = model->nsensordata; g_io.sb = model->nbody;
+    g_io.sq = model->nq; g_io.sqv = model->nv; g_io.sv = model->nv; g_io.su = model->nu; g_io.ssd = model->nsensordata; g_io.sb = model->nbody;
     g_io.qpos = qpos; g_io.qvel = qvel; g_io.qacc_warmstart = qacc_warmstart; g_io.time = time;
     g_io.ctrl = ctrl; g_io.qfrc_applied = qfrc_applied; g_io.xfrc_applied = xfrc_applied;
     g_io.qacc = qacc; g_io.sensordata = sensordata; g_io.actuator_velocity = actuator_velocity;

@@ -86,3 +86,27 @@ def test_reference_ctypes_wrapper_imports_against_this_library(built, tmp_path):
     out = subprocess.run([sys.executable, "-c", code], cwd=tmp_path, capture_output=True, text=True)
     assert out.returncode == 0, out.stderr[-2000:]
     assert int(out.stdout.strip()) > 150
+
+
+REF_STAGE = os.path.join(REPO_DIR, "oracle", "_ref")
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF_STAGE, "example", "cassiemujoco.py")),
+                    reason="reference wrapper not staged (oracle/build_ref.sh runs where /root/reference exists)")
+def test_reference_python_wrapper_module_imports_and_loads_the_mjcf(built, tmp_path):
+    """The unmodified example/cassiemujoco.py calls cassie_mujoco_init("../model/cassie.xml") at import time
+    (reference example/cassiemujoco.py:26-27): with the staged layout example/ + model/ that must succeed against
+    this library -- model loading is host code and needs no GPU.  (Stepping it is the -m gpu test in
+    tests/test_dropin_gpu.py.)"""
+    import shutil
+    ex = tmp_path / "example"
+    ex.mkdir()
+    for f in ("cassiemujoco.py", "cassiemujoco_ctypes.py"):
+        shutil.copy(os.path.join(REF_STAGE, "example", f), ex / f)
+    os.symlink(LIB_PATH, ex / "libcassiemujoco.so")
+    os.symlink(os.path.join(REF_STAGE, "model"), tmp_path / "model")
+    code = ("import cassiemujoco as m, cassiemujoco_ctypes as c; "
+            "print(int(bool(c.cassie_mujoco_init(b'../model/cassie.xml'))), hasattr(m.CassieSim, 'step_pd'))")
+    out = subprocess.run([sys.executable, "-c", code], cwd=ex, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.split() == ["1", "True"]

@@ -194,3 +194,87 @@ def test_batch_step_pd_equals_independent_simulators(L):
     for s in sims:
         L.cassie_sim_free(s)
     L.cassie_batch_free(b)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The reference's UNMODIFIED Python wrapper (example/cassiemujoco.py:31-72) on top of this library.  oracle/build_ref.sh
+# stages the two wrapper files and the MJCF models into the git-ignored oracle/_ref/ in the build container; the
+# directory travels to the GPU box with the snapshot.
+REF_STAGE = os.path.join(REPO_DIR, "oracle", "_ref")
+
+_WRAPPER_SCRIPT = r"""
+import json, sys
+import numpy as np
+from cassiemujoco import *          # the reference's module: dlopens ./libcassiemujoco.so, cassie_mujoco_init at import
+sim = CassieSim("../model/cassie.xml")
+u = pd_in_t()
+off = [0.0045, 0, 0.4973, -1.1997, -1.5968]
+for leg in (u.leftLeg, u.rightLeg):
+    for i in range(5):
+        leg.motorPd.pGain[i], leg.motorPd.dGain[i], leg.motorPd.pTarget[i] = [70, 70, 100, 100, 50][i], [7, 7, 8, 8, 5][i], off[i]
+traj = []
+for s in range(60):
+    y = sim.step_pd(u)
+    traj.append(list(sim.qpos()))
+print(json.dumps({"qpos": traj, "nq": sim.nq, "nv": sim.nv, "time": sim.time(), "pelvis_z_est": y.pelvis.position[2],
+                  "foot_pos": list(sim.foot_pos()), "foot_forces": [float(x) for x in sim.get_foot_forces()]}))
+"""
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF_STAGE, "example", "cassiemujoco.py")),
+                    reason="reference wrapper not staged (oracle/build_ref.sh runs where /root/reference exists)")
+def test_unmodified_reference_python_wrapper_end_to_end(L, tmp_path):
+    """CassieSim("../model/cassie.xml").step_pd(pd_in_t) x 60 through the reference's own cassiemujoco.py + ctypes
+    binding + MJCF file, against the same 60 steps through the C ABI directly."""
+    import json
+    import shutil
+    import subprocess
+    import sys
+    ex = tmp_path / "example"
+    ex.mkdir()
+    for f in ("cassiemujoco.py", "cassiemujoco_ctypes.py"):
+        shutil.copy(os.path.join(REF_STAGE, "example", f), ex / f)
+    os.symlink(os.path.join(REPO_DIR, "cassie-mujoco-sim_amd", "lib", "libcassiemujoco.so"), ex / "libcassiemujoco.so")
+    os.symlink(os.path.join(REF_STAGE, "model"), tmp_path / "model")
+    out = subprocess.run([sys.executable, "-c", _WRAPPER_SCRIPT], cwd=ex, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    res = json.loads(out.stdout.strip().splitlines()[-1])
+    assert (res["nq"], res["nv"]) == (35, 32)
+    assert abs(res["time"] - 60 * 0.0005) < 1e-12
+
+    xml = os.path.join(REF_STAGE, "model", "cassie.xml").encode()
+    c = L.cassie_sim_init(xml, False)
+    assert c
+    u = pd_input(np.random.default_rng(0), scale=0.0)
+    y = T.state_out_t()
+    traj = []
+    for s in range(60):
+        L.cassie_sim_step_pd(c, ctypes.byref(y), ctypes.byref(u))
+        traj.append(np.ctypeslib.as_array(L.cassie_sim_qpos(c), shape=(35,)).copy())
+    L.cassie_sim_free(c)
+    assert np.array_equal(np.array(res["qpos"]), np.array(traj))    # same library, same inputs: bit for bit
+    assert abs(res["pelvis_z_est"] - y.pelvis.position[2]) < 1e-12
+    assert 0.9 < traj[-1][2] < 1.02
+    assert len(res["foot_pos"]) == 6 and abs(res["foot_pos"][2]) < 0.2 and all(f >= 0 for f in res["foot_forces"])
+
+
+def test_single_simulator_is_faster_than_real_time(L):
+    """The reference's implicit requirement: one cassie_sim_step_pd per 0.5 ms of simulated time, i.e. >= 2 kHz
+    (reference example/cassiesim.c:284-293 prints SLOWER THAN REAL TIME otherwise)."""
+    import time
+    c = L.cassie_sim_init(MODEL, False)
+    u = pd_input(np.random.default_rng(1))
+    y = T.state_out_t()
+    for s in range(200):
+        L.cassie_sim_step_pd(c, ctypes.byref(y), ctypes.byref(u))
+    t0 = time.perf_counter()
+    n = 2000
+    for s in range(n):
+        L.cassie_sim_step_pd(c, ctypes.byref(y), ctypes.byref(u))
+    rate = n / (time.perf_counter() - t0)
+    L.cassie_sim_free(c)
+    print("single cassie_sim_t: %.0f cassie_sim_step_pd per second" % rate)
+    os.makedirs(os.path.join(REPO_DIR, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(REPO_DIR, "gpurun_out", "single_sim_rate.txt"), "w") as f:
+        f.write("%.1f cassie_sim_step_pd/s (one cassie_sim_t, host API, every step crosses PCIe)\n" % rate)
+    assert rate > 2000.0

@@ -49,6 +49,81 @@ def test_two_rank_sharding_and_observation_allgather():
         assert tmax == float(world)
 
 
+class _FakeBatch:
+    """Stands in for the GPU batch: a step adds (global env id + 1) * nsub to column 0 of the observation block and
+    counts the steps in column 1; targets of the bound policy step go to column 2."""
+
+    def __init__(self, ids, tg):
+        self.ids, self.tg = ids, tg
+        self.obs = torch.zeros((len(ids), 96), dtype=torch.float64)
+        self.bound = None
+        self.seen = []
+
+    def step(self, nsub):
+        self.obs[:, 0] += torch.from_numpy((self.ids + 1.0) * nsub)
+        self.obs[:, 1] += nsub
+        self.obs[:, 2] = torch.from_numpy(self.tg[self.bound][:, 0])
+
+    def bind(self, p):
+        self.bound = p
+
+    def restart(self, g):
+        import bench
+        rows = np.nonzero(self.ids % bench.NGROUP == g)[0]
+        self.obs[rows, :2] = 0
+
+
+def _schedule_worker(rank, world, port, n, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+    ids = bench.shard_env_ids(rank, world, n)
+    tg = bench.pd_targets(ids, 8)
+    fb = _FakeBatch(ids, tg)
+    allobs = torch.zeros((world * n, 96), dtype=torch.float64)
+    snaps = []
+
+    def gather():
+        bench.gather_observations(fb.obs, world, allobs)
+        snaps.append(allobs.numpy().copy())
+    sch = bench.Schedule(step=fb.step, bind_targets=fb.bind, restart=fb.restart, gather=gather, substeps_per_launch=bench.HOLD)
+    sch.run(0, 70)                                                    # "pre-roll + warm-up": ends inside policy step 1
+    ticks = iter([10.0, 10.0 + (rank + 1)])                           # this rank "takes" rank + 1 seconds
+    dt = bench.timed_region(sch, 70, 180, dist.barrier, clock=lambda: next(ticks))
+    ret[rank] = (snaps, fb.obs.numpy().copy(), bench.max_over_ranks(dt, world), sch.launches, sch.gathers)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_schedule_gathers_every_policy_step_and_reduces_the_time():
+    """bench.main()'s control flow for N > 1 (launch / restart / gather schedule, fences, max-over-ranks time) with a
+    stand-in for the GPU batch: every gather must deliver all ranks' blocks of the SAME policy step in global env
+    order, and the reported time is the slowest rank's."""
+    import bench
+    world, n = 2, 8
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 31500 + os.getpid() % 2000
+    mp.spawn(_schedule_worker, args=(world, port, n, ret), nprocs=world, join=True)
+    glob_ids = np.arange(world * n)
+    glob_tg = bench.pd_targets(glob_ids, 8)
+    for r in range(world):
+        snaps, own, tmax, launches, gathers = ret[r]
+        assert tmax == float(world)                                   # the slowest rank's elapsed time
+        assert gathers == 4 and len(snaps) == 4                       # at steps 50, 100, 150, 200 (not at 0, not at the end)
+        assert launches == 4                                          # of the timed region: 30 + 50 + 50 + 50
+        for i, snap in enumerate(snaps):
+            steps = 50.0 * (i + 1)
+            # restart groups 0..i have restarted at policy steps 0..i: env e (group e % NGROUP <= i) has run 50 * (i - group) steps
+            grp = glob_ids % bench.NGROUP
+            ran = np.where(grp <= i, steps - 50.0 * grp, steps)
+            assert np.array_equal(snap[:, 1], ran)
+            assert np.array_equal(snap[:, 0], (glob_ids + 1.0) * ran)
+            assert np.array_equal(snap[:, 2], glob_tg[i][:, 0])       # targets of the policy step that produced the block
+        assert np.array_equal(own[:, 1], np.where(grp[r * n:(r + 1) * n] <= 4, 250.0 - 50.0 * grp[r * n:(r + 1) * n], 250.0))
+
+
 def test_shards_partition_the_env_range():
     import bench
     ids = np.concatenate([bench.shard_env_ids(r, 8, 8192) for r in range(8)])
