@@ -9,8 +9,13 @@
  * PARITY UNPINNED: the reference tree holds no golden vector, test or fixture for
  * this path and the real library cannot be run in this
  * container.  This file restates MuJoCo's published computation model (SURVEY.md
- * App. B) and is pinned only by analytically derivable known answers
- * (tests/test_oracle_known_answers.py).  It is the checker for the HIP kernels
+ * App. B) and is pinned only by known answers that need no MuJoCo: model facts
+ * (tests/test_model.py) and independent mathematics per stage -- dense J M^-1 J^T + R,
+ * the KKT conditions and an independent QP solve of the constraint problem, Newton's
+ * second law for the whole robot, energy conservation, CRBA vs the bodies' kinetic
+ * energy (tests/test_oracle_pins.py).  tests/mujoco_ref.py + oracle/mj_harness.c run the
+ * genuine mj_step1 + mj_step2 beside it on any machine that has a MuJoCo
+ * (tests/test_true_reference.py; skipped here).  It is the checker for the HIP kernels
  * and the "port" CPU baseline of bench.py -- nothing under cassie-mujoco-sim_amd/
  * may link or call it.
  */
