@@ -12,7 +12,9 @@ MODEL_DIR = os.path.join(REPO_DIR, "models")
 with open(os.path.join(PKG_DIR, "csrc", "cm_model.h")) as _f:
     _hdr = _f.read()
 MACROS = cstruct.parse_defines(_hdr)
-CmModel = cstruct.parse_structs(_hdr, MACROS)["cm_model_t"]
+_structs = cstruct.parse_structs(_hdr, MACROS)
+CmModel = _structs["cm_model_t"]
+CmDriveState = _structs["cm_drive_state_t"]
 
 _lib = None
 
@@ -77,6 +79,10 @@ def _declare(L):
     L.phys_batch_forward.argtypes = [vp, vp]
     L.phys_batch_sync.argtypes = [vp]
     L.phys_batch_set_pd_mode.argtypes = [vp, c.c_int]
+    L.phys_batch_set_drive_mode.argtypes = [vp, c.c_int]
+    L.phys_batch_upload_drive_state.argtypes = [vp, vp, c.c_int, c.c_int]
+    L.phys_batch_download_drive_state.argtypes = [vp, vp, c.c_int, c.c_int]
+    L.phys_batch_uses_applied.argtypes = [vp]
     L.phys_batch_set_generic_kernel.argtypes = [vp, ctypes.c_int]
     L.phys_batch_profile_step.argtypes = [vp, vp]
     L.phys_batch_profile_substeps.argtypes = [vp, ctypes.c_int, vp]

@@ -10,11 +10,17 @@ import os
 
 import numpy as np
 
-from ._lib import CmModel, MODEL_DIR, lib
+from ._lib import CmDriveState, CmModel, MODEL_DIR, lib
 
 # field ids (enum in cassie_phys.h)
 (F_QPOS, F_QVEL, F_QACC_WARMSTART, F_TIME, F_CTRL, F_QFRC_APPLIED, F_XFRC_APPLIED, F_QACC, F_SENSORDATA,
- F_ACTUATOR_VELOCITY, F_XPOS, F_XQUAT, F_PD_PTARGET, F_PD_KP, F_PD_KD, F_BODY_CFRC) = range(16)
+ F_ACTUATOR_VELOCITY, F_XPOS, F_XQUAT, F_PD_PTARGET, F_PD_KP, F_PD_KD, F_BODY_CFRC, F_DRIVE_CMD, F_MEAS, F_PD_DTARGET,
+ F_PD_TORQUE) = range(20)
+
+# drive modes (CM_DRIVE_* in cm_model.h) and the layout of the measurement block F_MEAS (CM_MEAS_*)
+DRIVE_OFF, DRIVE_TORQUE, DRIVE_PD = 0, 1, 2
+MEAS_DRIVE_POS, MEAS_DRIVE_VEL, MEAS_DRIVE_TORQUE, MEAS_JOINT_POS, MEAS_JOINT_VEL = 0, 10, 20, 30, 36
+MEAS_ORIENTATION, MEAS_ANGVEL, MEAS_LINACC, MEAS_MAG, MEAS_DIM = 42, 46, 49, 52, 56
 
 WARN_CONTACT_FULL, WARN_CONSTRAINT_FULL, WARN_UNSUPPORTED_PAIR, WARN_DIVERGED = 1, 2, 4, 8
 
@@ -152,6 +158,23 @@ class Batch:
 
     def set_pd_mode(self, on=True):
         lib().phys_batch_set_pd_mode(self._h, 1 if on else 0)
+
+    def set_drive_mode(self, mode):
+        """DRIVE_OFF / DRIVE_TORQUE (cassie_sim_step_ethercat on the device) / DRIVE_PD (pd_input's motor PD on the encoder
+        measurements): the encoder + motor models of reference src/cassiemujoco.c:558-664 run in the step kernel."""
+        if lib().phys_batch_set_drive_mode(self._h, int(mode)) != 0:
+            raise RuntimeError("set_drive_mode failed: " + (lib().phys_last_error() or b"").decode())
+
+    def get_drive_state(self, env0=0, n=None):
+        n = self.nenv - env0 if n is None else n
+        out = (CmDriveState * n)()
+        if lib().phys_batch_download_drive_state(self._h, ctypes.byref(out), env0, n) != 0:
+            raise RuntimeError("drive state download failed")
+        return out
+
+    def set_drive_state(self, states, env0=0):
+        if lib().phys_batch_upload_drive_state(self._h, ctypes.byref(states), env0, len(states)) != 0:
+            raise RuntimeError("drive state upload failed")
 
     def sync(self):
         if lib().phys_batch_sync(self._h) != 0:

@@ -74,6 +74,8 @@ struct cassie_batch {
     int mjsteps;                        /* physics steps per control step: round(5e-4 / timestep), reference :1128-1131 */
     cassie_hostenv_t **env;
     double *sensordata, *actvel, *ctrl; /* pinned host mirrors [nenv][dim] */
+    int device_drives;                  /* encoder / motor models on the device (cassie_batch_set_device_drives) */
+    double *cmd, *meas;                 /* pinned [nenv][11] commands up, [nenv][CM_MEAS_DIM] measurements down */
     cassie_out_t *ytmp;
     /* fork-join pool */
     pthread_t *threads;
@@ -160,6 +162,41 @@ static void job_ethercat(struct cassie_batch *b, int e0, int e1)
                                 b->actvel + (size_t)e * b->nu, b->ctrl + (size_t)e * b->nu, &b->y_out[e]);
 }
 
+/* --- device-drive mode: commands up, drive-level pass, measurements down, then the physics --- */
+static void job_cmd_pd(struct cassie_batch *b, int e0, int e1)
+{
+    for (int e = e0; e < e1; ++e) cassie_hostenv_command_pd(b->env[e], &b->u_pd[e], b->cmd + (size_t)e * 11);
+}
+static void job_cmd_user(struct cassie_batch *b, int e0, int e1)
+{
+    for (int e = e0; e < e1; ++e) cassie_hostenv_command(b->env[e], &b->u_user[e], b->cmd + (size_t)e * 11);
+}
+static void job_cmd_ethercat(struct cassie_batch *b, int e0, int e1)
+{
+    for (int e = e0; e < e1; ++e) cassie_hostenv_command_ethercat(b->env[e], &b->u_in[e], b->cmd + (size_t)e * 11);
+}
+static void job_meas_pd(struct cassie_batch *b, int e0, int e1)
+{
+    for (int e = e0; e < e1; ++e) {
+        cassie_hostenv_apply_meas(b->env[e], b->meas + (size_t)e * CM_MEAS_DIM, &b->ytmp[e]);
+        cassie_hostenv_step_pd_post(b->env[e], &b->ytmp[e], &b->y_state[e]);
+    }
+}
+static void job_meas_out(struct cassie_batch *b, int e0, int e1)
+{
+    for (int e = e0; e < e1; ++e) cassie_hostenv_apply_meas(b->env[e], b->meas + (size_t)e * CM_MEAS_DIM, &b->y_out[e]);
+}
+static int launch_device_drives(struct cassie_batch *b)
+{
+    int rc = phys_batch_upload_async(b->pb, PHYS_F_DRIVE_CMD, b->cmd, 0, b->nenv);
+    rc |= phys_batch_drive_pass(b->pb, CM_DRIVE_TORQUE, NULL);
+    rc |= phys_batch_download_async(b->pb, PHYS_F_MEAS, b->meas, 0, b->nenv);
+    rc |= phys_batch_mark(b->pb);
+    rc |= phys_batch_step(b->pb, 1, NULL);          /* reads the ctrl the drive pass left in HBM */
+    rc |= phys_batch_wait_mark(b->pb);              /* measurements are on the host; the physics kernel is still running */
+    return rc;
+}
+
 /* ctrl up, one physics step for every env, measurements for the next step down -- all asynchronous */
 static int launch_physics(struct cassie_batch *b)
 {
@@ -239,6 +276,7 @@ void cassie_batch_free(cassie_batch_t *b)
     if (b->pb) { phys_batch_sync(b->pb); phys_batch_free(b->pb); }
     if (b->env) { for (int e = 0; e < b->nenv; ++e) cassie_hostenv_free(b->env[e]); free(b->env); }
     phys_host_free(b->sensordata); phys_host_free(b->actvel); phys_host_free(b->ctrl);
+    phys_host_free(b->cmd); phys_host_free(b->meas);
     free(b->ytmp);
     if (b->m) phys_model_free(b->m);
     free(b);
@@ -250,10 +288,43 @@ phys_batch_t *cassie_batch_phys(cassie_batch_t *b) { return b ? b->pb : NULL; }
 phys_model_t *cassie_batch_model(cassie_batch_t *b) { return b ? b->m : NULL; }
 cassie_hostenv_t *cassie_batch_hostenv(cassie_batch_t *b, int env) { return (b && env >= 0 && env < b->nenv) ? b->env[env] : NULL; }
 
+int cassie_batch_set_device_drives(cassie_batch_t *b, int on)
+{
+    if (!b) return -1;
+    on = on != 0;
+    if (on == b->device_drives) return 0;
+    if (on && b->mjsteps != 1) return -1;
+    cm_drive_state_t *st = malloc(sizeof(cm_drive_state_t) * (size_t)b->nenv);
+    if (!st) return -1;
+    int rc = phys_batch_sync(b->pb);
+    if (on) {
+        if (!b->cmd) b->cmd = phys_host_alloc(sizeof(double) * (size_t)b->nenv * 11);
+        if (!b->meas) b->meas = phys_host_alloc(sizeof(double) * (size_t)b->nenv * CM_MEAS_DIM);
+        if (!b->cmd || !b->meas) { free(st); return -1; }
+        for (int e = 0; e < b->nenv; ++e) cassie_hostenv_get_drive_state(b->env[e], &st[e]);
+        rc |= phys_batch_upload_drive_state(b->pb, st, 0, b->nenv);
+    } else {
+        rc |= phys_batch_download_drive_state(b->pb, st, 0, b->nenv);
+        for (int e = 0; rc == 0 && e < b->nenv; ++e) cassie_hostenv_set_drive_state(b->env[e], &st[e]);
+        /* the host models read the physics outputs of the last step from the host mirrors */
+        rc |= phys_batch_download(b->pb, PHYS_F_SENSORDATA, b->sensordata, 0, b->nenv);
+        rc |= phys_batch_download(b->pb, PHYS_F_ACTUATOR_VELOCITY, b->actvel, 0, b->nenv);
+    }
+    free(st);
+    if (rc == 0) b->device_drives = on;
+    return rc;
+}
+
 int cassie_batch_step_pd(cassie_batch_t *b, const pd_in_t *u, state_out_t *y)
 {
     if (!b || !u || !y) return -1;
     b->u_pd = u; b->y_state = y;
+    if (b->device_drives) {
+        run_parallel(b, job_cmd_pd);
+        int rc = launch_device_drives(b);
+        run_parallel(b, job_meas_pd);   /* cassie_out from the device's measurements, then the estimator, over the kernel */
+        return rc | phys_batch_sync(b->pb);
+    }
     run_parallel(b, job_pd_pre);
     int rc = launch_physics(b);
     run_parallel(b, job_pd_post); /* estimator overlaps the kernel and the copies */
@@ -265,6 +336,12 @@ int cassie_batch_step(cassie_batch_t *b, const cassie_user_in_t *u, cassie_out_t
 {
     if (!b || !u || !y) return -1;
     b->u_user = u; b->y_out = y;
+    if (b->device_drives) {
+        run_parallel(b, job_cmd_user);
+        int rc = launch_device_drives(b);
+        run_parallel(b, job_meas_out);
+        return rc | phys_batch_sync(b->pb);
+    }
     run_parallel(b, job_user);
     int rc = launch_physics(b);
     rc |= phys_batch_sync(b->pb);
@@ -275,6 +352,12 @@ int cassie_batch_step_ethercat(cassie_batch_t *b, const cassie_in_t *u, cassie_o
 {
     if (!b || !u || !y) return -1;
     b->u_in = u; b->y_out = y;
+    if (b->device_drives) {
+        run_parallel(b, job_cmd_ethercat);
+        int rc = launch_device_drives(b);
+        run_parallel(b, job_meas_out);
+        return rc | phys_batch_sync(b->pb);
+    }
     run_parallel(b, job_ethercat);
     int rc = launch_physics(b);
     rc |= phys_batch_sync(b->pb);
@@ -326,6 +409,12 @@ int cassie_batch_full_reset(cassie_batch_t *b, const unsigned char *mask)
         rc |= phys_batch_clear_warn(b->pb, e, 1);
         memset(b->ctrl + (size_t)e * b->nu, 0, sizeof(double) * b->nu);
         cassie_hostenv_reset(b->env[e]);
+        if (b->device_drives) { /* the torque delay line that cassie_hostenv_reset clears lives in HBM in this mode */
+            cm_drive_state_t st;
+            rc |= phys_batch_download_drive_state(b->pb, &st, e, 1);
+            memset(st.torque_delay, 0, sizeof st.torque_delay);
+            rc |= phys_batch_upload_drive_state(b->pb, &st, e, 1);
+        }
     }
     free(q); free(z);
     return rc;

@@ -178,7 +178,33 @@ typedef struct cm_model {
     int sensor_body[CM_MAXSENSOR], sensor_root[CM_MAXSENSOR]; /* frame sensors: body of the site and that body's root */
     double sensor_squat[CM_MAXSENSOR][4], sensor_spos[CM_MAXSENSOR][3]; /* frame sensors: site frame in its body */
     int sensor_slot[CM_MAXSENSOR];        /* accelerometers: 0, 1, ... in sensor order (-1 otherwise / beyond two) */
+    int sensor_bits[CM_MAXSENSOR];        /* sensor user[0]: encoder resolution in bits (model/cassie.xml:272-287), 0 if none */
 } cm_model_t;
+
+/* Drive-level I/O state of one env: what `struct cassie_sim` keeps beside mjData for cassie_sim_step_ethercat
+ * (reference src/cassiemujoco.c:210-217, :255-265): the encoder velocity filters and the motors' torque delay lines.
+ * Layout-compatible with the host env's drive_filter_t[10] / joint_filter_t[6] / torque_delay[10][6]. */
+#define CM_NUM_DRIVES 10
+#define CM_NUM_JOINTS 6
+#define CM_DRIVE_FILTER_NB 9
+#define CM_JOINT_FILTER_NB 4
+#define CM_JOINT_FILTER_NA 3
+#define CM_TORQUE_DELAY_CYCLES 6
+typedef struct cm_drive_state {
+    int drive_x[CM_NUM_DRIVES][CM_DRIVE_FILTER_NB];                    /* integer FIR history of the drive encoders */
+    int pad[6];
+    double joint_x[CM_NUM_JOINTS][CM_JOINT_FILTER_NB], joint_y[CM_NUM_JOINTS][CM_JOINT_FILTER_NA]; /* IIR history */
+    double torque_delay[CM_NUM_DRIVES][CM_TORQUE_DELAY_CYCLES];
+} cm_drive_state_t;
+
+/* The measurement block the device-side encoder / motor models write every step: the cassie_out_t fields that
+ * cassie_sensor_data and cassie_motor_data fill (reference src/cassiemujoco.c:737-803), as doubles */
+enum { CM_MEAS_DRIVE_POS = 0, CM_MEAS_DRIVE_VEL = 10, CM_MEAS_DRIVE_TORQUE = 20, CM_MEAS_JOINT_POS = 30, CM_MEAS_JOINT_VEL = 36,
+       CM_MEAS_ORIENTATION = 42, CM_MEAS_ANGVEL = 46, CM_MEAS_LINACC = 49, CM_MEAS_MAG = 52, CM_MEAS_DIM = 56 };
+/* drive modes of the step kernel */
+enum { CM_DRIVE_OFF = 0,     /* ctrl (or the exact-state PD of phys_batch_set_pd_mode) goes straight to the actuators */
+       CM_DRIVE_TORQUE = 1,  /* cassie_sim_step_ethercat on the device: commanded drive torques -> motor model + delay line */
+       CM_DRIVE_PD = 2 };    /* pd_input's motor PD on the ENCODER measurements of the previous step, then the same */
 
 /* Optional per-env "extended" outputs of a step (what the reference reads out of mjData for its
  * derived getters: contact list + forces, body velocities, site frames, com; SURVEY.md 8b field census). */

@@ -1313,6 +1313,7 @@ bool HostModel::compile(cm_model_t *o, std::string *err) const {
             for (int i = 0; i < 4; ++i) o->sensor_squat[s][i] = site_quat[4 * site + i];
             for (int i = 0; i < 3; ++i) o->sensor_spos[s][i] = site_pos[3 * site + i];
         }
+        o->sensor_bits[s] = nuser_sensor > 0 ? (int)sensor_user[(size_t)nuser_sensor * s] : 0;
         o->sensor_slot[s] = -1;
         if (sensor_type[s] == CM_SENS_ACCELEROMETER) {
             int slot = 0;

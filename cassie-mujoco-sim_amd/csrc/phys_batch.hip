@@ -36,9 +36,12 @@ struct phys_batch {
     size_t hfield_stride = 0, hfield_floats = 0; /* stride 0: one grid shared by all envs; else one grid of hfield_floats per env */
     hipStream_t stream = nullptr;
     hipStream_t last_stream = nullptr; /* the stream of the most recent launch (callers may pass their own) */
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_mark = nullptr;
     bool use_applied = false;       /* qfrc_applied / xfrc_applied are passed only once uploaded */
     bool pd_mode = false;
+    int drive_mode = CM_DRIVE_OFF;
+    cm_drive_state_t *d_drive = nullptr; /* [nenv], allocated when a drive mode is first selected */
+    bool use_pd_dtarget = false, use_pd_torque = false;
     long long *d_prof = nullptr;
     cm_ext_t *d_ext = nullptr;
 };
@@ -73,6 +76,17 @@ static ck::PhysIO make_io(phys_batch *b, int nsub, int integrate) {
     io.hfield_stride = b->hfield_stride;
     if (b->pd_mode) {
         io.pd_ptarget = b->d_field[PHYS_F_PD_PTARGET]; io.pd_kp = b->d_field[PHYS_F_PD_KP]; io.pd_kd = b->d_field[PHYS_F_PD_KD];
+    }
+    io.drive_mode = b->d_drive ? b->drive_mode : CM_DRIVE_OFF;
+    if (io.drive_mode != CM_DRIVE_OFF) {
+        io.drive_state = b->d_drive;
+        io.drive_cmd = b->d_field[PHYS_F_DRIVE_CMD];
+        io.meas = b->d_field[PHYS_F_MEAS];
+        if (io.drive_mode == CM_DRIVE_PD) {
+            io.pd_ptarget = b->d_field[PHYS_F_PD_PTARGET]; io.pd_kp = b->d_field[PHYS_F_PD_KP]; io.pd_kd = b->d_field[PHYS_F_PD_KD];
+            io.pd_dtarget = b->use_pd_dtarget ? b->d_field[PHYS_F_PD_DTARGET] : nullptr;
+            io.pd_torque = b->use_pd_torque ? b->d_field[PHYS_F_PD_TORQUE] : nullptr;
+        }
     }
     io.prof = b->d_prof;
     io.ext = b->d_ext;
@@ -109,6 +123,13 @@ static int launch(phys_batch *b, int nsub, int integrate, hipStream_t s) {
     return hip_ok(hipGetLastError(), "cassie_step_kernel launch") ? 0 : -1;
 }
 
+/* optional inputs are handed to the kernel only once somebody uploaded or bound them */
+static void note_field_in_use(phys_batch *b, int field) {
+    if (field == PHYS_F_QFRC_APPLIED || field == PHYS_F_XFRC_APPLIED) b->use_applied = true;
+    if (field == PHYS_F_PD_DTARGET) b->use_pd_dtarget = true;
+    if (field == PHYS_F_PD_TORQUE) b->use_pd_torque = true;
+}
+
 /* rows [env0, env0 + n) of a field between a dense host array and HBM (dense, or strided when the field is a column
  * block of a caller-owned tensor), asynchronously on the batch's stream */
 static bool copy_rows(phys_batch *b, int field, void *host, int env0, int n, bool to_device, const char *what) {
@@ -140,7 +161,8 @@ phys_batch_t *phys_batch_create(const cm_model_t *model, int nenv, int device) {
     b->host_model = *model;
     const int d[PHYS_F_COUNT] = {model->nq, model->nv, model->nv, 1, model->nu, model->nv, model->nbody * 6,
                                  model->nv, model->nsensordata, model->nu, model->nbody * 3, model->nbody * 4,
-                                 model->nu, model->nu, model->nu, model->nbody * 3};
+                                 model->nu, model->nu, model->nu, model->nbody * 3,
+                                 model->nu + 1, CM_MEAS_DIM, model->nu, model->nu};
     bool ok = true;
     for (int f = 0; f < PHYS_F_COUNT; ++f) {
         b->dim[f] = d[f]; b->stride[f] = d[f]; b->d_field[f] = nullptr; b->owned[f] = true;
@@ -156,6 +178,7 @@ phys_batch_t *phys_batch_create(const cm_model_t *model, int nenv, int device) {
     ok = ok && hip_ok(hipMemset(b->d_info, 0, sizeof(int) * 4 * nenv), "hipMemset(info)");
     ok = ok && hip_ok(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking), "hipStreamCreate");
     ok = ok && hip_ok(hipEventCreate(&b->ev0), "hipEventCreate") && hip_ok(hipEventCreate(&b->ev1), "hipEventCreate");
+    ok = ok && hip_ok(hipEventCreateWithFlags(&b->ev_mark, hipEventDisableTiming), "hipEventCreate");
     if (ok) {
         /* every env starts at qpos0 */
         std::vector<double> q0((size_t)nenv * model->nq);
@@ -177,8 +200,10 @@ void phys_batch_free(phys_batch_t *b) {
     if (b->d_info) (void)hipFree(b->d_info);
     if (b->d_hfield) (void)hipFree(b->d_hfield);
     if (b->d_ext) (void)hipFree(b->d_ext);
+    if (b->d_drive) (void)hipFree(b->d_drive);
     if (b->ev0) (void)hipEventDestroy(b->ev0);
     if (b->ev1) (void)hipEventDestroy(b->ev1);
+    if (b->ev_mark) (void)hipEventDestroy(b->ev_mark);
     if (b->stream) (void)hipStreamDestroy(b->stream);
     delete b;
 }
@@ -258,7 +283,7 @@ int phys_batch_set_hfield_env(phys_batch_t *b, int env, const float *data, int n
 int phys_batch_upload(phys_batch_t *b, int field, const double *host, int env0, int n) {
     if (!b || !host || field < 0 || field >= PHYS_F_COUNT || env0 < 0 || n < 0 || env0 + n > b->nenv) return -1;
     (void)hipSetDevice(b->device);
-    if (field == PHYS_F_QFRC_APPLIED || field == PHYS_F_XFRC_APPLIED) b->use_applied = true;
+    note_field_in_use(b, field);
     return copy_rows(b, field, (void *)host, env0, n, true, "upload") && hip_ok(hipStreamSynchronize(b->stream), "upload sync") ? 0 : -1;
 }
 
@@ -271,7 +296,7 @@ int phys_batch_download(phys_batch_t *b, int field, double *host, int env0, int 
 int phys_batch_upload_async(phys_batch_t *b, int field, const double *host, int env0, int n) {
     if (!b || !host || field < 0 || field >= PHYS_F_COUNT || env0 < 0 || n < 0 || env0 + n > b->nenv) return -1;
     (void)hipSetDevice(b->device);
-    if (field == PHYS_F_QFRC_APPLIED || field == PHYS_F_XFRC_APPLIED) b->use_applied = true;
+    note_field_in_use(b, field);
     return copy_rows(b, field, (void *)host, env0, n, true, "upload_async") ? 0 : -1;
 }
 
@@ -332,7 +357,7 @@ int phys_batch_bind_strided(phys_batch_t *b, int field, void *device_ptr, int ro
     b->d_field[field] = (double *)device_ptr;
     b->stride[field] = row_stride;
     b->owned[field] = false;
-    if (field == PHYS_F_QFRC_APPLIED || field == PHYS_F_XFRC_APPLIED) b->use_applied = true;
+    note_field_in_use(b, field);
     return 0;
 }
 
@@ -352,6 +377,67 @@ int phys_batch_set_pd_mode(phys_batch_t *b, int on) {
     if (!b) return -1;
     b->pd_mode = on != 0;
     return 0;
+}
+
+static bool ensure_drive_state(phys_batch *b) {
+    if (b->d_drive) return true;
+    if (b->host_model.nu != CM_NUM_DRIVES || b->host_model.nsensordata < 29) {
+        phys_set_last_error("the drive-level models need Cassie's 10 drives and 29 sensor words");
+        return false;
+    }
+    if (!quiesce(b)) return false;
+    const size_t bytes = sizeof(cm_drive_state_t) * (size_t)b->nenv;
+    if (!hip_ok(hipMalloc((void **)&b->d_drive, bytes), "hipMalloc(drive state)")) return false;
+    return hip_ok(hipMemsetAsync(b->d_drive, 0, bytes, b->stream), "hipMemset(drive state)") && hip_ok(hipStreamSynchronize(b->stream), "sync");
+}
+
+int phys_batch_set_drive_mode(phys_batch_t *b, int mode) {
+    if (!b || mode < CM_DRIVE_OFF || mode > CM_DRIVE_PD) return -1;
+    (void)hipSetDevice(b->device);
+    if (mode != CM_DRIVE_OFF && !ensure_drive_state(b)) return -1;
+    b->drive_mode = mode;
+    return 0;
+}
+
+int phys_batch_drive_pass(phys_batch_t *b, int mode, void *stream) {
+    if (!b || (mode != CM_DRIVE_TORQUE && mode != CM_DRIVE_PD)) return -1;
+    (void)hipSetDevice(b->device);
+    if (!ensure_drive_state(b)) return -1;
+    const int keep = b->drive_mode;
+    b->drive_mode = mode;
+    ck::PhysIO io = make_io(b, 1, 1);
+    b->drive_mode = keep;
+    hipStream_t s = stream ? (hipStream_t)stream : b->stream;
+    b->last_stream = s;
+    hipLaunchKernelGGL(ck::cassie_drive_kernel, dim3(b->nenv), dim3(WV_WAVE), 0, s, io, b->d_field[PHYS_F_CTRL]);
+    return hip_ok(hipGetLastError(), "cassie_drive_kernel launch") ? 0 : -1;
+}
+
+int phys_batch_mark(phys_batch_t *b) {
+    if (!b) return -1;
+    (void)hipSetDevice(b->device);
+    return hip_ok(hipEventRecord(b->ev_mark, b->stream), "hipEventRecord") ? 0 : -1;
+}
+int phys_batch_wait_mark(phys_batch_t *b) {
+    if (!b) return -1;
+    (void)hipSetDevice(b->device);
+    return hip_ok(hipEventSynchronize(b->ev_mark), "hipEventSynchronize") ? 0 : -1;
+}
+
+int phys_batch_upload_drive_state(phys_batch_t *b, const cm_drive_state_t *host, int env0, int n) {
+    if (!b || !host || env0 < 0 || n < 0 || env0 + n > b->nenv) return -1;
+    (void)hipSetDevice(b->device);
+    if (!ensure_drive_state(b)) return -1;
+    return hip_ok(hipMemcpyAsync(b->d_drive + env0, host, sizeof(cm_drive_state_t) * (size_t)n, hipMemcpyHostToDevice, b->stream), "drive state upload") &&
+                   hip_ok(hipStreamSynchronize(b->stream), "drive state sync") ? 0 : -1;
+}
+
+int phys_batch_download_drive_state(phys_batch_t *b, cm_drive_state_t *host, int env0, int n) {
+    if (!b || !host || env0 < 0 || n < 0 || env0 + n > b->nenv) return -1;
+    (void)hipSetDevice(b->device);
+    if (!ensure_drive_state(b)) return -1;
+    return hip_ok(hipMemcpyAsync(host, b->d_drive + env0, sizeof(cm_drive_state_t) * (size_t)n, hipMemcpyDeviceToHost, b->stream), "drive state download") &&
+                   hip_ok(hipStreamSynchronize(b->stream), "drive state sync") ? 0 : -1;
 }
 
 int phys_batch_sync(phys_batch_t *b) {

@@ -91,6 +91,14 @@ struct PhysIO {
      * speed-torque limit -- the motor law of pd_input_step followed by
      * motor() (reference src/cassiemujoco.c:638-664) on the exact joint state */
     const double *pd_ptarget, *pd_kp, *pd_kd; /* [nenv][nu] each */
+    /* optional drive-level I/O on the device (reference src/cassiemujoco.c:558-664, :737-803):
+     * encoder quantisation + integer FIR / IIR velocity filters, motor speed-torque curve + STO + six-cycle torque
+     * delay, every substep, bit for bit the host chain of csrc/cassie_hostpath.c.  drive_mode is a CM_DRIVE_* value */
+    int drive_mode;
+    cm_drive_state_t *drive_state;  /* [nenv] filter histories and delay lines */
+    const double *drive_cmd;        /* CM_DRIVE_TORQUE: [nenv][nu + 1] commanded drive torques (cassie_in_t) and the STO flag */
+    const double *pd_dtarget, *pd_torque; /* CM_DRIVE_PD: optional [nenv][nu] velocity targets and feed-forward torques */
+    double *meas;                   /* [nenv][CM_MEAS_DIM] the cassie_out_t measurement fields of the step */
     cm_ext_t *ext;              /* optional [nenv] extended outputs (may be null) */
     long long *prof;            /* optional [nenv][NSTAMP] shader-clock stamps of the last substep (may be null) */
 };
@@ -118,6 +126,7 @@ struct EnvShared {
     double com[NB][3];              /* subtree com, valid at root bodies */
     double qpos[CM_MAXQ], qvel[NVP], qacc_ws[NVP], qacc[NVP], ctrl[CM_MAXU];
     double qfrc_smooth[NVP];
+    double sens[CM_MAXSENSORDATA], actvel[CM_MAXU]; /* sensordata / actuator_velocity of the previous step (inputs of the drive-level models) */
     /* contacts */
     double c_dist[CM_MAXCON], c_pos[CM_MAXCON][3], c_frame[CM_MAXCON][9], c_fri[CM_MAXCON][3];
     double c_solref[CM_MAXCON][2], c_solimp[CM_MAXCON][5], c_margin[CM_MAXCON];
@@ -596,6 +605,98 @@ WV_DEVICE double solve_backward(double w, const double (&lcol)[NVP], int lane, i
     }
 }
 
+/* ---------------------------------------------------- drive-level I/O (H6 / H7) ---- */
+/* sensordata slots of the ten drive encoders and the six joint encoders (reference src/cassiemujoco.c:754-755) */
+WV_DEVICE int drive_sensor_slot(int i) { return i < 5 ? i : i + 3; }   /* 0 1 2 3 4 8 9 10 11 12 */
+WV_DEVICE int joint_sensor_slot(int j) { return j < 3 ? j + 5 : j + 10; } /* 5 6 7 13 14 15 */
+
+/* One cassie_motor_data + cassie_sensor_data pass for one env, lanes = drives (0..9), joint encoders (10..15), IMU
+ * words (16..28).  Every floating-point operation is individually rounded in the order the reference's C performs it
+ * (drive_encoder :558-593, joint_encoder :596-635, motor :638-664), and the FIR runs in 32-bit integers, so with
+ * identical sensordata / actuator_velocity in, the measurement block, the filter histories, the delay lines and the
+ * ctrl values are bit for bit those of the host chain (csrc/cassie_hostpath.c, itself pinned to the reference's own
+ * compiled code by tests/test_hostpath.py). */
+template <class SH>
+WV_DEVICE void drive_level_io(const PhysIO &io, SH &S, ModelPtr m, int env, int lane) {
+    const double TWO_PI = 2 * 3.14159265358979323846, PI = 3.14159265358979323846;
+    cm_drive_state_t *ds = io.drive_state + env;
+    double *meas = io.meas + (size_t)env * CM_MEAS_DIM;
+    const int nu = m->nu;
+    if (lane < CM_NUM_DRIVES) {
+        const int i = lane;
+        const double ratio = m->act_gear[i], tmax = m->act_ctrlrange[i][1];
+        const double wmax = wv::div_rn(wv::mul_rn(wv::mul_rn(m->act_maxrpm[i], 2.0), PI), 60.0);
+        /* the command: a drive torque from the caller, or pd_input's motor PD on the measurements of the previous step */
+        double u;
+        bool sto = false;
+        if (io.drive_mode == CM_DRIVE_TORQUE) {
+            u = io.drive_cmd[(size_t)env * (nu + 1) + i];
+            sto = io.drive_cmd[(size_t)env * (nu + 1) + nu] != 0.0;
+        } else {
+            const size_t o = (size_t)env * nu + i;
+            const double p = meas[CM_MEAS_DRIVE_POS + i], v = meas[CM_MEAS_DRIVE_VEL + i];
+            const double pt = io.pd_ptarget[o], dt = io.pd_dtarget ? io.pd_dtarget[o] : 0.0, ff = io.pd_torque ? io.pd_torque[o] : 0.0;
+            u = wv::add_rn(wv::add_rn(ff, wv::mul_rn(io.pd_kp[o], wv::sub_rn(pt, p))), wv::mul_rn(io.pd_kd[o], wv::sub_rn(dt, v)));
+        }
+        /* motor(): speed-torque curve, STO, delay line (reference :638-664) */
+        const double w = S.actvel[i];
+        double tlim = wv::mul_rn(wv::mul_rn(2.0, tmax), wv::sub_rn(1.0, wv::div_rn(fabs(w), wmax)));
+        tlim = fmax(fmin(tlim, tmax), 0.0);
+        if (sto) u = 0.0;
+        const double tau = copysign(fmin(fabs(wv::div_rn(u, ratio)), tlim), u);
+        double dl[CM_TORQUE_DELAY_CYCLES];
+        for (int k = 0; k < CM_TORQUE_DELAY_CYCLES; ++k) dl[k] = ds->torque_delay[i][k];
+        const double ctrl_i = dl[CM_TORQUE_DELAY_CYCLES - 1];
+        for (int k = CM_TORQUE_DELAY_CYCLES - 1; k > 0; --k) ds->torque_delay[i][k] = dl[k - 1];
+        ds->torque_delay[i][0] = tau;
+        S.ctrl[i] = ctrl_i;
+        meas[CM_MEAS_DRIVE_TORQUE + i] = wv::mul_rn(ctrl_i, ratio);
+        /* drive_encoder(): truncation to encoder counts, 9-tap integer FIR (reference :558-593) */
+        const int slot = drive_sensor_slot(i), bits = m->sensor_bits[slot];
+        const double counts = (double)(1 << bits);
+        const int ev = (int)wv::mul_rn(wv::div_rn(S.sens[slot], TWO_PI), counts);
+        const double scale = wv::div_rn(wv::div_rn(TWO_PI, counts), ratio);
+        meas[CM_MEAS_DRIVE_POS + i] = wv::mul_rn((double)ev, scale);
+        int x[CM_DRIVE_FILTER_NB];
+        bool allzero = true;
+        for (int k = 0; k < CM_DRIVE_FILTER_NB; ++k) { x[k] = ds->drive_x[i][k]; allzero &= x[k] == 0; }
+        if (allzero) for (int k = 0; k < CM_DRIVE_FILTER_NB; ++k) x[k] = ev;
+        for (int k = CM_DRIVE_FILTER_NB - 1; k > 0; --k) x[k] = x[k - 1];
+        x[0] = ev;
+        const int fir[CM_DRIVE_FILTER_NB] = {2727, 534, -2658, -795, 72, 110, 19, -6, -3};
+        int y = 0;
+        for (int k = 0; k < CM_DRIVE_FILTER_NB; ++k) { y += x[k] * fir[k]; ds->drive_x[i][k] = x[k]; }
+        meas[CM_MEAS_DRIVE_VEL + i] = wv::div_rn(wv::mul_rn((double)y, scale), PI);
+    } else if (lane < CM_NUM_DRIVES + CM_NUM_JOINTS) {
+        /* joint_encoder(): IIR on the quantised position (reference :596-635) */
+        const int j = lane - CM_NUM_DRIVES, slot = joint_sensor_slot(j), bits = m->sensor_bits[slot];
+        const double counts = (double)(1 << bits);
+        const int ev = (int)wv::mul_rn(wv::div_rn(S.sens[slot], TWO_PI), counts);
+        const double scale = wv::div_rn(TWO_PI, counts);
+        const double pos = wv::mul_rn((double)ev, scale);
+        double x[CM_JOINT_FILTER_NB], yv[CM_JOINT_FILTER_NA];
+        bool allzero = true;
+        for (int k = 0; k < CM_JOINT_FILTER_NB; ++k) { x[k] = ds->joint_x[j][k]; allzero &= x[k] == 0; }
+        for (int k = 0; k < CM_JOINT_FILTER_NA; ++k) yv[k] = ds->joint_y[j][k];
+        if (allzero) for (int k = 0; k < CM_JOINT_FILTER_NB; ++k) x[k] = pos;
+        for (int k = CM_JOINT_FILTER_NB - 1; k > 0; --k) x[k] = x[k - 1];
+        x[0] = pos;
+        for (int k = CM_JOINT_FILTER_NA - 1; k > 0; --k) yv[k] = yv[k - 1];
+        const double fb[CM_JOINT_FILTER_NB] = {12.348, 12.348, -12.348, -12.348}, fa[CM_JOINT_FILTER_NA] = {1.0, -1.7658, 0.79045};
+        double y0 = 0.0;
+        for (int k = 0; k < CM_JOINT_FILTER_NB; ++k) y0 = wv::add_rn(y0, wv::mul_rn(x[k], fb[k]));
+        for (int k = 1; k < CM_JOINT_FILTER_NA; ++k) y0 = wv::sub_rn(y0, wv::mul_rn(yv[k], fa[k]));
+        yv[0] = y0;
+        for (int k = 0; k < CM_JOINT_FILTER_NB; ++k) ds->joint_x[j][k] = x[k];
+        for (int k = 0; k < CM_JOINT_FILTER_NA; ++k) ds->joint_y[j][k] = yv[k];
+        meas[CM_MEAS_JOINT_POS + j] = pos;
+        meas[CM_MEAS_JOINT_VEL + j] = y0;
+    } else if (lane < 29) {
+        /* IMU words: orientation, angular velocity, linear acceleration, magnetic field (reference :769-773) */
+        meas[CM_MEAS_ORIENTATION + (lane - 16)] = S.sens[lane];
+    }
+}
+
 /* ======================================================== the env step ==== */
 template <int NVP, class TOPO>
 WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
@@ -613,6 +714,11 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
         S.qacc_ws[lane] = io.qacc_warmstart[(size_t)env * io.sv + lane];
     }
     if (lane < nu) S.ctrl[lane] = io.ctrl[(size_t)env * io.su + lane];
+    if (io.drive_mode) {
+        /* what the last step (or forward) of an earlier launch measured: the inputs of this launch's first drive-level pass */
+        if (lane < m->nsensordata) S.sens[lane] = io.sensordata[(size_t)env * io.ssd + lane];
+        if (lane < nu) S.actvel[lane] = io.actuator_velocity[(size_t)env * io.su + lane];
+    }
     double time = io.time[env];
 
     /* ---------------- per-lane model indices (the fp64 constants are loaded where they are used, to keep
@@ -659,7 +765,10 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
             if (lane < nv) { double v = S.qvel[lane]; badv |= !(v == v) || fabs(v) > 1e10; }
             if (wv::ballot(badv) != 0ull) { warn |= WARN_DIVERGED; break; }
         }
-        if (io.pd_ptarget) {
+        if (io.drive_mode) {
+            if (io.integrate) drive_level_io(io, S, m, env, lane); /* mj_forward leaves the drive-level state alone */
+            wv::sync();
+        } else if (io.pd_ptarget) {
             if (lane < nu) {
                 const size_t o = (size_t)env * io.su + lane;
                 const double ratio = m->act_gear[lane], tmax = m->act_ctrlrange[lane][1];
@@ -1499,6 +1608,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
                     double v = sout[i];
                     if (cut > 0 && stype != CM_SENS_FRAMEQUAT) v = clampd(v, -cut, cut);
                     io.sensordata[(size_t)env * io.ssd + adr + i] = v;
+                    if (io.drive_mode) S.sens[adr + i] = v;
                 }
             }
         }
@@ -1817,9 +1927,17 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
             mulmatTvec3(outv, pa + 9, lin);
             const double cut = m->sensor_cutoff[lane];
             const int adr = m->sensor_adr[lane];
-            for (int i = 0; i < 3; ++i) io.sensordata[(size_t)env * io.ssd + adr + i] = cut > 0 ? clampd(outv[i], -cut, cut) : outv[i];
+            for (int i = 0; i < 3; ++i) {
+                const double v = cut > 0 ? clampd(outv[i], -cut, cut) : outv[i];
+                io.sensordata[(size_t)env * io.ssd + adr + i] = v;
+                if (io.drive_mode) S.sens[adr + i] = v;
+            }
         }
-        if (lane < nu) io.actuator_velocity[(size_t)env * io.su + lane] = m->act_gear[lane] * S.qvel[m->act_dofid[lane]];
+        if (lane < nu) {
+            const double av = m->act_gear[lane] * S.qvel[m->act_dofid[lane]];
+            io.actuator_velocity[(size_t)env * io.su + lane] = av;
+            if (io.drive_mode) S.actvel[lane] = av;
+        }
         if (io.info && lane == 0) {
             io.info[(size_t)env * 4 + 0] = ncon; io.info[(size_t)env * 4 + 1] = nefc;
             io.info[(size_t)env * 4 + 2] = iters; io.info[(size_t)env * 4 + 3] = nguarded;
@@ -1900,6 +2018,26 @@ WV_GLOBAL void __launch_bounds__(WV_WAVE) WV_OCC cassie_step_kernel(PhysIO io) {
     const int env = wv::env_id();
     if (env >= io.nenv) return;
     env_step<NVP, TOPO>(io, S, env);
+}
+
+/* The drive-level pass on its own, one wave per env: cassie_motor_data + cassie_sensor_data for every env on the
+ * sensordata / actuator_velocity the last physics step left in HBM; writes ctrl (for the next physics launch), the
+ * measurement block and the drive state.  The batched host API launches it ahead of the physics kernel so that the
+ * measurements reach the host -- and the state estimators start -- while the physics is still running. */
+struct DriveShared { double sens[CM_MAXSENSORDATA], actvel[CM_MAXU], ctrl[CM_MAXU]; };
+
+WV_GLOBAL void __launch_bounds__(WV_WAVE) cassie_drive_kernel(PhysIO io, double *ctrl_out) {
+    WV_SHARED DriveShared S;
+    const int env = wv::env_id();
+    if (env >= io.nenv) return;
+    const ModelPtr m = (ModelPtr)(io.models + (size_t)env * io.model_stride);
+    const int lane = wv::lane(), nu = m->nu;
+    if (lane < m->nsensordata) S.sens[lane] = io.sensordata[(size_t)env * io.ssd + lane];
+    if (lane < nu) S.actvel[lane] = io.actuator_velocity[(size_t)env * io.su + lane];
+    wv::sync();
+    drive_level_io(io, S, m, env, lane);
+    wv::sync();
+    if (lane < nu) ctrl_out[(size_t)env * io.su + lane] = S.ctrl[lane];
 }
 
 }  // namespace ck

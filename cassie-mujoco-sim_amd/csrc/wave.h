@@ -101,6 +101,13 @@ WV_DEVICE double wave_sum(double v) {
     return readlane(v, 63);
 }
 
+/* individually rounded IEEE double operations the compiler may not contract into FMAs or reassociate: the encoder /
+ * motor models must reproduce the reference's host arithmetic bit for bit (reference src/cassiemujoco.c:558-664) */
+WV_DEVICE double mul_rn(double a, double b) { return __dmul_rn(a, b); }
+WV_DEVICE double add_rn(double a, double b) { return __dadd_rn(a, b); }
+WV_DEVICE double sub_rn(double a, double b) { return __dsub_rn(a, b); }
+WV_DEVICE double div_rn(double a, double b) { return __ddiv_rn(a, b); }
+
 /* hardware reciprocal estimate (v_rcp_f64) */
 WV_DEVICE double rcp_estimate(double x) { return __builtin_amdgcn_rcp(x); }
 

@@ -55,6 +55,16 @@ void cassie_hostenv_step_pd_pre(cassie_hostenv_t *e, const cassie_hostmodel_t *h
                                 const double *sensordata, const double *actuator_velocity, double *ctrl, cassie_out_t *y);
 void cassie_hostenv_step_pd_post(cassie_hostenv_t *e, const cassie_out_t *y, state_out_t *out); /* state_output_step, :1156 */
 
+/* Host half of a step when the drive-level models run on the device (phys_batch_drive_pass): the
+ * Agility blocks produce the command -- cmd[0..9] the cassie_in_t drive torques, cmd[10] the STO flag -- and the
+ * device's measurement block (CM_MEAS_* layout) is copied into cassie_out afterwards. */
+void cassie_hostenv_command_ethercat(cassie_hostenv_t *e, const cassie_in_t *u, double *cmd);
+void cassie_hostenv_command(cassie_hostenv_t *e, const cassie_user_in_t *u, double *cmd);     /* cassie_core_sim_step first */
+void cassie_hostenv_command_pd(cassie_hostenv_t *e, const pd_in_t *u, double *cmd);           /* pd_input_step first */
+void cassie_hostenv_apply_meas(cassie_hostenv_t *e, const double *meas, cassie_out_t *y);
+void cassie_hostenv_get_drive_state(const cassie_hostenv_t *e, cm_drive_state_t *out);
+void cassie_hostenv_set_drive_state(cassie_hostenv_t *e, const cm_drive_state_t *in);
+
 /* cores this process may really use: min(affinity mask, cgroup CPU quota) */
 int cassie_host_cpu_count(void);
 
@@ -76,6 +86,12 @@ int cassie_batch_step_pd(cassie_batch_t *b, const pd_in_t *u, state_out_t *y);
 /* one cassie_sim_step / cassie_sim_step_ethercat for every env */
 int cassie_batch_step(cassie_batch_t *b, const cassie_user_in_t *u, cassie_out_t *y);
 int cassie_batch_step_ethercat(cassie_batch_t *b, const cassie_in_t *u, cassie_out_t *y);
+/* on != 0: the encoder / motor models of every env run on the device (one small launch ahead of the physics kernel)
+ * instead of on the host threads; only the 11 command doubles go up and the 56 measurement doubles come down per env
+ * and step, and the state estimators still overlap the physics kernel.  Outputs are bit for bit those of the host
+ * mode.  The filter histories / delay lines move to HBM (and back to the host envs when switched off).  Needs
+ * timestep = 0.5 ms (one physics step per control step); returns -1 otherwise. */
+int cassie_batch_set_device_drives(cassie_batch_t *b, int on);
 /* cassie_sim_foot_forces for every env: cfrc is [nenv][12] (left force xyz at 0..2, right force xyz at 6..8, the
  * other entries zero like the single-env getter), from the per-body contact forces the last step left in HBM */
 int cassie_batch_foot_forces(cassie_batch_t *b, double *cfrc);

@@ -69,6 +69,11 @@ enum { PHYS_F_QPOS, PHYS_F_QVEL, PHYS_F_QACC_WARMSTART, PHYS_F_TIME, PHYS_F_CTRL
        PHYS_F_PD_PTARGET, PHYS_F_PD_KP, PHYS_F_PD_KD, /* on-device joint PD, see phys_batch_set_pd_mode */
        PHYS_F_BODY_CFRC, /* [nbody][3]: net contact force on every body, world frame (reaction on geom2's body, minus it on
                             geom1's; the foot rows are cassie_sim_foot_forces), of the last substep of a launch */
+       PHYS_F_DRIVE_CMD,  /* [nu + 1]: commanded drive torques (the cassie_in_t torques, output side) and the STO flag (non-zero =
+                             safe torque off), read every substep in CM_DRIVE_TORQUE mode */
+       PHYS_F_MEAS,       /* [CM_MEAS_DIM]: the measurement fields of cassie_out_t written by the device-side encoder / motor
+                             models (layout: CM_MEAS_* in cm_model.h) */
+       PHYS_F_PD_DTARGET, PHYS_F_PD_TORQUE, /* [nu] each: optional velocity targets / feed-forward torques of CM_DRIVE_PD */
        PHYS_F_COUNT };
 
 /* mj_makeData (reference :441-447) for nenv environments on HIP device `device`;
@@ -115,6 +120,26 @@ int phys_batch_sync(phys_batch_t *b);
  * pd_input_step (reference include/pd_input.h:34) followed by the speed-torque limit of motor()
  * (reference src/cassiemujoco.c:638-664), evaluated on the exact joint state; PHYS_F_CTRL is then ignored */
 int phys_batch_set_pd_mode(phys_batch_t *b, int on);
+/* Drive-level I/O on the device: with mode != CM_DRIVE_OFF every substep first runs
+ * cassie_motor_data + cassie_sensor_data (reference src/cassiemujoco.c:737-803: encoder quantisation, integer FIR / IIR
+ * velocity filters, motor speed-torque curve, STO, six-cycle torque delay) for every env, bit for bit the host chain,
+ * on the sensordata / actuator_velocity the previous step left in HBM, writes PHYS_F_MEAS and takes ctrl from the
+ * delay line.  CM_DRIVE_TORQUE reads the command from PHYS_F_DRIVE_CMD (cassie_sim_step_ethercat semantics);
+ * CM_DRIVE_PD computes it as torque + kp (ptarget - position) + kd (dtarget - velocity) on the measured drive
+ * position / velocity of the previous step (pd_input_step's motor PD, reference include/pd_input.h:34).  The filter
+ * histories and delay lines live in HBM (one cm_drive_state_t per env, zero-initialised like a fresh cassie_sim_t). */
+int phys_batch_set_drive_mode(phys_batch_t *b, int mode);
+/* the drive-level pass alone (no physics), whatever the drive mode of the step kernel is: reads PHYS_F_DRIVE_CMD (mode
+ * CM_DRIVE_TORQUE) or the PD fields (CM_DRIVE_PD), PHYS_F_SENSORDATA and PHYS_F_ACTUATOR_VELOCITY; writes PHYS_F_CTRL,
+ * PHYS_F_MEAS and the drive state.  Follow it with phys_batch_step in CM_DRIVE_OFF mode: together the two launches are
+ * one cassie_sim_step_ethercat, and the measurements can travel to the host while the physics runs. */
+int phys_batch_drive_pass(phys_batch_t *b, int mode, void *stream);
+/* a marker on the batch's stream and a host wait for it (everything queued before the marker has completed) */
+int phys_batch_mark(phys_batch_t *b);
+int phys_batch_wait_mark(phys_batch_t *b);
+int phys_batch_upload_drive_state(phys_batch_t *b, const cm_drive_state_t *host, int env0, int n);
+int phys_batch_download_drive_state(phys_batch_t *b, cm_drive_state_t *host, int env0, int n);
+
 /* times `reps` launches of nsub steps with HIP events on the launch stream; returns mean ms per launch */
 int phys_batch_time_steps(phys_batch_t *b, int nsub, int reps, float *mean_ms);
 

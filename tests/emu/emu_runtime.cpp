@@ -147,6 +147,14 @@ static bool topo_matches(const cm_model_t *m, const unsigned long long *t, int n
     return true;
 }
 
+/* drive-level I/O of the next emu_phys_run calls (mode = CM_DRIVE_*; all pointers may be null when mode is 0) */
+static int g_drive_mode = 0;
+static cm_drive_state_t *g_drive_state = nullptr;
+static const double *g_drive_cmd = nullptr, *g_pd_dtarget = nullptr, *g_pd_torque = nullptr;
+static double *g_meas = nullptr;
+extern "C" void emu_set_drive_io(int mode, cm_drive_state_t *state, const double *cmd, double *meas, const double *pd_dtarget, const double *pd_torque) {
+    g_drive_mode = mode; g_drive_state = state; g_drive_cmd = cmd; g_meas = meas; g_pd_dtarget = pd_dtarget; g_pd_torque = pd_torque;
+}
 extern "C" int emu_phys_run(const cm_model_t *model, int nenv, int nsub, int integrate, double *qpos, double *qvel,
                             double *qacc_warmstart, double *time, const double *ctrl, const double *qfrc_applied,
                             const double *xfrc_applied, double *qacc, double *sensordata, double *actuator_velocity,
@@ -163,6 +171,8 @@ extern "C" int emu_phys_run(const cm_model_t *model, int nenv, int nsub, int int
     g_io.hfield = hfield;
     g_io.hfield_stride = 0;
     g_io.pd_ptarget = pd_ptarget; g_io.pd_kp = pd_kp; g_io.pd_kd = pd_kd;
+    g_io.drive_mode = g_drive_mode; g_io.drive_state = g_drive_state; g_io.drive_cmd = g_drive_cmd; g_io.meas = g_meas;
+    g_io.pd_dtarget = g_pd_dtarget; g_io.pd_torque = g_pd_torque;
     for (int e = 0; e < nenv; ++e) {
         g_env = e;
         if (!g_force_runtime_topology && topo_matches(model, ck::TopoCassie32::table, ck::TopoCassie32::nv)) run_block(body32s);

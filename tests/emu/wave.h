@@ -42,6 +42,11 @@ inline bool debug_force_guarded() { return g_force_guarded != 0; }
 inline int fresh_lane() { return lane(); }
 template <class P> inline P opaque_ptr(P p) { return p; }
 inline double rcp_estimate(double x) { return (double)(1.0f / (float)x); } /* deliberately low precision, like the hardware estimate */
+/* individually rounded double operations (the emulator is built without FMA contraction: baseline x86-64) */
+inline double mul_rn(double a, double b) { volatile double r = a * b; return r; }
+inline double add_rn(double a, double b) { volatile double r = a + b; return r; }
+inline double sub_rn(double a, double b) { volatile double r = a - b; return r; }
+inline double div_rn(double a, double b) { volatile double r = a / b; return r; }
 inline int popc64(unsigned long long x) { return __builtin_popcountll(x); }
 }  // namespace wv
 #endif
