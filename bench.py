@@ -9,8 +9,10 @@ one batch: every env of the batch advances by one 0.5 ms physics step
 Workload (BASELINE.json configs[1]): 4096 envs per GPU, cassie model, EPISODES of 1000 steps from the
 cassie_sim_init pose (reference src/cassiemujoco.c:1023-1029); per-env random PD targets (offset + U(-0.3, 0.3)
 rad, gains of reference example/cassietest_jac.py:51-52, :68) re-drawn every 50 steps from a table that is resident
-in HBM; the PD law + motor speed-torque limit run on the device inside the step kernel, so no host buffer is touched
-in the timed region.  Episodes are STAGGERED: env e restarts from the init pose every 1000 steps at phase
+in HBM.  Everything of a cassie_sim_step_pd that is not a closed Agility block runs on the device inside the step
+kernel (--mode drive-pd, the default: pd_input's motor PD on the encoder measurements, the motor model with its
+torque delay, the encoder models, the physics; --mode exact-pd: PD on the exact joint state, no delay), so no host
+buffer is touched in the timed region.  Episodes are STAGGERED: env e restarts from the init pose every 1000 steps at phase
 50 * (e mod 20), so at any moment the batch holds every phase of the episode in equal parts and the measured rate is
 the episode average whatever --steps / --warmup are (synchronised episodes would make a short run measure whichever
 phase it happened to land in -- e.g. the contact-free first 3.7 mm of the drop).  Before the warm-up the schedule is
@@ -22,6 +24,7 @@ The JSON line carries, beside the contract's fields:
   max_qpos_err    BASELINE.json's second half of the metric: after the timed region, sampled envs of the timed batch
                   are replayed on the CPU reference (oracle/, the fp64 restatement of mj_step1 + mj_step2) through the
                   same schedule (pre-roll, warm-up, timed steps, restarts) and the final qpos compared
+  value_exact_pd  (or value_drive_pd) a short run of the other device mode, with its own parity figure
   value_step_pd   the same workload through the drop-in API itself (cassie_batch_step_pd = cassie_sim_step_pd for every
                   env: Agility blocks + encoder / motor models, see include/cassie_batch.h) -- PCIe- and host-inclusive
   roofline        algorithmic HBM bytes of one launch (1976 B per env-step) divided by the mean kernel
@@ -194,10 +197,10 @@ class OracleEnvs:
         return np.array([[b.ncon, b.nefc, b.solver_iter] for b in self.buf])
 
 
-def replay_on_oracle(model, env_ids, targets_of, total_steps, hfield=None, threads=1):
+def replay_on_oracle(model, env_ids, targets_of, total_steps, hfield=None, threads=1, envs=None):
     """The schedule of the timed batch (restarts, PD targets, step count) for the envs `env_ids` on the CPU reference.
-    targets_of(p) -> [len(env_ids)][10] targets of policy step p."""
-    o = OracleEnvs(model, env_ids, hfield)
+    targets_of(p) -> [len(env_ids)][10] targets of policy step p.  `envs`: OracleEnvs (exact-state PD) or HostChainEnvs."""
+    o = (envs or OracleEnvs)(model, env_ids, hfield)
     cur = {}
     sch = Schedule(step=lambda nsub: o.step(nsub, cur["t"], threads),
                    bind_targets=lambda p: cur.__setitem__("t", targets_of(p)),
@@ -228,7 +231,7 @@ def cpu_baseline(model, budget_s=12.0):
             "sample": "%d envs x %d steps, same PD workload and episode schedule, oracle/cassie_oracle.c, OpenMP over envs" % (nenv, pol * HOLD)}
 
 
-def step_pd_host_api(n, steps=200, warmup=50):
+def step_pd_host_api(n, steps=200, warmup=50, device_drives=False):
     """The full cassie_sim_step_pd semantics for n envs (include/cassie_batch.h): Agility blocks + encoder / motor
     models on the host thread pool, ctrl / sensordata over PCIe every step, physics on the GPU.  Host-bound by the
     closed Agility code."""
@@ -239,8 +242,12 @@ def step_pd_host_api(n, steps=200, warmup=50):
     L.cassie_batch_step_pd.argtypes = [ctypes.c_void_p] * 3
     L.cassie_batch_free.argtypes = [ctypes.c_void_p]
     L.cassie_batch_nthreads.argtypes = [ctypes.c_void_p]
+    L.cassie_batch_set_device_drives.argtypes = [ctypes.c_void_p, ctypes.c_int]
     b = L.cassie_batch_create(os.path.join(MODEL_DIR, "cassie.cmodel").encode(), n, 0, 0)
     if not b:
+        return None
+    if device_drives and L.cassie_batch_set_device_drives(b, 1) != 0:
+        L.cassie_batch_free(b)
         return None
     u = np.zeros((n, 119))                      # pd_in_t as 119 doubles: [left task 30 | left motor 25 | right 55 | telemetry 9]
     y = np.zeros((n, 124))                      # state_out_t is 992 bytes
@@ -260,9 +267,179 @@ def step_pd_host_api(n, steps=200, warmup=50):
     nthreads = L.cassie_batch_nthreads(b)
     L.cassie_batch_free(b)
     return {"value": n * steps / dt, "unit": "env-steps/s", "host_threads": nthreads, "host_cores_usable": L.cassie_host_cpu_count(), "host_cores_online": os.cpu_count(),
-            "ms_per_step": 1e3 * dt / steps,
-            "what": "cassie_batch_step_pd: pd_input + cassie_core_sim + motor/encoder models + state_output on host threads, "
-                    "PCIe ctrl/sensordata copies and the physics kernel every step"}
+            "ms_per_step": 1e3 * dt / steps, "drive_level_models": "device" if device_drives else "host",
+            "what": "cassie_batch_step_pd: pd_input + cassie_core_sim + state_output on host threads, motor / encoder models on the %s, "
+                    "PCIe copies (%s) and the physics kernel every step"
+                    % (("device (stand-alone drive pass ahead of the physics kernel)", "11 command doubles up, 56 measurement doubles down per env")
+                       if device_drives else ("host threads", "10 ctrl doubles up, 39 sensordata / actuator_velocity doubles down per env"))}
+
+
+class HostChainEnvs:
+    """Envs on the CPU with the drive-level semantics of CM_DRIVE_PD: oracle physics + the host chain of
+    csrc/cassie_hostpath.c (the reference's own encoder / motor arithmetic) + pd_input's motor PD on the measurements."""
+
+    def __init__(self, model, env_ids, hfield=None):
+        import oracle_py
+        from cassie_amd import phys as P
+        from hostchain_py import HostChain
+        if hfield is not None:
+            oracle_py.set_hfield(hfield)
+        self.model, self.ids, self.P = model, np.asarray(env_ids), P
+        self.orcs = [None] * len(self.ids)
+        self.chains = [HostChain(model) for _ in self.ids]
+        self.meas = np.zeros((len(self.ids), P.MEAS_DIM))
+        for i in range(len(self.ids)):
+            self.reset(i, fresh_chain=False)
+
+    def reset(self, i, fresh_chain=True):
+        from oracle_py import Oracle
+        self.orcs[i] = Oracle(self.model.pod, self.model.qpos_init())
+        self.orcs[i].forward()                      # what cassie_sim_init leaves: the init pose's sensordata
+        if fresh_chain:
+            self.chains[i].reset()                  # a fresh cassie_sim_t: zero filter histories and delay lines
+        self.meas[i] = 0
+
+    def restart(self, group):
+        for i, e in enumerate(self.ids):
+            if int(e) % NGROUP == group:
+                self.reset(i)
+
+    def step(self, nsub, targets, threads=1):
+        from hostchain_py import pd_command
+        for i, (o, hc) in enumerate(zip(self.orcs, self.chains)):
+            for _ in range(nsub):
+                ctrl, self.meas[i], _y = hc.ethercat(pd_command(self.meas[i], targets[i], PD_KP, PD_KD), False, o.sensordata.copy(), o.actuator_velocity.copy())
+                o.ctrl[:] = ctrl
+                o.step()
+
+    def qpos(self):
+        return np.array([o.qpos.copy() for o in self.orcs])
+
+    def counts(self):
+        return np.array([[o.d.ncon, o.d.nefc, o.d.solver_iter] for o in self.orcs])
+
+    def init_sensordata(self):
+        return self.orcs[0].sensordata.copy()
+
+
+def device_rollout(model, mode, n, steps, warmup, rank, world, local_rank, substeps_per_launch=HOLD, parity_envs=64, hfield=None):
+    """One timed device-resident rollout of the workload in `mode`:
+
+      "drive-pd"  CM_DRIVE_PD: every substep runs pd_input's motor PD on the ENCODER measurements of the
+                  previous step (13 / 18-bit truncation, integer FIR / IIR velocity filters), the motor model with its
+                  speed-torque curve and six-cycle torque delay, then the physics -- the drive-level semantics of
+                  cassie_sim_step_pd, bit for bit the host chain of csrc/cassie_hostpath.c, minus the closed Agility blocks'
+                  safety layer and estimator.  An episode restart is a fresh cassie_sim_t (init pose, zero filters / delays).
+      "exact-pd"  the PD law on the exact joint state + the motor's speed-torque limit, no delay, no quantisation.
+
+    State and inputs are resident in HBM before the timed region.  Returns timings and, on rank 0, the comparison of
+    sampled envs with their replay on the CPU reference."""
+    import torch
+    import torch.distributed as dist
+    from cassie_amd import Batch
+    from cassie_amd import phys as P
+    pod = model.pod
+    drive = mode == "drive-pd"
+    env_ids = shard_env_ids(rank, world, n)
+    total_steps = PREROLL + warmup + steps
+    npolicy = (total_steps + HOLD - 1) // HOLD + 1
+    dev = torch.device("cuda", local_rank)
+    b = Batch(model, n, device=local_rank)
+    if hfield is not None:
+        b.set_hfield(hfield)
+    # qpos | qvel | sensordata are column blocks of ONE observation tensor the kernel reads and writes in place -- the
+    # very buffer the all-gather sends
+    nq, nv, nsd, nu = pod.nq, pod.nv, pod.nsensordata, pod.nu
+    nobs = nq + nv + nsd
+    init_row = torch.zeros(nobs, dtype=torch.float64, device=dev)
+    init_row[:nq] = torch.from_numpy(model.qpos_init()).to(dev)
+    if drive:   # the drive-level models read the previous step's sensordata: a restarted env carries the init pose's
+        init_row[nq + nv:] = torch.from_numpy(HostChainEnvs(model, [0], hfield).init_sensordata()).to(dev)
+    obs = init_row.repeat(n, 1).contiguous()
+    warm = torch.zeros((n, nv), dtype=torch.float64, device=dev)
+    esz = obs.element_size()
+    b.bind(P.F_QPOS, obs.data_ptr(), row_stride=nobs)
+    b.bind(P.F_QVEL, obs.data_ptr() + nq * esz, row_stride=nobs)
+    b.bind(P.F_SENSORDATA, obs.data_ptr() + (nq + nv) * esz, row_stride=nobs)
+    b.bind(P.F_QACC_WARMSTART, warm.data_ptr())
+    targets_host = pd_targets(env_ids, npolicy)
+    targets = torch.from_numpy(targets_host).to(dev)       # [npolicy][n][10]
+    kp = torch.from_numpy(np.tile(PD_KP, (n, 1))).to(dev)
+    kd = torch.from_numpy(np.tile(PD_KD, (n, 1))).to(dev)
+    b.bind(P.F_PD_KP, kp.data_ptr())
+    b.bind(P.F_PD_KD, kd.data_ptr())
+    if drive:
+        actvel = torch.zeros((n, nu), dtype=torch.float64, device=dev)
+        meas = torch.zeros((n, P.MEAS_DIM), dtype=torch.float64, device=dev)
+        b.bind(P.F_ACTUATOR_VELOCITY, actvel.data_ptr())
+        b.bind(P.F_MEAS, meas.data_ptr())
+        b.set_drive_mode(P.DRIVE_PD)
+    else:
+        b.set_pd_mode(True)
+    rows_of = [np.nonzero(env_ids % NGROUP == g)[0] for g in range(NGROUP)]
+    group_rows = [torch.from_numpy(r).to(dev) for r in rows_of]
+    obs_all = torch.empty((world * n, nobs), dtype=torch.float64, device=dev) if world > 1 else None
+    launch_stream = torch.cuda.Stream(device=dev)   # a real (non-null) stream: the kernel and the timing events share it
+    stream = launch_stream.cuda_stream
+
+    def restart(group):
+        rows = group_rows[group]
+        if not rows.numel():
+            return
+        if drive:
+            obs[rows] = init_row
+            actvel[rows] = 0
+            meas[rows] = 0
+            b.clear_drive_state(int(rows_of[group][0]), NGROUP, int(rows.numel()), stream)
+        else:
+            obs[rows, : nq + nv] = init_row[: nq + nv]
+        warm[rows] = 0
+
+    sch = Schedule(step=lambda nsub: b.step(nsub, stream),
+                   bind_targets=lambda p: b.bind(P.F_PD_PTARGET, targets[p].data_ptr()),
+                   restart=restart,
+                   gather=(lambda: gather_observations(obs, world, obs_all)) if world > 1 else None,
+                   substeps_per_launch=substeps_per_launch)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    torch.cuda.synchronize(dev)
+    ev = [torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)]
+    with torch.cuda.stream(launch_stream):
+        sch.run(0, PREROLL + warmup)
+        elapsed = timed_region(sch, PREROLL + warmup, steps, fence, mark=lambda i: ev[i].record(launch_stream))
+    res = {"mode": mode, "n": n, "steps": steps, "warmup": warmup, "launches": sch.launches,
+           "kernel_ms": ev[0].elapsed_time(ev[1]) / sch.launches,   # mean stream time per launch (includes the rare restart / gather)
+           "elapsed": max_over_ranks(elapsed, world, dev)}
+    w, info = b.warnings()
+    res["envs_with_warnings"] = int(np.count_nonzero(w))
+    res["mean_constraint_rows"], res["mean_pgs_iterations"], res["mean_pgs_guarded_sweeps"] = (float(info[:, k].mean()) for k in (1, 2, 3))
+    if rank == 0:
+        # ---- the metric's second half: sampled envs of the timed batch against the CPU reference, same schedule ----
+        nsample = max(1, min(parity_envs, n))
+        sample = np.unique(np.linspace(0, n - 1, nsample).astype(int))
+        q_gpu = obs[:, :nq].cpu().numpy()[sample]
+        from cassie_amd._lib import lib
+        threads = lib().cassie_host_cpu_count()
+        orc = replay_on_oracle(model, env_ids[sample], lambda p: targets_host[p][sample], total_steps, hfield, threads,
+                               envs=HostChainEnvs if drive else OracleEnvs)
+        q_ref = orc.qpos()
+        err_abs = np.abs(q_gpu - q_ref)
+        err_rel = err_abs / np.maximum(1.0, np.abs(q_ref))
+        res["parity"] = {"reference": "oracle/cassie_oracle.c (fp64 CPU restatement of mj_step1 + mj_step2; parity with genuine MuJoCo unpinned)"
+                                      + (" + the host chain csrc/cassie_hostpath.c (encoder / motor arithmetic pinned bit-exactly to the reference's code)" if drive else ""),
+                         "envs_compared": int(len(sample)), "steps_replayed": int(total_steps),
+                         "max_qpos_err": float(err_abs.max()), "max_qpos_rel_err": float(err_rel.max()),
+                         "frac_envs_with_equal_ncon_nefc_iters": float(np.mean(np.all(info[sample][:, :3] == orc.counts(), axis=1))),
+                         "tolerance_rel": 1e-6, "ok": bool(err_rel.max() <= 1e-6)}
+        if drive:
+            res["parity"]["note"] = ("an encoder count that truncates differently on a last-bit physics difference moves a motor torque by "
+                                     "kp * 2 pi / 2^bits / gear for one step: agreement is to rounding only as long as no count flips")
+    b.close()
+    return res
 
 
 def true_reference(model_name, q0, targets, nsteps):
@@ -294,6 +471,9 @@ def main():
     ap.add_argument("--parity-envs", type=int, default=64, help="envs of the timed batch replayed on the CPU reference")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-step-pd", action="store_true")
+    ap.add_argument("--no-other-mode", action="store_true", help="skip the short run of the other device mode")
+    ap.add_argument("--mode", default="drive-pd", choices=["drive-pd", "exact-pd"],
+                    help="what the device-resident kernel computes per substep (see device_rollout)")
     args = ap.parse_args()
 
     import torch
@@ -312,98 +492,19 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    from cassie_amd import Batch, Model
-    from cassie_amd import phys as P
+    from cassie_amd import Model
 
     model = Model(args.model)
     pod = model.pod
     n = args.envs_per_gpu
-    env_ids = shard_env_ids(rank, world, n)
-    total_steps = PREROLL + args.warmup + args.steps
-    npolicy = (total_steps + HOLD - 1) // HOLD + 1
-
-    b = Batch(model, n, device=local_rank)
     hfield = None
     if args.model == "cassie_hfield":   # terrain of reference example/test_hfield.py:39-41, shared by all envs
         hfield = np.random.default_rng(99).random((200, 200)).astype(np.float32)
         hfield[95:105, 95:105] = 0
-        b.set_hfield(hfield)
-    dev = torch.device("cuda", local_rank)
-    # state and inputs live in HBM before the timed region starts.  qpos | qvel | sensordata are column blocks of ONE
-    # observation tensor the kernel reads and writes in place -- the very buffer the all-gather sends
-    nq, nv, nsd = pod.nq, pod.nv, pod.nsensordata
-    nobs = nq + nv + nsd
-    obs = torch.zeros((n, nobs), dtype=torch.float64, device=dev)
-    init_row = torch.zeros(nobs, dtype=torch.float64, device=dev)
-    init_row[:nq] = torch.from_numpy(model.qpos_init()).to(dev)
-    obs[:] = init_row
-    warm = torch.zeros((n, nv), dtype=torch.float64, device=dev)
-    esz = obs.element_size()
-    b.bind(P.F_QPOS, obs.data_ptr(), row_stride=nobs)
-    b.bind(P.F_QVEL, obs.data_ptr() + nq * esz, row_stride=nobs)
-    b.bind(P.F_SENSORDATA, obs.data_ptr() + (nq + nv) * esz, row_stride=nobs)
-    b.bind(P.F_QACC_WARMSTART, warm.data_ptr())
-    targets_host = pd_targets(env_ids, npolicy)
-    targets = torch.from_numpy(targets_host).to(dev)       # [npolicy][n][10]
-    kp = torch.from_numpy(np.tile(PD_KP, (n, 1))).to(dev)
-    kd = torch.from_numpy(np.tile(PD_KD, (n, 1))).to(dev)
-    b.bind(P.F_PD_KP, kp.data_ptr())
-    b.bind(P.F_PD_KD, kd.data_ptr())
-    b.set_pd_mode(True)
-    group_rows = [torch.from_numpy(np.nonzero(env_ids % NGROUP == g)[0]).to(dev) for g in range(NGROUP)]
-    obs_all = torch.empty((world * n, nobs), dtype=torch.float64, device=dev) if world > 1 else None
-    launch_stream = torch.cuda.Stream(device=dev)   # a real (non-null) stream: the kernel and the timing events share it
-    stream = launch_stream.cuda_stream
-
-    def restart(group):
-        rows = group_rows[group]
-        if rows.numel():
-            obs[rows, : nq + nv] = init_row[: nq + nv]
-            warm[rows] = 0
-
-    sch = Schedule(step=lambda nsub: b.step(nsub, stream),
-                   bind_targets=lambda p: b.bind(P.F_PD_PTARGET, targets[p].data_ptr()),
-                   restart=restart,
-                   gather=(lambda: gather_observations(obs, world, obs_all)) if world > 1 else None,
-                   substeps_per_launch=args.substeps_per_launch)
-
-    def fence():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-
-    torch.cuda.synchronize(dev)
-    ev = [torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)]
-    with torch.cuda.stream(launch_stream):
-        sch.run(0, PREROLL + args.warmup)
-        elapsed = timed_region(sch, PREROLL + args.warmup, args.steps, fence, mark=lambda i: ev[i].record(launch_stream))
-    ev0, ev1 = ev
-    timed_launches = sch.launches
-    launch_ms_stream = ev0.elapsed_time(ev1) / timed_launches   # mean stream time per launch (includes the rare restart / gather)
-    elapsed = max_over_ranks(elapsed, world, dev)
-
-    w, info = b.warnings()
-    nwarn = int(np.count_nonzero(w))
+    r = device_rollout(model, args.mode, n, args.steps, args.warmup, rank, world, local_rank, args.substeps_per_launch, args.parity_envs, hfield)
 
     if rank == 0:
-        # ---- the metric's second half: sampled envs of the timed batch against the CPU reference ----
-        nsample = max(1, min(args.parity_envs, n))
-        sample = np.unique(np.linspace(0, n - 1, nsample).astype(int))
-        q_gpu = obs[:, :nq].cpu().numpy()[sample]
-        threads = 1
-        try:
-            from cassie_amd._lib import lib
-            threads = lib().cassie_host_cpu_count()
-        except Exception:
-            pass
-        orc = replay_on_oracle(model, env_ids[sample], lambda p: targets_host[p][sample], total_steps, hfield, threads)
-        q_ref = orc.qpos()
-        err_abs = np.abs(q_gpu - q_ref)
-        err_rel = err_abs / np.maximum(1.0, np.abs(q_ref))
-        counts_equal = float(np.mean(np.all(info[sample][:, :3] == orc.counts(), axis=1)))
-
-        # dominant-kernel duration: HIP events on the launch stream around the K timed launches
-        kern_ms = launch_ms_stream
+        elapsed, kern_ms, timed_launches = r["elapsed"], r["kernel_ms"], r["launches"]
         steps_per_launch = args.steps / timed_launches
         # read qpos+qvel+qacc_warmstart+ctrl, write qpos+qvel+qacc+sensordata+actuator_velocity (1976 B for cassie)
         algo_bytes = 8 * ((pod.nq + 2 * pod.nv + pod.nu) + (pod.nq + 2 * pod.nv + pod.nsensordata + pod.nu))
@@ -411,26 +512,26 @@ def main():
         achieved = algo_bytes * n * steps_per_launch / (kern_ms * 1e-3) / 1e9
         value = world * n * args.steps / elapsed
         traffic, traffic_src = pmc_traffic(n * steps_per_launch)
+        api = {"drive-pd": "phys_batch_step in CM_DRIVE_PD mode (device-resident, include/cassie_phys.h): pd_input's motor PD on the encoder "
+                           "measurements + motor model with torque delay + physics in one kernel -- cassie_sim_step_pd's drive-level semantics "
+                           "without the Agility safety layer / estimator",
+               "exact-pd": "phys_batch_step with phys_batch_set_pd_mode (device-resident): PD law on the exact joint state + motor speed-torque "
+                           "limit + physics in one kernel (no encoder quantisation, no torque delay)"}[args.mode]
         out = {
             "metric": "env-steps/sec (whole node) at N envs; max |qpos_err| vs CPU ref", "value": value, "unit": "env-steps/s",
-            "max_qpos_err": float(err_abs.max()), "max_qpos_rel_err": float(err_rel.max()),
+            "max_qpos_err": r["parity"]["max_qpos_err"], "max_qpos_rel_err": r["parity"]["max_qpos_rel_err"],
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%d envs/GPU, %s.xml, %d-step episodes from the cassie_sim_init pose restarted at staggered phases "
                                    "(untimed pre-roll of %d steps), random joint-PD targets re-drawn every %d steps; `value` is the "
-                                   "device-resident API (phys_batch_step: PD law + motor limit + physics in one kernel, cassie_sim_step_pd's "
-                                   "motor-PD semantics without the Agility host blocks); `value_step_pd` is cassie_sim_step_pd itself, batched"
+                                   "device-resident API; `value_step_pd` is cassie_sim_step_pd itself, batched (Agility blocks on host threads)"
                                    % (n, args.model, EPISODE, PREROLL, HOLD),
-                       "api_of_value": "phys_batch_step (device-resident, include/cassie_phys.h)",
+                       "api_of_value": api, "mode": args.mode,
                        "envs_total": world * n, "parallelism": "env-sharded x%d" % world,
                        "obs_allgather_every_steps": HOLD if world > 1 else None,
                        "substeps_per_launch": steps_per_launch, "launches_timed": timed_launches,
                        "preroll_steps": PREROLL, "episode_steps": EPISODE},
-            "parity": {"reference": "oracle/cassie_oracle.c (fp64 CPU restatement of mj_step1 + mj_step2; parity with genuine MuJoCo unpinned)",
-                       "envs_compared": int(len(sample)), "steps_replayed": int(total_steps),
-                       "max_qpos_err": float(err_abs.max()), "max_qpos_rel_err": float(err_rel.max()),
-                       "frac_envs_with_equal_ncon_nefc_iters": counts_equal, "tolerance_rel": 1e-6,
-                       "ok": bool(err_rel.max() <= 1e-6)},
+            "parity": r["parity"],
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "cassie_step_kernel<%d>" % (32 if pod.nv <= 32 else 40), "kernel_ms": kern_ms, "algorithmic_bytes_per_env_step": algo_bytes, "env_steps_per_launch": n * steps_per_launch,
@@ -439,20 +540,28 @@ def main():
             "roofline_fp64": {"bound": "fp64-valu", "achieved": value * 0.22e6 / 1e12, "peak": 78.6, "unit": "TFLOP/s",
                               "frac": value * 0.22e6 / 1e12 / 78.6,
                               "note": "algorithmic flops (SURVEY.md 8a estimate), not counting lanes that idle or recompute"},
-            "envs_with_warnings": nwarn,
-            "mean_constraint_rows": float(info[:, 1].mean()), "mean_pgs_iterations": float(info[:, 2].mean()), "mean_pgs_guarded_sweeps": float(info[:, 3].mean()),
+            "envs_with_warnings": r["envs_with_warnings"],
+            "mean_constraint_rows": r["mean_constraint_rows"], "mean_pgs_iterations": r["mean_pgs_iterations"], "mean_pgs_guarded_sweeps": r["mean_pgs_guarded_sweeps"],
         }
         if world == 1 and args.model == "cassie":
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(model)
-            out["true_reference"] = true_reference(args.model, model.qpos_init(), targets_host[:, sample[:8]], EPISODE)
+            tsample = np.arange(8)
+            out["true_reference"] = true_reference(args.model, model.qpos_init(), pd_targets(tsample, EPISODE // HOLD + 1), EPISODE)
+            if not args.no_other_mode:
+                other = "exact-pd" if args.mode == "drive-pd" else "drive-pd"
+                o = device_rollout(model, other, n, min(args.steps, 400), min(args.warmup, 50), 0, 1, local_rank, args.substeps_per_launch, 16, hfield)
+                out[other.replace("-", "_")] = {"value": n * o["steps"] / o["elapsed"], "unit": "env-steps/s", "steps": o["steps"], "warmup": o["warmup"],
+                                                "kernel_ms": o["kernel_ms"], "parity": o["parity"], "mean_constraint_rows": o["mean_constraint_rows"],
+                                                "mean_pgs_iterations": o["mean_pgs_iterations"]}
+                out["value_" + other.replace("-", "_")] = out[other.replace("-", "_")]["value"]
             if not args.no_step_pd:
-                b.close()
                 sp = step_pd_host_api(n)
+                sd = step_pd_host_api(n, device_drives=True)
                 out["step_pd_host_api"] = sp
-                out["value_step_pd"] = sp["value"] if sp else None
+                out["step_pd_device_drives"] = sd
+                out["value_step_pd"] = max([x["value"] for x in (sp, sd) if x] or [None])
         print(json.dumps(out), flush=True)
-    b.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -83,6 +83,10 @@ def _declare(L):
     L.phys_batch_upload_drive_state.argtypes = [vp, vp, c.c_int, c.c_int]
     L.phys_batch_download_drive_state.argtypes = [vp, vp, c.c_int, c.c_int]
     L.phys_batch_uses_applied.argtypes = [vp]
+    L.phys_batch_drive_pass.argtypes = [vp, c.c_int, vp]
+    L.phys_batch_mark.argtypes = [vp]
+    L.phys_batch_clear_drive_state.argtypes = [vp, c.c_int, c.c_int, c.c_int, vp]
+    L.phys_batch_wait_mark.argtypes = [vp]
     L.phys_batch_set_generic_kernel.argtypes = [vp, ctypes.c_int]
     L.phys_batch_profile_step.argtypes = [vp, vp]
     L.phys_batch_profile_substeps.argtypes = [vp, ctypes.c_int, vp]

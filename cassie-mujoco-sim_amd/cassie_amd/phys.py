@@ -165,6 +165,17 @@ class Batch:
         if lib().phys_batch_set_drive_mode(self._h, int(mode)) != 0:
             raise RuntimeError("set_drive_mode failed: " + (lib().phys_last_error() or b"").decode())
 
+    def drive_pass(self, mode=DRIVE_TORQUE, stream=None):
+        """The drive-level models alone (no physics): reads the command / PD fields and the last step's sensordata and
+        actuator_velocity, writes F_CTRL, F_MEAS and the drive state."""
+        if lib().phys_batch_drive_pass(self._h, int(mode), stream) != 0:
+            raise RuntimeError("drive_pass failed: " + (lib().phys_last_error() or b"").decode())
+
+    def clear_drive_state(self, first=0, stride=1, count=None, stream=None):
+        count = (self.nenv - first + stride - 1) // stride if count is None else count
+        if lib().phys_batch_clear_drive_state(self._h, first, stride, count, stream) != 0:
+            raise RuntimeError("clear_drive_state failed")
+
     def get_drive_state(self, env0=0, n=None):
         n = self.nenv - env0 if n is None else n
         out = (CmDriveState * n)()

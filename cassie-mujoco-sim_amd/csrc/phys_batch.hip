@@ -424,6 +424,15 @@ int phys_batch_wait_mark(phys_batch_t *b) {
     return hip_ok(hipEventSynchronize(b->ev_mark), "hipEventSynchronize") ? 0 : -1;
 }
 
+int phys_batch_clear_drive_state(phys_batch_t *b, int first, int stride, int count, void *stream) {
+    if (!b || first < 0 || stride < 1 || count < 0 || (count > 0 && first + (size_t)(count - 1) * stride >= (size_t)b->nenv)) return -1;
+    (void)hipSetDevice(b->device);
+    if (!ensure_drive_state(b)) return -1;
+    if (count == 0) return 0;
+    return hip_ok(hipMemset2DAsync(b->d_drive + first, sizeof(cm_drive_state_t) * (size_t)stride, 0, sizeof(cm_drive_state_t), (size_t)count,
+                                   stream ? (hipStream_t)stream : b->stream), "hipMemset2D(drive state)") ? 0 : -1;
+}
+
 int phys_batch_upload_drive_state(phys_batch_t *b, const cm_drive_state_t *host, int env0, int n) {
     if (!b || !host || env0 < 0 || n < 0 || env0 + n > b->nenv) return -1;
     (void)hipSetDevice(b->device);

@@ -137,6 +137,9 @@ int phys_batch_drive_pass(phys_batch_t *b, int mode, void *stream);
 /* a marker on the batch's stream and a host wait for it (everything queued before the marker has completed) */
 int phys_batch_mark(phys_batch_t *b);
 int phys_batch_wait_mark(phys_batch_t *b);
+/* zeroes the drive state (a fresh cassie_sim_t's filters and delay lines) of envs first, first + stride, ... (count of
+ * them), asynchronously on `stream` (NULL = the batch's own): episode restarts of a device-resident rollout */
+int phys_batch_clear_drive_state(phys_batch_t *b, int first, int stride, int count, void *stream);
 int phys_batch_upload_drive_state(phys_batch_t *b, const cm_drive_state_t *host, int env0, int n);
 int phys_batch_download_drive_state(phys_batch_t *b, cm_drive_state_t *host, int env0, int n);
 

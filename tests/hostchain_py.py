@@ -81,6 +81,11 @@ class HostChain:
         self.L.cassie_hostenv_ethercat(self.env, ctypes.byref(self.hm), ctypes.byref(u), sd.ctypes.data, av.ctypes.data, ctrl.ctypes.data, ctypes.byref(y))
         return ctrl, meas_of(y), y
 
+    def reset(self):
+        """A fresh cassie_sim_t's host state: zero filter histories and delay lines."""
+        self.L.cassie_hostenv_free(self.env)
+        self.env = self.L.cassie_hostenv_alloc()
+
     def state_bytes(self):
         """(drive FIR histories, joint IIR histories, torque delay lines) as raw bytes, in cm_drive_state_t's field order."""
         dx = np.ctypeslib.as_array(self.L.cassie_hostenv_drive_filter(self.env), (10, 9)).copy()

@@ -73,3 +73,43 @@ def test_config2_exact_workload_on_the_emulator(cassie):
         assert np.array_equal(emu.info[:, :3], orc.counts()), p
         qo = orc.qpos()
         assert np.max(np.abs(emu.qpos - qo) / np.maximum(1, np.abs(qo))) < 1e-7, p
+
+
+def test_emulated_drive_pd_path_against_the_host_chain_replay(cassie, monkeypatch):
+    """bench.py's default mode (CM_DRIVE_PD) end to end with the emulator executing the kernel: restarts are a fresh
+    cassie_sim_t (init pose and its sensordata, zero filter histories / delay lines); the CPU replay (oracle physics +
+    host chain) must reproduce every env's final qpos."""
+    import ctypes
+    from cassie_amd import phys as P
+    from cassie_amd._lib import CmDriveState
+    monkeypatch.setattr(bench, "HOLD", 10)
+    monkeypatch.setattr(bench, "EPISODE", 40)
+    monkeypatch.setattr(bench, "NGROUP", 4)
+    pod = cassie.pod
+    n, total = 4, 75
+    ids = np.arange(n)
+    tg = bench.pd_targets(ids, total // 10 + 2)
+    ref = bench.HostChainEnvs(cassie, ids)
+    init_sens = ref.init_sensordata()
+    emu = EmuBatch(pod, n)
+    emu.qpos[:] = cassie.qpos_init()
+    emu.sensordata[:] = init_sens
+    emu.pd_kp, emu.pd_kd = np.tile(bench.PD_KP, (n, 1)), np.tile(bench.PD_KD, (n, 1))
+    emu.drive_mode = P.DRIVE_PD
+
+    def bind(p):
+        emu.pd_ptarget = np.ascontiguousarray(tg[p])
+
+    def restart(g):
+        for r in np.nonzero(ids % bench.NGROUP == g)[0]:
+            emu.qpos[r] = cassie.qpos_init()
+            emu.qvel[r] = 0
+            emu.qacc_warmstart[r] = 0
+            emu.sensordata[r] = init_sens
+            emu.actuator_velocity[r] = 0
+            emu.meas[r] = 0
+            ctypes.memset(ctypes.addressof(emu.drive_state[int(r)]), 0, ctypes.sizeof(CmDriveState))
+    bench.Schedule(step=emu.step, bind_targets=bind, restart=restart).run(0, total)
+    orc = bench.replay_on_oracle(cassie, ids, lambda p: tg[p], total, envs=bench.HostChainEnvs)
+    assert np.max(np.abs(emu.qpos - orc.qpos())) < 1e-11
+    assert np.array_equal(emu.info[:, :3], orc.counts())

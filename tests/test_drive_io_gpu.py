@@ -50,7 +50,7 @@ def test_torque_mode_bitwise_against_the_host_chain(cassie, standalone):
         sd, av = b.get(P.F_SENSORDATA), b.get(P.F_ACTUATOR_VELOCITY)          # what the previous step left in HBM
         b.set(P.F_DRIVE_CMD, np.concatenate([u, sto[:, None]], axis=1))
         if standalone:
-            assert lib().phys_batch_drive_pass(b._h, P.DRIVE_TORQUE, None) == 0
+            b.drive_pass(P.DRIVE_TORQUE)
             ctrl_dev = b.get(P.F_CTRL)
         b.step(1)
         meas = b.get(P.F_MEAS)
