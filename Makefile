@@ -64,7 +64,7 @@ oracle/libcassie_oracle.so: oracle/cassie_oracle.c oracle/cassie_oracle.h $(CSRC
 	gcc -O2 -std=gnu11 -fPIC -shared -fopenmp -I$(CSRC) -Ioracle oracle/cassie_oracle.c -o $@ -lm
 
 tests/emu/libcassie_emu.so: tests/emu/emu_runtime.cpp tests/emu/wave.h $(CSRC)/physics_kernel.h $(CSRC)/cm_model.h
-	g++ -O2 -std=c++17 -fPIC -shared -Itests/emu -I$(CSRC) tests/emu/emu_runtime.cpp -o $@
+	g++ -O2 -std=c++17 -fPIC -shared -Wl,-Bsymbolic -Itests/emu -I$(CSRC) tests/emu/emu_runtime.cpp -o $@
 
 models: product
 	python3 tools/make_models.py $(REF)/model models

@@ -6,7 +6,8 @@ from . import cstruct
 
 PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))      # .../cassie-mujoco-sim_amd
 REPO_DIR = os.path.dirname(PKG_DIR)
-LIB_PATH = os.path.join(PKG_DIR, "lib", "libcassiemujoco.so")
+# CASSIE_LIB selects another build of the same library (tools/build_variant.sh: compiler-option experiments)
+LIB_PATH = os.environ.get("CASSIE_LIB") or os.path.join(PKG_DIR, "lib", "libcassiemujoco.so")
 MODEL_DIR = os.path.join(REPO_DIR, "models")
 
 with open(os.path.join(PKG_DIR, "csrc", "cm_model.h")) as _f:
@@ -85,6 +86,7 @@ def _declare(L):
     L.phys_batch_uses_applied.argtypes = [vp]
     L.phys_batch_drive_pass.argtypes = [vp, c.c_int, vp]
     L.phys_batch_mark.argtypes = [vp]
+    L.phys_batch_derive.argtypes = [vp, c.POINTER(c.c_int), vp]
     L.phys_batch_clear_drive_state.argtypes = [vp, c.c_int, c.c_int, c.c_int, vp]
     L.phys_batch_wait_mark.argtypes = [vp]
     L.phys_batch_set_generic_kernel.argtypes = [vp, ctypes.c_int]

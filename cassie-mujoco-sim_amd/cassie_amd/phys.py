@@ -15,7 +15,12 @@ from ._lib import CmDriveState, CmModel, MODEL_DIR, lib
 # field ids (enum in cassie_phys.h)
 (F_QPOS, F_QVEL, F_QACC_WARMSTART, F_TIME, F_CTRL, F_QFRC_APPLIED, F_XFRC_APPLIED, F_QACC, F_SENSORDATA,
  F_ACTUATOR_VELOCITY, F_XPOS, F_XQUAT, F_PD_PTARGET, F_PD_KP, F_PD_KD, F_BODY_CFRC, F_DRIVE_CMD, F_MEAS, F_PD_DTARGET,
- F_PD_TORQUE) = range(20)
+ F_PD_TORQUE, F_DERIVED, F_QM) = range(22)
+
+# layout of the derived block F_DERIVED (CM_DRV_* in cm_model.h); MAXV = CM_MAXV
+MAXV = 40
+DRV_COM_POS, DRV_COM_VEL, DRV_ANGMOM, DRV_FOOT_POS, DRV_FOOT_VEL, DRV_FOOT_FORCE, DRV_TOE_FORCE, DRV_HEEL_FORCE, DRV_MASS = 0, 3, 6, 9, 15, 27, 39, 45, 51
+DRV_FOOT_JACP, DRV_FOOT_JACR, DRV_DIM = 52, 52 + 6 * MAXV, 52 + 12 * MAXV
 
 # drive modes (CM_DRIVE_* in cm_model.h) and the layout of the measurement block F_MEAS (CM_MEAS_*)
 DRIVE_OFF, DRIVE_TORQUE, DRIVE_PD = 0, 1, 2
@@ -164,6 +169,13 @@ class Batch:
         measurements): the encoder + motor models of reference src/cassiemujoco.c:558-664 run in the step kernel."""
         if lib().phys_batch_set_drive_mode(self._h, int(mode)) != 0:
             raise RuntimeError("set_drive_mode failed: " + (lib().phys_last_error() or b"").decode())
+
+    def derive(self, ids, stream=None):
+        """Batched derived getters: one forward pass + a reduction kernel fill F_DERIVED and F_QM for every env.
+        ids = (left foot body, right foot body, left heel site, right heel site, left toe site, right toe site), -1 = absent."""
+        arr = (ctypes.c_int * 6)(*[int(i) for i in ids])
+        if lib().phys_batch_derive(self._h, arr, stream) != 0:
+            raise RuntimeError("derive failed: " + (lib().phys_last_error() or b"").decode())
 
     def drive_pass(self, mode=DRIVE_TORQUE, stream=None):
         """The drive-level models alone (no physics): reads the command / PD fields and the last step's sensordata and

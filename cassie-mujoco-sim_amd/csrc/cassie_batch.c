@@ -383,6 +383,19 @@ int cassie_batch_foot_forces(cassie_batch_t *b, double *cfrc)
     return rc;
 }
 
+int cassie_batch_derive(cassie_batch_t *b, double *derived, double *qM)
+{
+    if (!b) return -1;
+    const int ids[6] = {phys_model_name2id(b->m, 1 /* mjOBJ_BODY */, "left-foot"), phys_model_name2id(b->m, 1, "right-foot"),
+                        phys_model_name2id(b->m, 6 /* mjOBJ_SITE */, "left-heel"), phys_model_name2id(b->m, 6, "right-heel"),
+                        phys_model_name2id(b->m, 6, "left-toe"), phys_model_name2id(b->m, 6, "right-toe")};
+    int rc = phys_batch_derive(b->pb, ids, NULL);
+    if (derived) rc |= phys_batch_download(b->pb, PHYS_F_DERIVED, derived, 0, b->nenv);
+    if (qM) rc |= phys_batch_download(b->pb, PHYS_F_QM, qM, 0, b->nenv);
+    rc |= phys_batch_sync(b->pb);
+    return rc;
+}
+
 int cassie_batch_full_reset(cassie_batch_t *b, const unsigned char *mask)
 {
     /* cassie_sim_full_reset per env (reference :2008-2033): pose, velocities, controls, perturbations, torque delay,

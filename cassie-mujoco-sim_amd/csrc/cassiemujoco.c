@@ -58,6 +58,7 @@ struct cassie_sim {
     cassie_hostmodel_t hm;
     int left_foot_body, right_foot_body, left_heel, right_heel, left_toe, right_toe;
     unsigned long long hfield_hash; /* of the samples last uploaded (callers write through cassie_sim_hfielddata) */
+    bool applied_in_use;      /* qfrc_applied / xfrc_applied have been non-zero at some point */
 };
 
 struct cassie_state {
@@ -74,6 +75,16 @@ static double zero_scratch[64];            /* returned for failed name lookups *
 static float zero_scratch_f[8];
 
 static int nsize(const cassie_sim_t *c, int what) { return phys_model_size(c->m, what); }
+
+/* A cassie_sim_t lives in pinned host memory: its mirrors of the physics state (d, ext) are the source / target of the
+ * asynchronous copies around every step, which then run as true DMA transfers queued behind one another on the stream
+ * with a single host synchronisation per step instead of one per array. */
+static cassie_sim_t *sim_alloc(void)
+{
+    cassie_sim_t *c = phys_host_alloc(sizeof(cassie_sim_t));
+    if (!c) fprintf(stderr, "cassiemujoco: cannot allocate the simulator (no usable HIP device?) -- this library has no CPU fallback\n");
+    return c;
+}
 
 static bool load_global_model(const char *path)
 {
@@ -157,38 +168,51 @@ static void sim_push(cassie_sim_t *c)
 {
     sim_recompile(c); /* the caller may have edited model arrays through the accessors */
     sim_push_hfield(c);
-    phys_batch_upload(c->b, PHYS_F_QPOS, c->d.qpos, 0, 1);
-    phys_batch_upload(c->b, PHYS_F_QVEL, c->d.qvel, 0, 1);
-    phys_batch_upload(c->b, PHYS_F_CTRL, c->d.ctrl, 0, 1);
-    phys_batch_upload(c->b, PHYS_F_TIME, &c->d.time, 0, 1);
-    phys_batch_upload(c->b, PHYS_F_QFRC_APPLIED, c->d.qfrc_applied, 0, 1);
-    phys_batch_upload(c->b, PHYS_F_XFRC_APPLIED, c->d.xfrc_applied, 0, 1);
+    phys_batch_upload_async(c->b, PHYS_F_QPOS, c->d.qpos, 0, 1);
+    phys_batch_upload_async(c->b, PHYS_F_QVEL, c->d.qvel, 0, 1);
+    phys_batch_upload_async(c->b, PHYS_F_CTRL, c->d.ctrl, 0, 1);
+    phys_batch_upload_async(c->b, PHYS_F_TIME, &c->d.time, 0, 1);
+    /* perturbations reach the device (and switch the kernel's applied-force path on) only once some are set */
+    if (!c->applied_in_use) {
+        for (size_t i = 0; i < sizeof c->d.qfrc_applied / sizeof(double) && !c->applied_in_use; ++i) c->applied_in_use = c->d.qfrc_applied[i] != 0;
+        for (size_t i = 0; i < sizeof c->d.xfrc_applied / sizeof(double) && !c->applied_in_use; ++i) c->applied_in_use = c->d.xfrc_applied[i] != 0;
+    }
+    if (c->applied_in_use) {
+        phys_batch_upload_async(c->b, PHYS_F_QFRC_APPLIED, c->d.qfrc_applied, 0, 1);
+        phys_batch_upload_async(c->b, PHYS_F_XFRC_APPLIED, c->d.xfrc_applied, 0, 1);
+    }
     if (c->d.warmstart_dirty) {
-        phys_batch_upload(c->b, PHYS_F_QACC_WARMSTART, c->d.qacc_warmstart, 0, 1);
+        phys_batch_upload_async(c->b, PHYS_F_QACC_WARMSTART, c->d.qacc_warmstart, 0, 1);
         c->d.warmstart_dirty = 0;
     }
 }
 
+/* queued behind the kernel; sim_finish waits for everything and unpacks */
 static void sim_pull_kinematics(cassie_sim_t *c)
 {
-    phys_batch_download(c->b, PHYS_F_XPOS, c->d.xpos, 0, 1);
-    phys_batch_download(c->b, PHYS_F_XQUAT, c->d.xquat, 0, 1);
-    phys_batch_download_ext(c->b, &c->ext, 0, 1);
-    int ns = nsize(c, PHYS_NSITE);
-    for (int s = 0; s < ns && s < CM_MAXSITE; ++s)
-        for (int i = 0; i < 3; ++i) c->d.site_xpos[3 * s + i] = c->ext.site_xpos[s][i];
+    phys_batch_download_async(c->b, PHYS_F_XPOS, c->d.xpos, 0, 1);
+    phys_batch_download_async(c->b, PHYS_F_XQUAT, c->d.xquat, 0, 1);
+    phys_batch_download_ext_async(c->b, &c->ext, 0, 1);
 }
 
 static void sim_pull_all(cassie_sim_t *c)
 {
-    phys_batch_download(c->b, PHYS_F_QPOS, c->d.qpos, 0, 1);
-    phys_batch_download(c->b, PHYS_F_QVEL, c->d.qvel, 0, 1);
-    phys_batch_download(c->b, PHYS_F_QACC, c->d.qacc, 0, 1);
-    phys_batch_download(c->b, PHYS_F_QACC_WARMSTART, c->d.qacc_warmstart, 0, 1);
-    phys_batch_download(c->b, PHYS_F_TIME, &c->d.time, 0, 1);
-    phys_batch_download(c->b, PHYS_F_SENSORDATA, c->d.sensordata, 0, 1);
-    phys_batch_download(c->b, PHYS_F_ACTUATOR_VELOCITY, c->d.actuator_velocity, 0, 1);
+    phys_batch_download_async(c->b, PHYS_F_QPOS, c->d.qpos, 0, 1);
+    phys_batch_download_async(c->b, PHYS_F_QVEL, c->d.qvel, 0, 1);
+    phys_batch_download_async(c->b, PHYS_F_QACC, c->d.qacc, 0, 1);
+    phys_batch_download_async(c->b, PHYS_F_QACC_WARMSTART, c->d.qacc_warmstart, 0, 1);
+    phys_batch_download_async(c->b, PHYS_F_TIME, &c->d.time, 0, 1);
+    phys_batch_download_async(c->b, PHYS_F_SENSORDATA, c->d.sensordata, 0, 1);
+    phys_batch_download_async(c->b, PHYS_F_ACTUATOR_VELOCITY, c->d.actuator_velocity, 0, 1);
     sim_pull_kinematics(c);
+}
+
+static void sim_finish(cassie_sim_t *c)
+{
+    phys_batch_sync(c->b);
+    int ns = nsize(c, PHYS_NSITE);
+    for (int s = 0; s < ns && s < CM_MAXSITE; ++s)
+        for (int i = 0; i < 3; ++i) c->d.site_xpos[3 * s + i] = c->ext.site_xpos[s][i];
 }
 
 /* mj_step1 + mj_step2 (reference :1130-1134) */
@@ -197,6 +221,7 @@ static void physics_step(cassie_sim_t *c, int nsteps)
     sim_push(c);
     phys_batch_step(c->b, nsteps, NULL);
     sim_pull_all(c);
+    sim_finish(c);
 }
 
 /* mj_forward (reference :971, :1029, :1223) */
@@ -204,10 +229,11 @@ static void physics_forward(cassie_sim_t *c)
 {
     sim_push(c);
     phys_batch_forward(c->b, NULL);
-    phys_batch_download(c->b, PHYS_F_QACC, c->d.qacc, 0, 1);
-    phys_batch_download(c->b, PHYS_F_SENSORDATA, c->d.sensordata, 0, 1);
-    phys_batch_download(c->b, PHYS_F_ACTUATOR_VELOCITY, c->d.actuator_velocity, 0, 1);
+    phys_batch_download_async(c->b, PHYS_F_QACC, c->d.qacc, 0, 1);
+    phys_batch_download_async(c->b, PHYS_F_SENSORDATA, c->d.sensordata, 0, 1);
+    phys_batch_download_async(c->b, PHYS_F_ACTUATOR_VELOCITY, c->d.actuator_velocity, 0, 1);
     sim_pull_kinematics(c);
+    sim_finish(c);
 }
 
 /* position-dependent quantities only (the mj_kinematics / mj_fwdPosition / mj_comVel calls the
@@ -219,6 +245,7 @@ static void refresh_derived(const cassie_sim_t *cc)
     sim_push(c);
     phys_batch_forward(c->b, NULL);
     sim_pull_kinematics(c);
+    sim_finish(c);
 }
 
 /* --------------------------------------------------------------- instances --- */
@@ -254,7 +281,7 @@ static bool sim_attach_physics(cassie_sim_t *c)
 cassie_sim_t *cassie_sim_init(const char *modelfile, bool reinit)
 {
     if (!library_initialized && !cassie_mujoco_init(modelfile)) return NULL;
-    cassie_sim_t *c = calloc(1, sizeof(cassie_sim_t));
+    cassie_sim_t *c = sim_alloc();
     if (!c) return NULL;
     if (reinit && !load_global_model(modelfile)) { free(c); return NULL; }
     c->m = phys_model_copy(initial_model);
@@ -291,7 +318,7 @@ void cassie_sim_copy(cassie_sim_t *dst, const cassie_sim_t *src)
 cassie_sim_t *cassie_sim_duplicate(const cassie_sim_t *src)
 {
     /* the reference version dereferences an uninitialised model pointer (:1075-1076); this one works */
-    cassie_sim_t *c = calloc(1, sizeof(cassie_sim_t));
+    cassie_sim_t *c = sim_alloc();
     if (!c) return NULL;
     c->m = phys_model_copy(src->m);
     c->host = cassie_hostenv_alloc();
@@ -306,7 +333,7 @@ void cassie_sim_free(cassie_sim_t *c)
     if (c->b) phys_batch_free(c->b);
     cassie_hostenv_free(c->host);
     if (c->m) phys_model_free(c->m);
-    free(c);
+    phys_host_free(c);
 }
 
 /* ---------------------------------------------------------------- stepping --- */

@@ -201,6 +201,19 @@ typedef struct cm_drive_state {
  * cassie_sensor_data and cassie_motor_data fill (reference src/cassiemujoco.c:737-803), as doubles */
 enum { CM_MEAS_DRIVE_POS = 0, CM_MEAS_DRIVE_VEL = 10, CM_MEAS_DRIVE_TORQUE = 20, CM_MEAS_JOINT_POS = 30, CM_MEAS_JOINT_VEL = 36,
        CM_MEAS_ORIENTATION = 42, CM_MEAS_ANGVEL = 46, CM_MEAS_LINACC = 49, CM_MEAS_MAG = 52, CM_MEAS_DIM = 56 };
+/* The derived block of an env (phys_batch_derive): what the reference's reward-side getters read out of mjData
+ * (reference src/cassiemujoco.c:1254-1301 Jacobians, :1604-1700 foot kinematics / centre of mass / momentum,
+ * :1812-1898 foot and heel / toe forces), as one row of doubles per env */
+enum { CM_DRV_COM_POS = 0, CM_DRV_COM_VEL = 3, CM_DRV_ANGMOM = 6,
+       CM_DRV_FOOT_POS = 9,     /* [2][3] cassie_sim_foot_positions (mid-foot offset applied) */
+       CM_DRV_FOOT_VEL = 15,    /* [2][6] cassie_sim_foot_velocities (com-frame spatial velocity of the foot bodies) */
+       CM_DRV_FOOT_FORCE = 27,  /* [12]   cassie_sim_foot_forces layout: left xyz at 0..2, right xyz at 6..8 */
+       CM_DRV_TOE_FORCE = 39, CM_DRV_HEEL_FORCE = 45, /* [2][3] each, cassie_sim_heeltoe_forces */
+       CM_DRV_MASS = 51,
+       CM_DRV_FOOT_JACP = 52,   /* [2][3][CM_MAXV] translational Jacobians of the foot bodies' origins (cassie_sim_get_jacobian) */
+       CM_DRV_FOOT_JACR = 52 + 6 * CM_MAXV, /* [2][3][CM_MAXV] rotational */
+       CM_DRV_DIM = 52 + 12 * CM_MAXV };
+
 /* drive modes of the step kernel */
 enum { CM_DRIVE_OFF = 0,     /* ctrl (or the exact-state PD of phys_batch_set_pd_mode) goes straight to the actuators */
        CM_DRIVE_TORQUE = 1,  /* cassie_sim_step_ethercat on the device: commanded drive torques -> motor model + delay line */
@@ -211,7 +224,8 @@ enum { CM_DRIVE_OFF = 0,     /* ctrl (or the exact-state PD of phys_batch_set_pd
 typedef struct cm_ext {
     int ncon, nefc, solver_iter, pad;
     int con_geom1[CM_MAXCON], con_geom2[CM_MAXCON]; /* ids in the FULL geom list */
-    int con_dim[CM_MAXCON], con_pad[CM_MAXCON];
+    int con_dim[CM_MAXCON], con_body1[CM_MAXCON]; /* bodies of geom1 / geom2 */
+    int con_body2[CM_MAXCON], con_pad2[CM_MAXCON];
     double con_dist[CM_MAXCON], con_pos[CM_MAXCON][3], con_frame[CM_MAXCON][9];
     double con_force[CM_MAXCON][3];       /* contact-frame force: normal, tangent 1, tangent 2 (mj_contactForce role) */
     double cvel[CM_MAXBODY][6];           /* com-frame spatial velocity [rot; lin] */

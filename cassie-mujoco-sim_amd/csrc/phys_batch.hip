@@ -133,6 +133,7 @@ static void note_field_in_use(phys_batch *b, int field) {
 /* rows [env0, env0 + n) of a field between a dense host array and HBM (dense, or strided when the field is a column
  * block of a caller-owned tensor), asynchronously on the batch's stream */
 static bool copy_rows(phys_batch *b, int field, void *host, int env0, int n, bool to_device, const char *what) {
+    if (!b->d_field[field]) { phys_set_last_error("this field is allocated by phys_batch_derive; call it first"); return false; }
     const size_t row = (size_t)b->dim[field], st = (size_t)b->stride[field];
     double *dev = b->d_field[field] + st * env0;
     if (n == 0) return true;
@@ -162,10 +163,11 @@ phys_batch_t *phys_batch_create(const cm_model_t *model, int nenv, int device) {
     const int d[PHYS_F_COUNT] = {model->nq, model->nv, model->nv, 1, model->nu, model->nv, model->nbody * 6,
                                  model->nv, model->nsensordata, model->nu, model->nbody * 3, model->nbody * 4,
                                  model->nu, model->nu, model->nu, model->nbody * 3,
-                                 model->nu + 1, CM_MEAS_DIM, model->nu, model->nu};
+                                 model->nu + 1, CM_MEAS_DIM, model->nu, model->nu, CM_DRV_DIM, model->nv * model->nv};
     bool ok = true;
     for (int f = 0; f < PHYS_F_COUNT; ++f) {
         b->dim[f] = d[f]; b->stride[f] = d[f]; b->d_field[f] = nullptr; b->owned[f] = true;
+        if (f == PHYS_F_DERIVED || f == PHYS_F_QM) continue; /* large and optional: allocated by the first phys_batch_derive */
         size_t bytes = sizeof(double) * (size_t)nenv * (d[f] > 0 ? d[f] : 1);
         ok = ok && hip_ok(hipMalloc((void **)&b->d_field[f], bytes), "hipMalloc(field)");
         if (ok) ok = hip_ok(hipMemset(b->d_field[f], 0, bytes), "hipMemset(field)");
@@ -476,6 +478,42 @@ int phys_batch_download_ext(phys_batch_t *b, cm_ext_t *host, int env0, int n) {
     return hip_ok(hipMemcpyAsync(host, b->d_ext + env0, sizeof(cm_ext_t) * (size_t)n, hipMemcpyDeviceToHost, b->stream), "ext download") &&
                    hip_ok(hipStreamSynchronize(b->stream), "ext sync")
                ? 0 : -1;
+}
+
+int phys_batch_download_ext_async(phys_batch_t *b, cm_ext_t *host, int env0, int n) {
+    if (!b || !host || !b->d_ext || env0 < 0 || n < 0 || env0 + n > b->nenv) return -1;
+    (void)hipSetDevice(b->device);
+    return hip_ok(hipMemcpyAsync(host, b->d_ext + env0, sizeof(cm_ext_t) * (size_t)n, hipMemcpyDeviceToHost, b->stream), "ext download") ? 0 : -1;
+}
+
+int phys_batch_derive(phys_batch_t *b, const int ids[6], void *stream) {
+    if (!b || !ids) return -1;
+    (void)hipSetDevice(b->device);
+    hipStream_t s = stream ? (hipStream_t)stream : b->stream;
+    for (int f : {PHYS_F_DERIVED, PHYS_F_QM}) {
+        if (b->d_field[f]) continue;
+        const size_t bytes = sizeof(double) * (size_t)b->nenv * b->dim[f];
+        if (!hip_ok(hipMalloc((void **)&b->d_field[f], bytes), "hipMalloc(derived)")) return -1;
+        if (!hip_ok(hipMemsetAsync(b->d_field[f], 0, bytes, s), "hipMemset(derived)")) return -1;
+        b->owned[f] = true;
+    }
+    const bool had_ext = b->d_ext != nullptr;
+    if (!had_ext && phys_batch_enable_ext(b, 1) != 0) return -1;
+    int rc = launch(b, 1, 0, s); /* forward: the read-out of the current state */
+    ck::DeriveIO io;
+    memset(&io, 0, sizeof io);
+    io.models = b->d_models; io.model_stride = b->model_stride; io.nenv = b->nenv;
+    io.ext = b->d_ext; io.xpos = b->d_field[PHYS_F_XPOS]; io.xquat = b->d_field[PHYS_F_XQUAT];
+    io.derived = b->d_field[PHYS_F_DERIVED]; io.qM = b->d_field[PHYS_F_QM];
+    for (int i = 0; i < 6; ++i) io.ids[i] = ids[i];
+    hipLaunchKernelGGL(ck::cassie_derive_kernel, dim3(b->nenv), dim3(WV_WAVE), 0, s, io);
+    rc |= hip_ok(hipGetLastError(), "cassie_derive_kernel launch") ? 0 : -1;
+    if (!had_ext) {
+        /* the read-out buffer is 20 KB per env and makes every step write it: keep it only for the caller who asked for it */
+        if (!hip_ok(hipStreamSynchronize(s), "derive sync")) rc = -1;
+        rc |= phys_batch_enable_ext(b, 0);
+    }
+    return rc;
 }
 
 int phys_batch_set_generic_kernel(phys_batch_t *b, int on) {

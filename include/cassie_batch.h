@@ -95,6 +95,12 @@ int cassie_batch_set_device_drives(cassie_batch_t *b, int on);
 /* cassie_sim_foot_forces for every env: cfrc is [nenv][12] (left force xyz at 0..2, right force xyz at 6..8, the
  * other entries zero like the single-env getter), from the per-body contact forces the last step left in HBM */
 int cassie_batch_foot_forces(cassie_batch_t *b, double *cfrc);
+/* The other reward-side getters for every env in one go (phys_batch_derive: one forward pass + a reduction kernel):
+ * derived[nenv][CM_DRV_DIM] holds, per env, what cassie_sim_cm_position / cm_velocity / angular_momentum /
+ * foot_positions / foot_velocities / foot_forces / heeltoe_forces / get_jacobian_full("left-foot" | "right-foot") return
+ * (layout CM_DRV_* in cm_model.h), qM[nenv][nv * nv] what cassie_sim_full_mass_matrix returns.  Either pointer may be NULL
+ * (the values then stay in HBM as PHYS_F_DERIVED / PHYS_F_QM of cassie_batch_phys(b), bindable to caller tensors). */
+int cassie_batch_derive(cassie_batch_t *b, double *derived, double *qM);
 /* cassie_sim_full_reset for the envs whose mask byte is non-zero (mask NULL = all) */
 int cassie_batch_full_reset(cassie_batch_t *b, const unsigned char *mask);
 

@@ -74,6 +74,8 @@ enum { PHYS_F_QPOS, PHYS_F_QVEL, PHYS_F_QACC_WARMSTART, PHYS_F_TIME, PHYS_F_CTRL
        PHYS_F_MEAS,       /* [CM_MEAS_DIM]: the measurement fields of cassie_out_t written by the device-side encoder / motor
                              models (layout: CM_MEAS_* in cm_model.h) */
        PHYS_F_PD_DTARGET, PHYS_F_PD_TORQUE, /* [nu] each: optional velocity targets / feed-forward torques of CM_DRIVE_PD */
+       PHYS_F_DERIVED,    /* [CM_DRV_DIM]: the derived block of phys_batch_derive (layout: CM_DRV_* in cm_model.h) */
+       PHYS_F_QM,         /* [nv * nv]: dense joint-space inertia matrix (mj_fullM role), written by phys_batch_derive */
        PHYS_F_COUNT };
 
 /* mj_makeData (reference :441-447) for nenv environments on HIP device `device`;
@@ -150,6 +152,17 @@ int phys_batch_time_steps(phys_batch_t *b, int nsub, int reps, float *mean_ms);
  * then every step/forward refreshes them in HBM; download copies envs [env0, env0 + n) to the host */
 int phys_batch_enable_ext(phys_batch_t *b, int on);
 int phys_batch_download_ext(phys_batch_t *b, cm_ext_t *host, int env0, int n);
+int phys_batch_download_ext_async(phys_batch_t *b, cm_ext_t *host, int env0, int n); /* pair with phys_batch_sync */
+
+/* Batched derived getters: one forward pass (mj_forward role: nothing is integrated) that leaves the
+ * full read-out of every env in HBM, then a small kernel that reduces it to PHYS_F_DERIVED -- whole-model centre of
+ * mass / velocity / angular momentum, foot positions / velocities, foot and heel / toe contact forces, the feet's
+ * Jacobians -- and PHYS_F_QM, i.e. what cassie_sim_cm_position / cm_velocity / angular_momentum / foot_positions /
+ * foot_velocities / foot_forces / heeltoe_forces / get_jacobian_full / full_mass_matrix return for one simulator
+ * (reference src/cassiemujoco.c:1254-1301, :1604-1712, :1812-1898), for every env, as device fields (bindable).
+ * ids = {left foot body, right foot body, left heel site, right heel site, left toe site, right toe site}, -1 = absent.
+ * The forces are those of the CURRENT state (like after cassie_sim_forward).  Costs about one physics step. */
+int phys_batch_derive(phys_batch_t *b, const int ids[6], void *stream);
 
 /* validation aid: run the generic instantiation of the step kernel (dof-tree topology read from the model at run
  * time) even when the model matches one of the compile-time-topology instantiations */

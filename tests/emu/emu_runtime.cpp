@@ -181,4 +181,31 @@ extern "C" int emu_phys_run(const cm_model_t *model, int nenv, int nsub, int int
     }
     return 0;
 }
+/* phys_batch_derive on the emulator: a forward pass with the read-out enabled, then the derive kernel, env by env */
+static ck::DeriveIO g_dio;
+static void body_derive() { ck::cassie_derive_kernel(g_dio); }
+extern "C" int emu_derive(const cm_model_t *model, int nenv, double *qpos, double *qvel, double *qacc_warmstart, double *time,
+                          const double *ctrl, double *qacc, double *sensordata, double *actuator_velocity, int *warn, int *info,
+                          const float *hfield, const int *ids, double *derived, double *qM) {
+    cm_ext_t *ext = (cm_ext_t *)calloc((size_t)nenv, sizeof(cm_ext_t));
+    double *xpos = (double *)calloc((size_t)nenv * model->nbody * 3, sizeof(double)), *xquat = (double *)calloc((size_t)nenv * model->nbody * 4, sizeof(double));
+    memset(&g_io, 0, sizeof g_io);
+    g_io.models = model; g_io.nenv = nenv; g_io.nsub = 1; g_io.integrate = 0;
+    g_io.sq = model->nq; g_io.sqv = model->nv; g_io.sv = model->nv; g_io.su = model->nu; g_io.ssd = model->nsensordata; g_io.sb = model->nbody;
+    g_io.qpos = qpos; g_io.qvel = qvel; g_io.qacc_warmstart = qacc_warmstart; g_io.time = time; g_io.ctrl = ctrl;
+    g_io.qacc = qacc; g_io.sensordata = sensordata; g_io.actuator_velocity = actuator_velocity; g_io.warn = warn; g_io.info = info;
+    g_io.xpos_out = xpos; g_io.xquat_out = xquat; g_io.hfield = hfield; g_io.ext = ext;
+    memset(&g_dio, 0, sizeof g_dio);
+    g_dio.models = model; g_dio.nenv = nenv; g_dio.ext = ext; g_dio.xpos = xpos; g_dio.xquat = xquat; g_dio.derived = derived; g_dio.qM = qM;
+    for (int i = 0; i < 6; ++i) g_dio.ids[i] = ids[i];
+    for (int e = 0; e < nenv; ++e) {
+        g_env = e;
+        if (topo_matches(model, ck::TopoCassie32::table, ck::TopoCassie32::nv)) run_block(body32s);
+        else if (topo_matches(model, ck::TopoCassieTray38::table, ck::TopoCassieTray38::nv)) run_block(body40s);
+        else run_block(model->nv <= 32 ? body32 : body40);
+        run_block(body_derive);
+    }
+    free(ext); free(xpos); free(xquat);
+    return 0;
+}
 extern "C" unsigned long emu_sizeof_shared32(void) { return sizeof(ck::EnvShared<32>); }

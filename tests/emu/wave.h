@@ -15,7 +15,7 @@
 #include <cstdint>
 
 #define WV_DEVICE inline
-#define WV_GLOBAL
+#define WV_GLOBAL static /* internal linkage: the product library exports host stubs of the same kernel names */
 #define WV_SHARED static
 #define WV_WAVE 64
 #define WV_CONST_AS

@@ -15,6 +15,7 @@ def lib():
         _lib = ctypes.CDLL(os.path.join(REPO_DIR, "tests", "emu", "libcassie_emu.so"))
         _lib.emu_phys_run.argtypes = [ctypes.POINTER(CmModel)] + [ctypes.c_int] * 3 + [ctypes.c_void_p] * 18
         _lib.emu_set_drive_io.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 5
+        _lib.emu_derive.argtypes = [ctypes.POINTER(CmModel), ctypes.c_int] + [ctypes.c_void_p] * 14
     return _lib
 
 
@@ -52,6 +53,18 @@ class EmuBatch:
                            p(self.xfrc_applied), p(self.qacc), p(self.sensordata), p(self.actuator_velocity),
                            p(self.warn), p(self.info), p(self.xpos), p(self.xquat), p(self.pd_ptarget), p(self.pd_kp),
                            p(self.pd_kd), p(self.hfield))
+
+    def derive(self, ids):
+        """phys_batch_derive on the emulator: -> (derived [nenv][CM_DRV_DIM], qM [nenv][nv][nv])."""
+        from cassie_amd import phys as P
+        p = lambda a: None if a is None else a.ctypes.data
+        derived = np.zeros((self.nenv, P.DRV_DIM))
+        qM = np.zeros((self.nenv, self.pod.nv, self.pod.nv))
+        idarr = np.asarray(ids, dtype=np.int32)
+        lib().emu_derive(ctypes.byref(self.pod), self.nenv, p(self.qpos), p(self.qvel), p(self.qacc_warmstart), p(self.time), p(self.ctrl),
+                         p(self.qacc), p(self.sensordata), p(self.actuator_velocity), p(self.warn), p(self.info), p(self.hfield),
+                         p(idarr), p(derived), p(qM))
+        return derived, qM
 
     def step(self, nsub=1):
         self._run(nsub, 1)

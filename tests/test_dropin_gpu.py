@@ -278,3 +278,68 @@ def test_single_simulator_is_faster_than_real_time(L):
     with open(os.path.join(REPO_DIR, "gpurun_out", "single_sim_rate.txt"), "w") as f:
         f.write("%.1f cassie_sim_step_pd/s (one cassie_sim_t, host API, every step crosses PCIe)\n" % rate)
     assert rate > 2000.0
+
+
+def test_batched_derived_getters_against_the_single_simulator_getters(L, cassie):
+    """cassie_batch_derive: centre of mass / velocity / angular momentum, foot positions / velocities /
+    forces, heel-toe forces, foot Jacobians and the mass matrix of every env against the single-simulator getters
+    (reference src/cassiemujoco.c:1254-1301, :1604-1712, :1812-1898) evaluated on the same states."""
+    from cassie_amd import phys as P
+    L.cassie_batch_derive.argtypes = [VP, VP, VP]
+    L.cassie_sim_forward.argtypes = [VP]
+    for f in ("cassie_sim_cm_velocity", "cassie_sim_angular_momentum", "cassie_sim_foot_velocities"):
+        getattr(L, f).argtypes = [VP, VP]
+    L.cassie_sim_get_jacobian_full.argtypes = [VP, VP, VP, ctypes.c_char_p]
+    n = 6
+    bt = L.cassie_batch_create(MODEL, n, 0, 2)
+    rng = np.random.default_rng(3)
+    us = (T.pd_in_t * n)()
+    for e in range(n):
+        us[e] = pd_input(rng, scale=0.3)
+    ys = (T.state_out_t * n)()
+    for _ in range(400):                                   # onto the floor, every env on its own trajectory
+        assert L.cassie_batch_step_pd(bt, ctypes.byref(us), ctypes.byref(ys)) == 0
+    from cassie_amd._lib import lib as _l
+    pb = L.cassie_batch_phys(bt)
+    q, v = np.zeros((n, 35)), np.zeros((n, 32))
+    _l().phys_batch_download(pb, P.F_QPOS, q.ctypes.data, 0, n)
+    _l().phys_batch_download(pb, P.F_QVEL, v.ctypes.data, 0, n)
+    D, QM = np.zeros((n, P.DRV_DIM)), np.zeros((n, 32 * 32))
+    assert L.cassie_batch_derive(bt, D.ctypes.data, QM.ctypes.data) == 0
+    c = L.cassie_sim_init(MODEL, False)
+    saw_force = False
+    for e in range(n):
+        np.ctypeslib.as_array(L.cassie_sim_qpos(c), (35,))[:] = q[e]
+        np.ctypeslib.as_array(L.cassie_sim_qvel(c), (32,))[:] = v[e]
+        L.cassie_sim_forward(c)
+        out = lambda k: np.zeros(k)
+        cm, cv, am, fp, fv, ff, toe, heel, M = out(3), out(3), out(3), out(6), out(12), out(12), out(6), out(6), out(1024)
+        L.cassie_sim_foot_forces(c, ff.ctypes.data)                           # of the forward pass just made
+        L.cassie_sim_heeltoe_forces(c, toe.ctypes.data, heel.ctypes.data)
+        L.cassie_sim_cm_position(c, cm.ctypes.data)
+        L.cassie_sim_cm_velocity(c, cv.ctypes.data)
+        L.cassie_sim_angular_momentum(c, am.ctypes.data)
+        L.cassie_sim_foot_positions(c, fp.ctypes.data)
+        L.cassie_sim_foot_velocities(c, fv.ctypes.data)
+        L.cassie_sim_full_mass_matrix(c, M.ctypes.data)
+        d = D[e]
+        assert np.allclose(d[P.DRV_COM_POS: P.DRV_COM_POS + 3], cm, atol=1e-12)
+        assert np.allclose(d[P.DRV_COM_VEL: P.DRV_COM_VEL + 3], cv, atol=1e-12)
+        assert np.allclose(d[P.DRV_ANGMOM: P.DRV_ANGMOM + 3], am, atol=1e-11)
+        assert np.allclose(d[P.DRV_FOOT_POS: P.DRV_FOOT_POS + 6], fp, atol=1e-12)
+        assert np.allclose(d[P.DRV_FOOT_VEL: P.DRV_FOOT_VEL + 12], fv, atol=1e-12)
+        assert np.allclose(QM[e], M, atol=1e-11)
+        # forces: both solves stop at the same tolerance but start from different warm starts
+        assert np.allclose(d[P.DRV_FOOT_FORCE: P.DRV_FOOT_FORCE + 12], ff, rtol=5e-3, atol=0.05)
+        assert np.allclose(d[P.DRV_TOE_FORCE: P.DRV_TOE_FORCE + 6], toe, rtol=5e-3, atol=0.05)
+        assert np.allclose(d[P.DRV_HEEL_FORCE: P.DRV_HEEL_FORCE + 6], heel, rtol=5e-3, atol=0.05)
+        saw_force |= ff[2] + ff[8] > 100
+        for side, name in enumerate((b"left-foot", b"right-foot")):
+            jp, jr = np.zeros(96), np.zeros(96)
+            L.cassie_sim_get_jacobian_full(c, jp.ctypes.data, jr.ctypes.data, name)
+            Jp = d[P.DRV_FOOT_JACP + side * 3 * P.MAXV: P.DRV_FOOT_JACP + (side + 1) * 3 * P.MAXV].reshape(3, P.MAXV)[:, :32]
+            Jr = d[P.DRV_FOOT_JACR + side * 3 * P.MAXV: P.DRV_FOOT_JACR + (side + 1) * 3 * P.MAXV].reshape(3, P.MAXV)[:, :32]
+            assert np.allclose(Jp, jp.reshape(3, 32), atol=1e-12) and np.allclose(Jr, jr.reshape(3, 32), atol=1e-12)
+    assert saw_force
+    L.cassie_sim_free(c)
+    L.cassie_batch_free(bt)
