@@ -301,16 +301,22 @@ def test_batched_derived_getters_against_the_single_simulator_getters(L, cassie)
         assert L.cassie_batch_step_pd(bt, ctypes.byref(us), ctypes.byref(ys)) == 0
     from cassie_amd._lib import lib as _l
     pb = L.cassie_batch_phys(bt)
-    q, v = np.zeros((n, 35)), np.zeros((n, 32))
+    q, v, ct = np.zeros((n, 35)), np.zeros((n, 32)), np.zeros((n, 10))
     _l().phys_batch_download(pb, P.F_QPOS, q.ctypes.data, 0, n)
     _l().phys_batch_download(pb, P.F_QVEL, v.ctypes.data, 0, n)
+    _l().phys_batch_download(pb, P.F_CTRL, ct.ctypes.data, 0, n)
+    L.cassie_sim_ctrl.restype = DP
+    L.cassie_sim_ctrl.argtypes = [VP]
     D, QM = np.zeros((n, P.DRV_DIM)), np.zeros((n, 32 * 32))
+    # the fresh simulator below solves its contact forces from a zero warm start: give the batch the same one
+    _l().phys_batch_upload(pb, P.F_QACC_WARMSTART, np.zeros((n, 32)).ctypes.data, 0, n)
     assert L.cassie_batch_derive(bt, D.ctypes.data, QM.ctypes.data) == 0
     c = L.cassie_sim_init(MODEL, False)
     saw_force = False
     for e in range(n):
         np.ctypeslib.as_array(L.cassie_sim_qpos(c), (35,))[:] = q[e]
         np.ctypeslib.as_array(L.cassie_sim_qvel(c), (32,))[:] = v[e]
+        np.ctypeslib.as_array(L.cassie_sim_ctrl(c), (10,))[:] = ct[e]       # the motor torques act in the forward pass
         L.cassie_sim_forward(c)
         out = lambda k: np.zeros(k)
         cm, cv, am, fp, fv, ff, toe, heel, M = out(3), out(3), out(3), out(6), out(12), out(12), out(6), out(6), out(1024)
@@ -329,10 +335,9 @@ def test_batched_derived_getters_against_the_single_simulator_getters(L, cassie)
         assert np.allclose(d[P.DRV_FOOT_POS: P.DRV_FOOT_POS + 6], fp, atol=1e-12)
         assert np.allclose(d[P.DRV_FOOT_VEL: P.DRV_FOOT_VEL + 12], fv, atol=1e-12)
         assert np.allclose(QM[e], M, atol=1e-11)
-        # forces: both solves stop at the same tolerance but start from different warm starts
-        assert np.allclose(d[P.DRV_FOOT_FORCE: P.DRV_FOOT_FORCE + 12], ff, rtol=5e-3, atol=0.05)
-        assert np.allclose(d[P.DRV_TOE_FORCE: P.DRV_TOE_FORCE + 6], toe, rtol=5e-3, atol=0.05)
-        assert np.allclose(d[P.DRV_HEEL_FORCE: P.DRV_HEEL_FORCE + 6], heel, rtol=5e-3, atol=0.05)
+        assert np.allclose(d[P.DRV_FOOT_FORCE: P.DRV_FOOT_FORCE + 12], ff, rtol=1e-9, atol=1e-8)
+        assert np.allclose(d[P.DRV_TOE_FORCE: P.DRV_TOE_FORCE + 6], toe, rtol=1e-9, atol=1e-8)
+        assert np.allclose(d[P.DRV_HEEL_FORCE: P.DRV_HEEL_FORCE + 6], heel, rtol=1e-9, atol=1e-8)
         saw_force |= ff[2] + ff[8] > 100
         for side, name in enumerate((b"left-foot", b"right-foot")):
             jp, jr = np.zeros(96), np.zeros(96)
