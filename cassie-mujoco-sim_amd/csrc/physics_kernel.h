@@ -758,6 +758,15 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
 #else
     for (int sub = 0; sub < io.nsub; ++sub) {
 #endif
+        /* Outputs that every substep recomputes (sensordata, qacc, actuator_velocity, xpos / xquat, the solver statistics)
+         * are stored only by the LAST substep of a launch: the others' values would be overwritten anyway, and on this
+         * hardware vector stores share the loads' completion counter (vmcnt), so a store that is still in flight holds up
+         * the next stage's first model read. */
+#ifdef CK_STORE_EVERY_SUBSTEP
+        const bool lastsub = true;
+#else
+        const bool lastsub = sub == io.nsub - 1 || !io.integrate;
+#endif
         /* divergence guard (mj_checkPos/mj_checkVel role): sticky flag, state left alone */
         {
             bool badv = false;
@@ -1607,13 +1616,13 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
                     if (i >= dim) continue;
                     double v = sout[i];
                     if (cut > 0 && stype != CM_SENS_FRAMEQUAT) v = clampd(v, -cut, cut);
-                    io.sensordata[(size_t)env * io.ssd + adr + i] = v;
+                    if (lastsub) io.sensordata[(size_t)env * io.ssd + adr + i] = v;
                     if (io.drive_mode) S.sens[adr + i] = v;
                 }
             }
         }
         CK_STAMP(29);
-        if (io.xpos_out && isbody) {
+        if (io.xpos_out && isbody && lastsub) {
             for (int i = 0; i < 3; ++i) io.xpos_out[((size_t)env * io.sb + b) * 3 + i] = S.x.s.xpos[b][i];
             if (io.xquat_out) for (int i = 0; i < 4; ++i) io.xquat_out[((size_t)env * io.sb + b) * 4 + i] = S.x.s.xquat[b][i];
         }
@@ -1930,20 +1939,20 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
             const int adr = m->sensor_adr[lane];
             for (int i = 0; i < 3; ++i) {
                 const double v = cut > 0 ? clampd(outv[i], -cut, cut) : outv[i];
-                io.sensordata[(size_t)env * io.ssd + adr + i] = v;
+                if (lastsub) io.sensordata[(size_t)env * io.ssd + adr + i] = v;
                 if (io.drive_mode) S.sens[adr + i] = v;
             }
         }
         if (lane < nu) {
             const double av = m->act_gear[lane] * S.qvel[m->act_dofid[lane]];
-            io.actuator_velocity[(size_t)env * io.su + lane] = av;
+            if (lastsub) io.actuator_velocity[(size_t)env * io.su + lane] = av;
             if (io.drive_mode) S.actvel[lane] = av;
         }
-        if (io.info && lane == 0) {
+        if (io.info && lane == 0 && lastsub) {
             io.info[(size_t)env * 4 + 0] = ncon; io.info[(size_t)env * 4 + 1] = nefc;
             io.info[(size_t)env * 4 + 2] = iters; io.info[(size_t)env * 4 + 3] = nguarded;
         }
-        if (isdof) io.qacc[(size_t)env * io.sv + k_] = qacc;
+        if (isdof && lastsub) io.qacc[(size_t)env * io.sv + k_] = qacc;
         if (!io.integrate) break;
         CK_STAMP(13);
 

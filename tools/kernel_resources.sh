@@ -10,7 +10,7 @@ cat > $T/one.hip <<'EOS'
 template __global__ void ck::cassie_step_kernel<32, ck::TopoCassie32>(ck::PhysIO);
 EOS
 /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 --offload-device-only -Iinclude -Icassie-mujoco-sim_amd/csrc \
-  -ffp-contract=on $EXTRA -Rpass-analysis=kernel-resource-usage ${KEEP:+-save-temps=obj} -c $T/one.hip -o $T/one.o 2>&1 |
+  -ffp-contract=on -mllvm -amdgpu-sched-strategy=iterative-ilp $EXTRA -Rpass-analysis=kernel-resource-usage ${KEEP:+-save-temps=obj} -c $T/one.hip -o $T/one.o 2>&1 |
   grep -E "VGPRs:|AGPRs|Spill|ScratchSize|Occupancy|LDS Size|SGPRs:" | sed 's/.*remark: *//; s/ \[-Rpass.*//'
 [ -n "$KEEP" ] && cp $T/one-hip-amdgcn-amd-amdhsa-gfx950.s "$KEEP" || true
 rm -rf $T
