@@ -345,6 +345,8 @@ def device_rollout(model, mode, n, steps, warmup, rank, world, local_rank, subst
     npolicy = (total_steps + HOLD - 1) // HOLD + 1
     dev = torch.device("cuda", local_rank)
     b = Batch(model, n, device=local_rank)
+    if os.environ.get("CASSIE_NO_BALANCE"):
+        b.set_balance(False)            # A/B switch for the longest-job-first launch order
     if hfield is not None:
         b.set_hfield(hfield)
     # qpos | qvel | sensordata are column blocks of ONE observation tensor the kernel reads and writes in place -- the

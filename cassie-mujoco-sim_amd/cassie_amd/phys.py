@@ -210,6 +210,10 @@ class Batch:
             raise RuntimeError("timing failed: " + (lib().phys_last_error() or b"").decode())
         return ms.value
 
+    def set_balance(self, on=True):
+        """Longest-job-first launch order from the previous launch's per-env cost (default on for >= 2048 envs)."""
+        lib().phys_batch_set_balance(self._h, 1 if on else 0)
+
     def set_generic_kernel(self, on=True):
         """Validation aid: use the run-time-topology instantiation of the step kernel."""
         lib().phys_batch_set_generic_kernel(self._h, 1 if on else 0)

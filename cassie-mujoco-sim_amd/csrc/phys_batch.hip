@@ -43,6 +43,11 @@ struct phys_batch {
     cm_drive_state_t *d_drive = nullptr; /* [nenv], allocated when a drive mode is first selected */
     bool use_pd_dtarget = false, use_pd_torque = false;
     long long *d_prof = nullptr;
+    /* launch-order balancing (see ck::cassie_order_kernel) */
+    bool balance = true;
+    unsigned *d_cost = nullptr;
+    int *d_order = nullptr;
+    int launches_since_order = 0;
     cm_ext_t *d_ext = nullptr;
 };
 
@@ -90,6 +95,7 @@ static ck::PhysIO make_io(phys_batch *b, int nsub, int integrate) {
     }
     io.prof = b->d_prof;
     io.ext = b->d_ext;
+    if (b->balance && b->d_order) { io.order = b->d_order; io.cost = b->d_cost; }
     return io;
 }
 
@@ -120,7 +126,14 @@ static int launch(phys_batch *b, int nsub, int integrate, hipStream_t s) {
         hipLaunchKernelGGL((ck::cassie_step_kernel<32, ck::TopoRuntime>), grid, block, 0, s, io);
     else
         hipLaunchKernelGGL((ck::cassie_step_kernel<40, ck::TopoRuntime>), grid, block, 0, s, io);
-    return hip_ok(hipGetLastError(), "cassie_step_kernel launch") ? 0 : -1;
+    if (!hip_ok(hipGetLastError(), "cassie_step_kernel launch")) return -1;
+    /* the next launch's order from this one's per-env cost: after every long launch, now and then after short ones */
+    if (io.order && integrate && (nsub >= 8 || ++b->launches_since_order >= 16)) {
+        b->launches_since_order = 0;
+        hipLaunchKernelGGL(ck::cassie_order_kernel, dim3(1), dim3(ck::ORDER_THREADS), 0, s, b->d_cost, b->d_order, b->nenv);
+        if (!hip_ok(hipGetLastError(), "cassie_order_kernel launch")) return -1;
+    }
+    return 0;
 }
 
 /* optional inputs are handed to the kernel only once somebody uploaded or bound them */
@@ -178,6 +191,14 @@ phys_batch_t *phys_batch_create(const cm_model_t *model, int nenv, int device) {
     ok = ok && hip_ok(hipMemset(b->d_warn, 0, sizeof(int) * nenv), "hipMemset(warn)");
     ok = ok && hip_ok(hipMalloc((void **)&b->d_info, sizeof(int) * 4 * nenv), "hipMalloc(info)");
     ok = ok && hip_ok(hipMemset(b->d_info, 0, sizeof(int) * 4 * nenv), "hipMemset(info)");
+    if (nenv >= 2048) { /* fewer envs than a couple per wave slot leave nothing to balance */
+        std::vector<int> ident((size_t)nenv);
+        for (int e = 0; e < nenv; ++e) ident[(size_t)e] = e;
+        ok = ok && hip_ok(hipMalloc((void **)&b->d_order, sizeof(int) * (size_t)nenv), "hipMalloc(order)");
+        ok = ok && hip_ok(hipMemcpy(b->d_order, ident.data(), sizeof(int) * (size_t)nenv, hipMemcpyHostToDevice), "hipMemcpy(order)");
+        ok = ok && hip_ok(hipMalloc((void **)&b->d_cost, sizeof(unsigned) * (size_t)nenv), "hipMalloc(cost)");
+        ok = ok && hip_ok(hipMemset(b->d_cost, 0, sizeof(unsigned) * (size_t)nenv), "hipMemset(cost)");
+    }
     ok = ok && hip_ok(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking), "hipStreamCreate");
     ok = ok && hip_ok(hipEventCreate(&b->ev0), "hipEventCreate") && hip_ok(hipEventCreate(&b->ev1), "hipEventCreate");
     ok = ok && hip_ok(hipEventCreateWithFlags(&b->ev_mark, hipEventDisableTiming), "hipEventCreate");
@@ -203,6 +224,8 @@ void phys_batch_free(phys_batch_t *b) {
     if (b->d_hfield) (void)hipFree(b->d_hfield);
     if (b->d_ext) (void)hipFree(b->d_ext);
     if (b->d_drive) (void)hipFree(b->d_drive);
+    if (b->d_order) (void)hipFree(b->d_order);
+    if (b->d_cost) (void)hipFree(b->d_cost);
     if (b->ev0) (void)hipEventDestroy(b->ev0);
     if (b->ev1) (void)hipEventDestroy(b->ev1);
     if (b->ev_mark) (void)hipEventDestroy(b->ev_mark);
@@ -514,6 +537,12 @@ int phys_batch_derive(phys_batch_t *b, const int ids[6], void *stream) {
         rc |= phys_batch_enable_ext(b, 0);
     }
     return rc;
+}
+
+int phys_batch_set_balance(phys_batch_t *b, int on) {
+    if (!b) return -1;
+    b->balance = on != 0;
+    return 0;
 }
 
 int phys_batch_set_generic_kernel(phys_batch_t *b, int on) {

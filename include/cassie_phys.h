@@ -164,6 +164,11 @@ int phys_batch_download_ext_async(phys_batch_t *b, cm_ext_t *host, int env0, int
  * The forces are those of the CURRENT state (like after cassie_sim_forward).  Costs about one physics step. */
 int phys_batch_derive(phys_batch_t *b, const int ids[6], void *stream);
 
+/* Launch-order balancing (on by default for batches of 2048 envs and more): every launch records what each env cost
+ * and the next launch starts the expensive envs first, so the wave slots finish together instead of the launch waiting
+ * for whichever slot drew the slow envs last.  Results do not depend on it (envs are independent). */
+int phys_batch_set_balance(phys_batch_t *b, int on);
+
 /* validation aid: run the generic instantiation of the step kernel (dof-tree topology read from the model at run
  * time) even when the model matches one of the compile-time-topology instantiations */
 int phys_batch_set_generic_kernel(phys_batch_t *b, int on);

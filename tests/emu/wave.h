@@ -14,6 +14,7 @@
 #include <cstddef>
 #include <cstdint>
 
+#define CK_EMULATED 1
 #define WV_DEVICE inline
 #define WV_GLOBAL static /* internal linkage: the product library exports host stubs of the same kernel names */
 #define WV_SHARED static
