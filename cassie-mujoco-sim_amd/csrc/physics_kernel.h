@@ -332,35 +332,223 @@ WV_DEVICE int capsule_box(RawContact &c0, RawContact &c1, const double *pc, cons
 }
 
 
-/* ---- height field: tangent plane of the grid triangle under the sample centre (same definition as the oracle) ---- */
+/* ---- box vs box (same definition, same arithmetic order and the same tie rules as oracle/cassie_oracle.c box_box):
+ * separating-axis test over 15 axes, then either the incident face clipped against the reference face -- lane =
+ * candidate vertex of the clipped polygon: 0-3 incident vertices, 4-7 rectangle corners, 8-23 edge crossings; at most
+ * the 4 deepest are kept, in candidate order -- or one edge-edge contact (lane 0).  Everything up to the candidates is
+ * wave-uniform and computed redundantly by every lane.  Returns whether this lane holds a contact. ---- */
+WV_DEVICE bool box_box_lane(RawContact &rc, int lane, const double *p1, const double *m1, const double *s1, const double *p2, const double *m2,
+                            const double *s2, double margin) {
+    const double BB_TIE = 1e-10;
+    double A[3][3], B[3][3], d[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]}, ta[3], tb[3], C[3][3], Q[3][3];
+    for (int i = 0; i < 3; ++i) for (int k = 0; k < 3; ++k) { A[i][k] = m1[3 * k + i]; B[i][k] = m2[3 * k + i]; }
+    for (int i = 0; i < 3; ++i) { ta[i] = dot3(d, A[i]); tb[i] = dot3(d, B[i]); }
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { C[i][j] = dot3(A[i], B[j]); Q[i][j] = fabs(C[i][j]); }
+    int best = -1;
+    double bestscore = 0;
+    bool separated = false;
+    for (int k = 0; k < 15; ++k) {
+        double sep, sc;
+        if (k < 3) {
+            sep = fabs(ta[k]) - (s1[k] + (s2[0] * Q[k][0] + s2[1] * Q[k][1] + s2[2] * Q[k][2]));
+            sc = sep;
+        } else if (k < 6) {
+            const int j = k - 3;
+            sep = fabs(tb[j]) - (s2[j] + (s1[0] * Q[0][j] + s1[1] * Q[1][j] + s1[2] * Q[2][j]));
+            sc = sep - BB_TIE;
+        } else {
+            const int i = (k - 6) / 3, j = (k - 6) % 3, i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+            const double len2 = 1.0 - C[i][j] * C[i][j];
+            if (len2 < 1e-6) continue;
+            const double proj = ta[i2] * C[i1][j] - ta[i1] * C[i2][j];
+            const double ra = s1[i1] * Q[i2][j] + s1[i2] * Q[i1][j], rb = s2[j1] * Q[i][j2] + s2[j2] * Q[i][j1];
+            sep = (fabs(proj) - (ra + rb)) / sqrt(len2);
+            sc = (sep < 0 ? 1.05 * sep : sep) - 2 * BB_TIE;
+        }
+        if (sep > margin) separated = true;
+        if (best < 0 || sc > bestscore) { best = k; bestscore = sc; }
+    }
+    if (separated) return false;
+
+    if (best >= 6) {
+        const int i = (best - 6) / 3, j = (best - 6) % 3;
+        double n[3], pa[3] = {p1[0], p1[1], p1[2]}, pb[3] = {p2[0], p2[1], p2[2]};
+        cross3(n, A[i], B[j]);
+        normalize3(n);
+        if (dot3(n, d) < 0) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; }
+        for (int k = 0; k < 3; ++k) {
+            if (k != i) { const double sg = dot3(n, A[k]) > 0 ? 1.0 : -1.0; for (int x = 0; x < 3; ++x) pa[x] += sg * s1[k] * A[k][x]; }
+            if (k != j) { const double sg = dot3(n, B[k]) > 0 ? -1.0 : 1.0; for (int x = 0; x < 3; ++x) pb[x] += sg * s2[k] * B[k][x]; }
+        }
+        const double ab[3] = {pb[0] - pa[0], pb[1] - pa[1], pb[2] - pa[2]};
+        const double uaub = C[i][j], q1 = dot3(A[i], ab), q2 = -dot3(B[j], ab), den = 1.0 - uaub * uaub;
+        const double al = clampd((q1 + uaub * q2) / den, -s1[i], s1[i]), be = clampd((uaub * q1 + q2) / den, -s2[j], s2[j]);
+        double ca[3], cb[3];
+        for (int x = 0; x < 3; ++x) { ca[x] = pa[x] + al * A[i][x]; cb[x] = pb[x] + be * B[j][x]; }
+        const double cd[3] = {cb[0] - ca[0], cb[1] - ca[1], cb[2] - ca[2]};
+        rc.dist = dot3(cd, n);
+        for (int x = 0; x < 3; ++x) { rc.normal[x] = n[x]; rc.tangent[x] = 0; rc.pos[x] = 0.5 * (ca[x] + cb[x]); }
+        return lane == 0 && !(rc.dist > margin);
+    }
+
+    const bool refA = best < 3;
+    const int a = best % 3, a1 = (a + 1) % 3, a2 = (a + 2) % 3;
+    double R[3][3], I[3][3];
+    for (int i = 0; i < 3; ++i) for (int k = 0; k < 3; ++k) { R[i][k] = refA ? A[i][k] : B[i][k]; I[i][k] = refA ? B[i][k] : A[i][k]; }
+    const double *pr = refA ? p1 : p2, *pi = refA ? p2 : p1, *sr = refA ? s1 : s2, *si = refA ? s2 : s1;
+    const double dri[3] = {pi[0] - pr[0], pi[1] - pr[1], pi[2] - pr[2]};
+    const double sgn = dot3(dri, R[a]) >= 0 ? 1.0 : -1.0;
+    double n[3] = {sgn * R[a][0], sgn * R[a][1], sgn * R[a][2]};
+    int kf = 0;
+    double kbest = fabs(dot3(n, I[0]));
+    for (int k = 1; k < 3; ++k) { const double v = fabs(dot3(n, I[k])); if (v > kbest + 1e-9) { kbest = v; kf = k; } }
+    const int k1 = (kf + 1) % 3, k2 = (kf + 2) % 3;
+    const double isg = dot3(n, I[kf]) > 0 ? -1.0 : 1.0;
+    double cr[3], ci[3];
+    for (int x = 0; x < 3; ++x) { cr[x] = pr[x] + sgn * sr[a] * R[a][x]; ci[x] = pi[x] + isg * si[kf] * I[kf][x]; }
+    const double h1 = sr[a1], h2 = sr[a2];
+    const double su[4] = {1, -1, -1, 1}, sv[4] = {1, 1, -1, -1};
+    double pu[4], pv[4], pw[4];
+    for (int q = 0; q < 4; ++q) {
+        double x[3];
+        for (int t = 0; t < 3; ++t) x[t] = ci[t] + su[q] * si[k1] * I[k1][t] + sv[q] * si[k2] * I[k2][t] - cr[t];
+        pu[q] = dot3(x, R[a1]); pv[q] = dot3(x, R[a2]); pw[q] = dot3(x, n);
+    }
+    const double tol = 1e-12;
+    /* lane = candidate */
+    double cu = 0, cv = 0, cw = 0;
+    bool valid = false;
+    if (lane < 4) {
+        const int q = lane;
+        cu = pu[q]; cv = pv[q]; cw = pw[q];
+        valid = fabs(cu) <= h1 + tol && fabs(cv) <= h2 + tol;
+    } else if (lane < 8) {
+        const int q = lane - 4;
+        const double e1u = pu[1] - pu[0], e1v = pv[1] - pv[0], e1w = pw[1] - pw[0], e2u = pu[3] - pu[0], e2v = pv[3] - pv[0], e2w = pw[3] - pw[0];
+        const double det = e1u * e2v - e1v * e2u;
+        const double gu = (e1w * e2v - e1v * e2w) / det, gv = (e1u * e2w - e1w * e2u) / det;
+        const double u = su[q] * h1, v = sv[q] * h2;
+        int pos = 0, neg = 0;
+        for (int e = 0; e < 4; ++e) {
+            const int f = (e + 1) & 3;
+            const double cr2 = (pu[f] - pu[e]) * (v - pv[e]) - (pv[f] - pv[e]) * (u - pu[e]);
+            if (cr2 > tol) ++pos; else if (cr2 < -tol) ++neg;
+        }
+        cu = u; cv = v; cw = pw[0] + gu * (u - pu[0]) + gv * (v - pv[0]);
+        valid = !(pos && neg);
+    } else if (lane < 24) {
+        const int e = (lane - 8) >> 2, l = (lane - 8) & 3, f = (e + 1) & 3;
+        const bool along_u = l < 2;
+        const double lim = (l & 1) ? -(along_u ? h1 : h2) : (along_u ? h1 : h2);
+        const double x0 = along_u ? pu[e] : pv[e], x1 = along_u ? pu[f] : pv[f];
+        const double y0 = along_u ? pv[e] : pu[e], y1 = along_u ? pv[f] : pu[f], hy = along_u ? h2 : h1;
+        const double dx = x1 - x0;
+        if (!(fabs(dx) < 1e-14)) {
+            const double sp = (lim - x0) / dx;
+            if (sp > 0 && sp < 1) {
+                const double y = y0 + sp * (y1 - y0);
+                if (!(fabs(y) > hy)) {
+                    cu = along_u ? lim : y; cv = along_u ? y : lim; cw = pw[e] + sp * (pw[f] - pw[e]);
+                    valid = true;
+                }
+            }
+        }
+    }
+    if (valid && cw > margin) valid = false;
+    const unsigned long long vmask = wv::ballot(valid);
+    bool keep = valid;
+    if (wv::popc64(vmask) > 4) {
+        int rank = 0;
+        for (int r = 0; r < 24; ++r) {
+            const double wr = wv::readlane(cw, r);
+            if (r == lane || !((vmask >> r) & 1ull)) continue;
+            if (wr < cw - 1e-9 || (fabs(wr - cw) <= 1e-9 && r < lane)) ++rank;
+        }
+        if (rank >= 4) keep = false;
+    }
+    if (keep) {
+        rc.dist = cw;
+        for (int x = 0; x < 3; ++x) {
+            const double px = cr[x] + cu * R[a1][x] + cv * R[a2][x] + cw * n[x];
+            rc.pos[x] = px - 0.5 * cw * n[x];
+            rc.normal[x] = refA ? n[x] : -n[x];
+            rc.tangent[x] = 0;
+        }
+    }
+    return keep;
+}
+
+/* ---- height field: closest feature of the terrain surface over every grid triangle under the sample sphere's footprint
+ *      (same definition, same candidate order as oracle/cassie_oracle.c) ---- */
+WV_DEVICE void closest_on_triangle(const double *p, const double *a, const double *b, const double *c, double *q) {
+    double ab[3], ac[3], ap[3], bp[3], cp[3];
+    for (int i = 0; i < 3; ++i) { ab[i] = b[i] - a[i]; ac[i] = c[i] - a[i]; ap[i] = p[i] - a[i]; bp[i] = p[i] - b[i]; cp[i] = p[i] - c[i]; }
+    const double d1 = dot3(ab, ap), d2 = dot3(ac, ap), d3 = dot3(ab, bp), d4 = dot3(ac, bp), d5 = dot3(ab, cp), d6 = dot3(ac, cp);
+    double v = 0, w = 0;
+    const double vc = d1 * d4 - d3 * d2, vb = d5 * d2 - d1 * d6, va = d3 * d6 - d5 * d4;
+    if (d1 <= 0 && d2 <= 0) { v = 0; w = 0; }
+    else if (d3 >= 0 && d4 <= d3) { v = 1; w = 0; }
+    else if (vc <= 0 && d1 >= 0 && d3 <= 0) { v = d1 / (d1 - d3); w = 0; }
+    else if (d6 >= 0 && d5 <= d6) { v = 0; w = 1; }
+    else if (vb <= 0 && d2 >= 0 && d6 <= 0) { v = 0; w = d2 / (d2 - d6); }
+    else if (va <= 0 && (d4 - d3) >= 0 && (d5 - d6) >= 0) { w = (d4 - d3) / ((d4 - d3) + (d5 - d6)); v = 1 - w; }
+    else { const double den = 1.0 / (va + vb + vc); v = vb * den; w = vc * den; }
+    for (int i = 0; i < 3; ++i) q[i] = a[i] + v * ab[i] + w * ac[i];
+}
+WV_DEVICE void hfield_triangle(const double *p, const double *a, const double *b, const double *c, double &best, double *bestn) {
+    double ab[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]}, ac[3] = {c[0] - a[0], c[1] - a[1], c[2] - a[2]}, n[3];
+    cross3(n, ab, ac);
+    if (n[2] < 0) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; }
+    const double inv = 1.0 / sqrt(dot3(n, n));
+    n[0] *= inv; n[1] *= inv; n[2] *= inv;
+    const double ap[3] = {p[0] - a[0], p[1] - a[1], p[2] - a[2]}, s = dot3(n, ap);
+    if (s >= 0) {
+        double q[3];
+        closest_on_triangle(p, a, b, c, q);
+        const double d[3] = {p[0] - q[0], p[1] - q[1], p[2] - q[2]}, len = sqrt(dot3(d, d));
+        if (len < best) {
+            best = len;
+            if (len > 1e-12) { bestn[0] = d[0] / len; bestn[1] = d[1] / len; bestn[2] = d[2] / len; }
+            else { bestn[0] = n[0]; bestn[1] = n[1]; bestn[2] = n[2]; }
+        }
+    } else {
+        const double e0 = (b[0] - a[0]) * (p[1] - a[1]) - (b[1] - a[1]) * (p[0] - a[0]);
+        const double e1 = (c[0] - b[0]) * (p[1] - b[1]) - (c[1] - b[1]) * (p[0] - b[0]);
+        const double e2 = (a[0] - c[0]) * (p[1] - c[1]) - (a[1] - c[1]) * (p[0] - c[0]);
+        const bool inside = (e0 >= 0 && e1 >= 0 && e2 >= 0) || (e0 <= 0 && e1 <= 0 && e2 <= 0);
+        if (inside && s < best) { best = s; bestn[0] = n[0]; bestn[1] = n[1]; bestn[2] = n[2]; }
+    }
+}
 WV_DEVICE int hfield_sphere(RawContact &c, ModelPtr m, const float *data, const double *ph, const double *mh, const double *ps,
                             double r, double margin) {
     if (!data || m->hfield_nrow < 2 || m->hfield_ncol < 2) return 0;
     const double sx = m->hfield_size[0], sy = m->hfield_size[1], sz = m->hfield_size[2];
     double d[3] = {ps[0] - ph[0], ps[1] - ph[1], ps[2] - ph[2]}, p[3];
     mulmatTvec3(p, mh, d);
-    if (fabs(p[0]) > sx || fabs(p[1]) > sy || p[2] - r > sz + margin) return 0;
+    const double reach = r + (margin > 0 ? margin : 0);
+    if (fabs(p[0]) > sx + reach || fabs(p[1]) > sy + reach || p[2] - r > sz + margin) return 0;
     const int nc = m->hfield_ncol, nr = m->hfield_nrow;
     const double dx = 2 * sx / (nc - 1), dy = 2 * sy / (nr - 1);
-    const double u = (p[0] + sx) / dx, v = (p[1] + sy) / dy;
-    int j = (int)floor(u), i = (int)floor(v);
-    if (j > nc - 2) j = nc - 2;
-    if (i > nr - 2) i = nr - 2;
-    if (j < 0) j = 0;
-    if (i < 0) i = 0;
-    const double fu = u - j, fv = v - i;
-    const double z00 = sz * data[i * nc + j], z10 = sz * data[i * nc + j + 1], z01 = sz * data[(i + 1) * nc + j], z11 = sz * data[(i + 1) * nc + j + 1];
-    double gx, gy, z0;
-    const double x0 = -sx + j * dx, y0 = -sy + i * dy;
-    if (fu + fv <= 1.0) { gx = (z10 - z00) / dx; gy = (z01 - z00) / dy; z0 = z00; }
-    else { gx = (z11 - z01) / dx; gy = (z11 - z10) / dy; z0 = z11 - gx * dx - gy * dy; }
-    const double inv = 1.0 / sqrt(1.0 + gx * gx + gy * gy);
-    double nl[3] = {-gx * inv, -gy * inv, inv};
-    const double height = z0 + gx * (p[0] - x0) + gy * (p[1] - y0);
-    const double dist = (p[2] - height) * inv - r;
+    int j0 = (int)floor((p[0] - reach + sx) / dx), j1 = (int)floor((p[0] + reach + sx) / dx);
+    int i0 = (int)floor((p[1] - reach + sy) / dy), i1 = (int)floor((p[1] + reach + sy) / dy);
+    if (j0 < 0) j0 = 0;
+    if (i0 < 0) i0 = 0;
+    if (j1 > nc - 2) j1 = nc - 2;
+    if (i1 > nr - 2) i1 = nr - 2;
+    double best = 1e300, bn[3] = {0, 0, 1};
+    for (int i = i0; i <= i1; ++i)
+        for (int j = j0; j <= j1; ++j) {
+            const double x0 = -sx + j * dx, y0 = -sy + i * dy;
+            const double v00[3] = {x0, y0, sz * data[i * nc + j]}, v10[3] = {x0 + dx, y0, sz * data[i * nc + j + 1]};
+            const double v01[3] = {x0, y0 + dy, sz * data[(i + 1) * nc + j]}, v11[3] = {x0 + dx, y0 + dy, sz * data[(i + 1) * nc + j + 1]};
+            hfield_triangle(p, v00, v10, v01, best, bn);
+            hfield_triangle(p, v11, v01, v10, best, bn);
+        }
+    if (best > 1e299) return 0;
+    const double dist = best - r;
     if (dist > margin) return 0;
     double nw[3];
-    mulmatvec3(nw, mh, nl);
+    mulmatvec3(nw, mh, bn);
     c.dist = dist;
     for (int k = 0; k < 3; ++k) { c.normal[k] = nw[k]; c.pos[k] = ps[k] - nw[k] * (r + 0.5 * dist); c.tangent[k] = 0; }
     return 1;
@@ -1183,12 +1371,35 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
                     } else if (t1 == CM_GEOM_HFIELD && t2 == CM_GEOM_SPHERE) {
                         n = hfield_sphere(rc0, m, env_hfield, p1, m1, p2, s20, margin);
                     } else if (t1 == CM_GEOM_HFIELD && t2 == CM_GEOM_CAPSULE) {
+                        /* the two end spheres as against a plane, plus interior sample spheres no further apart than a grid
+                         * cell; an interior sample that is deeper than both ends replaces the shallower end (same rule and
+                         * order as the oracle's hfield_capsule) */
                         double axis[3] = {m2[2], m2[5], m2[8]};
-                        RawContact tmp;
-                        double e0[3] = {p2[0] + s21 * axis[0], p2[1] + s21 * axis[1], p2[2] + s21 * axis[2]};
-                        if (hfield_sphere(tmp, m, env_hfield, p1, m1, e0, s20, margin)) { rc0 = tmp; n = 1; }
-                        double e1[3] = {p2[0] - s21 * axis[0], p2[1] - s21 * axis[1], p2[2] - s21 * axis[2]};
-                        if (hfield_sphere(tmp, m, env_hfield, p1, m1, e1, s20, margin)) { if (n == 0) rc0 = tmp; else rc1 = tmp; ++n; }
+                        const double cell = 2 * m->hfield_size[0] / (m->hfield_ncol > 1 ? m->hfield_ncol - 1 : 1);
+                        int ni = (int)ceil(2 * s21 / cell) - 1;
+                        if (ni < 0) ni = 0;
+                        if (ni > 4) ni = 4;
+                        RawContact mid;
+                        bool have0, have1, have_mid = false;
+                        {
+                            double e0[3] = {p2[0] + s21 * axis[0], p2[1] + s21 * axis[1], p2[2] + s21 * axis[2]};
+                            have0 = hfield_sphere(rc0, m, env_hfield, p1, m1, e0, s20, margin) != 0;
+                            double e1[3] = {p2[0] - s21 * axis[0], p2[1] - s21 * axis[1], p2[2] - s21 * axis[2]};
+                            have1 = hfield_sphere(rc1, m, env_hfield, p1, m1, e1, s20, margin) != 0;
+                        }
+                        for (int k = 1; k <= ni; ++k) {
+                            const double t = s21 * (1.0 - 2.0 * k / (ni + 1));
+                            double e[3] = {p2[0] + t * axis[0], p2[1] + t * axis[1], p2[2] + t * axis[2]};
+                            RawContact cur;
+                            if (hfield_sphere(cur, m, env_hfield, p1, m1, e, s20, margin) && (!have_mid || cur.dist < mid.dist)) { mid = cur; have_mid = true; }
+                        }
+                        if (have_mid && (!have0 || mid.dist < rc0.dist) && (!have1 || mid.dist < rc1.dist)) {
+                            const bool drop1 = !have0 ? false : (!have1 ? true : rc0.dist <= rc1.dist);
+                            if (drop1) { rc1 = mid; have1 = true; } else { rc0 = mid; have0 = true; }
+                        }
+                        if (have0 && have1) n = 2;
+                        else if (have0) n = 1;
+                        else if (have1) { rc0 = rc1; n = 1; }
                         for (int i = 0; i < 3; ++i) { rc0.tangent[i] = axis[i]; rc1.tangent[i] = axis[i]; }
                     } else if (t1 == CM_GEOM_SPHERE && t2 == CM_GEOM_BOX) {
                         double sb[3] = {s20, s21, m->pair_size[p][5]};
@@ -1243,24 +1454,9 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
                     }
                 }
             } else if (t1 == CM_GEOM_BOX && t2 == CM_GEOM_BOX) {
-                if (lane < 16) {
-                    const bool second = lane >= 8;
-                    const double *pa = second ? p2 : p1, *ma = second ? m2 : m1, *pb = second ? p1 : p2, *mb = second ? m1 : m2;
-                    const int oa = second ? 3 : 0, ob = second ? 0 : 3;
-                    double sa[3] = {m->pair_size[p][oa], m->pair_size[p][oa + 1], m->pair_size[p][oa + 2]};
-                    double sb[3] = {m->pair_size[p][ob], m->pair_size[p][ob + 1], m->pair_size[p][ob + 2]};
-                    const int i = lane & 7;
-                    double v[3] = {(i & 1) ? sa[0] : -sa[0], (i & 2) ? sa[1] : -sa[1], (i & 4) ? sa[2] : -sa[2]}, w[3], nw[3];
-                    mulmatvec3(w, ma, v);
-                    for (int k = 0; k < 3; ++k) w[k] += pa[k];
-                    const double dist = point_box(w, pb, mb, sb, nw);
-                    if (!(dist > margin)) {
-                        hit = true;
-                        rc.dist = dist;
-                        const double sgn = second ? 1.0 : -1.0;
-                        for (int k = 0; k < 3; ++k) { rc.normal[k] = sgn * nw[k]; rc.tangent[k] = 0; rc.pos[k] = w[k] - nw[k] * 0.5 * dist; }
-                    }
-                }
+                double s1[3] = {m->pair_size[p][0], m->pair_size[p][1], m->pair_size[p][2]};
+                double s2[3] = {m->pair_size[p][3], m->pair_size[p][4], m->pair_size[p][5]};
+                hit = box_box_lane(rc, lane, p1, m1, s1, p2, m2, s2, margin);
             } else {
                 warn |= WARN_UNSUPPORTED_PAIR;
             }

@@ -478,77 +478,309 @@ static int plane_box(raw_contact_t *c, const double *pp, const double *mp, const
     }
     return n;
 }
-/* box vs box, vertex-in-box contacts only (edge-edge crossings are not generated -- documented limitation):
- * the 8 vertices of box 1 inside box 2, then the 8 vertices of box 2 inside box 1, first 4 found */
+/* box vs box: separating-axis test over the 15 candidate axes (3 + 3 face normals, 9 edge x edge), then
+ *   face axis : the incident face of the other box is clipped against the reference face's rectangle; the vertices of
+ *               the clipped polygon -- incident vertices inside the rectangle (candidates 0-3), rectangle corners inside
+ *               the projected incident face (4-7), crossings of incident edges with the rectangle's edge lines (8-23) --
+ *               that lie below the reference face are contacts, at most the 4 deepest, reported in candidate order;
+ *   edge axis : one contact midway between the closest points of the two edges.
+ * Face axes win ties (A's before B's), an edge axis must beat them by 5 %.  MuJoCo's own routine (a port of the same
+ * idea, engine_collision_box.c) differs in its tie-breaking and in how it culls to 4 points; the contact sets agree for
+ * resting and edge-crossing configurations but are not bit-compatible. */
+typedef struct { double u, v, w; int valid; } bb_cand_t;
+#define BB_TIE 1e-10
 static int box_box(raw_contact_t *c, const double *p1, const double *m1, const double *s1, const double *p2, const double *m2, const double *s2,
                    double margin) {
-    int n = 0;
-    for (int pass = 0; pass < 2 && n < 4; ++pass) {
-        const double *pa = pass ? p2 : p1, *ma = pass ? m2 : m1, *sa = pass ? s2 : s1; /* box whose vertices are tested */
-        const double *pb = pass ? p1 : p2, *mb = pass ? m1 : m2, *sb = pass ? s1 : s2; /* box they may be inside of */
-        for (int i = 0; i < 8 && n < 4; ++i) {
-            double v[3] = {(i & 1) ? sa[0] : -sa[0], (i & 2) ? sa[1] : -sa[1], (i & 4) ? sa[2] : -sa[2]}, w[3], nw[3];
-            mulmatvec3(w, ma, v);
-            for (int k = 0; k < 3; ++k) w[k] += pa[k];
-            double dist = point_box(w, pb, mb, sb, nw);
-            if (dist > margin) continue;
-            c[n].dist = dist;
-            /* nw points out of the containing box towards the intruding vertex; the contact normal goes from geom1 to geom2 */
-            double sgn = pass ? 1.0 : -1.0;
-            for (int k = 0; k < 3; ++k) { c[n].normal[k] = sgn * nw[k]; c[n].tangent[k] = 0; c[n].pos[k] = w[k] - nw[k] * 0.5 * dist; }
-            ++n;
+    double A[3][3], B[3][3], d[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]}, ta[3], tb[3], C[3][3], Q[3][3];
+    for (int i = 0; i < 3; ++i) for (int k = 0; k < 3; ++k) { A[i][k] = m1[3 * k + i]; B[i][k] = m2[3 * k + i]; }
+    for (int i = 0; i < 3; ++i) { ta[i] = dot3(d, A[i]); tb[i] = dot3(d, B[i]); }
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { C[i][j] = dot3(A[i], B[j]); Q[i][j] = fabs(C[i][j]); }
+    double score[15];
+    int best = -1;
+    for (int k = 0; k < 15; ++k) {
+        double sep, sc;
+        if (k < 3) {
+            sep = fabs(ta[k]) - (s1[k] + (s2[0] * Q[k][0] + s2[1] * Q[k][1] + s2[2] * Q[k][2]));
+            sc = sep;
+        } else if (k < 6) {
+            const int j = k - 3;
+            sep = fabs(tb[j]) - (s2[j] + (s1[0] * Q[0][j] + s1[1] * Q[1][j] + s1[2] * Q[2][j]));
+            sc = sep - BB_TIE;
+        } else {
+            const int i = (k - 6) / 3, j = (k - 6) % 3, i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+            const double len2 = 1.0 - C[i][j] * C[i][j];
+            if (len2 < 1e-6) { score[k] = -1e300; continue; }        /* (nearly) parallel edges: no axis */
+            const double proj = ta[i2] * C[i1][j] - ta[i1] * C[i2][j];
+            const double ra = s1[i1] * Q[i2][j] + s1[i2] * Q[i1][j], rb = s2[j1] * Q[i][j2] + s2[j2] * Q[i][j1];
+            sep = (fabs(proj) - (ra + rb)) / sqrt(len2);
+            sc = (sep < 0 ? 1.05 * sep : sep) - 2 * BB_TIE;
         }
+        if (sep > margin) return 0;                                  /* a separating axis */
+        score[k] = sc;
     }
+    for (int k = 0; k < 15; ++k) if (best < 0 || score[k] > score[best]) best = k;
+
+    if (best >= 6) {
+        const int i = (best - 6) / 3, j = (best - 6) % 3;
+        double n[3], pa[3] = {p1[0], p1[1], p1[2]}, pb[3] = {p2[0], p2[1], p2[2]};
+        cross3(n, A[i], B[j]);
+        normalize3(n);
+        if (dot3(n, d) < 0) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; }
+        for (int k = 0; k < 3; ++k) {
+            if (k != i) { const double sg = dot3(n, A[k]) > 0 ? 1.0 : -1.0; for (int x = 0; x < 3; ++x) pa[x] += sg * s1[k] * A[k][x]; }
+            if (k != j) { const double sg = dot3(n, B[k]) > 0 ? -1.0 : 1.0; for (int x = 0; x < 3; ++x) pb[x] += sg * s2[k] * B[k][x]; }
+        }
+        const double ab[3] = {pb[0] - pa[0], pb[1] - pa[1], pb[2] - pa[2]};
+        const double uaub = C[i][j], q1 = dot3(A[i], ab), q2 = -dot3(B[j], ab), den = 1.0 - uaub * uaub;
+        const double al = clampd((q1 + uaub * q2) / den, -s1[i], s1[i]), be = clampd((uaub * q1 + q2) / den, -s2[j], s2[j]);
+        double ca[3], cb[3];
+        for (int x = 0; x < 3; ++x) { ca[x] = pa[x] + al * A[i][x]; cb[x] = pb[x] + be * B[j][x]; }
+        const double cd[3] = {cb[0] - ca[0], cb[1] - ca[1], cb[2] - ca[2]};
+        c[0].dist = dot3(cd, n);
+        if (c[0].dist > margin) return 0;
+        for (int x = 0; x < 3; ++x) { c[0].normal[x] = n[x]; c[0].tangent[x] = 0; c[0].pos[x] = 0.5 * (ca[x] + cb[x]); }
+        return 1;
+    }
+
+    /* face contact: reference box R owns the face, incident box I is clipped against it */
+    const int refA = best < 3, a = best % 3, a1 = (a + 1) % 3, a2 = (a + 2) % 3;
+    const double (*R)[3] = refA ? A : B, (*I)[3] = refA ? B : A;
+    const double *pr = refA ? p1 : p2, *pi = refA ? p2 : p1, *sr = refA ? s1 : s2, *si = refA ? s2 : s1;
+    const double dri[3] = {pi[0] - pr[0], pi[1] - pr[1], pi[2] - pr[2]};
+    const double sgn = dot3(dri, R[a]) >= 0 ? 1.0 : -1.0;
+    double n[3] = {sgn * R[a][0], sgn * R[a][1], sgn * R[a][2]};    /* outward normal of the reference face */
+    int kf = 0;
+    double kbest = fabs(dot3(n, I[0]));
+    for (int k = 1; k < 3; ++k) { const double v = fabs(dot3(n, I[k])); if (v > kbest + 1e-9) { kbest = v; kf = k; } }
+    const int k1 = (kf + 1) % 3, k2 = (kf + 2) % 3;
+    const double isg = dot3(n, I[kf]) > 0 ? -1.0 : 1.0;
+    double cr[3], ci[3];
+    for (int x = 0; x < 3; ++x) { cr[x] = pr[x] + sgn * sr[a] * R[a][x]; ci[x] = pi[x] + isg * si[kf] * I[kf][x]; }
+    const double h1 = sr[a1], h2 = sr[a2];
+    /* incident face vertices in reference-face coordinates (u, v along the face, w = height above it) */
+    static const double su[4] = {1, -1, -1, 1}, sv[4] = {1, 1, -1, -1};
+    double pu[4], pv[4], pw[4];
+    for (int q = 0; q < 4; ++q) {
+        double x[3];
+        for (int t = 0; t < 3; ++t) x[t] = ci[t] + su[q] * si[k1] * I[k1][t] + sv[q] * si[k2] * I[k2][t] - cr[t];
+        pu[q] = dot3(x, R[a1]); pv[q] = dot3(x, R[a2]); pw[q] = dot3(x, n);
+    }
+    bb_cand_t cand[24];
+    const double tol = 1e-12;
+    for (int q = 0; q < 4; ++q) {                                    /* 0-3: incident vertices inside the rectangle */
+        cand[q].u = pu[q]; cand[q].v = pv[q]; cand[q].w = pw[q];
+        cand[q].valid = fabs(pu[q]) <= h1 + tol && fabs(pv[q]) <= h2 + tol;
+    }
+    /* the incident face's plane over (u, v): w = w0 + gu (u - u0) + gv (v - v0) from three of its vertices */
+    const double e1u = pu[1] - pu[0], e1v = pv[1] - pv[0], e1w = pw[1] - pw[0], e2u = pu[3] - pu[0], e2v = pv[3] - pv[0], e2w = pw[3] - pw[0];
+    const double det = e1u * e2v - e1v * e2u;
+    const double gu = (e1w * e2v - e1v * e2w) / det, gv = (e1u * e2w - e1w * e2u) / det;
+    for (int q = 0; q < 4; ++q) {                                    /* 4-7: rectangle corners inside the projected incident face */
+        const double u = su[q] * h1, v = sv[q] * h2;
+        int pos = 0, neg = 0;
+        for (int e = 0; e < 4; ++e) {
+            const int f = (e + 1) & 3;
+            const double cr2 = (pu[f] - pu[e]) * (v - pv[e]) - (pv[f] - pv[e]) * (u - pu[e]);
+            if (cr2 > tol) ++pos; else if (cr2 < -tol) ++neg;
+        }
+        cand[4 + q].u = u; cand[4 + q].v = v; cand[4 + q].w = pw[0] + gu * (u - pu[0]) + gv * (v - pv[0]);
+        cand[4 + q].valid = !(pos && neg);
+    }
+    for (int e = 0; e < 4; ++e)                                       /* 8-23: incident edges x rectangle edge lines */
+        for (int l = 0; l < 4; ++l) {
+            const int f = (e + 1) & 3, q = 8 + 4 * e + l;
+            const int along_u = l < 2;                               /* lines u = +h1, u = -h1, v = +h2, v = -h2 */
+            const double lim = (l & 1) ? -(along_u ? h1 : h2) : (along_u ? h1 : h2);
+            const double x0 = along_u ? pu[e] : pv[e], x1 = along_u ? pu[f] : pv[f];
+            const double y0 = along_u ? pv[e] : pu[e], y1 = along_u ? pv[f] : pu[f], hy = along_u ? h2 : h1;
+            cand[q].valid = 0; cand[q].u = cand[q].v = cand[q].w = 0;
+            const double dx = x1 - x0;
+            if (fabs(dx) < 1e-14) continue;
+            const double sp = (lim - x0) / dx;
+            if (!(sp > 0 && sp < 1)) continue;
+            const double y = y0 + sp * (y1 - y0);
+            if (fabs(y) > hy) continue;                               /* strictly: corners are candidates 4-7 */
+            cand[q].u = along_u ? lim : y; cand[q].v = along_u ? y : lim; cand[q].w = pw[e] + sp * (pw[f] - pw[e]);
+            cand[q].valid = 1;
+        }
+    int nvalid = 0;
+    for (int q = 0; q < 24; ++q) { if (cand[q].valid && cand[q].w > margin) cand[q].valid = 0; nvalid += cand[q].valid; }
+    if (nvalid > 4)                                                   /* keep the 4 deepest; within 1e-9 the earlier candidate wins */
+        for (int q = 0; q < 24; ++q) {
+            if (!cand[q].valid) continue;
+            int rank = 0;
+            for (int r = 0; r < 24; ++r) {
+                if (r == q || !cand[r].valid) continue;
+                if (cand[r].w < cand[q].w - 1e-9 || (fabs(cand[r].w - cand[q].w) <= 1e-9 && r < q)) ++rank;
+            }
+            if (rank >= 4) cand[q].valid = 2;                         /* dropped (marked, so ranks of the others stay put) */
+        }
+    int nc = 0;
+    for (int q = 0; q < 24 && nc < 4; ++q) {
+        if (cand[q].valid != 1) continue;
+        c[nc].dist = cand[q].w;
+        for (int x = 0; x < 3; ++x) {
+            const double px = cr[x] + cand[q].u * R[a1][x] + cand[q].v * R[a2][x] + cand[q].w * n[x];
+            c[nc].pos[x] = px - 0.5 * cand[q].w * n[x];
+            c[nc].normal[x] = refA ? n[x] : -n[x];
+            c[nc].tangent[x] = 0;
+        }
+        ++nc;
+    }
+    return nc;
+}
+
+/* test hook: box-box contacts for two boxes given by centre, rotation matrix (row-major, axes in columns) and half sizes;
+ * out[4][7] = dist, pos, normal */
+int co_test_box_box(const double *p1, const double *m1, const double *s1, const double *p2, const double *m2, const double *s2, double margin, double *out) {
+    raw_contact_t c[4];
+    int n = box_box(c, p1, m1, s1, p2, m2, s2, margin);
+    for (int k = 0; k < n; ++k) { out[7 * k] = c[k].dist; for (int i = 0; i < 3; ++i) { out[7 * k + 1 + i] = c[k].pos[i]; out[7 * k + 4 + i] = c[k].normal[i]; } }
     return n;
 }
 
 
-/* ---- height field (this repository's definition; MuJoCo uses prism decomposition + a generic convex routine):
- * a sample sphere touches the terrain through the tangent plane of the grid triangle that lies under its
- * centre.  Grid layout as in MuJoCo: nrow x ncol samples, x <-> columns over [-sx, sx], y <-> rows over
- * [-sy, sy], elevation = sample * size[2].  Each cell is split along the diagonal joining (col+1,row) and
- * (col,row+1). ---- */
+/* ---- height field.  MuJoCo decomposes the cells under a geom's bounding box into triangular prisms and runs its
+ * generic convex routine on every prism; this repository's definition keeps the part of that which matters for a sample
+ * sphere -- EVERY grid triangle under the sphere's footprint is a candidate, the closest feature (face, edge or vertex of
+ * the terrain surface, so the rims of taller neighbouring cells count) gives the contact, the deepest candidate is kept:
+ *   above a triangle's plane:  distance to the closest point of the triangle, normal from that point to the centre;
+ *   below it and inside its vertical prism (the centre is in the ground): signed distance to the plane, the plane's normal.
+ * Grid layout as in MuJoCo: nrow x ncol samples, x <-> columns over [-sx, sx], y <-> rows over [-sy, sy],
+ * elevation = sample * size[2].  Each cell is split along the diagonal joining (col+1,row) and (col,row+1). ---- */
+static void closest_on_triangle(const double *p, const double *a, const double *b, const double *c, double *q) {
+    /* Ericson, Real-Time Collision Detection 5.1.5 */
+    double ab[3], ac[3], ap[3], bp[3], cp[3];
+    for (int i = 0; i < 3; ++i) { ab[i] = b[i] - a[i]; ac[i] = c[i] - a[i]; ap[i] = p[i] - a[i]; bp[i] = p[i] - b[i]; cp[i] = p[i] - c[i]; }
+    const double d1 = dot3(ab, ap), d2 = dot3(ac, ap), d3 = dot3(ab, bp), d4 = dot3(ac, bp), d5 = dot3(ab, cp), d6 = dot3(ac, cp);
+    double v = 0, w = 0;   /* q = a + v ab + w ac */
+    const double vc = d1 * d4 - d3 * d2, vb = d5 * d2 - d1 * d6, va = d3 * d6 - d5 * d4;
+    if (d1 <= 0 && d2 <= 0) { v = 0; w = 0; }
+    else if (d3 >= 0 && d4 <= d3) { v = 1; w = 0; }
+    else if (vc <= 0 && d1 >= 0 && d3 <= 0) { v = d1 / (d1 - d3); w = 0; }
+    else if (d6 >= 0 && d5 <= d6) { v = 0; w = 1; }
+    else if (vb <= 0 && d2 >= 0 && d6 <= 0) { v = 0; w = d2 / (d2 - d6); }
+    else if (va <= 0 && (d4 - d3) >= 0 && (d5 - d6) >= 0) { w = (d4 - d3) / ((d4 - d3) + (d5 - d6)); v = 1 - w; }
+    else { const double den = 1.0 / (va + vb + vc); v = vb * den; w = vc * den; }
+    for (int i = 0; i < 3; ++i) q[i] = a[i] + v * ab[i] + w * ac[i];
+}
+/* one grid triangle against the sample centre p (height-field frame): updates the best (smallest) distance */
+static void hfield_triangle(const double *p, const double *a, const double *b, const double *c, double *best, double *bestn) {
+    double ab[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]}, ac[3] = {c[0] - a[0], c[1] - a[1], c[2] - a[2]}, n[3];
+    cross3(n, ab, ac);
+    if (n[2] < 0) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; }
+    const double inv = 1.0 / sqrt(dot3(n, n));
+    n[0] *= inv; n[1] *= inv; n[2] *= inv;
+    const double ap[3] = {p[0] - a[0], p[1] - a[1], p[2] - a[2]}, s = dot3(n, ap);
+    if (s >= 0) {
+        double q[3];
+        closest_on_triangle(p, a, b, c, q);
+        const double d[3] = {p[0] - q[0], p[1] - q[1], p[2] - q[2]}, len = sqrt(dot3(d, d));
+        if (len < *best) {
+            *best = len;
+            if (len > 1e-12) { bestn[0] = d[0] / len; bestn[1] = d[1] / len; bestn[2] = d[2] / len; }
+            else { bestn[0] = n[0]; bestn[1] = n[1]; bestn[2] = n[2]; }
+        }
+    } else {
+        /* centre under this triangle's plane: counts only inside the triangle's vertical prism */
+        const double e0 = (b[0] - a[0]) * (p[1] - a[1]) - (b[1] - a[1]) * (p[0] - a[0]);
+        const double e1 = (c[0] - b[0]) * (p[1] - b[1]) - (c[1] - b[1]) * (p[0] - b[0]);
+        const double e2 = (a[0] - c[0]) * (p[1] - c[1]) - (a[1] - c[1]) * (p[0] - c[0]);
+        const int inside = (e0 >= 0 && e1 >= 0 && e2 >= 0) || (e0 <= 0 && e1 <= 0 && e2 <= 0);
+        if (inside && s < *best) { *best = s; bestn[0] = n[0]; bestn[1] = n[1]; bestn[2] = n[2]; }
+    }
+}
 static int hfield_sphere(raw_contact_t *c, const cm_model_t *m, const float *data, const double *ph, const double *mh, const double *ps,
                          double r, double margin) {
     if (!data || m->hfield_nrow < 2 || m->hfield_ncol < 2) return 0;
     const double sx = m->hfield_size[0], sy = m->hfield_size[1], sz = m->hfield_size[2];
     double d[3] = {ps[0] - ph[0], ps[1] - ph[1], ps[2] - ph[2]}, p[3];
     mulmatTvec3(p, mh, d);
-    if (fabs(p[0]) > sx || fabs(p[1]) > sy || p[2] - r > sz + margin) return 0;
+    const double reach = r + (margin > 0 ? margin : 0);
+    if (fabs(p[0]) > sx + reach || fabs(p[1]) > sy + reach || p[2] - r > sz + margin) return 0;
     const int nc = m->hfield_ncol, nr = m->hfield_nrow;
     const double dx = 2 * sx / (nc - 1), dy = 2 * sy / (nr - 1);
-    double u = (p[0] + sx) / dx, v = (p[1] + sy) / dy;
-    int j = (int)floor(u), i = (int)floor(v);
-    if (j > nc - 2) j = nc - 2;
-    if (i > nr - 2) i = nr - 2;
-    if (j < 0) j = 0;
-    if (i < 0) i = 0;
-    const double fu = u - j, fv = v - i;
-    const double z00 = sz * data[i * nc + j], z10 = sz * data[i * nc + j + 1], z01 = sz * data[(i + 1) * nc + j], z11 = sz * data[(i + 1) * nc + j + 1];
-    /* plane z = z0 + gx (x - x0) + gy (y - y0) of the triangle under the centre */
-    double gx, gy, z0, x0 = -sx + j * dx, y0 = -sy + i * dy;
-    if (fu + fv <= 1.0) { gx = (z10 - z00) / dx; gy = (z01 - z00) / dy; z0 = z00; }
-    else { gx = (z11 - z01) / dx; gy = (z11 - z10) / dy; z0 = z11 - gx * dx - gy * dy; }
-    const double inv = 1.0 / sqrt(1.0 + gx * gx + gy * gy);
-    double nl[3] = {-gx * inv, -gy * inv, inv};
-    const double height = z0 + gx * (p[0] - x0) + gy * (p[1] - y0);
-    const double dist = (p[2] - height) * inv - r;
+    int j0 = (int)floor((p[0] - reach + sx) / dx), j1 = (int)floor((p[0] + reach + sx) / dx);
+    int i0 = (int)floor((p[1] - reach + sy) / dy), i1 = (int)floor((p[1] + reach + sy) / dy);
+    if (j0 < 0) j0 = 0;
+    if (i0 < 0) i0 = 0;
+    if (j1 > nc - 2) j1 = nc - 2;
+    if (i1 > nr - 2) i1 = nr - 2;
+    double best = 1e300, bn[3] = {0, 0, 1};
+    for (int i = i0; i <= i1; ++i)
+        for (int j = j0; j <= j1; ++j) {
+            const double x0 = -sx + j * dx, y0 = -sy + i * dy;
+            const double v00[3] = {x0, y0, sz * data[i * nc + j]}, v10[3] = {x0 + dx, y0, sz * data[i * nc + j + 1]};
+            const double v01[3] = {x0, y0 + dy, sz * data[(i + 1) * nc + j]}, v11[3] = {x0 + dx, y0 + dy, sz * data[(i + 1) * nc + j + 1]};
+            hfield_triangle(p, v00, v10, v01, &best, bn);
+            hfield_triangle(p, v11, v01, v10, &best, bn);
+        }
+    if (best > 1e299) return 0;
+    const double dist = best - r;
     if (dist > margin) return 0;
     double nw[3];
-    mulmatvec3(nw, mh, nl);
+    mulmatvec3(nw, mh, bn);
     c->dist = dist;
     for (int k = 0; k < 3; ++k) { c->normal[k] = nw[k]; c->pos[k] = ps[k] - nw[k] * (r + 0.5 * dist); c->tangent[k] = 0; }
     return 1;
 }
+/* test hook: one sphere (world centre ps, radius r) against the height field geom of the model; out = dist, pos, normal */
+int co_test_hfield_sphere(const cm_model_t *m, const double *ps, double r, double margin, double *out) {
+    if (m->hfield_geom < 0) return 0;
+    raw_contact_t c;
+    double mh[9];
+    quat2mat(mh, m->geom_quat[m->hfield_geom]);
+    int n = hfield_sphere(&c, m, g_hfield, m->geom_pos[m->hfield_geom], mh, ps, r, margin);
+    if (n) { out[0] = c.dist; for (int i = 0; i < 3; ++i) { out[1 + i] = c.pos[i]; out[4 + i] = c.normal[i]; } }
+    return n;
+}
+/* capsule: the two end spheres as against a plane, plus sample spheres along the axis no further apart than one grid cell
+ * (at most 4 interior ones).  An interior sample counts only when it is deeper than both ends -- a bump under the middle
+ * of the capsule -- and then replaces the shallower end; on flat ground this is exactly plane_capsule.  Contacts are
+ * reported in the order of their position along the axis, +h first. */
 static int hfield_capsule(raw_contact_t *c, const cm_model_t *m, const float *data, const double *ph, const double *mh, const double *pc,
                           const double *mc, const double *sc, double margin) {
-    const double ax[3] = {mc[2], mc[5], mc[8]};
-    int n = 0;
+    const double ax[3] = {mc[2], mc[5], mc[8]}, h = sc[1];
+    const double cell = 2 * m->hfield_size[0] / (m->hfield_ncol > 1 ? m->hfield_ncol - 1 : 1);
+    int ni = (int)ceil(2 * h / cell) - 1;  /* interior samples */
+    if (ni < 0) ni = 0;
+    if (ni > 4) ni = 4;
+    raw_contact_t end[2], mid;
+    int have_end[2] = {0, 0}, have_mid = 0;
+    double tmid = 0;
     for (int s = 0; s < 2; ++s) {
-        const double sg = s == 0 ? sc[1] : -sc[1];
-        double e[3] = {pc[0] + sg * ax[0], pc[1] + sg * ax[1], pc[2] + sg * ax[2]};
-        if (hfield_sphere(c + n, m, data, ph, mh, e, sc[0], margin)) { for (int k = 0; k < 3; ++k) c[n].tangent[k] = ax[k]; ++n; }
+        const double t = s == 0 ? h : -h;
+        double e[3] = {pc[0] + t * ax[0], pc[1] + t * ax[1], pc[2] + t * ax[2]};
+        have_end[s] = hfield_sphere(&end[s], m, data, ph, mh, e, sc[0], margin);
     }
+    for (int k = 1; k <= ni; ++k) {
+        const double t = h * (1.0 - 2.0 * k / (ni + 1));
+        double e[3] = {pc[0] + t * ax[0], pc[1] + t * ax[1], pc[2] + t * ax[2]};
+        raw_contact_t cur;
+        if (hfield_sphere(&cur, m, data, ph, mh, e, sc[0], margin) && (!have_mid || cur.dist < mid.dist)) { mid = cur; have_mid = 1; tmid = t; }
+    }
+    (void)tmid;
+    if (have_mid && (!have_end[0] || mid.dist < end[0].dist) && (!have_end[1] || mid.dist < end[1].dist)) {
+        /* the interior sample is the deepest point of the capsule: it takes the place of the shallower (or absent) end */
+        const int drop = !have_end[0] ? 0 : (!have_end[1] ? 1 : (end[0].dist <= end[1].dist ? 1 : 0));
+        end[drop] = mid;
+        have_end[drop] = 1;
+    }
+    int n = 0;
+    for (int s = 0; s < 2; ++s)
+        if (have_end[s]) { c[n] = end[s]; for (int k = 0; k < 3; ++k) c[n].tangent[k] = ax[k]; ++n; }
+    return n;
+}
+
+/* test hook: one capsule (world centre pc, rotation matrix mc with the axis in its third column, radius, half length) against
+ * the height field geom; out[2][7] = dist, pos, normal per contact */
+int co_test_hfield_capsule(const cm_model_t *m, const double *pc, const double *mc, double radius, double halflen, double margin, double *out) {
+    if (m->hfield_geom < 0) return 0;
+    raw_contact_t c[2];
+    double mh[9], sc[3] = {radius, halflen, 0};
+    quat2mat(mh, m->geom_quat[m->hfield_geom]);
+    int n = hfield_capsule(c, m, g_hfield, m->geom_pos[m->hfield_geom], mh, pc, mc, sc, margin);
+    for (int k = 0; k < n; ++k) { out[7 * k] = c[k].dist; for (int i = 0; i < 3; ++i) { out[7 * k + 1 + i] = c[k].pos[i]; out[7 * k + 4 + i] = c[k].normal[i]; } }
     return n;
 }
 

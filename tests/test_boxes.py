@@ -109,3 +109,100 @@ def test_stair_box_under_the_feet_is_not_culled(cassie):
         on_box = max(on_box, sum(1 for i in range(o.d.ncon) if o.d.contact[i].geom2 == 1 or o.d.contact[i].geom1 == 1))
     assert on_box >= 2
     assert np.max(np.abs(emu.qpos[0] - o.qpos)) < 1e-8
+
+
+# ---------------------------------------------------------------- box-box: SAT, face clipping, edge-edge ----
+def _rot(axis, ang):
+    axis = np.asarray(axis, float)
+    axis /= np.linalg.norm(axis)
+    K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+    return np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * K @ K
+
+
+def _bb(p1, R1, s1, p2, R2, s2):
+    from oracle_py import lib
+    L = lib()
+    L.co_test_box_box.argtypes = [ctypes.c_void_p] * 6 + [ctypes.c_double, ctypes.c_void_p]
+    a = [np.ascontiguousarray(x, dtype=np.float64) for x in (p1, R1, s1, p2, R2, s2)]
+    out = np.zeros(28)
+    n = L.co_test_box_box(*[x.ctypes.data for x in a], 0.0, out.ctypes.data)
+    return n, out.reshape(4, 7)[:n]
+
+
+TRAY = ([0, 0, 0], np.eye(3), [0.14, 0.14, 0.005])
+CUBE = [0.05, 0.05, 0.05]
+
+
+def test_box_box_face_contacts():
+    """Cube flat on the tray, aligned and turned by 45 degrees: its four bottom corners, penetration as depth, vertical
+    normals from box 1 to box 2; separated boxes give nothing."""
+    for Rz in (np.eye(3), _rot([0, 0, 1], np.pi / 4)):
+        n, c = _bb(*TRAY, [0.02, 0.03, 0.05], Rz, CUBE)
+        assert n == 4 and np.allclose(c[:, 0], -0.005) and np.allclose(c[:, 4:], [0, 0, 1])
+        corners = np.array([[0.02, 0.03, 0]] * 4) + (Rz @ (0.05 * np.array([[1, 1, 0], [-1, 1, 0], [-1, -1, 0], [1, -1, 0]])).T).T
+        assert np.allclose(sorted(map(tuple, c[:, 1:3])), sorted(map(tuple, corners[:, :2])))
+        assert np.allclose(c[:, 3], 0.0025)                                  # midway between the two surfaces
+    assert _bb(*TRAY, [0.5, 0, 0.05], np.eye(3), CUBE)[0] == 0
+    assert _bb(*TRAY, [0.0, 0, 0.0551], np.eye(3), CUBE)[0] == 0            # 0.1 mm above the tray
+
+
+def test_box_box_overhang_is_clipped_to_the_supporting_face():
+    """The cube hangs over the tray's edge (turned 45 degrees): contacts lie on the tray (|x| <= 0.14), include crossings
+    of the cube's edges with the tray's rim, and never the corner that is out in the air."""
+    n, c = _bb(*TRAY, [0.13, 0.0, 0.05], _rot([0, 0, 1], np.pi / 4), CUBE)
+    assert n == 4 and np.all(np.abs(c[:, 1]) <= 0.14 + 1e-12) and np.all(np.abs(c[:, 2]) <= 0.14 + 1e-12)
+    assert np.any(np.isclose(c[:, 1], 0.14))                                  # a rim crossing
+    assert not np.any(np.isclose(c[:, 1], 0.13 + 0.05 * np.sqrt(2)))         # the overhanging corner
+
+
+def test_box_box_edge_edge_contact():
+    """Two bars, each turned 45 degrees about its long axis, crossing at right angles edge to edge: ONE contact at the
+    crossing point, along the common perpendicular -- the configuration vertex-in-box tests cannot see at all."""
+    RA, RB = _rot([1, 0, 0], np.pi / 4), _rot([0, 0, 1], np.pi / 2) @ _rot([1, 0, 0], np.pi / 4)
+    bar = [0.5, 0.05, 0.05]
+    n, c = _bb([0, 0, 0], RA, bar, [0.03, 0.02, 2 * 0.05 * np.sqrt(2) - 0.003], RB, bar)
+    assert n == 1 and abs(c[0, 0] + 0.003) < 1e-12
+    assert np.allclose(c[0, 1:4], [0.03, 0.0, 0.05 * np.sqrt(2) - 0.0015], atol=1e-12) and np.allclose(c[0, 4:], [0, 0, 1])
+    # swapping the boxes flips the normal (it always points from box 1 to box 2)
+    n, c2 = _bb([0.03, 0.02, 2 * 0.05 * np.sqrt(2) - 0.003], RB, bar, [0, 0, 0], RA, bar)
+    assert n == 1 and np.allclose(c2[0, 4:], [0, 0, -1]) and np.allclose(c2[0, 1:4], c[0, 1:4])
+
+
+def test_box_box_corner_into_face():
+    Rc = _rot([1, -1, 0], np.arccos(1 / np.sqrt(3)))                          # a body diagonal pointing down
+    n, c = _bb(*TRAY, [0.0, 0.0, 0.005 + 0.05 * np.sqrt(3) - 0.002], Rc, CUBE)
+    assert n == 1 and abs(c[0, 0] + 0.002) < 1e-9 and np.allclose(c[0, 4:], [0, 0, 1]) and np.allclose(c[0, 1:3], 0, atol=1e-9)
+
+
+def test_emulated_kernel_matches_oracle_for_tumbling_cube(tray):
+    """The cube starts tilted above the tray's rim (robot held up by stiff, damped joints so the tray stays put), lands on
+    a corner, tips over an edge and settles on a face: 1-, 2-, 3- and 4-point contacts occur; the emulated kernel must
+    follow the oracle contact for contact."""
+    from cassie_amd._lib import CmModel
+    pod = CmModel.from_buffer_copy(tray.pod)
+    q = tray.qpos_init()
+    for i in range(3):
+        pod.jnt_stiffness[i], pod.dof_damping[i], pod.qpos_spring[i] = 1e5, 1e4, q[i]
+        pod.dof_stiffness[i], pod.dof_springref[i] = 1e5, q[i]        # the kernel reads the per-dof records
+    for i in range(3, 6):
+        pod.dof_damping[i] = 1e4
+    for k in range(6, 32):
+        pod.dof_damping[k] = 50
+    q[35:38] = [0.12, 0.05, 1.30]
+    ang = 0.6
+    axis = np.array([1.0, 0.4, 0.2]) / np.linalg.norm([1.0, 0.4, 0.2])
+    q[38:42] = [np.cos(ang / 2), *(np.sin(ang / 2) * axis)]
+    o = Oracle(pod, q)
+    emu = EmuBatch(pod, 1)
+    emu.qpos[:] = q
+    cube = tray.name2id(1, "cup_box")
+    cube_counts = set()
+    for s in range(700):
+        emu.step()
+        o.step()
+        assert (emu.info[0, 0], emu.info[0, 1], emu.info[0, 2]) == (o.d.ncon, o.d.nefc, o.d.solver_iter), s
+        cube_counts.add(sum(1 for i in range(o.d.ncon) if cube in (pod.geom_bodyid[o.d.contact[i].geom1], pod.geom_bodyid[o.d.contact[i].geom2])))
+    assert np.max(np.abs(emu.qpos[0] - o.qpos)) < 1e-8
+    assert {1, 2, 4} <= cube_counts                     # corner, edge and face contacts were passed through
+    assert abs(o.qpos[37] - (1.01 + 0.17 + 0.005 + 0.05)) < 0.01   # and the cube rests flat on the tray
+    assert not emu.warn.any()

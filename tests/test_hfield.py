@@ -72,3 +72,111 @@ def test_no_terrain_data_means_no_contact(hf):
     o = Oracle(hf.pod, hf.qpos_init())
     o.step(300)
     assert o.d.ncon == 0 and o.qpos[2] < 0.9                     # falls freely without samples
+
+
+def _probe(hf, ps, r):
+    import ctypes
+    L = oracle_py.lib()
+    L.co_test_hfield_sphere.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double, ctypes.c_double, ctypes.c_void_p]
+    out = np.zeros(7)
+    p = np.ascontiguousarray(ps, dtype=np.float64)
+    n = L.co_test_hfield_sphere(ctypes.byref(hf.pod), p.ctypes.data, r, 0.0, out.ctypes.data)
+    return (n, out[0], out[1:4], out[4:7])
+
+
+def test_step_terrain_rim_and_wall_are_felt(hf):
+    """Advisor finding (round 1): a sample sphere used to see only the triangle under its centre, so a taller
+    neighbouring cell was invisible.  A mesa (elevation 0.2 for x >= 0.15, else 0; the height field geom sits at z = -0.1, so
+    the low ground is world z = -0.1 and the top z = +0.1) against spheres: beside the rim, over the low ground, on top, and
+    sunk into the low ground."""
+    nc = 200
+    xs = -5 + 10.0 * np.arange(nc) / (nc - 1)
+    h = np.zeros((200, 200), dtype=np.float32)
+    h[:, xs >= 0.15] = 1.0
+    jr = int(np.argmax(xs >= 0.15))                  # first raised column; the slope runs from xs[jr - 1] to xs[jr]
+    oracle_py.set_hfield(h)
+    try:
+        # over the low ground, far from the mesa: plain vertical contact
+        n, dist, pos, nrm = _probe(hf, [-0.5, 0.0, -0.1 + 0.03], 0.05)
+        assert n == 1 and abs(dist - (-0.02)) < 1e-12 and np.allclose(nrm, [0, 0, 1])
+        # above the low ground but within reach of the slope's rim only: the old definition found nothing here
+        c = np.array([xs[jr] - 0.09, 0.0, 0.1 + 0.02])  # level with the mesa top, 0.09 m before it: low ground is 0.22 m below
+        n, dist, pos, nrm = _probe(hf, c, 0.1)
+        assert n == 1
+        rim = np.array([xs[jr], 0.0, 0.1])
+        rim_dist = np.linalg.norm(c - rim) - 0.1                         # the rim of the raised cells; the steep face just below
+        assert rim_dist - 1e-3 < dist <= rim_dist + 1e-12               # it (5 cm run, 20 cm rise) is a hair closer still
+        assert nrm[0] < -0.9 and nrm[2] > 0                              # pushed back, away from the mesa
+        # on top of the mesa
+        n, dist, pos, nrm = _probe(hf, [1.0, 0.3, 0.1 + 0.04], 0.05)
+        assert n == 1 and abs(dist + 0.01) < 1e-12 and np.allclose(nrm, [0, 0, 1])
+        # centre below the surface of the low ground: penetration along the surface normal
+        n, dist, pos, nrm = _probe(hf, [-0.5, 0.2, -0.1 - 0.01], 0.03)
+        assert n == 1 and abs(dist - (-0.04)) < 1e-12 and np.allclose(nrm, [0, 0, 1])
+        # high above everything: culled
+        assert _probe(hf, [0.0, 0.0, 0.5], 0.05)[0] == 0
+    finally:
+        oracle_py.set_hfield(None)
+
+
+def test_emulated_kernel_matches_oracle_at_a_terrain_step(hf):
+    """Robot dropped with one foot over a 6 cm ledge: kernel (emulated) and oracle agree contact for contact."""
+    nc = 200
+    xs = -5 + 10.0 * np.arange(nc) / (nc - 1)
+    ys = xs
+    h = np.zeros((200, 200), dtype=np.float32)
+    h[ys >= 0.05, :] = 0.3                              # left foot (y = +0.135) lands on a ledge 0.06 m high
+    oracle_py.set_hfield(h)
+    try:
+        pod = hf.pod
+        q = hf.qpos_init()
+        o = Oracle(pod, q)
+        emu = EmuBatch(pod, 1)
+        emu.qpos[:] = q
+        emu.hfield = h.ravel().copy()
+        for s in range(400):
+            emu.step()
+            o.step()
+            assert (emu.info[0, 0], emu.info[0, 1]) == (o.d.ncon, o.d.nefc), s
+        assert o.d.ncon >= 2
+        assert np.max(np.abs(emu.qpos[0] - o.qpos)) < 1e-8
+        zs = sorted(o.d.contact[i].pos[2] for i in range(o.d.ncon))
+        assert zs[-1] - zs[0] > 0.04                    # contacts on both levels
+    finally:
+        oracle_py.set_hfield(None)
+
+
+def test_capsule_feels_a_bump_under_its_middle(hf):
+    """A horizontal capsule (radius 2 cm, 16 cm long, like Cassie's foot) over flat ground with one raised sample under its
+    middle: two end spheres alone would report nothing; the interior samples find the bump.  Without the bump the capsule is
+    treated exactly like against a plane: its two end spheres."""
+    import ctypes
+    L = oracle_py.lib()
+    L.co_test_hfield_capsule.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_void_p]
+    nc = 200
+    xs = -5 + 10.0 * np.arange(nc) / (nc - 1)
+    j = int(np.argmin(np.abs(xs - 1.0)))
+    i = int(np.argmin(np.abs(xs - 0.5)))
+    h = np.zeros((200, 200), dtype=np.float32)
+    h[i, j] = 0.25                                   # a 5 cm spike at (xs[j], xs[i]); ground at world z = -0.1
+    mc = np.array([0.0, 0, 1, 0, 1, 0, -1, 0, 0])    # capsule axis (third column) along world x
+    out = np.zeros(14)
+
+    def probe(z):
+        pc = np.array([xs[j], xs[i], z])
+        n = L.co_test_hfield_capsule(ctypes.byref(hf.pod), pc.ctypes.data, mc.ctypes.data, 0.02, 0.08, 0.0, out.ctypes.data)
+        return n, out.reshape(2, 7).copy()
+    oracle_py.set_hfield(h)
+    try:
+        n, c = probe(-0.1 + 0.05 + 0.015)             # 1.5 cm above the spike's tip minus radius: touches the spike only
+        assert n == 1 and abs(c[0, 0] - (-0.005)) < 1e-9
+        assert abs(c[0, 1] - xs[j]) < 1e-6 and c[0, 6] > 0.99          # at the middle, pushing up
+        n, c = probe(-0.1 + 0.015)                    # pressed down to the ground: the spike (deepest) and one end
+        assert n == 2 and min(c[0, 0], c[1, 0]) < -0.04
+        xs_contact = sorted([c[0, 1], c[1, 1]])
+        assert abs(xs_contact[0] - xs[j]) < 0.03 or abs(xs_contact[1] - xs[j]) < 0.03
+        oracle_py.set_hfield(np.zeros((200, 200), dtype=np.float32))
+        n, c = probe(-0.1 + 0.015)
+        assert n == 2 and np.allclose(c[:, 0], -0.005) and np.allclose(sorted(c[:, 1]), [xs[j] - 0.08, xs[j] + 0.08])   # the two ends
+    finally:
+        oracle_py.set_hfield(None)
