@@ -36,6 +36,8 @@ extern "C" {
 #define CM_MAXSITE   16
 #define CM_MAXSENSOR 24
 #define CM_MAXSENSORDATA 40
+#define CM_MAXHFPAIR 10      /* height-field pairs whose samples fit one wave pass (more: tested in the pair loop itself) */
+#define CM_HF_SLOTS  6       /* sample spheres per height-field pair: two ends + at most four interior ones */
 #define CM_MAXCON    16      /* contacts kept per env-step */
 #define CM_MAXEFC    63      /* constraint rows per env-step (lane 63 is the qfrc_smooth column) */
 
@@ -150,6 +152,11 @@ typedef struct cm_model {
     int pair_root[CM_MAXPAIR][2];
     uint64_t pair_dofmask[CM_MAXPAIR][2];
     double pair_invweight[CM_MAXPAIR];
+
+    /* height-field pairs (geom1 is the height field), in pair order: the kernel spreads their sample spheres over the
+     * lanes of one wave pass ahead of the pair loop (CM_HF_SLOTS lanes per pair) */
+    int nhfpair, hfpair[CM_MAXHFPAIR];
+    int pair_hfslot[CM_MAXPAIR];          /* index into hfpair, -1 for the other pairs */
 
     /* equality constraints (connect only) */
     int eq_body1[CM_MAXEQ], eq_body2[CM_MAXEQ], eq_active[CM_MAXEQ];

@@ -1215,10 +1215,18 @@ bool HostModel::compile(cm_model_t *o, std::string *err) const {
     }
     if ((int)pairs.size() > CM_MAXPAIR) return fail("too many candidate collision pairs");
     o->npair = (int)pairs.size();
+    o->nhfpair = 0;
+    for (int i = 0; i < CM_MAXHFPAIR; ++i) o->hfpair[i] = 0;
+    for (int i = 0; i < CM_MAXPAIR; ++i) o->pair_hfslot[i] = -1;
     for (int i = 0; i < o->npair; ++i) {
         const int g1 = pairs[i].g1, g2 = pairs[i].g2;
         o->pair_geom1[i] = g1; o->pair_geom2[i] = g2;
         o->pair_type[i] = o->geom_type[g1] | (o->geom_type[g2] << 8);
+        if (o->geom_type[g1] == CM_GEOM_HFIELD && i < o->npair_simple &&
+            (o->geom_type[g2] == CM_GEOM_SPHERE || o->geom_type[g2] == CM_GEOM_CAPSULE)) {
+            if (o->nhfpair < CM_MAXHFPAIR) { o->pair_hfslot[i] = o->nhfpair; o->hfpair[o->nhfpair] = i; }
+            o->nhfpair++;                 /* beyond CM_MAXHFPAIR the kernel tests every height-field pair in the pair loop */
+        }
         o->pair_margin[i] = std::max(o->geom_margin[g1], o->geom_margin[g2]);
         o->pair_includemargin[i] = o->pair_margin[i] - std::max(o->geom_gap[g1], o->geom_gap[g2]);
         o->pair_rbound[i][0] = o->geom_rbound[g1]; o->pair_rbound[i][1] = o->geom_rbound[g2];

@@ -536,14 +536,28 @@ WV_DEVICE int hfield_sphere(RawContact &c, ModelPtr m, const float *data, const 
     if (j1 > nc - 2) j1 = nc - 2;
     if (i1 > nr - 2) i1 = nr - 2;
     double best = 1e300, bn[3] = {0, 0, 1};
-    for (int i = i0; i <= i1; ++i)
+    /* touch the first and the last sample of every grid row of the footprint before any of them is needed: all the
+     * footprint's cache lines are then in flight together (one memory latency instead of one per cell) */
+    float touch = 0.0f;
+    for (int i = i0; i <= i1 + 1; ++i) touch += data[i * nc + j0] + data[i * nc + j1 + 1];
+    if (touch == -1.2345e30f) best = 0;      /* never true for elevations in [0, 1]: keeps the loads alive */
+    const double reach2 = reach * reach;
+    for (int i = i0; i <= i1; ++i) {
+        const double y0 = -sy + i * dy;
+        const double ey = p[1] < y0 ? y0 - p[1] : (p[1] > y0 + dy ? p[1] - (y0 + dy) : 0.0);
         for (int j = j0; j <= j1; ++j) {
-            const double x0 = -sx + j * dx, y0 = -sy + i * dy;
-            const double v00[3] = {x0, y0, sz * data[i * nc + j]}, v10[3] = {x0 + dx, y0, sz * data[i * nc + j + 1]};
-            const double v01[3] = {x0, y0 + dy, sz * data[(i + 1) * nc + j]}, v11[3] = {x0 + dx, y0 + dy, sz * data[(i + 1) * nc + j + 1]};
+            const double x0 = -sx + j * dx;
+            /* exact culls: a cell whose rectangle is further than the reach in plan, or whose highest corner is more than
+             * the reach below the sphere, cannot hold a point within contact distance */
+            const double ex = p[0] < x0 ? x0 - p[0] : (p[0] > x0 + dx ? p[0] - (x0 + dx) : 0.0);
+            if (ex * ex + ey * ey > reach2) continue;
+            const double z00 = sz * data[i * nc + j], z10 = sz * data[i * nc + j + 1], z01 = sz * data[(i + 1) * nc + j], z11 = sz * data[(i + 1) * nc + j + 1];
+            if (p[2] - reach > fmax(fmax(z00, z10), fmax(z01, z11))) continue;
+            const double v00[3] = {x0, y0, z00}, v10[3] = {x0 + dx, y0, z10}, v01[3] = {x0, y0 + dy, z01}, v11[3] = {x0 + dx, y0 + dy, z11};
             hfield_triangle(p, v00, v10, v01, best, bn);
             hfield_triangle(p, v11, v01, v10, best, bn);
         }
+    }
     if (best > 1e299) return 0;
     const double dist = best - r;
     if (dist > margin) return 0;
@@ -1319,11 +1333,93 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
             if (wv::ballot(nearby) != 0ull) npass = m->npair_simple;
         }
         CK_STAMP(21);
+        /* Height-field pairs ahead of the pair loop: their sample spheres -- the sphere itself, or a capsule's two ends and
+         * up to four interior samples -- go one to a lane (CM_HF_SLOTS lanes per pair), so the walks over the grid cells
+         * under the samples run side by side instead of one after the other in the pair's lane; the lanes of a pair then
+         * apply the capsule rule (oracle hfield_capsule) to the samples' results, and the pair loop below picks the
+         * result up from the pair's first lane. */
+        const bool hf_spread = env_hfield != nullptr && m->nhfpair > 0 && m->nhfpair <= CM_MAXHFPAIR;
+        int hf_n = 0;
+        RawContact hf0, hf1;
+        if (hf_spread) {
+            const int h = lane / CM_HF_SLOTS, k = lane % CM_HF_SLOTS;
+            const bool act = h < m->nhfpair;
+            const int p = m->hfpair[act ? h : 0];
+            const int g1 = m->pair_geom1[p], g2 = m->pair_geom2[p], t2 = m->pair_type[p] >> 8;
+            const double margin = m->pair_margin[p], s20 = m->pair_size[p][3], s21 = m->pair_size[p][4];
+            const double *p1 = S.x.s.geom_xpos[g1], *m1 = S.x.s.geom_xmat[g1], *p2 = S.x.s.geom_xpos[g2], *m2 = S.x.s.geom_xmat[g2];
+            const double axis[3] = {m2[2], m2[5], m2[8]};
+            const double cell = 2 * m->hfield_size[0] / (m->hfield_ncol > 1 ? m->hfield_ncol - 1 : 1);
+            int ni = 0;
+            bool mine = act && k == 0;
+            double t = 0;
+            if (t2 == CM_GEOM_CAPSULE) {
+                ni = (int)ceil(2 * s21 / cell) - 1;
+                if (ni < 0) ni = 0;
+                if (ni > 4) ni = 4;
+                mine = act && k < 2 + ni;
+                t = k == 0 ? s21 : (k == 1 ? -s21 : s21 * (1.0 - 2.0 * (k - 1) / (ni + 1)));
+            }
+            RawContact rcs;
+            rcs.dist = 1e300;
+            bool has = false;
+            if (mine) {
+                /* block cull as in the pair loop */
+                const double dif[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
+                (void)dif;
+                double e[3] = {p2[0] + t * axis[0], p2[1] + t * axis[1], p2[2] + t * axis[2]};
+                has = hfield_sphere(rcs, m, env_hfield, p1, m1, e, s20, margin) != 0;
+            }
+            /* the samples of this lane's pair: distances (1e300 = no contact) */
+            const int lead = lane - k;
+            double dk[CM_HF_SLOTS];
+            const double mydist = has ? rcs.dist : 1e300;
+#pragma unroll
+            for (int q = 0; q < CM_HF_SLOTS; ++q) dk[q] = wv::shfl(mydist, (lead + q) & 63);
+            int src0 = 0, src1 = 1;
+            bool have0 = dk[0] < 1e299, have1 = dk[1] < 1e299;
+            if (t2 == CM_GEOM_CAPSULE) {
+                int kmid = -1;
+                for (int q = 2; q < CM_HF_SLOTS; ++q) if (dk[q] < 1e299 && (kmid < 0 || dk[q] < dk[kmid])) kmid = q;
+                if (kmid >= 0 && (!have0 || dk[kmid] < dk[0]) && (!have1 || dk[kmid] < dk[1])) {
+                    const bool drop1 = !have0 ? false : (!have1 ? true : dk[0] <= dk[1]);
+                    if (drop1) { src1 = kmid; have1 = true; } else { src0 = kmid; have0 = true; }
+                }
+            } else {
+                have1 = false;
+            }
+            /* fetch the chosen samples' contacts (every lane of the pair ends up with the pair's result) */
+            const int la = (lead + src0) & 63, lb = (lead + src1) & 63;
+            hf0.dist = wv::shfl(rcs.dist, la); hf1.dist = wv::shfl(rcs.dist, lb);
+            for (int i = 0; i < 3; ++i) {
+                hf0.pos[i] = wv::shfl(rcs.pos[i], la); hf0.normal[i] = wv::shfl(rcs.normal[i], la);
+                hf1.pos[i] = wv::shfl(rcs.pos[i], lb); hf1.normal[i] = wv::shfl(rcs.normal[i], lb);
+                hf0.tangent[i] = t2 == CM_GEOM_CAPSULE ? axis[i] : 0.0; hf1.tangent[i] = hf0.tangent[i];
+            }
+            if (have0 && have1) hf_n = 2;
+            else if (have0) hf_n = 1;
+            else if (have1) { hf0 = hf1; hf_n = 1; }
+            if (!act) hf_n = 0;
+        }
         for (int p0 = 0; p0 < npass; p0 += WV_WAVE) {
             const int p = p0 + lane;
             int n = 0;
             RawContact rc0, rc1;
-            if (p < npass) {
+            bool from_spread = false;
+            if (hf_spread) {
+                /* height-field pairs take their result from the first lane of their pair in the pre-pass */
+                const int slot = p < npass ? m->pair_hfslot[p] : -1;
+                const int src = slot >= 0 ? slot * CM_HF_SLOTS : lane;
+                const int nn = wv::shfl_i(hf_n, src);
+                RawContact a, b2;
+                a.dist = wv::shfl(hf0.dist, src); b2.dist = wv::shfl(hf1.dist, src);
+                for (int i = 0; i < 3; ++i) {
+                    a.pos[i] = wv::shfl(hf0.pos[i], src); a.normal[i] = wv::shfl(hf0.normal[i], src); a.tangent[i] = wv::shfl(hf0.tangent[i], src);
+                    b2.pos[i] = wv::shfl(hf1.pos[i], src); b2.normal[i] = wv::shfl(hf1.normal[i], src); b2.tangent[i] = wv::shfl(hf1.tangent[i], src);
+                }
+                if (slot >= 0) { n = nn; rc0 = a; rc1 = b2; from_spread = true; }
+            }
+            if (p < npass && !from_spread) {
                 const int g1 = m->pair_geom1[p], g2 = m->pair_geom2[p], tt = m->pair_type[p];
                 const int t1 = tt & 255, t2 = tt >> 8;
                 const double margin = m->pair_margin[p];
