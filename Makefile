@@ -42,8 +42,9 @@ else
 AGILITY_LINK :=
 endif
 
-.PHONY: all product oracle emu models clean
-all: product oracle emu
+.PHONY: all product oracle emu models clean apps
+all: product oracle emu apps
+apps: $(PKG)/bin/cassiesim
 product: $(PRODUCT)
 oracle: oracle/libcassie_oracle.so
 emu: tests/emu/libcassie_emu.so
@@ -61,6 +62,11 @@ $(OBJD)/%.hip.o: $(CSRC)/%.hip $(wildcard $(CSRC)/*.h) $(wildcard include/*.h)
 $(PRODUCT): $(OBJS)
 	@mkdir -p $(LIBD)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS) $(AGILITY_LINK) -lm -lpthread
+
+# the UDP lock-step server (reference example/cassiesim.c role) against the product library
+$(PKG)/bin/cassiesim: $(PKG)/apps/cassiesim.c $(PRODUCT)
+	@mkdir -p $(PKG)/bin
+	gcc -O2 -std=gnu11 -Iinclude -I$(CSRC) $< -o $@ -L$(LIBD) -lcassiemujoco -Wl,-rpath,'$$ORIGIN/../lib' -lm
 
 oracle/libcassie_oracle.so: oracle/cassie_oracle.c oracle/cassie_oracle.h $(CSRC)/cm_model.h
 	gcc -O2 -std=gnu11 -fPIC -shared -fopenmp -I$(CSRC) -Ioracle oracle/cassie_oracle.c -o $@ -lm

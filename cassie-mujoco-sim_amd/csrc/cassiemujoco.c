@@ -1131,6 +1131,51 @@ void cassie_set_state(cassie_sim_t *c, const cassie_state_t *s)
     cassie_hostenv_copy(c->host, s->host);
 }
 
+/* On-disk form of a cassie_state_t (the reference keeps states in memory only, :3380-3452):
+ *   8 bytes magic "CASSIEST", u32 version, u32 sizeof(sim_data_t), u32 host image size, u32 reserved,
+ *   the sim_data_t (time, qpos, qvel, qacc, warm start, ctrl, applied forces, sensordata, ...), the host image
+ *   (cassie_out_t, encoder filters, torque delay lines, Agility block states).
+ * Native byte order and layout: a checkpoint of this library for this library, like a memcpy of the struct would be. */
+#define STATE_MAGIC "CASSIEST"
+#define STATE_VERSION 1u
+int cassie_state_save(const cassie_state_t *s, const char *path)
+{
+    if (!s || !path) return -1;
+    FILE *f = fopen(path, "wb");
+    if (!f) return -1;
+    const unsigned hdr[4] = {STATE_VERSION, (unsigned)sizeof(sim_data_t), (unsigned)cassie_hostenv_image_size(), 0u};
+    void *img = malloc(hdr[2]);
+    if (!img) { fclose(f); return -1; }
+    cassie_hostenv_to_image(s->host, img);
+    int ok = fwrite(STATE_MAGIC, 8, 1, f) == 1 && fwrite(hdr, sizeof hdr, 1, f) == 1 && fwrite(&s->d, sizeof s->d, 1, f) == 1 &&
+             fwrite(img, hdr[2], 1, f) == 1;
+    free(img);
+    ok = fclose(f) == 0 && ok;
+    return ok ? 0 : -1;
+}
+int cassie_state_load(cassie_state_t *s, const char *path)
+{
+    if (!s || !path) return -1;
+    FILE *f = fopen(path, "rb");
+    if (!f) return -1;
+    char magic[8];
+    unsigned hdr[4];
+    int rc = -1;
+    if (fread(magic, 8, 1, f) == 1 && memcmp(magic, STATE_MAGIC, 8) == 0 && fread(hdr, sizeof hdr, 1, f) == 1 &&
+        hdr[0] == STATE_VERSION && hdr[1] == sizeof(sim_data_t) && hdr[2] == cassie_hostenv_image_size()) {
+        sim_data_t d;
+        void *img = malloc(hdr[2]);
+        if (img && fread(&d, sizeof d, 1, f) == 1 && fread(img, hdr[2], 1, f) == 1) {
+            s->d = d;
+            cassie_hostenv_from_image(s->host, img);
+            rc = 0;
+        }
+        free(img);
+    }
+    fclose(f);
+    return rc;
+}
+
 /* --------------------------------------------------------------- visualisation --- */
 /* Rendering (GLFW / OpenGL / ffmpeg, reference :2248-3378) is outside the hot path.  These behave like
  * the reference library when GLFW could not be loaded: no window is ever created. */

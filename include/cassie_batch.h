@@ -65,6 +65,11 @@ void cassie_hostenv_apply_meas(cassie_hostenv_t *e, const double *meas, cassie_o
 void cassie_hostenv_get_drive_state(const cassie_hostenv_t *e, cm_drive_state_t *out);
 void cassie_hostenv_set_drive_state(cassie_hostenv_t *e, const cm_drive_state_t *in);
 
+/* flat byte image of an env's host state (cassie_out, filters, delay lines, the three Agility block states): checkpoints */
+size_t cassie_hostenv_image_size(void);
+void cassie_hostenv_to_image(const cassie_hostenv_t *e, void *image);
+void cassie_hostenv_from_image(cassie_hostenv_t *e, const void *image);
+
 /* cores this process may really use: min(affinity mask, cgroup CPU quota) */
 int cassie_host_cpu_count(void);
 

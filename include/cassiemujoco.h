@@ -181,6 +181,10 @@ void cassie_sim_torque_delay(cassie_sim_t *sim, double *t);
 void cassie_sim_set_torque_delay(cassie_sim_t *sim, double *t);
 
 /* ---- state snapshots (reference :3380-3452) ---- */
+/* checkpoint files (an extension): a cassie_state_t -- physics state, encoder filters, delay lines and
+ * the Agility block states -- written to / read from disk; 0 on success, -1 on I/O error or foreign / stale file */
+int cassie_state_save(const cassie_state_t *state, const char *path);
+int cassie_state_load(cassie_state_t *state, const char *path);
 cassie_state_t *cassie_state_alloc(void);
 cassie_state_t *cassie_state_duplicate(const cassie_state_t *src);
 void cassie_state_copy(cassie_state_t *dst, const cassie_state_t *src);
