@@ -118,14 +118,20 @@ static int launch(phys_batch *b, int nsub, int integrate, hipStream_t s) {
         for (int k = 0; k < nv; ++k) if (hm.dof_ancmask[k] != table[k]) return false;
         return true;
     };
-    if (matches(ck::TopoCassie32::table, ck::TopoCassie32::nv))
-        hipLaunchKernelGGL((ck::cassie_step_kernel<32, ck::TopoCassie32>), grid, block, 0, s, io);
-    else if (matches(ck::TopoCassieTray38::table, ck::TopoCassieTray38::nv))
-        hipLaunchKernelGGL((ck::cassie_step_kernel<40, ck::TopoCassieTray38>), grid, block, 0, s, io);
-    else if (hm.nv <= 32)
-        hipLaunchKernelGGL((ck::cassie_step_kernel<32, ck::TopoRuntime>), grid, block, 0, s, io);
+    /* ... and the collision code of an instantiation is what the model's pair list needs (FEAT_*): plain cassie.xml has
+     * neither height-field nor whole-wave (plane-box / box-box) pairs */
+    const bool hf = hm.nhfpair > 0 || hm.hfield_geom >= 0, wp = hm.npair > hm.npair_simple;
+    if (matches(ck::TopoCassie32::table, ck::TopoCassie32::nv)) {
+        if (!hf && !wp) hipLaunchKernelGGL((ck::cassie_step_kernel<32, ck::TopoCassie32, 0>), grid, block, 0, s, io);
+        else if (hf && !wp) hipLaunchKernelGGL((ck::cassie_step_kernel<32, ck::TopoCassie32, ck::FEAT_HFIELD>), grid, block, 0, s, io);
+        else hipLaunchKernelGGL((ck::cassie_step_kernel<32, ck::TopoCassie32, ck::FEAT_ALL>), grid, block, 0, s, io);
+    } else if (matches(ck::TopoCassieTray38::table, ck::TopoCassieTray38::nv)) {
+        if (!hf) hipLaunchKernelGGL((ck::cassie_step_kernel<40, ck::TopoCassieTray38, ck::FEAT_WAVEPAIRS>), grid, block, 0, s, io);
+        else hipLaunchKernelGGL((ck::cassie_step_kernel<40, ck::TopoCassieTray38, ck::FEAT_ALL>), grid, block, 0, s, io);
+    } else if (hm.nv <= 32)
+        hipLaunchKernelGGL((ck::cassie_step_kernel<32, ck::TopoRuntime, ck::FEAT_ALL>), grid, block, 0, s, io);
     else
-        hipLaunchKernelGGL((ck::cassie_step_kernel<40, ck::TopoRuntime>), grid, block, 0, s, io);
+        hipLaunchKernelGGL((ck::cassie_step_kernel<40, ck::TopoRuntime, ck::FEAT_ALL>), grid, block, 0, s, io);
     if (!hip_ok(hipGetLastError(), "cassie_step_kernel launch")) return -1;
     /* the next launch's order from this one's per-env cost: after every long launch, now and then after short ones */
     if (io.order && integrate && (nsub >= 8 || ++b->launches_since_order >= 16)) {

@@ -118,7 +118,6 @@ struct EnvShared {
             double cvel[NB][6], cfrc[NB][6];
             double cdof_dot[NVP][6], buf[NVP][6];
             double geom_xpos[NG][3], geom_xmat[NG][9];
-            double xfrc[NB][6];
         } s;
         double Yr[NROW][YP];        /* Y staged row-major by constraint row for broadcast reads */
     } x;
@@ -131,6 +130,12 @@ struct EnvShared {
     double qpos[CM_MAXQ], qvel[NVP], qacc_ws[NVP], qacc[NVP], ctrl[CM_MAXU];
     double qfrc_smooth[NVP];
     double sens[CM_MAXSENSORDATA], actvel[CM_MAXU]; /* sensordata / actuator_velocity of the previous step (inputs of the drive-level models) */
+    /* drive-level state of the env for the length of a launch (cm_drive_state_t in HBM between launches) and the drive
+     * positions / velocities last measured (what CM_DRIVE_PD's law reads) */
+    int drv_x[CM_NUM_DRIVES][CM_DRIVE_FILTER_NB];
+    double drv_jx[CM_NUM_JOINTS][CM_JOINT_FILTER_NB], drv_jy[CM_NUM_JOINTS][CM_JOINT_FILTER_NA];
+    double drv_delay[CM_NUM_DRIVES][CM_TORQUE_DELAY_CYCLES];
+    double drv_pos[CM_NUM_DRIVES], drv_vel[CM_NUM_DRIVES];
     /* contacts */
     double c_dist[CM_MAXCON], c_pos[CM_MAXCON][3], c_frame[CM_MAXCON][9], c_fri[CM_MAXCON][3];
     double c_solref[CM_MAXCON][2], c_solimp[CM_MAXCON][5], c_margin[CM_MAXCON];
@@ -822,10 +827,43 @@ WV_DEVICE int joint_sensor_slot(int j) { return j < 3 ? j + 5 : j + 10; } /* 5 6
  * identical sensordata / actuator_velocity in, the measurement block, the filter histories, the delay lines and the
  * ctrl values are bit for bit those of the host chain (csrc/cassie_hostpath.c, itself pinned to the reference's own
  * compiled code by tests/test_hostpath.py). */
+/* CK_DRIVE_NOINLINE keeps the drive-level pass out of the step kernel's register allocation (an experiment knob) */
+#if defined(CK_DRIVE_NOINLINE) && !defined(CK_EMULATED)
+#define WV_DRIVE_FN __device__ __noinline__
+#else
+#define WV_DRIVE_FN WV_DEVICE
+#endif
+/* the env's drive-level state between HBM (cm_drive_state_t + the measurement block) and the launch's LDS copy */
 template <class SH>
-WV_DEVICE void drive_level_io(const PhysIO &io, SH &S, ModelPtr m, int env, int lane) {
-    const double TWO_PI = 2 * 3.14159265358979323846, PI = 3.14159265358979323846;
+WV_DEVICE void drive_state_load(const PhysIO &io, SH &S, int env, int lane) {
+    const cm_drive_state_t *ds = io.drive_state + env;
+    const double *meas = io.meas + (size_t)env * CM_MEAS_DIM;
+    if (lane < CM_NUM_DRIVES) {
+        for (int k = 0; k < CM_DRIVE_FILTER_NB; ++k) S.drv_x[lane][k] = ds->drive_x[lane][k];
+        for (int k = 0; k < CM_TORQUE_DELAY_CYCLES; ++k) S.drv_delay[lane][k] = ds->torque_delay[lane][k];
+        S.drv_pos[lane] = meas[CM_MEAS_DRIVE_POS + lane]; S.drv_vel[lane] = meas[CM_MEAS_DRIVE_VEL + lane];
+    } else if (lane < CM_NUM_DRIVES + CM_NUM_JOINTS) {
+        const int j = lane - CM_NUM_DRIVES;
+        for (int k = 0; k < CM_JOINT_FILTER_NB; ++k) S.drv_jx[j][k] = ds->joint_x[j][k];
+        for (int k = 0; k < CM_JOINT_FILTER_NA; ++k) S.drv_jy[j][k] = ds->joint_y[j][k];
+    }
+}
+template <class SH>
+WV_DEVICE void drive_state_store(const PhysIO &io, SH &S, int env, int lane) {
     cm_drive_state_t *ds = io.drive_state + env;
+    if (lane < CM_NUM_DRIVES) {
+        for (int k = 0; k < CM_DRIVE_FILTER_NB; ++k) ds->drive_x[lane][k] = S.drv_x[lane][k];
+        for (int k = 0; k < CM_TORQUE_DELAY_CYCLES; ++k) ds->torque_delay[lane][k] = S.drv_delay[lane][k];
+    } else if (lane < CM_NUM_DRIVES + CM_NUM_JOINTS) {
+        const int j = lane - CM_NUM_DRIVES;
+        for (int k = 0; k < CM_JOINT_FILTER_NB; ++k) ds->joint_x[j][k] = S.drv_jx[j][k];
+        for (int k = 0; k < CM_JOINT_FILTER_NA; ++k) ds->joint_y[j][k] = S.drv_jy[j][k];
+    }
+}
+
+template <class SH>
+WV_DRIVE_FN void drive_level_io(const PhysIO &io, SH &S, ModelPtr m, int env, int lane, bool write_meas) {
+    const double TWO_PI = 2 * 3.14159265358979323846, PI = 3.14159265358979323846;
     double *meas = io.meas + (size_t)env * CM_MEAS_DIM;
     const int nu = m->nu;
     if (lane < CM_NUM_DRIVES) {
@@ -840,7 +878,7 @@ WV_DEVICE void drive_level_io(const PhysIO &io, SH &S, ModelPtr m, int env, int 
             sto = io.drive_cmd[(size_t)env * (nu + 1) + nu] != 0.0;
         } else {
             const size_t o = (size_t)env * nu + i;
-            const double p = meas[CM_MEAS_DRIVE_POS + i], v = meas[CM_MEAS_DRIVE_VEL + i];
+            const double p = S.drv_pos[i], v = S.drv_vel[i];
             const double pt = io.pd_ptarget[o], dt = io.pd_dtarget ? io.pd_dtarget[o] : 0.0, ff = io.pd_torque ? io.pd_torque[o] : 0.0;
             u = wv::add_rn(wv::add_rn(ff, wv::mul_rn(io.pd_kp[o], wv::sub_rn(pt, p))), wv::mul_rn(io.pd_kd[o], wv::sub_rn(dt, v)));
         }
@@ -851,28 +889,32 @@ WV_DEVICE void drive_level_io(const PhysIO &io, SH &S, ModelPtr m, int env, int 
         if (sto) u = 0.0;
         const double tau = copysign(fmin(fabs(wv::div_rn(u, ratio)), tlim), u);
         double dl[CM_TORQUE_DELAY_CYCLES];
-        for (int k = 0; k < CM_TORQUE_DELAY_CYCLES; ++k) dl[k] = ds->torque_delay[i][k];
+        for (int k = 0; k < CM_TORQUE_DELAY_CYCLES; ++k) dl[k] = S.drv_delay[i][k];
         const double ctrl_i = dl[CM_TORQUE_DELAY_CYCLES - 1];
-        for (int k = CM_TORQUE_DELAY_CYCLES - 1; k > 0; --k) ds->torque_delay[i][k] = dl[k - 1];
-        ds->torque_delay[i][0] = tau;
+        for (int k = CM_TORQUE_DELAY_CYCLES - 1; k > 0; --k) S.drv_delay[i][k] = dl[k - 1];
+        S.drv_delay[i][0] = tau;
         S.ctrl[i] = ctrl_i;
-        meas[CM_MEAS_DRIVE_TORQUE + i] = wv::mul_rn(ctrl_i, ratio);
         /* drive_encoder(): truncation to encoder counts, 9-tap integer FIR (reference :558-593) */
         const int slot = drive_sensor_slot(i), bits = m->sensor_bits[slot];
         const double counts = (double)(1 << bits);
         const int ev = (int)wv::mul_rn(wv::div_rn(S.sens[slot], TWO_PI), counts);
         const double scale = wv::div_rn(wv::div_rn(TWO_PI, counts), ratio);
-        meas[CM_MEAS_DRIVE_POS + i] = wv::mul_rn((double)ev, scale);
+        const double pos = wv::mul_rn((double)ev, scale);
         int x[CM_DRIVE_FILTER_NB];
         bool allzero = true;
-        for (int k = 0; k < CM_DRIVE_FILTER_NB; ++k) { x[k] = ds->drive_x[i][k]; allzero &= x[k] == 0; }
+        for (int k = 0; k < CM_DRIVE_FILTER_NB; ++k) { x[k] = S.drv_x[i][k]; allzero &= x[k] == 0; }
         if (allzero) for (int k = 0; k < CM_DRIVE_FILTER_NB; ++k) x[k] = ev;
         for (int k = CM_DRIVE_FILTER_NB - 1; k > 0; --k) x[k] = x[k - 1];
         x[0] = ev;
         const int fir[CM_DRIVE_FILTER_NB] = {2727, 534, -2658, -795, 72, 110, 19, -6, -3};
         int y = 0;
-        for (int k = 0; k < CM_DRIVE_FILTER_NB; ++k) { y += x[k] * fir[k]; ds->drive_x[i][k] = x[k]; }
-        meas[CM_MEAS_DRIVE_VEL + i] = wv::div_rn(wv::mul_rn((double)y, scale), PI);
+        for (int k = 0; k < CM_DRIVE_FILTER_NB; ++k) { y += x[k] * fir[k]; S.drv_x[i][k] = x[k]; }
+        const double vel = wv::div_rn(wv::mul_rn((double)y, scale), PI);
+        S.drv_pos[i] = pos; S.drv_vel[i] = vel;
+        if (write_meas) {
+            meas[CM_MEAS_DRIVE_POS + i] = pos; meas[CM_MEAS_DRIVE_VEL + i] = vel;
+            meas[CM_MEAS_DRIVE_TORQUE + i] = wv::mul_rn(ctrl_i, ratio);
+        }
     } else if (lane < CM_NUM_DRIVES + CM_NUM_JOINTS) {
         /* joint_encoder(): IIR on the quantised position (reference :596-635) */
         const int j = lane - CM_NUM_DRIVES, slot = joint_sensor_slot(j), bits = m->sensor_bits[slot];
@@ -882,8 +924,8 @@ WV_DEVICE void drive_level_io(const PhysIO &io, SH &S, ModelPtr m, int env, int 
         const double pos = wv::mul_rn((double)ev, scale);
         double x[CM_JOINT_FILTER_NB], yv[CM_JOINT_FILTER_NA];
         bool allzero = true;
-        for (int k = 0; k < CM_JOINT_FILTER_NB; ++k) { x[k] = ds->joint_x[j][k]; allzero &= x[k] == 0; }
-        for (int k = 0; k < CM_JOINT_FILTER_NA; ++k) yv[k] = ds->joint_y[j][k];
+        for (int k = 0; k < CM_JOINT_FILTER_NB; ++k) { x[k] = S.drv_jx[j][k]; allzero &= x[k] == 0; }
+        for (int k = 0; k < CM_JOINT_FILTER_NA; ++k) yv[k] = S.drv_jy[j][k];
         if (allzero) for (int k = 0; k < CM_JOINT_FILTER_NB; ++k) x[k] = pos;
         for (int k = CM_JOINT_FILTER_NB - 1; k > 0; --k) x[k] = x[k - 1];
         x[0] = pos;
@@ -893,18 +935,22 @@ WV_DEVICE void drive_level_io(const PhysIO &io, SH &S, ModelPtr m, int env, int 
         for (int k = 0; k < CM_JOINT_FILTER_NB; ++k) y0 = wv::add_rn(y0, wv::mul_rn(x[k], fb[k]));
         for (int k = 1; k < CM_JOINT_FILTER_NA; ++k) y0 = wv::sub_rn(y0, wv::mul_rn(yv[k], fa[k]));
         yv[0] = y0;
-        for (int k = 0; k < CM_JOINT_FILTER_NB; ++k) ds->joint_x[j][k] = x[k];
-        for (int k = 0; k < CM_JOINT_FILTER_NA; ++k) ds->joint_y[j][k] = yv[k];
-        meas[CM_MEAS_JOINT_POS + j] = pos;
-        meas[CM_MEAS_JOINT_VEL + j] = y0;
+        for (int k = 0; k < CM_JOINT_FILTER_NB; ++k) S.drv_jx[j][k] = x[k];
+        for (int k = 0; k < CM_JOINT_FILTER_NA; ++k) S.drv_jy[j][k] = yv[k];
+        if (write_meas) { meas[CM_MEAS_JOINT_POS + j] = pos; meas[CM_MEAS_JOINT_VEL + j] = y0; }
     } else if (lane < 29) {
         /* IMU words: orientation, angular velocity, linear acceleration, magnetic field (reference :769-773) */
-        meas[CM_MEAS_ORIENTATION + (lane - 16)] = S.sens[lane];
+        if (write_meas) meas[CM_MEAS_ORIENTATION + (lane - 16)] = S.sens[lane];
     }
 }
 
 /* ======================================================== the env step ==== */
-template <int NVP, class TOPO>
+/* FEAT selects the collision code a model needs, so that the instantiation for plain cassie.xml does not carry the
+ * register pressure of paths it never takes: FEAT_HFIELD = height-field pairs, FEAT_WAVEPAIRS = plane-box / box-box
+ * pairs handled by the whole wave.  The launcher picks the instantiation from the model (phys_batch.hip). */
+enum { FEAT_HFIELD = 1, FEAT_WAVEPAIRS = 2, FEAT_ALL = 3 };
+
+template <int NVP, class TOPO, int FEAT>
 WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
     const ModelPtr m_launch = (ModelPtr)(io.models + (size_t)env * io.model_stride);
     ModelPtr m = m_launch;
@@ -924,6 +970,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
         /* what the last step (or forward) of an earlier launch measured: the inputs of this launch's first drive-level pass */
         if (lane < m->nsensordata) S.sens[lane] = io.sensordata[(size_t)env * io.ssd + lane];
         if (lane < nu) S.actvel[lane] = io.actuator_velocity[(size_t)env * io.su + lane];
+        drive_state_load(io, S, env, lane);
     }
     double time = io.time[env];
 
@@ -980,8 +1027,12 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
             if (lane < nv) { double v = S.qvel[lane]; badv |= !(v == v) || fabs(v) > 1e10; }
             if (wv::ballot(badv) != 0ull) { warn |= WARN_DIVERGED; break; }
         }
+#ifdef CK_NO_DRIVE
+        if (false) {
+#else
         if (io.drive_mode) {
-            if (io.integrate) drive_level_io(io, S, m, env, lane); /* mj_forward leaves the drive-level state alone */
+#endif
+            if (io.integrate) drive_level_io(io, S, m, env, lane, lastsub); /* mj_forward leaves the drive-level state alone */
             wv::sync();
         } else if (io.pd_ptarget) {
             if (lane < nu) {
@@ -1338,10 +1389,10 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
          * under the samples run side by side instead of one after the other in the pair's lane; the lanes of a pair then
          * apply the capsule rule (oracle hfield_capsule) to the samples' results, and the pair loop below picks the
          * result up from the pair's first lane. */
-        const bool hf_spread = env_hfield != nullptr && m->nhfpair > 0 && m->nhfpair <= CM_MAXHFPAIR;
+        const bool hf_spread = (FEAT & FEAT_HFIELD) != 0 && env_hfield != nullptr && m->nhfpair > 0 && m->nhfpair <= CM_MAXHFPAIR;
         int hf_n = 0;
         RawContact hf0, hf1;
-        if (hf_spread) {
+        if constexpr ((FEAT & FEAT_HFIELD) != 0) if (hf_spread) {
             const int h = lane / CM_HF_SLOTS, k = lane % CM_HF_SLOTS;
             const bool act = h < m->nhfpair;
             const int p = m->hfpair[act ? h : 0];
@@ -1406,7 +1457,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
             int n = 0;
             RawContact rc0, rc1;
             bool from_spread = false;
-            if (hf_spread) {
+            if constexpr ((FEAT & FEAT_HFIELD) != 0) if (hf_spread) {
                 /* height-field pairs take their result from the first lane of their pair in the pre-pass */
                 const int slot = p < npass ? m->pair_hfslot[p] : -1;
                 const int src = slot >= 0 ? slot * CM_HF_SLOTS : lane;
@@ -1464,9 +1515,9 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
                         double q1[3] = {p1[0] + a1[0] * x1, p1[1] + a1[1] * x1, p1[2] + a1[2] * x1};
                         double q2[3] = {p2[0] + a2[0] * x2, p2[1] + a2[1] * x2, p2[2] + a2[2] * x2};
                         n = sphere_sphere(rc0, q1, s10, q2, s20, margin);
-                    } else if (t1 == CM_GEOM_HFIELD && t2 == CM_GEOM_SPHERE) {
+                    } else if ((FEAT & FEAT_HFIELD) != 0 && t1 == CM_GEOM_HFIELD && t2 == CM_GEOM_SPHERE) {
                         n = hfield_sphere(rc0, m, env_hfield, p1, m1, p2, s20, margin);
-                    } else if (t1 == CM_GEOM_HFIELD && t2 == CM_GEOM_CAPSULE) {
+                    } else if ((FEAT & FEAT_HFIELD) != 0 && t1 == CM_GEOM_HFIELD && t2 == CM_GEOM_CAPSULE) {
                         /* the two end spheres as against a plane, plus interior sample spheres no further apart than a grid
                          * cell; an interior sample that is deeper than both ends replaces the shallower end (same rule and
                          * order as the oracle's hfield_capsule) */
@@ -1519,7 +1570,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
         }
         CK_STAMP(22);
         /* pass 2, one pair at a time with the whole wave: lane = feature (box corner / vertex), first four hits kept */
-        for (int p = m->npair_simple; p < m->npair; ++p) {
+        if constexpr ((FEAT & FEAT_WAVEPAIRS) != 0) for (int p = m->npair_simple; p < m->npair; ++p) {
             const int g1 = m->pair_geom1[p], g2 = m->pair_geom2[p], tt = m->pair_type[p];
             const int t1 = tt & 255, t2 = tt >> 8;
             const double margin = m->pair_margin[p];
@@ -1679,15 +1730,16 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
                 S.qfrc_smooth[k_] = f;
             }
         }
+#ifndef CK_NO_XFRC
         if (io.xfrc_applied) {
-            /* Cartesian perturbations: [force, torque] at the body's inertial origin */
-            for (int e = lane; e < nbody * 6; e += WV_WAVE) S.x.s.xfrc[e / 6][e % 6] = io.xfrc_applied[((size_t)env * io.sb) * 6 + e];
-            wv::sync();
+            /* Cartesian perturbations: [force, torque] at the body's inertial origin, read straight from HBM (wave-uniform
+             * addresses; the perturbation API is not a hot path and its 1.5 KB tile is better spent elsewhere) */
             if (isdof) {
+                const double *xfa = io.xfrc_applied + ((size_t)env * io.sb) * 6;
                 double f = 0;
                 for (int bb = 1; bb < nbody; ++bb) {
                     if (!((m->body_dofmask[bb] >> k_) & 1ull)) continue;
-                    const double *xf = S.x.s.xfrc[bb];
+                    const double xf[6] = {xfa[bb * 6], xfa[bb * 6 + 1], xfa[bb * 6 + 2], xfa[bb * 6 + 3], xfa[bb * 6 + 4], xfa[bb * 6 + 5]};
                     if (xf[0] == 0 && xf[1] == 0 && xf[2] == 0 && xf[3] == 0 && xf[4] == 0 && xf[5] == 0) continue;
                     const double *c = S.com[m->body_rootid[bb]];
                     double off[3] = {S.x.s.xipos[bb][0] - c[0], S.x.s.xipos[bb][1] - c[1], S.x.s.xipos[bb][2] - c[2]};
@@ -1699,6 +1751,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
                 S.qfrc_smooth[k_] += f;
             }
         }
+#endif
         wv::sync();
         CK_STAMP(7);
 
@@ -2301,6 +2354,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
     }
 
     /* ---------------- store state ---------------- */
+    if (io.integrate && io.drive_mode) drive_state_store(io, S, env, lane);
     if (io.integrate) {
         if (lane < nq) io.qpos[(size_t)env * io.sq + lane] = S.qpos[lane];
         if (lane < nv) {
@@ -2318,14 +2372,14 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
 }
 
 /* one single-wave workgroup per environment */
-template <int NVP, class TOPO>
+template <int NVP, class TOPO, int FEAT = FEAT_ALL>
 WV_GLOBAL void __launch_bounds__(WV_WAVE) WV_OCC cassie_step_kernel(PhysIO io) {
     WV_SHARED EnvShared<NVP> S;
     const int slot = wv::env_id();
     if (slot >= io.nenv) return;
     const int env = io.order ? io.order[slot] : slot;
     const long long t0 = io.cost ? wv::clock() : 0;
-    env_step<NVP, TOPO>(io, S, env);
+    env_step<NVP, TOPO, FEAT>(io, S, env);
     if (io.cost && wv::lane() == 0) io.cost[env] = (unsigned)((wv::clock() - t0) >> 6); /* 64-clock units: 32 bits hold minutes */
 }
 
@@ -2362,7 +2416,13 @@ WV_GLOBAL void __launch_bounds__(ORDER_THREADS) cassie_order_kernel(const unsign
  * sensordata / actuator_velocity the last physics step left in HBM; writes ctrl (for the next physics launch), the
  * measurement block and the drive state.  The batched host API launches it ahead of the physics kernel so that the
  * measurements reach the host -- and the state estimators start -- while the physics is still running. */
-struct DriveShared { double sens[CM_MAXSENSORDATA], actvel[CM_MAXU], ctrl[CM_MAXU]; };
+struct DriveShared {
+    double sens[CM_MAXSENSORDATA], actvel[CM_MAXU], ctrl[CM_MAXU];
+    int drv_x[CM_NUM_DRIVES][CM_DRIVE_FILTER_NB];
+    double drv_jx[CM_NUM_JOINTS][CM_JOINT_FILTER_NB], drv_jy[CM_NUM_JOINTS][CM_JOINT_FILTER_NA];
+    double drv_delay[CM_NUM_DRIVES][CM_TORQUE_DELAY_CYCLES];
+    double drv_pos[CM_NUM_DRIVES], drv_vel[CM_NUM_DRIVES];
+};
 
 WV_GLOBAL void __launch_bounds__(WV_WAVE) cassie_drive_kernel(PhysIO io, double *ctrl_out) {
     WV_SHARED DriveShared S;
@@ -2372,9 +2432,11 @@ WV_GLOBAL void __launch_bounds__(WV_WAVE) cassie_drive_kernel(PhysIO io, double 
     const int lane = wv::lane(), nu = m->nu;
     if (lane < m->nsensordata) S.sens[lane] = io.sensordata[(size_t)env * io.ssd + lane];
     if (lane < nu) S.actvel[lane] = io.actuator_velocity[(size_t)env * io.su + lane];
+    drive_state_load(io, S, env, lane);
     wv::sync();
-    drive_level_io(io, S, m, env, lane);
+    drive_level_io(io, S, m, env, lane, true);
     wv::sync();
+    drive_state_store(io, S, env, lane);
     if (lane < nu) ctrl_out[(size_t)env * io.su + lane] = S.ctrl[lane];
 }
 

@@ -1,0 +1,17 @@
+# PMC passes of the bench's dominant kernel (separate --pmc runs with --kernel-trace only, as gpurun requires), then
+# tools/pmc_summary.py reduces the CSVs to gpurun_out/pmc_summary.json.  MODE=exact-pd|drive-pd (default drive-pd).
+mkdir -p gpurun_out/pmc; cd /tmp; export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+CMD="python $R/bench.py --mode ${MODE:-drive-pd} --steps 100 --warmup 50 --no-cpu-baseline --no-step-pd --no-other-mode --parity-envs 4"
+i=0
+for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU" \
+           "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_IFETCH SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS" \
+           "FETCH_SIZE" "WRITE_SIZE" \
+           "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_INSTS_FLAT SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA" \
+           "SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM" "SQ_INST_LEVEL_LDS"; do
+  i=$((i+1))
+  timeout 600 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $R/gpurun_out/pmc/p$i -- $CMD > $R/gpurun_out/pmc/p$i.log 2>&1
+done
+cd $R
+python tools/pmc_summary.py gpurun_out/pmc > gpurun_out/pmc_summary.json
+cat gpurun_out/pmc_summary.json | head -70
