@@ -1907,8 +1907,15 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
                 if (TOPO::is_static ? k < TOPO::nv : k < nv) {
                     if (rtype >= 0) {
                         const double ul = u3[0] * cc[kk][3] + u3[1] * cc[kk][4] + u3[2] * cc[kk][5];
+#ifndef CK_J_BRANCHY
+                        /* the two body-chain predicates applied by multiplication (exact: the factors are 0.0 / 1.0) */
+                        const double sp = bitf(maskp, k), sm = bitf(maskm, k);
+                        v = sp * (ul + wp[0] * cc[kk][0] + wp[1] * cc[kk][1] + wp[2] * cc[kk][2]) -
+                            sm * (ul + wm[0] * cc[kk][0] + wm[1] * cc[kk][1] + wm[2] * cc[kk][2]);
+#else
                         if ((maskp >> k) & 1ull) v += ul + wp[0] * cc[kk][0] + wp[1] * cc[kk][1] + wp[2] * cc[kk][2];
                         if ((maskm >> k) & 1ull) v -= ul + wm[0] * cc[kk][0] + wm[1] * cc[kk][1] + wm[2] * cc[kk][2];
+#endif
                         if (k == limdof) v = limsgn;
                         jvel += v * qv[kk];
                         jws += v * qw[kk];
