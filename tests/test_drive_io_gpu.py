@@ -169,3 +169,46 @@ def test_batched_step_pd_with_device_drives_equals_host_drives(built):
     assert outs[0].tobytes() == outs[1].tobytes()
     assert outs[0].tobytes() == outs[2].tobytes()
     assert np.all(np.isfinite(outs[0]))
+
+
+def test_batched_step_and_step_ethercat_with_device_drives(built):
+    """cassie_batch_step (cassie_user_in_t) and cassie_batch_step_ethercat (cassie_in_t) with the drive-level models on the
+    device return the same cassie_out_t bytes as with the models on the host threads."""
+    import os
+    L = lib()
+    VP = ctypes.c_void_p
+    L.cassie_batch_create.restype = VP
+    L.cassie_batch_create.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    L.cassie_batch_free.argtypes = [VP]
+    L.cassie_batch_step.argtypes = [VP, VP, VP]
+    L.cassie_batch_step_ethercat.argtypes = [VP, VP, VP]
+    L.cassie_batch_set_device_drives.argtypes = [VP, ctypes.c_int]
+    model = os.path.join(REPO_DIR, "models", "cassie.cmodel").encode()
+    n = 16
+    rng = np.random.default_rng(11)
+    for fn, utype, field in ((L.cassie_batch_step, T.cassie_user_in_t, "torque"), (L.cassie_batch_step_ethercat, T.cassie_in_t, None)):
+        outs = []
+        cmds = rng.uniform(-1, 1, (6, n, 10)) * LIMIT * 0.3
+        for device in (0, 1):
+            bt = L.cassie_batch_create(model, n, 0, 4)
+            assert bt and L.cassie_batch_set_device_drives(bt, device) == 0
+            us = (utype * n)()
+            ys = (T.cassie_out_t * n)()
+            traj = []
+            for s in range(150):
+                if s % 25 == 0:
+                    for e in range(n):
+                        c = cmds[s // 25][e]
+                        if field:
+                            for i in range(10):
+                                us[e].torque[i] = c[i]
+                        else:
+                            legs = [us[e].leftLeg, us[e].rightLeg]
+                            for i in range(10):
+                                leg = legs[i // 5]
+                                [leg.hipRollDrive, leg.hipYawDrive, leg.hipPitchDrive, leg.kneeDrive, leg.footDrive][i % 5].torque = c[i]
+                assert fn(bt, ctypes.byref(us), ctypes.byref(ys)) == 0
+                traj.append(bytes(ys))
+            L.cassie_batch_free(bt)
+            outs.append(traj)
+        assert outs[0] == outs[1]
