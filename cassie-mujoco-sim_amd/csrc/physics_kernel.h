@@ -675,8 +675,17 @@ WV_DEVICE void factor_pair_in_registers(ModelPtr m, double h, double (&col)[NVP]
  * reads per ancestor pair, no scalar registers, one LDS round trip per height instead of one per dof. */
 template <int NVP, class TOPO, class SH>
 WV_DEVICE void factor_pair_by_height(ModelPtr m, double h, SH &S, double (&col)[NVP], double (&colh)[NVP], int lane) {
+    /* The trunk dofs (the floating base: each one's ancestors are all the lower ones) come last and one to a height: a
+     * round through LDS for a single dof is all latency.  They are eliminated in registers instead (below), with
+     * v_readlane multipliers whose round trips overlap, so the height rounds stop where the trunk begins. */
+#ifndef CK_TRUNK_BY_HEIGHT
+    constexpr int first_trunk_height = TOPO::height[TOPO::trunk - 1];
+#else
+    constexpr int first_trunk_height = TOPO::nheight;
+#endif
 #pragma unroll
     for (int s = 0; s < TOPO::nheight; ++s) {
+        if (s >= first_trunk_height) continue;
 #pragma unroll
         for (int k = NVP - 1; k >= 0; --k) {
             if (TOPO::height[k] != s) continue;
@@ -711,6 +720,23 @@ WV_DEVICE void factor_pair_by_height(ModelPtr m, double h, SH &S, double (&col)[
             wv::sched_fence();
         }
     }
+#ifndef CK_TRUNK_BY_HEIGHT
+    /* trunk: same arithmetic (multiplier = entry * 1/D, rounded once; update = one FMA), multipliers by v_readlane */
+#pragma unroll
+    for (int k = TOPO::trunk - 1; k >= 0; --k) {
+        const double arm = m->dof_armature[k];
+        const double inv = fast_rcp(wv::readlane(col[k], k) + arm), invh = fast_rcp(wv::readlane(colh[k], k) + (arm + h * m->dof_damping[k]));
+        S.dinv[k] = inv; S.dinvH[k] = invh;
+        const int at = CK_TRI(k, 0) + (lane < k ? lane : k);
+        S.Lp[at] = col[k] * inv;
+        S.LHp[at] = colh[k] * invh;
+        double t[TOPO::trunk], th[TOPO::trunk];
+#pragma unroll
+        for (int i = k - 1; i >= 0; --i) { t[i] = wv::readlane(col[k], i) * inv; th[i] = wv::readlane(colh[k], i) * invh; }
+#pragma unroll
+        for (int i = k - 1; i >= 0; --i) { col[i] -= t[i] * col[k]; colh[i] -= th[i] * colh[k]; }
+    }
+#endif
     wv::sync();
     if (lane < TOPO::nv) S.rsd[lane] = sqrt(S.dinv[lane]);
 }
