@@ -233,3 +233,44 @@ def test_mass_matrix_against_kinetic_energy_of_the_bodies(cassie):
         I = ximat[b] @ np.diag(p.body_inertia[b][:3]) @ ximat[b].T
         ke += 0.5 * p.body_mass[b] * vl @ vl + 0.5 * w @ I @ w
     assert abs(ke - ke_M) < 1e-10 * max(1.0, ke)
+
+
+def test_yaw_equivariance_of_a_step_on_the_flat_floor(cassie):
+    """Physics on a horizontal floor does not care about heading: turn the whole robot (pose and base velocity) about the
+    vertical axis by psi and one step later everything is the un-turned result turned by psi -- joint angles identical,
+    pelvis position rotated, contact forces rotated.  Checks the frame conventions of kinematics, Jacobians, contact
+    frames and the quaternion integration against each other."""
+    pod = _tight(cassie.pod)                     # to convergence: Gauss-Seidel iterates depend on the basis the loop-closure
+    rng = np.random.default_rng(6)               # rows are written in (world x, y, z), the solution does not
+    base = _standing(cassie, 300)
+    q0, v0 = base.qpos.copy(), base.qvel.copy()
+    v0 += 0.05 * rng.standard_normal(pod.nv)
+    ctrl = base.ctrl.copy()
+    psi = 0.7
+    c, s = np.cos(psi), np.sin(psi)
+    Rz = np.array([[c, -s, 0], [s, c, 0], [0, 0, 1]])
+
+    def quat_mul(a, b):
+        return np.array([a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3], a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2],
+                         a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1], a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0]])
+    qz = np.array([np.cos(psi / 2), 0, 0, np.sin(psi / 2)])
+    q1, v1 = q0.copy(), v0.copy()
+    q1[0:3] = Rz @ q0[0:3]
+    q1[3:7] = quat_mul(qz, q0[3:7])
+    v1[0:3] = Rz @ v0[0:3]                       # the pelvis slides are world axes; its angular velocity is body-fixed
+    outs = []
+    for q, v in ((q0, v0), (q1, v1)):
+        o = Oracle(pod, q)
+        o.qvel[:] = v
+        o.ctrl[:] = ctrl
+        o.qacc_warmstart[:] = 0
+        o.step()
+        outs.append((o.qpos.copy(), o.qvel.copy(), _contact_world_forces(o).sum(0), o.d.ncon, o.sensordata.copy()))
+    (qa, va, fa, na, sa), (qb, vb, fb, nb, sb) = outs
+    assert na == nb and na >= 2
+    assert np.allclose(qb[7:], qa[7:], atol=1e-11) and np.allclose(vb[6:], va[6:], atol=1e-8)      # joints do not notice
+    assert np.allclose(qb[0:3], Rz @ qa[0:3], atol=1e-11) and np.allclose(vb[0:3], Rz @ va[0:3], atol=1e-8)
+    assert np.allclose(vb[3:6], va[3:6], atol=1e-8)
+    assert np.allclose(qb[3:7], quat_mul(qz, qa[3:7]), atol=1e-11) or np.allclose(qb[3:7], -quat_mul(qz, qa[3:7]), atol=1e-11)
+    assert np.allclose(fb, Rz @ fa, rtol=1e-7, atol=1e-6) and fa[2] > 100
+    assert np.allclose(sb[:16], sa[:16], atol=1e-11) and np.allclose(sb[20:26], sa[20:26], atol=1e-8)   # encoders, gyro, accelerometer: body-fixed
