@@ -992,6 +992,10 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
         S.qacc_ws[lane] = io.qacc_warmstart[(size_t)env * io.sv + lane];
     }
     if (lane < nu) S.ctrl[lane] = io.ctrl[(size_t)env * io.su + lane];
+    /* centres of mass are computed for tree roots only, but rows of the static world (body 0: the floor's side of every
+     * contact) are read too -- multiplied by an empty dof mask, which is harmless only if the value is finite.  LDS is
+     * not initialised: give every row a value once per launch. */
+    if (lane < NB) { S.com[lane][0] = 0.0; S.com[lane][1] = 0.0; S.com[lane][2] = 0.0; }
     if (io.drive_mode) {
         /* what the last step (or forward) of an earlier launch measured: the inputs of this launch's first drive-level pass */
         if (lane < m->nsensordata) S.sens[lane] = io.sensordata[(size_t)env * io.ssd + lane];
@@ -2410,6 +2414,16 @@ WV_GLOBAL void __launch_bounds__(WV_WAVE) WV_OCC cassie_step_kernel(PhysIO io) {
     WV_SHARED EnvShared<NVP> S;
     const int slot = wv::env_id();
     if (slot >= io.nenv) return;
+#ifdef CK_EMULATED
+    /* test hook: LDS is not initialised on the device; fill it with NaN patterns so that a read-before-write shows */
+    if (wv::g_poison_lds) {
+        if (wv::lane() == 0) {
+            const size_t lo = wv::g_poison_lo < sizeof S ? wv::g_poison_lo : sizeof S, hi = wv::g_poison_hi < sizeof S ? wv::g_poison_hi : sizeof S;
+            if (hi > lo) memset((char *)&S + lo, 0xff, hi - lo);
+        }
+        wv::sync();
+    }
+#endif
     const int env = io.order ? io.order[slot] : slot;
     const long long t0 = io.cost ? wv::clock() : 0;
     env_step<NVP, TOPO, FEAT>(io, S, env);

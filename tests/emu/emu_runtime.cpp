@@ -111,6 +111,8 @@ unsigned long long ballot(bool p) {
     return m;
 }
 int g_force_guarded = 0;
+int g_poison_lds = 0;
+unsigned long g_poison_lo = 0, g_poison_hi = ~0ul;
 double wave_sum(double v) { /* same association order as the device's DPP reduction (csrc/wave.h) */
     const int l = lane(), row = l >> 4;
     v += shfl(v, l ^ 1);
@@ -135,6 +137,17 @@ float wave_sum_f32(float v) { /* same tree in single precision */
 
 static ck::PhysIO g_io;
 extern "C" void emu_force_guarded_pgs(int on) { wv::g_force_guarded = on; }
+extern "C" void emu_poison_lds(int on) { wv::g_poison_lds = on; }
+extern "C" void emu_poison_range(unsigned long lo, unsigned long hi) { wv::g_poison_lo = lo; wv::g_poison_hi = hi; }
+extern "C" unsigned long emu_offsetof32(int which) {
+    typedef ck::EnvShared<32> E;
+    switch (which) {
+    case 0: return offsetof(E, x); case 1: return offsetof(E, Lp); case 2: return offsetof(E, LHp); case 3: return offsetof(E, accel);
+    case 4: return offsetof(E, dinv); case 5: return offsetof(E, cdof); case 6: return offsetof(E, com); case 7: return offsetof(E, qpos);
+    case 8: return offsetof(E, qfrc_smooth); case 9: return offsetof(E, sens); case 10: return offsetof(E, drv_x); case 11: return offsetof(E, c_dist);
+    case 12: return offsetof(E, c_dim); case 13: return offsetof(E, c_root); case 14: return offsetof(E, c_tran); default: return sizeof(E);
+    }
+}
 static int g_force_runtime_topology = 0;
 static void body32s() { ck::cassie_step_kernel<32, ck::TopoCassie32>(g_io); }
 static void body40s() { ck::cassie_step_kernel<40, ck::TopoCassieTray38>(g_io); }

@@ -13,6 +13,7 @@
 #include <cmath>
 #include <cstddef>
 #include <cstdint>
+#include <cstring>
 
 #define CK_EMULATED 1
 #define WV_DEVICE inline
@@ -39,6 +40,8 @@ inline long long clock() { return 0; }
 inline int opaque(int x) { return x; }
 inline void sched_fence() {}
 extern int g_force_guarded;
+extern int g_poison_lds;
+extern unsigned long g_poison_lo, g_poison_hi;
 inline bool debug_force_guarded() { return g_force_guarded != 0; }
 inline int fresh_lane() { return lane(); }
 template <class P> inline P opaque_ptr(P p) { return p; }

@@ -60,7 +60,7 @@ def _pd_rollout(model, n, sample, nsteps=1000, hfield=None, q0_of=None, generic=
             qo = np.array([oracle_py.arr(buf[i].qpos)[: pod.nq] for i in range(len(sample))])
             cnt = np.array([(buf[i].ncon, buf[i].nefc, buf[i].solver_iter) for i in range(len(sample))])
             bad = np.nonzero(np.any(info[sample][:, :3] != cnt, axis=1))[0]
-            assert bad.size == 0, (p, sample[bad][:5], info[sample][bad][:5], cnt[bad][:5])
+            assert bad.size == 0, (p, sample[bad][:8].tolist(), info[sample][bad][:8].tolist(), cnt[bad][:8].tolist(), w[sample][bad][:8].tolist())
             worst = max(worst, float(np.max(np.abs(q[sample] - qo) / np.maximum(1.0, np.abs(qo)))))
             rows_seen = max(rows_seen, int(cnt[:, 1].max()))
             assert worst <= REL_TOL, (p, worst)

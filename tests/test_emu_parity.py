@@ -204,3 +204,71 @@ def test_contact_and_row_caps_drop_the_same_rows_as_the_oracle(cassie):
             seen |= want
             assert np.max(np.abs(emu.qpos[0] - o.qpos)) < 1e-8, s
         assert seen & want_bits == want_bits
+
+
+def test_kernel_never_reads_lds_it_has_not_written(cassie):
+    """LDS is not initialised on the device: whatever a previous kernel left there -- possibly NaN bit patterns on a fresh
+    box -- must not reach the results.  The emulator fills the whole EnvShared block with 0xff bytes (NaNs) at the start of
+    every launch; trajectories through free fall, first contacts and standing must be identical to the un-poisoned run.
+    (Round 2 regression: the centre-of-mass row of the static world body was read -- under an all-zero mask, by
+    multiplication -- without ever being written.)"""
+    import bench
+    import emu_py
+    pod = cassie.pod
+    out = []
+    for poison in (0, 1):
+        emu_py.lib().emu_poison_lds(poison)
+        try:
+            emu = EmuBatch(pod, 2)
+            emu.qpos[:] = cassie.qpos_init()
+            emu.qpos[1, 2] -= 0.02
+            emu.pd_kp, emu.pd_kd = np.tile(bench.PD_KP, (2, 1)), np.tile(bench.PD_KD, (2, 1))
+            emu.pd_ptarget = np.ascontiguousarray(bench.pd_targets([3, 4], 1)[0])
+            emu.step(50)
+            emu.step(1)
+            emu.step(40)
+            out.append((emu.qpos.copy(), emu.qvel.copy(), emu.sensordata.copy(), emu.warn.copy(), emu.info.copy()))
+        finally:
+            emu_py.lib().emu_poison_lds(0)
+    assert not out[1][3].any() and out[1][4][:, 0].max() >= 1          # no divergence flag, contacts happened
+    for a, b in zip(out[0], out[1]):
+        assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("name,steps,drive", [("cassie_tray_box", 260, False), ("cassie_hfield", 120, False), ("cassie", 90, True)])
+def test_lds_poison_on_the_other_models_and_modes(name, steps, drive, built):
+    """Same check for the 40-dof instantiation with box pairs (the cube lands on the tray), the height-field pre-pass and
+    the drive-level mode."""
+    import bench
+    import emu_py
+    from cassie_amd import Model
+    from cassie_amd import phys as P
+    model = Model(name)
+    pod = model.pod
+    hf = None
+    if name == "cassie_hfield":
+        hf = np.random.default_rng(99).random((200, 200)).astype(np.float32).ravel()
+    out = []
+    for poison in (0, 1):
+        emu_py.lib().emu_poison_lds(poison)
+        try:
+            emu = EmuBatch(pod, 1)
+            emu.qpos[:] = model.qpos_init()
+            if hf is not None:
+                emu.hfield = hf
+                emu.qpos[0, 0] = 0.6
+            if name == "cassie_tray_box":
+                emu.qpos[0, 37] = 1.20                      # the cube starts just above the tray
+            emu.pd_kp, emu.pd_kd = np.tile(bench.PD_KP, (1, 1)), np.tile(bench.PD_KD, (1, 1))
+            emu.pd_ptarget = np.ascontiguousarray(bench.pd_targets([5], 1)[0])
+            if drive:
+                emu.forward()
+                emu.drive_mode = P.DRIVE_PD
+            for _ in range(steps // 10):
+                emu.step(10)
+            out.append((emu.qpos.copy(), emu.qvel.copy(), emu.sensordata.copy(), emu.meas.copy(), emu.warn.copy(), emu.info.copy()))
+        finally:
+            emu_py.lib().emu_poison_lds(0)
+    assert not out[1][4].any() and out[1][5][0, 0] >= 1
+    for a, b in zip(out[0], out[1]):
+        assert np.array_equal(a, b)
