@@ -214,6 +214,11 @@ class Batch:
         """Longest-job-first launch order from the previous launch's per-env cost (default on for >= 2048 envs)."""
         lib().phys_batch_set_balance(self._h, 1 if on else 0)
 
+    def poison_lds(self):
+        """Validation aid: NaN bit patterns into every CU's LDS before the next launch."""
+        if lib().phys_batch_debug_poison_lds(self._h) != 0:
+            raise RuntimeError("poison failed")
+
     def set_generic_kernel(self, on=True):
         """Validation aid: use the run-time-topology instantiation of the step kernel."""
         lib().phys_batch_set_generic_kernel(self._h, 1 if on else 0)

@@ -551,6 +551,21 @@ int phys_batch_set_balance(phys_batch_t *b, int on) {
     return 0;
 }
 
+/* validation aid: fills the LDS of every CU with NaN bit patterns (LDS is not cleared between kernels), so that a step
+ * kernel that reads LDS it has not written shows up in the results on any box, not only on a freshly booted one */
+__global__ void __launch_bounds__(64) cassie_poison_lds_kernel(int *sink) {
+    __shared__ unsigned long long blob[4975];   /* 39 800 B: the step kernel's footprint, so four of these fill a CU */
+    for (int i = threadIdx.x; i < 4975; i += 64) blob[i] = 0xffffffffffffffffull;
+    __syncthreads();
+    if (sink && blob[(threadIdx.x * 77) % 4975] == 1ull) sink[0] = 1; /* keeps the stores alive */
+}
+int phys_batch_debug_poison_lds(phys_batch_t *b) {
+    if (!b) return -1;
+    (void)hipSetDevice(b->device);
+    hipLaunchKernelGGL(cassie_poison_lds_kernel, dim3(8192), dim3(64), 0, b->stream, b->d_warn + 0 * 0 == nullptr ? nullptr : (int *)nullptr);
+    return hip_ok(hipGetLastError(), "poison launch") && hip_ok(hipStreamSynchronize(b->stream), "poison sync") ? 0 : -1;
+}
+
 int phys_batch_set_generic_kernel(phys_batch_t *b, int on) {
     if (!b) return -1;
     b->generic_kernel = on != 0;

@@ -995,7 +995,9 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
     /* centres of mass are computed for tree roots only, but rows of the static world (body 0: the floor's side of every
      * contact) are read too -- multiplied by an empty dof mask, which is harmless only if the value is finite.  LDS is
      * not initialised: give every row a value once per launch. */
+#ifndef CK_NO_COM_INIT /* (test knob: reinstates the round-2 bug so the poison checks can be seen to catch it) */
     if (lane < NB) { S.com[lane][0] = 0.0; S.com[lane][1] = 0.0; S.com[lane][2] = 0.0; }
+#endif
     if (io.drive_mode) {
         /* what the last step (or forward) of an earlier launch measured: the inputs of this launch's first drive-level pass */
         if (lane < m->nsensordata) S.sens[lane] = io.sensordata[(size_t)env * io.ssd + lane];

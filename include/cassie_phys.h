@@ -169,6 +169,10 @@ int phys_batch_derive(phys_batch_t *b, const int ids[6], void *stream);
  * for whichever slot drew the slow envs last.  Results do not depend on it (envs are independent). */
 int phys_batch_set_balance(phys_batch_t *b, int on);
 
+/* validation aid: fills every CU's LDS with NaN bit patterns before the next launch (LDS is neither initialised nor
+ * cleared between kernels) -- a step kernel that read LDS it had not written would then show it */
+int phys_batch_debug_poison_lds(phys_batch_t *b);
+
 /* validation aid: run the generic instantiation of the step kernel (dof-tree topology read from the model at run
  * time) even when the model matches one of the compile-time-topology instantiations */
 int phys_batch_set_generic_kernel(phys_batch_t *b, int on);

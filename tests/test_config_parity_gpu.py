@@ -21,6 +21,10 @@ pytestmark = pytest.mark.gpu
 REL_TOL = 1e-7
 
 
+def cassie_model(name):
+    return Model(name)
+
+
 def _pd_rollout(model, n, sample, nsteps=1000, hfield=None, q0_of=None, generic=False):
     """n envs under the bench workload on the GPU (PD mode, HOLD fused substeps per launch); envs `sample` also on
     the oracle; returns the worst relative qpos error over all policy steps."""
@@ -211,3 +215,44 @@ def test_strided_observation_block(cassie):
     assert np.array_equal(b.get(P.F_QVEL, 3, 5), o[3:8, pod.nq: pod.nq + pod.nv])   # 2-D download of a row range
     dense.close()
     b.close()
+
+
+@pytest.mark.parametrize("name,mode", [("cassie", "exact"), ("cassie", "drive"), ("cassie_hfield", "drive"), ("cassie_tray_box", "exact")])
+def test_results_do_not_depend_on_what_lds_held_before(name, mode, built):
+    """LDS is neither initialised nor cleared between kernels.  Every launch of this rollout is preceded by a kernel that
+    fills the LDS of all CUs with NaN bit patterns; the trajectories must be bit for bit those of an undisturbed batch
+    (tests/test_emu_parity.py has the emulator twin that found a read of an unwritten row in round 2)."""
+    model = cassie_model(name)
+    pod = model.pod
+    n = 2048
+    tg = bench.pd_targets(np.arange(n), 6)
+    hfield = None
+    if name == "cassie_hfield":
+        hfield = np.random.default_rng(99).random((200, 200)).astype(np.float32)
+    out = []
+    for poison in (False, True):
+        b = Batch(model, n)
+        if hfield is not None:
+            b.set_hfield(hfield)
+        q0 = np.tile(model.qpos_init(), (n, 1))
+        q0[:, 0] = np.linspace(-1, 1, n) if hfield is not None else 0.0
+        b.set(P.F_QPOS, q0)
+        b.set(P.F_PD_KP, np.tile(bench.PD_KP, (n, 1)))
+        b.set(P.F_PD_KD, np.tile(bench.PD_KD, (n, 1)))
+        if mode == "drive":
+            b.forward()
+            b.set_drive_mode(P.DRIVE_PD)
+        else:
+            b.set_pd_mode(True)
+        for p in range(6):
+            b.set(P.F_PD_PTARGET, tg[p])
+            if poison:
+                b.poison_lds()
+            b.step(50)
+        w, info = b.warnings()
+        out.append((b.get(P.F_QPOS), b.get(P.F_QVEL), b.get(P.F_SENSORDATA), w, info))
+        b.close()
+    assert not out[1][3].any()
+    assert out[1][4][:, 0].max() >= 2
+    for a, c in zip(out[0], out[1]):
+        assert np.array_equal(a, c)
