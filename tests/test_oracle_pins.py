@@ -274,3 +274,150 @@ def test_yaw_equivariance_of_a_step_on_the_flat_floor(cassie):
     assert np.allclose(qb[3:7], quat_mul(qz, qa[3:7]), atol=1e-11) or np.allclose(qb[3:7], -quat_mul(qz, qa[3:7]), atol=1e-11)
     assert np.allclose(fb, Rz @ fa, rtol=1e-7, atol=1e-6) and fa[2] > 100
     assert np.allclose(sb[:16], sa[:16], atol=1e-11) and np.allclose(sb[20:26], sa[20:26], atol=1e-8)   # encoders, gyro, accelerometer: body-fixed
+
+
+def _perturbed(pod, q, k, eps):
+    """q moved by eps along dof k (tangent space: the oracle's own position integrator with a unit velocity)."""
+    import ctypes
+    from oracle_py import lib
+    L = lib()
+    L.co_integrate_pos.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double]
+    qq = np.ascontiguousarray(q, dtype=np.float64).copy()
+    v = np.zeros(pod.nv)
+    v[k] = 1.0
+    L.co_integrate_pos(ctypes.byref(pod), qq.ctypes.data, v.ctypes.data, eps)
+    return qq
+
+
+def test_jacobians_against_finite_differences_of_the_kinematics(cassie):
+    """P5: the point Jacobian of a body (co_jac, what every constraint row is built from) against central differences of
+    forward kinematics along every dof; and the equality rows of efc_J against differences of their own residuals."""
+    import ctypes
+    from oracle_py import lib
+    pod = cassie.pod
+    rng = np.random.default_rng(12)
+    q = cassie.qpos_init()
+    q[7:] += 0.1 * rng.standard_normal(pod.nq - 7)
+    q[3:7] = [0.9, 0.2, -0.3, 0.1]
+    o = Oracle(pod, q)
+    o.forward()                                       # (normalises the quaternions it uses internally)
+    foot = cassie.name2id(1, "left-foot")
+    point = o.xpos[foot].copy()
+    jp = ((ctypes.c_double * 40) * 3)()
+    jr = ((ctypes.c_double * 40) * 3)()
+    lib().co_jac(ctypes.byref(pod), ctypes.byref(o.d), foot, (ctypes.c_double * 3)(*point), jp, jr)
+    Jp = np.array(jp)[:, : pod.nv]
+    n_eq = o.d.ne
+    Jeq = arr(o.d.efc_J)[:n_eq, : pod.nv].copy()
+    eps = 1e-6
+    Jp_fd, Jeq_fd = np.zeros((3, pod.nv)), np.zeros((n_eq, pod.nv))
+    for k in range(pod.nv):
+        vals = []
+        for sgn in (1, -1):
+            t = Oracle(pod, _perturbed(pod, o.qpos, k, sgn * eps))
+            t.forward()
+            vals.append((t.xpos[foot].copy(), arr(t.d.efc_pos)[:n_eq].copy()))
+        Jp_fd[:, k] = (vals[0][0] - vals[1][0]) / (2 * eps)
+        Jeq_fd[:, k] = (vals[0][1] - vals[1][1]) / (2 * eps)
+    assert np.max(np.abs(Jp - Jp_fd)) < 1e-8
+    assert np.max(np.abs(Jeq - Jeq_fd)) < 1e-7 and np.abs(Jeq).max() > 0.1
+
+
+def test_bias_forces_against_lagranges_equations(cassie):
+    """P6: the RNE bias force c(q, v) (Coriolis, centrifugal, gravity) against Lagrange's equations evaluated with finite
+    differences of quantities that are pinned elsewhere -- the mass matrix (test above: bodies' kinetic energy) and the
+    potential energy from forward kinematics:  c_k = (dM/dt v)_k - 1/2 v^T (dM/dq_k) v + dV/dq_k.  That form holds for true
+    coordinates (hinges, slides); the body-fixed angular velocities of the pelvis and of the two ball joints are
+    quasi-velocities, so they are kept at zero and only hinge / slide rows are compared."""
+    pod = cassie.pod
+    rng = np.random.default_rng(13)
+    q = cassie.qpos_init()
+    q[7:] += 0.1 * rng.standard_normal(pod.nq - 7)
+    q[2] = 3.0                                        # in the air
+    true_dofs = [k for k in range(pod.nv) if pod.jnt_type[pod.dof_jntid[k]] in (2, 3)]      # slides and hinges
+    v = np.zeros(pod.nv)
+    v[true_dofs] = rng.uniform(-2, 2, len(true_dofs))
+    o = Oracle(pod, q)
+    o.qvel[:] = v
+    o.forward()
+    bias = arr(o.d.qfrc_bias)[: pod.nv].copy()
+    mass = np.array(pod.body_mass[: pod.nbody])
+
+    def M_and_V(qq):
+        t = Oracle(pod, qq)
+        t.forward()
+        return t.qM.copy(), 9.81 * float((mass * arr(t.d.xipos)[: pod.nbody, 2]).sum())
+    eps = 1e-6
+    dM, dV = {}, {}
+    for k in true_dofs:
+        Mp, Vp = M_and_V(_perturbed(pod, o.qpos, k, eps))
+        Mm, Vm = M_and_V(_perturbed(pod, o.qpos, k, -eps))
+        dM[k], dV[k] = (Mp - Mm) / (2 * eps), (Vp - Vm) / (2 * eps)
+    Mdot = sum(dM[j] * v[j] for j in true_dofs)
+    want = np.array([(Mdot @ v)[k] - 0.5 * v @ dM[k] @ v + dV[k] for k in true_dofs])
+    got = bias[true_dofs]
+    assert np.max(np.abs(got - want)) < 2e-6 * max(1.0, np.max(np.abs(want))), np.max(np.abs(got - want))
+    assert np.max(np.abs(want)) > 10                  # gravity and velocity terms are really there
+
+
+def test_imu_sensors_against_finite_differences_of_the_imu_site(cassie):
+    """P11: gyro = angular velocity of the IMU site in its own frame, accelerometer = its linear acceleration minus gravity
+    in its own frame -- against first / second differences of the site's pose over consecutive steps of a robot standing
+    under PD control (contacts, constraint forces and all)."""
+    from scipy.spatial.transform import Rotation as Rot
+    import bench
+    pod = cassie.pod
+    o = _standing(cassie, 250)
+    o.qvel[3:6] += [0.3, -0.2, 0.25]                  # make it rock a little
+    h = pod.timestep
+    imu = 0                                           # the only site with frame sensors on the pelvis
+    frames, readings = [], []
+    for _ in range(5):
+        o.pd_ctrl(bench.PD_OFFSET, bench.PD_KP, bench.PD_KD)
+        o.step()                                      # sensors of this step describe the state it STARTED from
+        readings.append(o.sensordata.copy())
+        t = Oracle(pod, o.qpos.copy())
+        t.forward()
+        frames.append((arr(t.d.site_xpos)[imu].copy(), arr(t.d.site_xmat)[imu].reshape(3, 3).copy()))
+    # frames[i] = pose after step i = the pose that step i + 1's sensors describe
+    x0, R0 = frames[1]
+    x1, R1 = frames[2]
+    xm, _ = frames[0]
+    gyro, acc = readings[2][20:23], readings[2][23:26]
+    w_fd = Rot.from_matrix(R0.T @ R1).as_rotvec() / h                         # body-frame angular velocity over the step
+    a_fd = (x1 - 2 * x0 + xm) / h ** 2                                         # world acceleration, O(h) accurate
+    assert np.allclose(gyro, w_fd, atol=2e-2 * max(1.0, np.linalg.norm(w_fd)))
+    assert np.allclose(acc, R0.T @ (a_fd + np.array([0, 0, 9.81])), atol=0.35)
+    assert 8.5 < np.linalg.norm(acc) < 11.5                                   # standing: mostly gravity
+    quat = readings[2][16:20]
+    assert np.allclose(np.abs(Rot.from_matrix(R0).as_quat()[[3, 0, 1, 2]] @ quat), 1.0, atol=1e-9)   # framequat = the site's orientation
+
+
+def test_quaternion_integration_of_ball_and_free_joints(cassie):
+    """P12: positions of ball / free joints advance by the exponential of the body-frame angular velocity."""
+    from scipy.spatial.transform import Rotation as Rot
+    pod = cassie.pod
+    rng = np.random.default_rng(14)
+    q = cassie.qpos_init()
+    q[3:7] = Rot.random(random_state=1).as_quat()[[3, 0, 1, 2]]
+    v = rng.uniform(-3, 3, pod.nv)
+    q1 = _perturbed_by(pod, q, v, 0.01)
+    Rq0, Rq1 = Rot.from_quat(q[[4, 5, 6, 3]]), Rot.from_quat(q1[[4, 5, 6, 3]])
+    assert np.allclose((Rq0.inv() * Rq1).as_rotvec(), 0.01 * v[3:6], atol=1e-12)        # pelvis: body-frame omega
+    assert np.allclose(q1[0:3], q[0:3] + 0.01 * v[0:3], atol=1e-15)
+    ja = pod.jnt_qposadr[[j for j in range(pod.njnt) if pod.jnt_type[j] == 1][0]]        # first ball joint (achilles rod)
+    da = pod.jnt_dofadr[[j for j in range(pod.njnt) if pod.jnt_type[j] == 1][0]]
+    B0, B1 = Rot.from_quat(q[[ja + 1, ja + 2, ja + 3, ja]]), Rot.from_quat(q1[[ja + 1, ja + 2, ja + 3, ja]])
+    assert np.allclose((B0.inv() * B1).as_rotvec(), 0.01 * v[da:da + 3], atol=1e-12)
+    assert abs(np.linalg.norm(q1[3:7]) - 1) < 1e-15 and abs(np.linalg.norm(q1[ja:ja + 4]) - 1) < 1e-15
+
+
+def _perturbed_by(pod, q, v, dt):
+    import ctypes
+    from oracle_py import lib
+    L = lib()
+    L.co_integrate_pos.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double]
+    qq = np.ascontiguousarray(q, dtype=np.float64).copy()
+    vv = np.ascontiguousarray(v, dtype=np.float64)
+    L.co_integrate_pos(ctypes.byref(pod), qq.ctypes.data, vv.ctypes.data, dt)
+    return qq
