@@ -130,6 +130,15 @@ def timed_region(schedule, first, steps, fence, clock=time.perf_counter, mark=No
     return clock() - t0
 
 
+def _reduce_max(seconds, device):
+    """max-over-ranks through the collective even when there is a single rank (validation runs)."""
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
 def max_over_ranks(seconds, world, device=None):
     import torch
     import torch.distributed as dist
@@ -322,7 +331,7 @@ class HostChainEnvs:
         return self.orcs[0].sensordata.copy()
 
 
-def device_rollout(model, mode, n, steps, warmup, rank, world, local_rank, substeps_per_launch=HOLD, parity_envs=64, hfield=None):
+def device_rollout(model, mode, n, steps, warmup, rank, world, local_rank, substeps_per_launch=HOLD, parity_envs=64, hfield=None, collect=None):
     """One timed device-resident rollout of the workload in `mode`:
 
       "drive-pd"  CM_DRIVE_PD: every substep runs pd_input's motor PD on the ENCODER measurements of the
@@ -340,6 +349,7 @@ def device_rollout(model, mode, n, steps, warmup, rank, world, local_rank, subst
     from cassie_amd import phys as P
     pod = model.pod
     drive = mode == "drive-pd"
+    collect = world > 1 if collect is None else collect       # the observation all-gather, barriers, max-over-ranks reduction
     env_ids = shard_env_ids(rank, world, n)
     total_steps = PREROLL + warmup + steps
     npolicy = (total_steps + HOLD - 1) // HOLD + 1
@@ -380,7 +390,7 @@ def device_rollout(model, mode, n, steps, warmup, rank, world, local_rank, subst
         b.set_pd_mode(True)
     rows_of = [np.nonzero(env_ids % NGROUP == g)[0] for g in range(NGROUP)]
     group_rows = [torch.from_numpy(r).to(dev) for r in rows_of]
-    obs_all = torch.empty((world * n, nobs), dtype=torch.float64, device=dev) if world > 1 else None
+    obs_all = torch.empty((world * n, nobs), dtype=torch.float64, device=dev) if collect else None
     launch_stream = torch.cuda.Stream(device=dev)   # a real (non-null) stream: the kernel and the timing events share it
     stream = launch_stream.cuda_stream
 
@@ -400,11 +410,11 @@ def device_rollout(model, mode, n, steps, warmup, rank, world, local_rank, subst
     sch = Schedule(step=lambda nsub: b.step(nsub, stream),
                    bind_targets=lambda p: b.bind(P.F_PD_PTARGET, targets[p].data_ptr()),
                    restart=restart,
-                   gather=(lambda: gather_observations(obs, world, obs_all)) if world > 1 else None,
+                   gather=(lambda: gather_observations(obs, world, obs_all)) if collect else None,
                    substeps_per_launch=substeps_per_launch)
 
     def fence():
-        if world > 1:
+        if collect:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -415,7 +425,10 @@ def device_rollout(model, mode, n, steps, warmup, rank, world, local_rank, subst
         elapsed = timed_region(sch, PREROLL + warmup, steps, fence, mark=lambda i: ev[i].record(launch_stream))
     res = {"mode": mode, "n": n, "steps": steps, "warmup": warmup, "launches": sch.launches,
            "kernel_ms": ev[0].elapsed_time(ev[1]) / sch.launches,   # mean stream time per launch (includes the rare restart / gather)
-           "elapsed": max_over_ranks(elapsed, world, dev)}
+           "elapsed": _reduce_max(elapsed, dev) if collect else elapsed}
+    if collect and rank == 0:
+        # the gathered block of the last policy boundary must hold this rank's rows (global env order, rank-major)
+        res["gather_ok"] = bool(sch.gathers > 0)
     w, info = b.warnings()
     res["envs_with_warnings"] = int(np.count_nonzero(w))
     res["mean_constraint_rows"], res["mean_pgs_iterations"], res["mean_pgs_guarded_sweeps"] = (float(info[:, k].mean()) for k in (1, 2, 3))
@@ -474,6 +487,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-step-pd", action="store_true")
     ap.add_argument("--no-other-mode", action="store_true", help="skip the short run of the other device mode")
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="validation aid: initialise the process group and run the observation all-gather / barriers even with one rank")
     ap.add_argument("--mode", default="drive-pd", choices=["drive-pd", "exact-pd"],
                     help="what the device-resident kernel computes per substep (see device_rollout)")
     args = ap.parse_args()
@@ -490,8 +505,10 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the physics library has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    collect = world > 1 or args.force_collectives
+    if collect:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from cassie_amd import Model
@@ -503,7 +520,8 @@ def main():
     if args.model == "cassie_hfield":   # terrain of reference example/test_hfield.py:39-41, shared by all envs
         hfield = np.random.default_rng(99).random((200, 200)).astype(np.float32)
         hfield[95:105, 95:105] = 0
-    r = device_rollout(model, args.mode, n, args.steps, args.warmup, rank, world, local_rank, args.substeps_per_launch, args.parity_envs, hfield)
+    r = device_rollout(model, args.mode, n, args.steps, args.warmup, rank, world, local_rank, args.substeps_per_launch, args.parity_envs, hfield,
+                       collect=collect)
 
     if rank == 0:
         elapsed, kern_ms, timed_launches = r["elapsed"], r["kernel_ms"], r["launches"]
@@ -530,7 +548,7 @@ def main():
                                    % (n, args.model, EPISODE, PREROLL, HOLD),
                        "api_of_value": api, "mode": args.mode,
                        "envs_total": world * n, "parallelism": "env-sharded x%d" % world,
-                       "obs_allgather_every_steps": HOLD if world > 1 else None,
+                       "obs_allgather_every_steps": HOLD if collect else None,
                        "substeps_per_launch": steps_per_launch, "launches_timed": timed_launches,
                        "preroll_steps": PREROLL, "episode_steps": EPISODE},
             "parity": r["parity"],
@@ -564,7 +582,7 @@ def main():
                 out["step_pd_device_drives"] = sd
                 out["value_step_pd"] = max([x["value"] for x in (sp, sd) if x] or [None])
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if collect:
         dist.destroy_process_group()
 
 
