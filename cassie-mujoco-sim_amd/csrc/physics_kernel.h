@@ -33,6 +33,14 @@
  * qpos/qvel/ctrl/sensordata arrays are env-major in HBM so a wave's loads and stores are
  * contiguous; nsub steps per launch keep the state in LDS.
  *
+ * Round 2 added, in the same one-wave-per-env style: the drive-level I/O of cassie_sim_step_ethercat (motor model with
+ * torque delay, encoder quantisation and velocity filters; reference src/cassiemujoco.c:558-664, :737-803) as a
+ * per-substep prologue whose state lives in LDS for the length of a launch -- bit for bit the host chain; height-field
+ * contacts over every grid triangle under a sample sphere, the samples of all height-field pairs spread over the lanes of a
+ * pre-pass; box-box by separating axes with the clipped-face candidates one to a lane; FEAT_* template flags that keep
+ * collision code a model does not need out of its instantiation; outputs stored by the last substep only; a derive kernel
+ * for the batched getters; a longest-job-first launch order.
+ *
  * Numerically this follows the same algorithm as oracle/cassie_oracle.c but with
  * its own operation order (half solves, reciprocal multiplies, wave reductions,
  * chain sums), so parity is to a tolerance, not bitwise.
