@@ -115,7 +115,7 @@ struct PhysIO {
     unsigned *cost;
 };
 
-template <int NVP>
+template <int NVP, int NL = NVP * (NVP + 1) / 2>
 struct EnvShared {
     static constexpr int YP = NVP + 2; /* leading dimension of the Y staging tile: 16-byte aligned rows, conflict-free */
     union {
@@ -129,8 +129,9 @@ struct EnvShared {
         } s;
         double Yr[NROW][YP];        /* Y staged row-major by constraint row for broadcast reads */
     } x;
-    /* L^T D L factors of M and of M + hB, packed lower-triangular by rows: entry (k, i <= k) at k(k+1)/2 + i */
-    double Lp[NVP * (NVP + 1) / 2], LHp[NVP * (NVP + 1) / 2];
+    /* L^T D L factors of M and of M + hB, rows stored as LPack<TOPO, NVP> says (NL entries): a full lower triangle,
+     * entry (k, i <= k) at k(k+1)/2 + i, or block-dense rows for a compile-time topology that asks for them */
+    double Lp[NL], LHp[NL];
     double accel[2][28];            /* accelerometer partial results that must outlive the body tiles */
     double dinv[NVP], rsd[NVP], dinvH[NVP]; /* 1/D, 1/sqrt(D) of M; 1/D of M + hB */
     double cdof[NVP][6];
@@ -582,8 +583,8 @@ WV_DEVICE int hfield_sphere(RawContact &c, ModelPtr m, const float *data, const 
 }
 
 /* parks one detected contact (geometry only) in the contact list; finish_contacts completes the entries */
-template <int NVP>
-WV_DEVICE void write_raw_contact(EnvShared<NVP> &S, int slot, int pair, const RawContact &r) {
+template <int NVP, int NL>
+WV_DEVICE void write_raw_contact(EnvShared<NVP, NL> &S, int slot, int pair, const RawContact &r) {
     S.c_dist[slot] = r.dist;
     S.c_pair[slot] = pair;
     for (int i = 0; i < 3; ++i) { S.c_pos[slot][i] = r.pos[i]; S.c_frame[slot][i] = r.normal[i]; S.c_frame[slot][3 + i] = r.tangent[i]; }
@@ -591,8 +592,8 @@ WV_DEVICE void write_raw_contact(EnvShared<NVP> &S, int slot, int pair, const Ra
 
 /* lane = contact: contact frame from (normal, tangent hint) and the pair's pre-mixed parameters (model compile
  * time, cm_model_t::pair_*), once per contact and outside the divergent pair loops */
-template <int NVP>
-WV_DEVICE void finish_contacts(EnvShared<NVP> &S, ModelPtr m, int lane, int ncon) {
+template <int NVP, int NL>
+WV_DEVICE void finish_contacts(EnvShared<NVP, NL> &S, ModelPtr m, int lane, int ncon) {
     if (lane < ncon) {
         const int p = S.c_pair[lane];
         double fr[9];
@@ -626,7 +627,65 @@ WV_DEVICE double impedance(const double *solimp, double pos, double margin) {
 
 /* dof-tree sparsity: compile-time tables for the in-scope models (topo_static.h), or the model's own
  * masks for anything else */
-struct TopoRuntime { static constexpr bool is_static = false; static constexpr int nv = 0; };
+struct TopoRuntime { static constexpr bool is_static = false; static constexpr bool packed = false; static constexpr int nv = 0; };
+
+/* Where entry (k, i < k) of a factor lives in EnvShared::Lp / LHp.
+ *   dense  : the full lower triangle by rows, (k, i) at k(k+1)/2 + i; the diagonal slot of a row is never read and takes
+ *            the row stores of the lanes at or past the diagonal.  A lane's row or column index is base + immediate.
+ *   packed : (TOPO::packed) a dof's ancestors are trunk dofs or dofs of its own block (TOPO::bstart), so row k keeps
+ *            only [its trunk entries | the entries of its block below k]: 392 slots instead of 820 for the 40-dof
+ *            tray model, 13.7 KB less LDS for the two factors, which is what lets four of its workgroups share a CU.
+ *            Costs a few integer ops per staged entry where a lane addresses its own row / column. */
+template <class TOPO, int NVP>
+struct LPack {
+    static constexpr bool packed = TOPO::packed;
+    static constexpr int trunk() { if constexpr (TOPO::packed) return TOPO::trunk; else return 0; }
+    static constexpr int bs(int k) { /* first dof of k's block */
+        if constexpr (TOPO::packed) { int s = 0; for (int b = 0; b < TOPO::nblock; ++b) if (TOPO::bstart[b] <= k) s = TOPO::bstart[b]; return s; }
+        else return 0;
+    }
+    static constexpr int len(int k) { if constexpr (TOPO::packed) return k < trunk() ? k : trunk() + (k - bs(k)); else return k + 1; }
+    static constexpr int base(int k) { int s = 0; for (int j = 0; j < k; ++j) s += len(j); return s; }
+    static constexpr int count = base(NVP) + (TOPO::packed ? 1 : 0);
+    static constexpr int dump = count - 1; /* packed: the slot that takes the stores of lanes outside the row */
+    static constexpr bool has(int k, int i) { return i < k && (!TOPO::packed || i < trunk() || i >= bs(k)); }
+    static constexpr int idx(int k, int i) { /* compile-time (k, i), has(k, i) */
+        if constexpr (TOPO::packed) return base(k) + (i < trunk() ? i : trunk() + i - bs(k)); else return CK_TRI(k, i);
+    }
+    static constexpr bool covers() { /* every ancestor pair of the topology has a slot */
+        if constexpr (TOPO::packed) {
+            for (int k = 0; k < NVP; ++k) for (int i = 0; i < k; ++i) if (((TOPO::table[k] >> i) & 1ull) && !has(k, i)) return false;
+        }
+        return true;
+    }
+    /* slot row k (compile time) offers lane `lane`: its entry (k, lane), else a slot nobody reads */
+    static WV_DEVICE int row_slot(int k, int lane) {
+        if constexpr (TOPO::packed) {
+            const int b = base(k), s = bs(k), T = trunk();
+            if (k < T) return lane < k ? b + lane : dump;
+            return lane < T ? b + lane : (lane >= s && lane < k) ? b + T - s + lane : dump;
+        } else return CK_TRI(k, 0) + (lane < k ? lane : k);
+    }
+    /* a lane's own row: where it starts and which block it belongs to */
+    struct Row { int base, bs; };
+    static WV_DEVICE Row row_of(int k_) {
+        Row r = {0, 0};
+        if constexpr (TOPO::packed) {
+            int B = 0;
+#pragma unroll
+            for (int b = 1; b < TOPO::nblock; ++b) if (k_ >= TOPO::bstart[b]) { r.bs = TOPO::bstart[b]; B = base(TOPO::bstart[b]); }
+            const int d = k_ - r.bs;
+            r.base = B + (r.bs > 0 ? d * trunk() : 0) + d * (d - 1) / 2;
+        } else r.base = CK_TRI(k_, 0);
+        return r;
+    }
+    /* entry (k_, i) of the lane's own row, i compile time: slot, and whether the row has it (i < k_ is the caller's) */
+    static WV_DEVICE bool row_has(const Row &r, int i) { if constexpr (TOPO::packed) return i < trunk() || i >= r.bs; else return true; }
+    static WV_DEVICE int row_idx(const Row &r, int i) { if constexpr (TOPO::packed) return r.base + (i < trunk() ? i : trunk() - r.bs + i); else return r.base + i; }
+    /* entry (k, k_) of the lane's own column, k compile time (k_ < k is the caller's) */
+    static WV_DEVICE bool col_has(int k, int k_) { if constexpr (TOPO::packed) return k_ < trunk() || k_ >= bs(k); else return true; }
+    static WV_DEVICE int col_idx(int k, int k_) { if constexpr (TOPO::packed) return (k_ < trunk() ? base(k) : base(k) + trunk() - bs(k)) + k_; else return CK_TRI(k, k_); }
+};
 
 template <class TOPO>
 WV_DEVICE unsigned long long anc_mask(ModelPtr m, int k) {
@@ -700,8 +759,8 @@ WV_DEVICE void factor_pair_by_height(ModelPtr m, double h, SH &S, double (&col)[
             const double arm = m->dof_armature[k]; /* diagonal terms, see the mass-matrix stage */
             const double inv = fast_rcp(wv::readlane(col[k], k) + arm), invh = fast_rcp(wv::readlane(colh[k], k) + (arm + h * m->dof_damping[k]));
             S.dinv[k] = inv; S.dinvH[k] = invh; /* every lane holds the same value: an unpredicated same-address store */
-            /* lanes at or past the diagonal all land on the (unused) diagonal slot: an unpredicated store */
-            const int at = CK_TRI(k, 0) + (lane < k ? lane : k);
+            /* lanes at or past the diagonal all land on one unused slot: an unpredicated store */
+            const int at = LPack<TOPO, NVP>::row_slot(k, lane);
             S.Lp[at] = col[k] * inv;
             S.LHp[at] = colh[k] * invh;
         }
@@ -715,8 +774,8 @@ WV_DEVICE void factor_pair_by_height(ModelPtr m, double h, SH &S, double (&col)[
 #pragma unroll
             for (int i = k - 1; i >= 0; --i) {
                 if (!((TOPO::table[k] >> i) & 1ull)) continue;
-                t[i] = S.Lp[CK_TRI(k, i)];
-                th[i] = S.LHp[CK_TRI(k, i)];
+                t[i] = S.Lp[LPack<TOPO, NVP>::idx(k, i)];
+                th[i] = S.LHp[LPack<TOPO, NVP>::idx(k, i)];
             }
             wv::sched_fence();
 #pragma unroll
@@ -735,7 +794,7 @@ WV_DEVICE void factor_pair_by_height(ModelPtr m, double h, SH &S, double (&col)[
         const double arm = m->dof_armature[k];
         const double inv = fast_rcp(wv::readlane(col[k], k) + arm), invh = fast_rcp(wv::readlane(colh[k], k) + (arm + h * m->dof_damping[k]));
         S.dinv[k] = inv; S.dinvH[k] = invh;
-        const int at = CK_TRI(k, 0) + (lane < k ? lane : k);
+        const int at = LPack<TOPO, NVP>::row_slot(k, lane);
         S.Lp[at] = col[k] * inv;
         S.LHp[at] = colh[k] * invh;
         double t[TOPO::trunk], th[TOPO::trunk];
@@ -985,7 +1044,9 @@ WV_DRIVE_FN void drive_level_io(const PhysIO &io, SH &S, ModelPtr m, int env, in
 enum { FEAT_HFIELD = 1, FEAT_WAVEPAIRS = 2, FEAT_ALL = 3 };
 
 template <int NVP, class TOPO, int FEAT>
-WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
+WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count> &S, int env) {
+    typedef LPack<TOPO, NVP> LP;
+    static_assert(LP::covers(), "packed factor rows must hold every ancestor pair");
     const ModelPtr m_launch = (ModelPtr)(io.models + (size_t)env * io.model_stride);
     ModelPtr m = m_launch;
     int lane = wv::lane();
@@ -2075,7 +2136,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
             double ta[NVP], tb[NVP], ra = 0, rb = 0;
             auto fetch = [&](int k, double (&t)[NVP], double &rs) {
 #pragma unroll
-                for (int i = k - 1; i >= 0; --i) if ((TOPO::table[k] >> i) & 1ull) t[i] = S.Lp[CK_TRI(k, i)];
+                for (int i = k - 1; i >= 0; --i) if ((TOPO::table[k] >> i) & 1ull) t[i] = S.Lp[LPack<TOPO, NVP>::idx(k, i)];
                 rs = S.rsd[k];
             };
             fetch(TOPO::nv - 1, ((TOPO::nv - 1) & 1) ? ta : tb, ((TOPO::nv - 1) & 1) ? ra : rb);
@@ -2302,8 +2363,15 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
             if (isdof) z *= S.rsd[k_];
             /* forward substitution with this lane's row of L staged first (all LDS reads in flight together) */
             double lrow[NVP];
+            const typename LP::Row myrow = LP::row_of(k_);
 #pragma unroll
-            for (int i = 0; i < NVP; ++i) lrow[i] = (isdof && i < k_) ? S.Lp[CK_TRI(k_, i)] : 0.0;
+            for (int i = 0; i < NVP; ++i) {
+                if constexpr (LP::packed) {
+                    const bool has = isdof && i < k_ && LP::row_has(myrow, i);
+                    const double v = S.Lp[has ? LP::row_idx(myrow, i) : 0];
+                    lrow[i] = has ? v : 0.0;
+                } else lrow[i] = (isdof && i < k_) ? S.Lp[CK_TRI(k_, i)] : 0.0;
+            }
             qacc = solve_forward<NVP, TOPO>(z, lrow, lane, nv);
         }
         {
@@ -2358,11 +2426,19 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
             /* (M + hB) x = M qacc  <=>  x = qacc - (M + hB)^-1 (hB qacc) */
             double w = isdof ? h * m->dof_damping[k_] * qacc : 0.0;
             double lcol[NVP], lrowh[NVP]; /* this lane's column and row of the factor of M + hB, staged before the chains */
+            const typename LP::Row myrow = LP::row_of(k_);
 #pragma unroll
             for (int k = 0; k < NVP; ++k) {
                 const bool inrange = TOPO::is_static ? k < TOPO::nv : k < nv;
-                lcol[k] = (inrange && isdof && k > k_) ? S.LHp[CK_TRI(k, k_)] : 0.0;
-                lrowh[k] = (isdof && k < k_) ? S.LHp[CK_TRI(k_, k)] : 0.0;
+                if constexpr (LP::packed) {
+                    const bool hasc = inrange && isdof && k > k_ && LP::col_has(k, k_), hasr = isdof && k < k_ && LP::row_has(myrow, k);
+                    const double vc = S.LHp[hasc ? LP::col_idx(k, k_) : 0], vr = S.LHp[hasr ? LP::row_idx(myrow, k) : 0];
+                    lcol[k] = hasc ? vc : 0.0;
+                    lrowh[k] = hasr ? vr : 0.0;
+                } else {
+                    lcol[k] = (inrange && isdof && k > k_) ? S.LHp[CK_TRI(k, k_)] : 0.0;
+                    lrowh[k] = (isdof && k < k_) ? S.LHp[CK_TRI(k_, k)] : 0.0;
+                }
             }
             const double dih = isdof ? S.dinvH[k_] : 0.0;
             w = solve_backward<NVP, TOPO>(w, lcol, lane, nv); /* L^-T */
@@ -2421,7 +2497,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP> &S, int env) {
 /* one single-wave workgroup per environment */
 template <int NVP, class TOPO, int FEAT = FEAT_ALL>
 WV_GLOBAL void __launch_bounds__(WV_WAVE) WV_OCC cassie_step_kernel(PhysIO io) {
-    WV_SHARED EnvShared<NVP> S;
+    WV_SHARED EnvShared<NVP, LPack<TOPO, NVP>::count> S;
     const int slot = wv::env_id();
     if (slot >= io.nenv) return;
 #ifdef CK_EMULATED
