@@ -658,6 +658,14 @@ struct LPack {
         }
         return true;
     }
+    static constexpr bool distinct() { /* the slots of all (k, i) pairs a row keeps are 0 .. dump - 1, each used once, in order */
+        if constexpr (TOPO::packed) {
+            int next = 0;
+            for (int k = 0; k < NVP; ++k) for (int i = 0; i < k; ++i) if (has(k, i)) { if (idx(k, i) != next) return false; ++next; }
+            return next == dump;
+        }
+        return true;
+    }
     /* slot row k (compile time) offers lane `lane`: its entry (k, lane), else a slot nobody reads */
     static WV_DEVICE int row_slot(int k, int lane) {
         if constexpr (TOPO::packed) {
@@ -1046,7 +1054,7 @@ enum { FEAT_HFIELD = 1, FEAT_WAVEPAIRS = 2, FEAT_ALL = 3 };
 template <int NVP, class TOPO, int FEAT>
 WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count> &S, int env) {
     typedef LPack<TOPO, NVP> LP;
-    static_assert(LP::covers(), "packed factor rows must hold every ancestor pair");
+    static_assert(LP::covers() && LP::distinct(), "packed factor rows must hold every ancestor pair, each in its own slot");
     const ModelPtr m_launch = (ModelPtr)(io.models + (size_t)env * io.model_stride);
     ModelPtr m = m_launch;
     int lane = wv::lane();

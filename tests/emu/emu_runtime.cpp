@@ -222,3 +222,30 @@ extern "C" int emu_derive(const cm_model_t *model, int nenv, double *qpos, doubl
     return 0;
 }
 extern "C" unsigned long emu_sizeof_shared32(void) { return sizeof(ck::EnvShared<32>); }
+
+/* packed factor rows (ck::LPack): the run-time-lane addressing agrees with the compile-time slots; returns the number of mismatches */
+template <class TOPO, int NVP>
+static int lpack_mismatches() {
+    typedef ck::LPack<TOPO, NVP> LP;
+    int bad = 0;
+    for (int k = 0; k < NVP; ++k) {
+        const typename LP::Row r = LP::row_of(k);
+        for (int i = 0; i < NVP; ++i) {
+            const bool has = LP::has(k, i);
+            const int want = has ? LP::idx(k, i) : -1;
+            if (has) {
+                bad += LP::row_slot(k, i) != want;
+                bad += !(LP::row_has(r, i) && LP::row_idx(r, i) == want);
+                bad += !(LP::col_has(k, i) && LP::col_idx(k, i) == want);
+            } else {
+                if (LP::packed) bad += LP::row_slot(k, i) != LP::dump;
+                if (i < k) bad += LP::row_has(r, i) || LP::col_has(k, i);
+            }
+        }
+    }
+    return bad;
+}
+extern "C" int emu_lpack_check(void) {
+    return lpack_mismatches<ck::TopoCassieTray38, 40>() + lpack_mismatches<ck::TopoCassie32, 32>() + lpack_mismatches<ck::TopoRuntime, 40>();
+}
+extern "C" int emu_lpack_count(int which) { return which ? ck::LPack<ck::TopoCassieTray38, 40>::count : ck::LPack<ck::TopoCassie32, 32>::count; }

@@ -272,3 +272,15 @@ def test_lds_poison_on_the_other_models_and_modes(name, steps, drive, built):
     assert not out[1][4].any() and out[1][5][0, 0] >= 1
     for a, b in zip(out[0], out[1]):
         assert np.array_equal(a, b)
+
+
+def test_packed_factor_rows_address_the_same_slots_from_every_side(built):
+    """The 40-dof tray kernel keeps its two factors in block-dense rows (ck::LPack, 392 slots instead of 820) so that four of
+    its workgroups fit a CU.  The slot of entry (k, i) is computed three ways in the kernel -- at compile time, from the
+    storing lane i of row k, and from the lane that owns row k / column i -- and all must agree, for the packed layout and
+    for the dense one."""
+    import emu_py
+    lib = emu_py.lib()
+    assert lib.emu_lpack_check() == 0
+    assert lib.emu_lpack_count(0) == 32 * 33 // 2          # cassie.xml keeps the full triangle (index = base + immediate)
+    assert lib.emu_lpack_count(1) == 392                   # 15 trunk + 2 x 156 leg + 51 cube + 13 padding + 1 dump slot
