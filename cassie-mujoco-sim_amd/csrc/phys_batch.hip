@@ -264,6 +264,14 @@ int phys_batch_set_model(phys_batch_t *b, const cm_model_t *model, int env) {
         return hip_ok(hipMemcpy(b->d_models, model, sizeof(cm_model_t), hipMemcpyHostToDevice), "hipMemcpy(model)") ? 0 : -1;
     }
     if (env >= b->nenv) return -1;
+    /* one launch serves every env with the kernel instantiation picked from the shared model: a per-env model may vary
+     * parameters, not the dof tree or the kinds of collision pairs */
+    if (memcmp(model->dof_ancmask, b->host_model.dof_ancmask, sizeof(model->dof_ancmask[0]) * (size_t)model->nv) != 0 ||
+        (model->nhfpair > 0) != (b->host_model.nhfpair > 0) || (model->hfield_geom >= 0) != (b->host_model.hfield_geom >= 0) ||
+        (model->npair > model->npair_simple) != (b->host_model.npair > b->host_model.npair_simple)) {
+        phys_set_last_error("phys_batch_set_model: a per-env model must keep the shared model's dof tree and collision pair kinds");
+        return -1;
+    }
     if (b->model_stride == 0) { /* expand to one model per env */
         cm_model_t *all = nullptr;
         if (!hip_ok(hipMalloc((void **)&all, sizeof(cm_model_t) * (size_t)b->nenv), "hipMalloc(models)")) return -1;
@@ -562,7 +570,7 @@ __global__ void __launch_bounds__(64) cassie_poison_lds_kernel(int *sink) {
 int phys_batch_debug_poison_lds(phys_batch_t *b) {
     if (!b) return -1;
     (void)hipSetDevice(b->device);
-    hipLaunchKernelGGL(cassie_poison_lds_kernel, dim3(8192), dim3(64), 0, b->stream, b->d_warn + 0 * 0 == nullptr ? nullptr : (int *)nullptr);
+    hipLaunchKernelGGL(cassie_poison_lds_kernel, dim3(8192), dim3(64), 0, b->stream, (int *)nullptr);
     return hip_ok(hipGetLastError(), "poison launch") && hip_ok(hipStreamSynchronize(b->stream), "poison sync") ? 0 : -1;
 }
 

@@ -122,6 +122,12 @@ def test_per_env_model_override(cassie):
     o = Oracle(heavy, cassie.qpos_init())
     o.step(50)
     assert np.max(np.abs(q[1] - o.qpos)) < 1e-11
+    # one launch serves every env with the kernel instantiation of the shared model: a per-env model with another dof
+    # tree is refused, not run through the wrong sparsity tables
+    other = CmModel.from_buffer_copy(pod)
+    other.dof_ancmask[7] ^= 1
+    with pytest.raises(RuntimeError, match="dof tree"):
+        b.set_model(other, env=2)
     b.close()
 
 
