@@ -396,39 +396,61 @@ int cassie_batch_derive(cassie_batch_t *b, double *derived, double *qM)
     return rc;
 }
 
+/* rows of one field for the envs that are being reset: the whole field comes down once, the masked rows are rewritten
+ * (row = the given values, or zeros) and it goes up once -- two transfers per field whatever the number of envs */
+static int reset_field(cassie_batch_t *b, int field, const unsigned char *mask, const double *row, double *scratch)
+{
+    const int dim = phys_batch_field_dim(b->pb, field);
+    int rc = mask ? phys_batch_download(b->pb, field, scratch, 0, b->nenv) : 0;
+    for (int e = 0; e < b->nenv; ++e) {
+        if (mask && !mask[e]) continue;
+        if (row) memcpy(scratch + (size_t)e * dim, row, sizeof(double) * (size_t)dim);
+        else memset(scratch + (size_t)e * dim, 0, sizeof(double) * (size_t)dim);
+    }
+    return rc | phys_batch_upload(b->pb, field, scratch, 0, b->nenv);
+}
+
 int cassie_batch_full_reset(cassie_batch_t *b, const unsigned char *mask)
 {
     /* cassie_sim_full_reset per env (reference :2008-2033): pose, velocities, controls, perturbations, torque delay,
      * estimator; plus the sticky device-side warning bits of the envs that are reset (mj_resetData clears
      * mjData.warning).  Time, filters and the solver warm start are left alone like the single-env version. */
     if (!b) return -1;
-    const int nq = b->pod.nq, nv = b->pod.nv, nz = nv > 6 * b->pod.nbody ? nv : 6 * b->pod.nbody;
-    double *q = malloc(sizeof(double) * nq), *z = calloc((size_t)nz, sizeof(double));
-    if (!q || !z) { free(q); free(z); return -1; }
+    const int nq = b->pod.nq, nb6 = 6 * b->pod.nbody;
+    const int widest = nq > nb6 ? nq : nb6;
+    double *q = malloc(sizeof(double) * nq), *scratch = malloc(sizeof(double) * (size_t)b->nenv * (size_t)widest);
+    if (!q || !scratch) { free(q); free(scratch); return -1; }
     memcpy(q, b->pod.qpos0, sizeof(double) * nq);
     q[0] = 0; q[1] = 0; q[2] = 1.01; q[3] = 1; q[4] = q[5] = q[6] = 0; /* reference :2010 */
     memcpy(q + 7, qpos_nominal_joints, sizeof qpos_nominal_joints);
-    int rc = 0;
+    int rc = phys_batch_sync(b->pb);
+    rc |= reset_field(b, PHYS_F_QPOS, mask, q, scratch);
+    rc |= reset_field(b, PHYS_F_QVEL, mask, NULL, scratch);
+    rc |= reset_field(b, PHYS_F_CTRL, mask, NULL, scratch);
+    rc |= reset_field(b, PHYS_F_QACC, mask, NULL, scratch);
+    if (phys_batch_uses_applied(b->pb)) { /* perturbations exist on the device only once somebody uploaded some */
+        rc |= reset_field(b, PHYS_F_QFRC_APPLIED, mask, NULL, scratch);
+        rc |= reset_field(b, PHYS_F_XFRC_APPLIED, mask, NULL, scratch);
+    }
+    cm_drive_state_t *st = NULL;
+    if (b->device_drives) { /* the torque delay line that cassie_hostenv_reset clears lives in HBM in this mode */
+        st = malloc(sizeof(cm_drive_state_t) * (size_t)b->nenv);
+        if (!st) { free(q); free(scratch); return -1; }
+        rc |= phys_batch_download_drive_state(b->pb, st, 0, b->nenv);
+    }
     for (int e = 0; e < b->nenv; ++e) {
         if (mask && !mask[e]) continue;
-        rc |= phys_batch_upload(b->pb, PHYS_F_QPOS, q, e, 1);
-        rc |= phys_batch_upload(b->pb, PHYS_F_QVEL, z, e, 1);
-        rc |= phys_batch_upload(b->pb, PHYS_F_CTRL, z, e, 1);
-        rc |= phys_batch_upload(b->pb, PHYS_F_QACC, z, e, 1);
-        if (phys_batch_uses_applied(b->pb)) { /* perturbations exist on the device only once somebody uploaded some */
-            rc |= phys_batch_upload(b->pb, PHYS_F_QFRC_APPLIED, z, e, 1);
-            rc |= phys_batch_upload(b->pb, PHYS_F_XFRC_APPLIED, z, e, 1);
+        int run = 1; /* warning bits: one clear per run of consecutive reset envs */
+        while (e + run < b->nenv && (!mask || mask[e + run])) ++run;
+        rc |= phys_batch_clear_warn(b->pb, e, run);
+        for (int k = e; k < e + run; ++k) {
+            memset(b->ctrl + (size_t)k * b->nu, 0, sizeof(double) * b->nu);
+            cassie_hostenv_reset(b->env[k]);
+            if (st) memset(st[k].torque_delay, 0, sizeof st[k].torque_delay);
         }
-        rc |= phys_batch_clear_warn(b->pb, e, 1);
-        memset(b->ctrl + (size_t)e * b->nu, 0, sizeof(double) * b->nu);
-        cassie_hostenv_reset(b->env[e]);
-        if (b->device_drives) { /* the torque delay line that cassie_hostenv_reset clears lives in HBM in this mode */
-            cm_drive_state_t st;
-            rc |= phys_batch_download_drive_state(b->pb, &st, e, 1);
-            memset(st.torque_delay, 0, sizeof st.torque_delay);
-            rc |= phys_batch_upload_drive_state(b->pb, &st, e, 1);
-        }
+        e += run - 1;
     }
-    free(q); free(z);
+    if (st) { rc |= phys_batch_upload_drive_state(b->pb, st, 0, b->nenv); free(st); }
+    free(q); free(scratch);
     return rc;
 }

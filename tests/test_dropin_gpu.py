@@ -196,6 +196,41 @@ def test_batch_step_pd_equals_independent_simulators(L):
     L.cassie_batch_free(b)
 
 
+@pytest.mark.parametrize("device_drives", [0, 1])
+def test_batch_masked_full_reset_equals_cassie_sim_full_reset(L, device_drives):
+    """cassie_batch_full_reset(mask) = cassie_sim_full_reset (reference src/cassiemujoco.c:2008-2033) on the masked envs
+    and nothing on the others: every env's state_out_t stays byte-identical to an independent simulator that was reset
+    (or not) at the same step -- with the drive-level models on the host threads and on the device."""
+    L.cassie_batch_full_reset.argtypes = [VP, VP]
+    L.cassie_batch_set_device_drives.argtypes = [VP, ctypes.c_int]
+    L.cassie_sim_full_reset.argtypes = [VP]
+    n, steps = 5, 150
+    rng = np.random.default_rng(11)
+    b = L.cassie_batch_create(MODEL, n, 0, 2)
+    assert b and L.cassie_batch_set_device_drives(b, device_drives) == 0
+    sims = [L.cassie_sim_init(MODEL, False) for _ in range(n)]
+    U = (T.pd_in_t * n)()
+    Y = (T.state_out_t * n)()
+    for k in range(steps):
+        if k % 50 == 0:
+            for e in range(n):
+                U[e] = pd_input(rng, scale=0.3)
+        if k in (60, 61, 110):
+            mask = np.array([[1, 0, 1, 1, 0], [0, 0, 0, 0, 1], [1, 1, 1, 1, 1]][(60, 61, 110).index(k)], dtype=np.uint8)
+            assert L.cassie_batch_full_reset(b, mask.ctypes.data if k != 110 else None) == 0
+            for e in range(n):
+                if mask[e]:
+                    L.cassie_sim_full_reset(sims[e])
+        assert L.cassie_batch_step_pd(b, ctypes.byref(U), ctypes.byref(Y)) == 0
+        for e in range(n):
+            y = T.state_out_t()
+            L.cassie_sim_step_pd(sims[e], ctypes.byref(y), ctypes.byref(U[e]))
+            assert bytes(y) == bytes(Y[e]), (k, e)
+    for s in sims:
+        L.cassie_sim_free(s)
+    L.cassie_batch_free(b)
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # The reference's UNMODIFIED Python wrapper (example/cassiemujoco.py:31-72) on top of this library.  oracle/build_ref.sh
 # stages the two wrapper files and the MJCF models into the git-ignored oracle/_ref/ in the build container; the
