@@ -969,19 +969,21 @@ void cassie_sim_body_acceleration(const cassie_sim_t *c, double accel[6], const 
 
 void cassie_sim_body_contact_force(const cassie_sim_t *c, double cfrc[6], const char *name)
 {
-    /* [torque about the body frame origin; force], world axes (mju_transformSpatial with flg_force) */
+    /* What the reference returns (:1781-1810): it hands mj_contactForce's [force; torque] (contact frame) to
+     * mju_transformSpatial, whose vectors are [rotational; translational], so the slots come out as
+     *   cfrc[0:3] = frame^T (force - (xpos_body - contact_pos) x torque),   cfrc[3:6] = frame^T torque.
+     * Every contact of the supported models is condim 1 or 3 -- no contact torque -- which leaves the summed contact
+     * force on the body in world axes in cfrc[0:3] (what callers of the reference read) and zeros in cfrc[3:6]. */
     memset(cfrc, 0, 6 * sizeof(double));
     int b = body_id(c, name);
     if (b < 0) return;
     for (int i = 0; i < c->ext.ncon; ++i) {
         int b1 = contact_body(c, c->ext.con_geom1[i]), b2 = contact_body(c, c->ext.con_geom2[i]);
         if (b != b1 && b != b2) continue;
-        double fw[3], r[3], tq[3];
+        double fw[3];
         contact_force_world(c, i, fw);
-        for (int k = 0; k < 3; ++k) r[k] = c->ext.con_pos[i][k] - c->d.xpos[3 * b + k];
-        cross3(tq, r, fw);
         double sgn = (b == b1) ? -1.0 : 1.0;
-        for (int k = 0; k < 3; ++k) { cfrc[k] += sgn * tq[k]; cfrc[3 + k] += sgn * fw[k]; }
+        for (int k = 0; k < 3; ++k) cfrc[k] += sgn * fw[k];
     }
 }
 

@@ -153,6 +153,8 @@ void cassie_sim_minimal_mass_matrix(const cassie_sim_t *sim, double M[256]);
 void cassie_sim_loop_constraint_info(const cassie_sim_t *sim, double J_cl[192], double err_cl[6]);
 void cassie_sim_body_velocities(const cassie_sim_t *sim, double cvel[6], const char *name);
 void cassie_sim_body_acceleration(const cassie_sim_t *sim, double accel[6], const char *name);
+/* cfrc[0:3] = summed contact force on the body, world axes; cfrc[3:6] = 0 for the condim-1/3 contacts of the supported
+ * models -- the slots the reference's call of mju_transformSpatial on a [force; torque] vector produces (:1781-1810) */
 void cassie_sim_body_contact_force(const cassie_sim_t *sim, double cfrc[6], const char *name);
 void cassie_sim_relative_pose(double pos1[3], double quat1[4], double pos2[3], double quat2[4],
                               double pos2_in_pos1[3], double quat2_in_quat1[4]);

@@ -293,6 +293,169 @@ def test_unmodified_reference_python_wrapper_end_to_end(L, tmp_path):
     assert len(res["foot_pos"]) == 6 and abs(res["foot_pos"][2]) < 0.2 and all(f >= 0 for f in res["foot_forces"])
 
 
+_SWEEP_SCRIPT = r"""
+import json, sys, warnings
+import numpy as np
+warnings.simplefilter("ignore")
+from cassiemujoco import *
+sim = CassieSim("../model/cassie.xml")
+assert (sim.nq, sim.nv, sim.nu, sim.nbody, sim.njnt) == (35, 32, 10, 26, 26), (sim.nq, sim.nv, sim.nu, sim.nbody, sim.njnt)
+u = pd_in_t()
+off = [0.0045, 0, 0.4973, -1.1997, -1.5968]
+for leg in (u.leftLeg, u.rightLeg):
+    for i in range(5):
+        leg.motorPd.pGain[i], leg.motorPd.dGain[i], leg.motorPd.pTarget[i] = [100, 100, 88, 96, 50][i], [10, 10, 8, 9.6, 5][i], off[i]
+def run(n):
+    for _ in range(n): y = sim.step_pd(u)
+    return y
+fin = lambda x: bool(np.all(np.isfinite(np.asarray(x, dtype=float))))
+def momentum_balance(applied=(0.0, 0.0, 0.0)):
+    # Newton for the whole robot over one step: m (v_com' - v_com) / h = foot contact forces + applied force + gravity, to O(h).
+    # Ties together center_of_mass_velocity, get_body_mass, the contact-force getters, apply_force and the physics itself.
+    m = float(np.sum(sim.get_body_mass())); v0 = np.array(sim.center_of_mass_velocity()); sim.step_pd(u); v1 = np.array(sim.center_of_mass_velocity())
+    ff = (ctypes.c_double * 12)(); cassie_sim_foot_forces(sim.c, ff); ff = np.array(ff[:])
+    ext = ff[0:3] + ff[6:9] + np.array(applied) + np.array([0, 0, -9.806 * m])
+    return float(np.abs(m * (v1 - v0) / 5e-4 - ext).max() / (9.806 * m)), ff
+run(150)                                                  # the feet have landed; only the feet touch the floor
+W = float(np.sum(sim.get_body_mass())) * 9.806
+# --- state vectors and clocks
+assert abs(sim.timestep() - 5e-4) < 1e-15 and abs(sim.time() - 150 * 5e-4) < 1e-9
+assert len(sim.qpos()) == 35 and len(sim.qpos_full()) == 35 and len(sim.qvel()) == 32 and len(sim.qvel_full()) == 32
+assert len(sim.qacc()) == 32 and len(sim.ctrl()) == 10 and fin(sim.qacc()) and fin(sim.ctrl()) and np.abs(sim.ctrl()).max() > 0.1
+assert len(sim.jnt_qposadr()) == 26 and len(sim.jnt_dofadr()) == 26 and sim.jnt_qposadr()[3] == 3 and sim.jnt_dofadr()[4] == 6
+# xpos / xquat are mj_step's: the pose before the last position update, i.e. within h |v| of qpos
+assert np.allclose(sim.xpos("cassie-pelvis"), sim.qpos()[:3], atol=2e-3) and np.allclose(sim.xquat("cassie-pelvis"), sim.qpos()[3:7], atol=2e-3)
+assert 0.8 < sim.qpos()[2] < 1.02
+# --- contact / force getters
+err, ff = momentum_balance(); assert err < 0.02, err
+lf, rf = sim.get_foot_forces(); assert abs(lf - np.linalg.norm(ff[0:3])) < 1e-9 and abs(rf - np.linalg.norm(ff[6:9])) < 1e-9 and lf + rf > 0.2 * W
+toe, heel = sim.get_heeltoe_forces(); assert np.allclose(toe[:3] + heel[:3], ff[0:3], atol=1e-9) and np.allclose(toe[3:] + heel[3:], ff[6:9], atol=1e-9)
+f6 = np.zeros(6); sim.get_body_contact_force(f6, "left-foot"); assert np.allclose(f6[:3], ff[0:3], atol=1e-9) and np.all(f6[3:] == 0)
+fp = sim.foot_pos(); assert len(fp) == 6 and abs(fp[2]) < 0.1 and abs(fp[5]) < 0.1
+fv = np.zeros(12); sim.foot_vel(fv); assert fin(fv) and np.abs(fv).max() < 2.0
+bv = np.zeros(6); sim.body_vel(bv, "cassie-pelvis"); assert fin(bv) and np.allclose(bv[:3], np.array(sim.qvel())[3:6] @ np.eye(3), atol=1.0)
+ba = np.zeros(6); sim.get_body_acceleration(ba, "cassie-pelvis"); assert fin(ba)
+fq = np.zeros(4); sim.foot_quat(fq); assert abs(np.linalg.norm(fq) - 1) < 1e-9
+assert not sim.check_self_collision() and not sim.check_obstacle_collision() and not sim.check_collision(2)
+# --- centroidal quantities
+com = sim.center_of_mass_position(); assert abs(com[0] - sim.qpos()[0]) < 0.2 and 0.5 < com[2] < 1.0
+assert fin(sim.center_of_mass_velocity()) and fin(sim.angular_momentum())
+I = np.array(sim.centroid_inertia()).reshape(3, 3); assert np.allclose(I, I.T, atol=1e-9) and np.all(np.linalg.eigvalsh(I) > 0)
+M = sim.full_mass_matrix(); assert np.allclose(M, M.T, atol=1e-10) and np.all(np.linalg.eigvalsh(M) > 0)
+assert abs(M[0, 0] - W / 9.806) < 1e-9                      # translational block = total mass
+v = np.array(sim.qvel()); assert abs(0.5 * v @ M @ v) < 50   # kinetic energy from the getter pair is sane
+Jc = sim.constraint_jacobian(); assert Jc.shape == (6, 32) and fin(Jc) and np.abs(Jc).max() > 0.01
+assert np.abs(sim.constraint_error()).max() < 5e-3          # the loop closures hold
+Mm = sim.minimal_mass_matrix(); assert Mm.shape == (16, 16) and fin(Mm)
+# --- Jacobians
+for nm in ("left-foot", "right-foot", "cassie-pelvis"):
+    jp = sim.get_jacobian(nm); jp2, jr2 = sim.get_jacobian_full(nm)
+    assert jp.shape == (96,) and np.array_equal(jp, jp2) and fin(jr2)
+jp, jr = sim.get_jacobian_full("cassie-pelvis")
+assert np.allclose(jp.reshape(3, 32)[:, :3], np.eye(3), atol=1e-12)
+js, jsr = sim.get_jacobian_full_site("left-toe"); assert fin(js) and np.abs(js).max() > 0.1
+assert len(sim.get_site_xpos("left-heel")) == 3 and abs(np.linalg.norm(sim.get_site_quat("left-heel")) - 1) < 1e-9
+assert abs(sim.get_site_xpos("left-heel")[2]) < 0.1
+rel = np.zeros(7); sim.get_object_relative_pose([0, 0, 0, 1, 0, 0, 0], [1, 2, 3, 1, 0, 0, 0], rel); assert np.allclose(rel, [1, 2, 3, 1, 0, 0, 0])
+# --- get_state / set_state replay (CassieSim.get_state needs a CassieState class the reference module does not define: use its ctypes functions)
+st = cassie_state_alloc(); cassie_get_state(sim.c, st); run(30); q1 = np.array(sim.qpos()); cassie_set_state(sim.c, st); run(30)
+assert np.array_equal(q1, np.array(sim.qpos())); cassie_state_free(st)
+# --- external force, then a heavier pelvis: Newton's balance keeps holding, with the new terms
+sim.apply_force([0, 0, 0.3 * W, 0, 0, 0]); run(10); err, ff2 = momentum_balance((0, 0, 0.3 * W)); assert err < 0.02, err
+sim.clear_forces(); run(10); err, ff3 = momentum_balance(); assert err < 0.02, err
+m = sim.get_body_mass(); assert m.shape == (26,) and abs(sim.get_body_mass("cassie-pelvis") - m[1]) < 1e-15
+sim.set_body_mass(m[1] + 5.0, name="cassie-pelvis"); assert abs(sim.get_body_mass("cassie-pelvis") - m[1] - 5) < 1e-12
+run(10); err, ff4 = momentum_balance(); assert err < 0.02, err
+Mh = sim.full_mass_matrix(); assert abs(Mh[0, 0] - W / 9.806 - 5) < 1e-9
+sim.set_body_mass(m); assert np.array_equal(sim.get_body_mass(), m)
+# --- other step entry points
+assert fin(sim.step(cassie_user_in_t()).pelvis.vectorNav.orientation[:])
+assert fin(sim.step_pd_no2khz(u).pelvis.position[:]) and fin(sim.integrate_pos().pelvis.position[:])
+# --- hold / release: the pelvis is pinned by stiff springs
+p0 = np.array(sim.qpos()[:3]); sim.hold(); run(300); assert np.abs(np.array(sim.qpos()[:3]) - p0).max() < 0.03 and np.abs(np.array(sim.qvel())[:6]).max() < 0.2; sim.release()
+# --- model parameter getters / setters (round trips)
+d = sim.get_dof_damping(); assert d.shape == (32,)
+assert sim.get_joint_num_dof("left-knee") == 1 and abs(sim.get_dof_damping("left-knee")[0] - d[sim.jnt_dofadr()[sim.mj_name2id("joint", "left-knee")]]) < 1e-15
+sim.set_dof_damping(2.5, name="left-knee"); assert sim.get_dof_damping("left-knee")[0] == 2.5
+sim.set_dof_damping(d); assert np.array_equal(sim.get_dof_damping(), d)
+ip = sim.get_body_ipos(); assert ip.shape == (26, 3) and np.allclose(sim.get_body_ipos("cassie-pelvis"), ip[1])
+sim.set_body_ipos(ip[1] + 0.01, name="cassie-pelvis"); assert np.allclose(sim.get_body_ipos("cassie-pelvis"), ip[1] + 0.01)
+sim.set_body_ipos(ip.flatten()); assert np.allclose(sim.get_body_ipos(), ip)
+bp = sim.get_body_pos("left-foot"); sim.set_body_pos("left-foot", bp + 0.001); assert np.allclose(sim.get_body_pos("left-foot"), bp + 0.001); sim.set_body_pos("left-foot", bp)
+fr = sim.get_geom_friction(); assert fr.shape == (sim.ngeom, 3) and np.allclose(sim.get_geom_friction("floor"), fr[0]) and np.allclose(sim.get_geom_name_friction("floor"), fr[0])
+sim.set_geom_friction([0.6, 1e-4, 5e-5], name="floor"); assert np.allclose(sim.get_geom_friction("floor"), [0.6, 1e-4, 5e-5])
+sim.set_geom_friction(fr.flatten()); assert np.allclose(sim.get_geom_friction(), fr)
+for get, set_, w in ((sim.get_geom_rgba, sim.set_geom_rgba, 4), (sim.get_geom_quat, sim.set_geom_quat, 4), (sim.get_geom_pos, sim.set_geom_pos, 3), (sim.get_geom_size, sim.set_geom_size, 3)):
+    allv = get(); one = get("box1"); assert allv.shape == (sim.ngeom * w,) and one.shape == (w,) and fin(allv)
+    k = sim.mj_name2id("geom", "box1"); assert np.allclose(allv[k * w:(k + 1) * w], one)
+    set_(one, name="box1"); set_(allv); assert np.allclose(get(), allv)
+sim.set_const(); sim.just_set_const()
+assert sim.mj_name2id("body", "cassie-pelvis") == 1 and sim.mj_name2id("body", "no-such-body") == -1
+# --- drive-level state: joint filters and the torque delay line (get_drive_filter is unusable in the reference module itself:
+#     its ctypes table rebinds cassie_sim_drive_filter with a two-argument signature, cassiemujoco_ctypes.py:886-888)
+td = sim.get_torque_delay(); assert td.shape == (10, 6); sim.set_torque_delay(td + 1.0); assert np.allclose(sim.get_torque_delay(), td + 1.0); sim.set_torque_delay(td)
+jf = sim.get_joint_filter(); x = [jf[i].x[k] for i in range(6) for k in range(4)]; yv = [jf[i].y[k] for i in range(6) for k in range(3)]
+sim.set_joint_filter(x, yv); jf2 = sim.get_joint_filter(); assert [jf2[i].x[k] for i in range(6) for k in range(4)] == x
+# --- full_reset, timestep, time
+sim.full_reset(); assert abs(sim.qpos()[2] - 1.01) < 1e-12 and np.all(np.array(sim.qvel()) == 0)
+sim.set_time(1.5); assert sim.time() == 1.5
+sim.set_qpos(list(sim.qpos())); sim.set_qvel(np.zeros(32)); sim.set_ctrl(np.zeros(10)); run(50); assert fin(sim.qpos())
+del sim
+# --- height-field model: terrain accessors
+hs = CassieSim("../model/cassie_hfield.xml")
+nr, nc, nd = hs.get_hfield_nrow(), hs.get_hfield_ncol(), hs.get_nhfielddata()
+assert nr * nc == nd and nd > 0 and hs.get_hfield_size().shape == (4,)
+h = np.clip(0.02 * np.add.outer(np.arange(nr) % 7, np.arange(nc) % 5) / 10.0, 0, 1).astype(np.float32).flatten()
+hs.set_hfield_data(h); assert np.allclose(hs.get_hfield_data(), h)
+sz = hs.get_hfield_size(); hs.set_hfield_size(sz); assert np.allclose(hs.get_hfield_size(), sz)
+for _ in range(200): yy = hs.step_pd(u)
+assert fin(hs.qpos()) and 0.7 < hs.qpos()[2] < 1.2
+"""
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF_STAGE, "example", "cassiemujoco.py")),
+                    reason="reference wrapper not staged (oracle/build_ref.sh runs where /root/reference exists)")
+def test_unmodified_reference_wrapper_api_sweep(L, tmp_path):
+    """Nearly every CassieSim method of the reference's unmodified example/cassiemujoco.py (:31-825) against this
+    library, with a physical or round-trip expectation for each: contact force getters carry the robot's weight, the
+    mass matrix is symmetric positive definite with the total mass in its translational block, Jacobians, loop-closure
+    error, get/set_state replay, hold / apply_force, every model-parameter getter / setter pair, the drive-level
+    filter and delay-line accessors, full_reset, and the height-field accessors on cassie_hfield.xml."""
+    import json
+    import shutil
+    import subprocess
+    import sys
+    ex = tmp_path / "example"
+    ex.mkdir()
+    for f in ("cassiemujoco.py", "cassiemujoco_ctypes.py"):
+        shutil.copy(os.path.join(REF_STAGE, "example", f), ex / f)
+    os.symlink(os.path.join(REPO_DIR, "cassie-mujoco-sim_amd", "lib", "libcassiemujoco.so"), ex / "libcassiemujoco.so")
+    os.symlink(os.path.join(REF_STAGE, "model"), tmp_path / "model")
+    # every top-level statement of the sweep runs even if an earlier one failed, so one run lists all the discrepancies
+    driver = r"""
+import json, sys, traceback
+src = open(sys.argv[1]).read().split("\n")
+chunks, cur = [], []
+for line in src:
+    if line and not line[0].isspace() and cur:
+        chunks.append("\n".join(cur)); cur = []
+    cur.append(line)
+chunks.append("\n".join(cur))
+ns, failures = {"__name__": "__main__"}, []
+for c in chunks:
+    try:
+        exec(compile(c, "<sweep>", "exec"), ns)
+    except BaseException as e:
+        failures.append({"statement": c.strip()[:400], "error": "".join(traceback.format_exception_only(type(e), e)).strip()[:300]})
+print(json.dumps({"failures": failures}))
+"""
+    (ex / "sweep.py").write_text(_SWEEP_SCRIPT)
+    out = subprocess.run([sys.executable, "-c", driver, "sweep.py"], cwd=ex, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    failures = json.loads(out.stdout.strip().splitlines()[-1])["failures"]
+    assert not failures, "\n".join("%s\n    -> %s" % (f["statement"], f["error"]) for f in failures)
+
+
 def test_single_simulator_is_faster_than_real_time(L):
     """The reference's implicit requirement: one cassie_sim_step_pd per 0.5 ms of simulated time, i.e. >= 2 kHz
     (reference example/cassiesim.c:284-293 prints SLOWER THAN REAL TIME otherwise)."""
