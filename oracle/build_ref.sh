@@ -31,3 +31,15 @@ cp "$REF/model/cassie.xml" "$REF/model/cassie_hfield.xml" "$REF/model/cassie_tra
 cp -r "$REF/model/cassie-stl-meshes" "$HERE/_ref/model/"
 [ -d "$REF/model/terrains" ] && cp -r "$REF/model/terrains" "$HERE/_ref/model/" || true
 echo "staged $HERE/_ref/example and $HERE/_ref/model"
+# The reference's own C example programs (example/*.c: the UDP simulator and controller, and the visualiser demos),
+# compiled UNMODIFIED from where they lie against this repository's include/ and product library -- the source-level
+# drop-in check for C users (tests/test_ref_programs.py).  Needs the product library (make product) to link.
+PROD="$HERE/../cassie-mujoco-sim_amd/lib"
+if [ -f "$PROD/libcassiemujoco.so" ]; then
+  mkdir -p "$HERE/_ref/bin"
+  for f in cassiesim cassiectrl cassietest cassievideo test_doublevis test_heelforce test_hfield test_terrain; do
+    gcc -O1 -w -std=gnu11 -I"$HERE/../include" "$REF/example/$f.c" -o "$HERE/_ref/bin/$f" \
+        -L"$PROD" -lcassiemujoco -Wl,-rpath,'$ORIGIN/../../../cassie-mujoco-sim_amd/lib' -lm -lpthread
+  done
+  echo "built the reference's example programs into $HERE/_ref/bin"
+fi
