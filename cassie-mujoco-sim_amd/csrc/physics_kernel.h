@@ -2301,9 +2301,19 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
                         if (est < 0.5f * tol) converged = true;
                         else if (est > 2.0f * tol) converged = false;
                         else {
-                            double improvement = 0;
-                            for (int t = 0; t < nrows; ++t) improvement -= wv::readlane(change, t);
-                            converged = improvement * scale < m->tolerance;
+#ifndef CK_PGS_ORDERED_SUM_IN_BAND
+                            /* inside the band a double-precision tree sum decides: the rows' changes are cost decreases (at
+                             * most +1e-10 each, or the guard had fired), so it differs from the ordered sum by rounding only,
+                             * and the ordered sum is formed just when the tree sum lands within 1e-9 of the tolerance */
+                            const double tree = -wv::wave_sum(change) * scale, tolv = m->tolerance;
+                            if (fabs(tree - tolv) > 1e-9 * tolv) converged = tree < tolv;
+                            else
+#endif
+                            {
+                                double improvement = 0;
+                                for (int t = 0; t < nrows; ++t) improvement -= wv::readlane(change, t);
+                                converged = improvement * scale < m->tolerance;
+                            }
                         }
                     }
                 }

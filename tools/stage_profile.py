@@ -39,4 +39,11 @@ for n in (int(a) for a in (sys.argv[1:] or ["512", "4096"])):
     for nm, a, c in sub:
         v = (st[:, c] - st[:, a]).astype(float)
         print("    %-22s %9.0f cycles" % (nm, v.mean()))
+    # what one PGS sweep costs: least squares of the sweep-loop clocks of the last substep on (1, sweeps, sweeps x rows)
+    sw = (st[:, 11] - st[:, 30]).astype(float)
+    it, ne = info[:, 2].astype(float), info[:, 1].astype(float)
+    A = np.stack([np.ones_like(it), it, it * np.ceil(ne / 4) * 4], axis=1)
+    coef, *_ = np.linalg.lstsq(A, sw, rcond=None)
+    print("    pgs sweeps ~ %.0f + %.0f per sweep + %.1f per (sweep x row, rows rounded up to 4); total cycles of the step vs sweeps: %.0f per sweep"
+          % (coef[0], coef[1], coef[2], np.polyfit(it, tot, 1)[0]))
     b.close()
