@@ -846,7 +846,7 @@ WV_DEVICE void pgs_rows(const double (&brow)[CM_MAXEFC], int nrows, int r_, doub
 template <int I>
 WV_DEVICE void pgs_row_fast(const double (&brow)[CM_MAXEFC], int r_, double lo_f, double &sres, double &mys) {
     if constexpr (I < CM_MAXEFC) {
-        const double delta = fmax(sres, lo_f);
+        const double delta = wv::max_raw(sres, lo_f); /* one v_max_f64: fmax() adds a canonicalising self-max to the row chain after every branch */
         if (r_ == I) mys = sres; /* the residual this row started from: its step is recomputed from it after the sweep */
         sres += brow[I] * wv::readlane(delta, I);
     }
@@ -2275,7 +2275,9 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
 #pragma unroll
             for (int t = 0; t < CM_MAXEFC; ++t) arow[t] *= ninvAii;
             const double cdiag = isrow ? rR * ninvAii : 0.0; /* the R part of B_jj = -(Y Y^T + R)_jj / A_jj, see above */
-            while (iters < m->iterations) {
+            const int maxiter = m->iterations;
+            const double tolerance = m->tolerance;
+            while (iters < maxiter) {
                 const int nrows = wv::opaque(nefc); /* keeps the row-bound tests out of loop-invariant hoisting */
                 bool converged;
                 {
@@ -2289,13 +2291,13 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
                      * A single-precision tree sum (issued before the guard ballot, so the two latencies overlap) decides it
                      * unless it lands within a factor two of the tolerance -- far outside what precision or the order of
                      * summation can move -- and only then is the ordered double-precision sum formed. */
-                    const float est = -wv::wave_sum_f32((float)change) * (float)scale, tol = (float)m->tolerance;
+                    const float est = -wv::wave_sum_f32((float)change) * (float)scale, tol = (float)tolerance;
                     if (wv::ballot(change > 1e-10) != 0ull || wv::debug_force_guarded()) { /* some row would have raised the cost: redo guarded */
                         double improvement = 0;
                         f = f0; sres = s0; ++nguarded;
                         pgs_rows<0>(arow, nrows, r_, Aii, halfAii, flo, f, sres, improvement);
                         sres = fma(cdiag, f - f0, sres);
-                        converged = improvement * scale < m->tolerance;
+                        converged = improvement * scale < tolerance;
                     } else {
                         if (r_ < nrows) { f += mydelta; sres = fma(cdiag, mydelta, sres); }
                         if (est < 0.5f * tol) converged = true;
@@ -2305,14 +2307,14 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
                             /* inside the band a double-precision tree sum decides: the rows' changes are cost decreases (at
                              * most +1e-10 each, or the guard had fired), so it differs from the ordered sum by rounding only,
                              * and the ordered sum is formed just when the tree sum lands within 1e-9 of the tolerance */
-                            const double tree = -wv::wave_sum(change) * scale, tolv = m->tolerance;
+                            const double tree = -wv::wave_sum(change) * scale, tolv = tolerance;
                             if (fabs(tree - tolv) > 1e-9 * tolv) converged = tree < tolv;
                             else
 #endif
                             {
                                 double improvement = 0;
                                 for (int t = 0; t < nrows; ++t) improvement -= wv::readlane(change, t);
-                                converged = improvement * scale < m->tolerance;
+                                converged = improvement * scale < tolerance;
                             }
                         }
                     }

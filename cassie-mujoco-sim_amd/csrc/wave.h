@@ -132,6 +132,8 @@ WV_DEVICE constexpr bool debug_force_guarded() { return false; }
 WV_DEVICE long long clock() { return (long long)__builtin_readcyclecounter(); }
 
 WV_DEVICE int popc64(unsigned long long x) { return __popcll(x); }
+/* max of two doubles that are known not to be signalling NaNs, as the single instruction */
+WV_DEVICE double max_raw(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 
 }  // namespace wv
 #endif

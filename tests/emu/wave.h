@@ -37,6 +37,7 @@ unsigned long long ballot(bool p);
 double wave_sum(double v);
 float wave_sum_f32(float v);
 inline long long clock() { return 0; }
+inline double max_raw(double a, double b) { return a > b ? a : b; }
 inline int opaque(int x) { return x; }
 inline void sched_fence() {}
 extern int g_force_guarded;
