@@ -2040,7 +2040,17 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
 
         /* ---- sensors, part 1 (lane = sensor): everything that does not need qacc is final here; the
          *      accelerometer parks its partial results in LDS because the body tiles are about to be recycled ---- */
-        const bool issens = lane < m->nsensor;
+        /* Who reads a substep's sensors: the launch's caller (the last substep's), and in a drive mode the next substep's
+         * encoder models (the joint / actuator positions) and the measurement block the LAST substep's drive pass writes
+         * (the IMU words of the substep before it).  The IMU sensors -- frame quaternion, gyro, magnetometer and the
+         * accelerometer with its second part after the solve -- are therefore evaluated by the last two substeps only. */
+#ifdef CK_IMU_EVERY_SUBSTEP
+        const bool need_imu = true, need_pos = true;
+#else
+        const bool need_imu = lastsub || (io.drive_mode && sub + 2 == io.nsub);
+        const bool need_pos = lastsub || io.drive_mode;
+#endif
+        const bool issens = lane < m->nsensor && need_pos;
         const int ls = issens ? lane : 0; /* every constant of the lane's sensor in one level of (unconditional) reads */
         const int stype = issens ? m->sensor_type[ls] : -1;
         const int aslot = (stype == CM_SENS_ACCELEROMETER) ? m->sensor_slot[ls] : -1; /* which accelerometer this lane is */
@@ -2049,7 +2059,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
         if (issens) {
             double sout[4] = {0, 0, 0, 0};
             if (sqadr >= 0) sout[0] = sgain * S.qpos[sqadr]; /* actuatorpos (gear * q) and jointpos */
-            else if (stype >= CM_SENS_FRAMEQUAT && stype <= CM_SENS_MAGNETOMETER) {
+            else if (need_imu && stype >= CM_SENS_FRAMEQUAT && stype <= CM_SENS_MAGNETOMETER) {
                 double sq[4] = {m->sensor_squat[ls][0], m->sensor_squat[ls][1], m->sensor_squat[ls][2], m->sensor_squat[ls][3]};
                 double q[4], sxmat[9], scvel[6];
                 mulquat(q, S.x.s.xquat[sb], sq);
@@ -2074,7 +2084,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
                     for (int i = 0; i < 6; ++i) pa[18 + i] = scvel[i];
                 }
             }
-            if (stype != CM_SENS_ACCELEROMETER) {
+            if (stype != CM_SENS_ACCELEROMETER && (need_imu || sqadr >= 0)) {
                 const double cut = m->sensor_cutoff[lane];
                 const int dim = m->sensor_dim[lane], adr = m->sensor_adr[lane];
                 for (int i = 0; i < 4; ++i) {
@@ -2123,7 +2133,8 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
         }
         /* first constraint row of every contact (lane = contact), for the contact-force read-out */
         int caddr = -1;
-        {
+        const bool want_cfrc = io.body_cfrc && (sub == io.nsub - 1 || !io.integrate); /* read out by the last substep only */
+        if (io.ext || want_cfrc) {
             int acc = nefc_before_contacts;
             for (int c = 0; c < ncon; ++c) {
                 const int dim = S.c_dim[c];
@@ -2324,7 +2335,6 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
             }
         }
         CK_STAMP(11);
-        const bool want_cfrc = io.body_cfrc && (sub == io.nsub - 1 || !io.integrate);
         if (io.ext || want_cfrc) {
             /* decode the pyramid: normal = sum of the edge forces, tangents = mu (f+ - f-) */
             const int a0 = caddr >= 0 ? caddr : 0;
@@ -2403,7 +2413,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
         CK_STAMP(12);
 
         /* ---- sensors, part 2: the accelerometer needs qacc ---- */
-        if (aslot >= 0) {
+        if (aslot >= 0 && need_imu) {
             const double *pa = S.accel[aslot];
             double acc_ang[3] = {pa[0], pa[1], pa[2]}, acc_lin[3] = {pa[3], pa[4], pa[5]}, acc_dif[3] = {pa[6], pa[7], pa[8]};
             for (unsigned long long mk = m->body_dofmask[sb]; mk; mk &= mk - 1) {
