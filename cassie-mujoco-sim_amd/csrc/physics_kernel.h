@@ -1129,6 +1129,14 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
 #else
         const bool lastsub = sub == io.nsub - 1 || !io.integrate;
 #endif
+        /* Body quaternions feed only the IMU frame sensor, the site / body orientation read-outs and xquat_out -- all of
+         * them values of the last substep (in a drive mode also of the one before it, see the sensors): the other
+         * substeps carry rotation matrices only through the kinematic recursion. */
+#ifdef CK_QUAT_EVERY_SUBSTEP
+        const bool need_quat = true;
+#else
+        const bool need_quat = lastsub || io.ext != nullptr || (io.drive_mode && sub + 2 == io.nsub);
+#endif
         /* divergence guard (mj_checkPos/mj_checkVel role): sticky flag, state left alone */
         {
             bool badv = false;
@@ -1220,7 +1228,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
                         for (int i = 0; i < 3; ++i)
                             for (int c = 0; c < 3; ++c) Rn[3 * i + c] = Rl[3 * i] * Rq[c] + Rl[3 * i + 1] * Rq[3 + c] + Rl[3 * i + 2] * Rq[6 + c];
                         for (int i = 0; i < 9; ++i) Rl[i] = Rn[i];
-                        mulquat(qlq, qlq, qj);
+                        if (need_quat) mulquat(qlq, qlq, qj);
                         /* rotation about the anchor: the origin moves so that the anchor stays put */
                         mulmatvec3(r, Rl, jp);
                         for (int i = 0; i < 3; ++i) pl[i] = al[i] - r[i];
@@ -1243,21 +1251,21 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
             if (lane < NB) {
                 for (int i = 0; i < 9; ++i) S.x.s.xmat[lane][i] = xm[i];
                 for (int i = 0; i < 3; ++i) S.x.s.xpos[lane][i] = xp[i];
-                for (int i = 0; i < 4; ++i) S.x.s.xquat[lane][i] = xq[i];
+                if (need_quat) for (int i = 0; i < 4; ++i) S.x.s.xquat[lane][i] = xq[i];
             }
             wv::sync();
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int a = kanc[r];
-                double Ra[9], pa[3], qa[4];
+                double Ra[9], pa[3], qa[4] = {1, 0, 0, 0};
                 if ((r & 1) == 0) {
                     for (int i = 0; i < 9; ++i) Ra[i] = S.x.s.xmat[a][i];
                     for (int i = 0; i < 3; ++i) pa[i] = S.x.s.xpos[a][i];
-                    for (int i = 0; i < 4; ++i) qa[i] = S.x.s.xquat[a][i];
+                    if (need_quat) for (int i = 0; i < 4; ++i) qa[i] = S.x.s.xquat[a][i];
                 } else {
                     for (int i = 0; i < 9; ++i) Ra[i] = bufB[a * 17 + i];
                     for (int i = 0; i < 3; ++i) pa[i] = bufB[a * 17 + 9 + i];
-                    for (int i = 0; i < 4; ++i) qa[i] = bufB[a * 17 + 12 + i];
+                    if (need_quat) for (int i = 0; i < 4; ++i) qa[i] = bufB[a * 17 + 12 + i];
                 }
                 if (a > 0 || r == 0) { /* the world's transform is the identity: nothing to compose beyond the root */
                     double Rn[9], pn[3];
@@ -1268,18 +1276,18 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
                     if (a > 0) {
                         for (int i = 0; i < 9; ++i) xm[i] = Rn[i];
                         for (int i = 0; i < 3; ++i) xp[i] = pn[i];
-                        mulquat(xq, qa, xq);
+                        if (need_quat) mulquat(xq, qa, xq);
                     }
                 }
                 if (lane < NB) {
                     if ((r & 1) == 0) {
                         for (int i = 0; i < 9; ++i) bufB[lane * 17 + i] = xm[i];
                         for (int i = 0; i < 3; ++i) bufB[lane * 17 + 9 + i] = xp[i];
-                        for (int i = 0; i < 4; ++i) bufB[lane * 17 + 12 + i] = xq[i];
+                        if (need_quat) for (int i = 0; i < 4; ++i) bufB[lane * 17 + 12 + i] = xq[i];
                     } else {
                         for (int i = 0; i < 9; ++i) S.x.s.xmat[lane][i] = xm[i];
                         for (int i = 0; i < 3; ++i) S.x.s.xpos[lane][i] = xp[i];
-                        for (int i = 0; i < 4; ++i) S.x.s.xquat[lane][i] = xq[i];
+                        if (need_quat) for (int i = 0; i < 4; ++i) S.x.s.xquat[lane][i] = xq[i];
                     }
                 }
                 wv::sync();
