@@ -1877,11 +1877,23 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
         const int r_ = lane;
         int rtype = -1, rid = 0, rsub = 0;
         int nefc = 0;
-        for (int e = 0; e < m->neq; ++e) {
-            if (!m->eq_active[e]) continue;
-            if (nefc + 3 > CM_MAXEFC) { warn |= WARN_CONSTRAINT_FULL; continue; }
-            if (r_ >= nefc && r_ < nefc + 3) { rtype = CM_CNSTR_EQUALITY; rid = e; rsub = r_ - nefc; }
-            nefc += 3;
+        {
+            /* all equalities active and within the cap (the usual case): three rows each, in order, in closed form */
+            const int neq = m->neq;
+            const bool eact = lane < neq && m->eq_active[lane < neq ? lane : 0] != 0;
+            const unsigned long long eall = neq >= 64 ? ~0ull : (1ull << neq) - 1;
+#ifndef CK_ROWS_SERIAL
+            if (wv::ballot(eact) == eall && 3 * neq <= CM_MAXEFC) {
+                if (r_ < 3 * neq) { rtype = CM_CNSTR_EQUALITY; rid = r_ / 3; rsub = r_ - 3 * rid; }
+                nefc = 3 * neq;
+            } else
+#endif
+            for (int e = 0; e < neq; ++e) {
+                if (!m->eq_active[e]) continue;
+                if (nefc + 3 > CM_MAXEFC) { warn |= WARN_CONSTRAINT_FULL; continue; }
+                if (r_ >= nefc && r_ < nefc + 3) { rtype = CM_CNSTR_EQUALITY; rid = e; rsub = r_ - nefc; }
+                nefc += 3;
+            }
         }
         {
             /* joint limits: lane = joint evaluates its own violation, ballots give the row slots in joint order */
@@ -1907,6 +1919,14 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
             }
         }
         const int nefc_before_contacts = nefc;
+        /* every contact a friction pyramid of four rows and all of them within the cap (the usual case): closed form */
+        const bool cpyr = lane < ncon && S.c_dim[lane < ncon ? lane : 0] == 3;
+#ifndef CK_ROWS_SERIAL
+        if (wv::ballot(cpyr) == (ncon >= 64 ? ~0ull : (1ull << ncon) - 1) && nefc + 4 * ncon <= CM_MAXEFC) {
+            if (r_ >= nefc && r_ < nefc + 4 * ncon) { rtype = CM_CNSTR_CONTACT_PYRAMIDAL; rid = (r_ - nefc) >> 2; rsub = (r_ - nefc) & 3; }
+            nefc += 4 * ncon;
+        } else
+#endif
         for (int c = 0; c < ncon; ++c) {
             const int dim = S.c_dim[c];
             if (dim != 1 && dim != 3) { warn |= WARN_UNSUPPORTED_PAIR; continue; }
