@@ -564,10 +564,7 @@ def main():
             "mean_constraint_rows": r["mean_constraint_rows"], "mean_pgs_iterations": r["mean_pgs_iterations"], "mean_pgs_guarded_sweeps": r["mean_pgs_guarded_sweeps"],
         }
         if world == 1 and args.model == "cassie":
-            if not args.no_cpu_baseline:
-                out["cpu_baseline"] = cpu_baseline(model)
-            tsample = np.arange(8)
-            out["true_reference"] = true_reference(args.model, model.qpos_init(), pd_targets(tsample, EPISODE // HOLD + 1), EPISODE)
+            # the GPU legs first, back to back with the timed region; the CPU legs (tens of seconds with an idle GPU) last
             if not args.no_other_mode:
                 other = "exact-pd" if args.mode == "drive-pd" else "drive-pd"
                 o = device_rollout(model, other, n, min(args.steps, 400), min(args.warmup, 50), 0, 1, local_rank, args.substeps_per_launch, 16, hfield)
@@ -581,6 +578,10 @@ def main():
                 out["step_pd_host_api"] = sp
                 out["step_pd_device_drives"] = sd
                 out["value_step_pd"] = max([x["value"] for x in (sp, sd) if x] or [None])
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(model)
+            tsample = np.arange(8)
+            out["true_reference"] = true_reference(args.model, model.qpos_init(), pd_targets(tsample, EPISODE // HOLD + 1), EPISODE)
         print(json.dumps(out), flush=True)
     if collect:
         dist.destroy_process_group()
