@@ -113,7 +113,9 @@ int phys_batch_clear_warn(phys_batch_t *b, int env0, int n);
 /* non-zero once PHYS_F_QFRC_APPLIED / PHYS_F_XFRC_APPLIED have been uploaded or bound (until then the kernel skips them) */
 int phys_batch_uses_applied(const phys_batch_t *b);
 /* mj_step1 + mj_step2, nsub times with ctrl held (reference :1130-1134), on `stream`
- * (a hipStream_t passed as void*, NULL = the batch's own stream); asynchronous */
+ * (a hipStream_t passed as void*, NULL = the batch's own stream); asynchronous.  The output fields (sensordata, qacc,
+ * xpos / xquat, the measurement block, solver statistics) hold the values of the LAST of the nsub steps -- what nsub
+ * single-step launches would leave; the state fields (qpos, qvel, time, warm start, drive-level state) advance nsub steps */
 int phys_batch_step(phys_batch_t *b, int nsub, void *stream);
 /* mj_forward (reference :971, :1029, :1223, :3293): no integration */
 int phys_batch_forward(phys_batch_t *b, void *stream);
