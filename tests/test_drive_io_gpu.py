@@ -84,9 +84,11 @@ def test_fused_substeps_equal_single_steps(cassie):
         else:
             for _ in range(50):
                 b.step(1)
-        out.append((b.get(P.F_QPOS), b.get(P.F_MEAS), [device_state_bytes(s) for s in b.get_drive_state()]))
+        out.append((b.get(P.F_QPOS), b.get(P.F_MEAS), [device_state_bytes(s) for s in b.get_drive_state()], b.get(P.F_SENSORDATA), b.get(P.F_XQUAT)))
         b.close()
     assert out[0][0].tobytes() == out[1][0].tobytes() and out[0][1].tobytes() == out[1][1].tobytes() and out[0][2] == out[1][2]
+    # outputs of a fused launch = its last substep's, IMU words and body quaternions included (evaluated by the last two substeps only)
+    assert out[0][3].tobytes() == out[1][3].tobytes() and out[0][4].tobytes() == out[1][4].tobytes()
 
 
 def test_pd_on_measurements_mode_against_host_chain_and_oracle(cassie):
