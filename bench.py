@@ -407,10 +407,30 @@ def device_rollout(model, mode, n, steps, warmup, rank, world, local_rank, subst
             obs[rows, : nq + nv] = init_row[: nq + nv]
         warm[rows] = 0
 
+    # The all-gather runs beside the next launch: the observation block is snapshotted on the launch stream (3 MB, device
+    # to device), RCCL sends the snapshot from a second stream, and the next snapshot waits for that gather to have read it.
+    snap = torch.empty_like(obs) if collect else None
+    comm_stream = torch.cuda.Stream(device=dev) if collect else None
+    gather_done = [None]
+
+    def gather():
+        cur = torch.cuda.current_stream(dev)
+        if gather_done[0] is not None:
+            cur.wait_event(gather_done[0])
+        snap.copy_(obs, non_blocking=True)
+        ready = torch.cuda.Event()
+        ready.record(cur)
+        with torch.cuda.stream(comm_stream):
+            comm_stream.wait_event(ready)
+            gather_observations(snap, world, obs_all)
+            done = torch.cuda.Event()
+            done.record(comm_stream)
+        gather_done[0] = done
+
     sch = Schedule(step=lambda nsub: b.step(nsub, stream),
                    bind_targets=lambda p: b.bind(P.F_PD_PTARGET, targets[p].data_ptr()),
                    restart=restart,
-                   gather=(lambda: gather_observations(obs, world, obs_all)) if collect else None,
+                   gather=gather if collect else None,
                    substeps_per_launch=substeps_per_launch)
 
     def fence():
@@ -428,7 +448,7 @@ def device_rollout(model, mode, n, steps, warmup, rank, world, local_rank, subst
            "elapsed": _reduce_max(elapsed, dev) if collect else elapsed}
     if collect and rank == 0:
         # the gathered block of the last policy boundary must hold this rank's rows (global env order, rank-major)
-        res["gather_ok"] = bool(sch.gathers > 0)
+        res["gather_ok"] = bool(sch.gathers > 0 and torch.equal(obs_all[rank * n:(rank + 1) * n], snap))
     w, info = b.warnings()
     res["envs_with_warnings"] = int(np.count_nonzero(w))
     res["mean_constraint_rows"], res["mean_pgs_iterations"], res["mean_pgs_guarded_sweeps"] = (float(info[:, k].mean()) for k in (1, 2, 3))
@@ -561,6 +581,7 @@ def main():
                               "frac": value * 0.22e6 / 1e12 / 78.6,
                               "note": "algorithmic flops (SURVEY.md 8a estimate), not counting lanes that idle or recompute"},
             "envs_with_warnings": r["envs_with_warnings"],
+            **({"obs_allgather_ok": r.get("gather_ok")} if collect else {}),   # rank 0's rows of the last gathered block = its snapshot
             "mean_constraint_rows": r["mean_constraint_rows"], "mean_pgs_iterations": r["mean_pgs_iterations"], "mean_pgs_guarded_sweeps": r["mean_pgs_guarded_sweeps"],
         }
         if world == 1 and args.model == "cassie":
