@@ -331,7 +331,8 @@ class HostChainEnvs:
         return self.orcs[0].sensordata.copy()
 
 
-def device_rollout(model, mode, n, steps, warmup, rank, world, local_rank, substeps_per_launch=HOLD, parity_envs=64, hfield=None, collect=None):
+def device_rollout(model, mode, n, steps, warmup, rank, world, local_rank, substeps_per_launch=HOLD, parity_envs=64, hfield=None, collect=None,
+                   all_outputs=False):
     """One timed device-resident rollout of the workload in `mode`:
 
       "drive-pd"  CM_DRIVE_PD: every substep runs pd_input's motor PD on the ENCODER measurements of the
@@ -355,6 +356,8 @@ def device_rollout(model, mode, n, steps, warmup, rank, world, local_rank, subst
     npolicy = (total_steps + HOLD - 1) // HOLD + 1
     dev = torch.device("cuda", local_rank)
     b = Batch(model, n, device=local_rank)
+    if all_outputs:
+        b.set_all_outputs_every_substep(True)
     if os.environ.get("CASSIE_NO_BALANCE"):
         b.set_balance(False)            # A/B switch for the longest-job-first launch order
     if hfield is not None:
@@ -593,6 +596,13 @@ def main():
                                                 "kernel_ms": o["kernel_ms"], "parity": o["parity"], "mean_constraint_rows": o["mean_constraint_rows"],
                                                 "mean_pgs_iterations": o["mean_pgs_iterations"]}
                 out["value_" + other.replace("-", "_")] = out[other.replace("-", "_")]["value"]
+                # `value` with every output evaluated by every substep: a fused launch returns its last substep's outputs, so by
+                # default the IMU sensor words and body quaternions of the substeps in between -- values nobody can read -- are
+                # not formed; this is what forming them anyway costs
+                a = device_rollout(model, args.mode, n, min(args.steps, 400), min(args.warmup, 50), 0, 1, local_rank, args.substeps_per_launch, 4, hfield,
+                                   all_outputs=True)
+                out["all_outputs_every_substep"] = {"value": n * a["steps"] / a["elapsed"], "unit": "env-steps/s", "steps": a["steps"],
+                                                    "kernel_ms": a["kernel_ms"], "max_qpos_err": a["parity"]["max_qpos_err"]}
             if not args.no_step_pd:
                 sp = step_pd_host_api(n)
                 sd = step_pd_host_api(n, device_drives=True)

@@ -214,6 +214,11 @@ class Batch:
         """Longest-job-first launch order from the previous launch's per-env cost (default on for >= 2048 envs)."""
         lib().phys_batch_set_balance(self._h, 1 if on else 0)
 
+    def set_all_outputs_every_substep(self, on=True):
+        """Measurement aid: every substep of a fused launch evaluates every output (IMU sensors, body quaternions), not only
+        the substeps whose values can be read."""
+        lib().phys_batch_set_all_outputs_every_substep(self._h, 1 if on else 0)
+
     def poison_lds(self):
         """Validation aid: NaN bit patterns into every CU's LDS before the next launch."""
         if lib().phys_batch_debug_poison_lds(self._h) != 0:

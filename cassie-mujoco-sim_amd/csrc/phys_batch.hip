@@ -44,6 +44,7 @@ struct phys_batch {
     bool use_pd_dtarget = false, use_pd_torque = false;
     long long *d_prof = nullptr;
     /* launch-order balancing (see ck::cassie_order_kernel) */
+    bool all_outputs = false;       /* measurement aid: see PhysIO::all_outputs_every_substep */
     bool balance = true;
     unsigned *d_cost = nullptr;
     int *d_order = nullptr;
@@ -93,6 +94,7 @@ static ck::PhysIO make_io(phys_batch *b, int nsub, int integrate) {
             io.pd_torque = b->use_pd_torque ? b->d_field[PHYS_F_PD_TORQUE] : nullptr;
         }
     }
+    io.all_outputs_every_substep = b->all_outputs ? 1 : 0;
     io.prof = b->d_prof;
     io.ext = b->d_ext;
     if (b->balance && b->d_order) { io.order = b->d_order; io.cost = b->d_cost; }
@@ -551,6 +553,12 @@ int phys_batch_derive(phys_batch_t *b, const int ids[6], void *stream) {
         rc |= phys_batch_enable_ext(b, 0);
     }
     return rc;
+}
+
+int phys_batch_set_all_outputs_every_substep(phys_batch_t *b, int on) {
+    if (!b) return -1;
+    b->all_outputs = on != 0;
+    return 0;
 }
 
 int phys_batch_set_balance(phys_batch_t *b, int on) {

@@ -113,6 +113,9 @@ struct PhysIO {
      * shader clocks its launch took; the launcher sorts the next launch's order by that cost, most expensive first */
     const int *order;
     unsigned *cost;
+    /* non-zero: every substep of a launch evaluates every output (IMU sensors, body quaternions) although only the last
+     * substep's can be read -- a measurement aid (bench.py reports the rate with it as a side figure) */
+    int all_outputs_every_substep;
 };
 
 template <int NVP, int NL = NVP * (NVP + 1) / 2>
@@ -1135,7 +1138,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
 #ifdef CK_QUAT_EVERY_SUBSTEP
         const bool need_quat = true;
 #else
-        const bool need_quat = lastsub || io.ext != nullptr || (io.drive_mode && sub + 2 == io.nsub);
+        const bool need_quat = lastsub || io.ext != nullptr || io.all_outputs_every_substep || (io.drive_mode && sub + 2 == io.nsub);
 #endif
         /* divergence guard (mj_checkPos/mj_checkVel role): sticky flag, state left alone */
         {
@@ -2075,8 +2078,8 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
 #ifdef CK_IMU_EVERY_SUBSTEP
         const bool need_imu = true, need_pos = true;
 #else
-        const bool need_imu = lastsub || (io.drive_mode && sub + 2 == io.nsub);
-        const bool need_pos = lastsub || io.drive_mode;
+        const bool need_imu = lastsub || io.all_outputs_every_substep || (io.drive_mode && sub + 2 == io.nsub);
+        const bool need_pos = lastsub || io.drive_mode || io.all_outputs_every_substep;
 #endif
         const bool issens = lane < m->nsensor && need_pos;
         const int ls = issens ? lane : 0; /* every constant of the lane's sensor in one level of (unconditional) reads */

@@ -166,6 +166,9 @@ int phys_batch_download_ext_async(phys_batch_t *b, cm_ext_t *host, int env0, int
  * The forces are those of the CURRENT state (like after cassie_sim_forward).  Costs about one physics step. */
 int phys_batch_derive(phys_batch_t *b, const int ids[6], void *stream);
 
+/* measurement aid: on = every substep of a fused launch evaluates every output (IMU sensors, body quaternions), although
+ * only the last substep's values can be read; off (default) = those are formed by the substeps whose values are read */
+int phys_batch_set_all_outputs_every_substep(phys_batch_t *b, int on);
 /* Launch-order balancing (on by default for batches of 2048 envs and more): every launch records what each env cost
  * and the next launch starts the expensive envs first, so the wave slots finish together instead of the launch waiting
  * for whichever slot drew the slow envs last.  Results do not depend on it (envs are independent). */
