@@ -573,6 +573,9 @@ def main():
                        "envs_total": world * n, "parallelism": "env-sharded x%d" % world,
                        "obs_allgather_every_steps": HOLD if collect else None,
                        "substeps_per_launch": steps_per_launch, "launches_timed": timed_launches,
+                       "outputs_of_a_launch": "its last substep's (sensordata, measurement block, xpos / xquat, solver statistics); IMU words and "
+                                              "body quaternions of the substeps in between, which nobody can read, are not formed -- "
+                                              "`all_outputs_every_substep` is the rate with them formed anyway",
                        "preroll_steps": PREROLL, "episode_steps": EPISODE},
             "parity": r["parity"],
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
