@@ -256,3 +256,24 @@ def test_results_do_not_depend_on_what_lds_held_before(name, mode, built):
     assert out[1][4][:, 0].max() >= 2
     for a, c in zip(out[0], out[1]):
         assert np.array_equal(a, c)
+
+
+def test_bench_rollout_with_the_collective_path_on_one_rank(cassie):
+    """bench.device_rollout with the multi-GPU machinery switched on (RCCL process group of one rank: barrier fences, the
+    observation all-gather that overlaps the next launch through a snapshot and a second stream, the max reduction):
+    the gathered block holds this rank's rows, and the rollout still matches its CPU replay."""
+    import os
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29600 + os.getpid() % 300))
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        r = bench.device_rollout(cassie, "drive-pd", 512, 200, 50, 0, 1, 0, bench.HOLD, 8, None, collect=True)
+    finally:
+        if created:
+            dist.destroy_process_group()
+    assert r["gather_ok"] is True
+    assert r["parity"]["ok"] and r["parity"]["frac_envs_with_equal_ncon_nefc_iters"] == 1.0
+    assert r["envs_with_warnings"] == 0
