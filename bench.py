@@ -148,7 +148,7 @@ def max_over_ranks(seconds, world, device=None):
     return float(t.item())
 
 
-def pmc_traffic(env_steps_per_launch):
+def pmc_traffic(env_steps_per_launch, model_name="cassie"):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (tools/gpu_pmc.sh: FETCH_SIZE and WRITE_SIZE in
     separate --pmc runs, corrected as MI355X_MICROARCH.md prescribes), scaled to this run's env-steps per launch.
     The counters cannot be collected from inside the timed process, so this is the last measured figure, or None."""
@@ -158,7 +158,8 @@ def pmc_traffic(env_steps_per_launch):
     def version(path):   # profiles/roundR/vN_pmc_summary.json -> (R, N)
         m = re.search(r"round(\d+).*?v(\d+)_pmc_summary", path)
         return (int(m.group(1)), int(m.group(2))) if m else (0, 0)
-    files = sorted(glob.glob(os.path.join(REPO, "profiles", "round*", "*pmc_summary.json")), key=version)
+    suffix = {"cassie": "", "cassie_hfield": "_hfield", "cassie_tray_box": "_tray"}.get(model_name, "")   # the passes of this model's kernel
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "round*", "*pmc_summary%s.json" % suffix)), key=version)
     for path in reversed(files):
         try:
             d = json.load(open(path))["derived"]
@@ -554,7 +555,7 @@ def main():
         assert args.model != "cassie" or algo_bytes == ALGO_BYTES_PER_ENV_STEP
         achieved = algo_bytes * n * steps_per_launch / (kern_ms * 1e-3) / 1e9
         value = world * n * args.steps / elapsed
-        traffic, traffic_src = pmc_traffic(n * steps_per_launch)
+        traffic, traffic_src = pmc_traffic(n * steps_per_launch, args.model)
         api = {"drive-pd": "phys_batch_step in CM_DRIVE_PD mode (device-resident, include/cassie_phys.h): pd_input's motor PD on the encoder "
                            "measurements + motor model with torque delay + physics in one kernel -- cassie_sim_step_pd's drive-level semantics "
                            "without the Agility safety layer / estimator",
