@@ -607,6 +607,7 @@ def main():
                                    all_outputs=True)
                 out["all_outputs_every_substep"] = {"value": n * a["steps"] / a["elapsed"], "unit": "env-steps/s", "steps": a["steps"],
                                                     "kernel_ms": a["kernel_ms"], "max_qpos_err": a["parity"]["max_qpos_err"]}
+                out["value_all_outputs_every_substep"] = out["all_outputs_every_substep"]["value"]
             if not args.no_step_pd:
                 sp = step_pd_host_api(n)
                 sd = step_pd_host_api(n, device_drives=True)
