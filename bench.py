@@ -25,6 +25,11 @@ The JSON line carries, beside the contract's fields:
                   are replayed on the CPU reference (oracle/, the fp64 restatement of mj_step1 + mj_step2) through the
                   same schedule (pre-roll, warm-up, timed steps, restarts) and the final qpos compared
   value_exact_pd  (or value_drive_pd) a short run of the other device mode, with its own parity figure
+  value_all_outputs_every_substep
+                  `value` when every substep of a launch also forms the outputs nobody can read: a launch of 50 fused substeps
+                  returns its LAST substep's sensordata / measurement block / xquat, so by default the IMU sensor words and
+                  body quaternions of the 48 substeps whose values are neither returned nor fed back are not evaluated
+                  (state trajectory and returned outputs are bit for bit the same either way)
   value_step_pd   the same workload through the drop-in API itself (cassie_batch_step_pd = cassie_sim_step_pd for every
                   env: Agility blocks + encoder / motor models, see include/cassie_batch.h) -- PCIe- and host-inclusive
   roofline        algorithmic HBM bytes of one launch (1976 B per env-step) divided by the mean kernel
