@@ -214,3 +214,28 @@ def test_batched_step_and_step_ethercat_with_device_drives(built):
             L.cassie_batch_free(bt)
             outs.append(traj)
         assert outs[0] == outs[1]
+
+
+def test_outputs_do_not_depend_on_eliding_unread_substep_outputs(cassie):
+    """A fused launch evaluates the IMU sensors and body quaternions only on the substeps whose values are read (the last
+    two); phys_batch_set_all_outputs_every_substep forms them on every substep.  State and every returned output must be
+    bit for bit the same either way, launch after launch."""
+    n = 32
+    tg = bench.pd_targets(np.arange(n), 4)
+    out = []
+    for every in (False, True):
+        b = Batch(cassie, n)
+        b.set(P.F_QPOS, np.tile(cassie.qpos_init(), (n, 1)))
+        b.forward()
+        b.set(P.F_PD_KP, np.tile(bench.PD_KP, (n, 1)))
+        b.set(P.F_PD_KD, np.tile(bench.PD_KD, (n, 1)))
+        b.set_drive_mode(P.DRIVE_PD)
+        b.set_all_outputs_every_substep(every)
+        snaps = []
+        for p in range(3):
+            b.set(P.F_PD_PTARGET, tg[p])
+            b.step(50)
+            snaps.append(b"".join(b.get(f).tobytes() for f in (P.F_QPOS, P.F_QVEL, P.F_SENSORDATA, P.F_MEAS, P.F_XQUAT, P.F_XPOS, P.F_ACTUATOR_VELOCITY)))
+        out.append(snaps)
+        b.close()
+    assert out[0] == out[1]
