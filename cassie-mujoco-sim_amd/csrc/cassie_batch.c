@@ -118,6 +118,9 @@ static void *worker(void *arg)
             }
         }
         seen = atomic_load_explicit(&b->generation, memory_order_acquire);
+        /* teardown bumps the generation too (so that a worker that was about to sleep on the old value does not): it is
+         * not a job */
+        if (atomic_load_explicit(&b->quit, memory_order_seq_cst)) return NULL;
         int e0, e1;
         slice(b, tid, &e0, &e1);
         b->job(b, e0, e1);
@@ -268,7 +271,11 @@ void cassie_batch_free(cassie_batch_t *b)
 {
     if (!b) return;
     if (b->threads) {
+        /* quit first, then a new generation value, then the wake: a worker that read quit == 0 and has not reached
+         * futex_wait yet finds the futex word changed and returns from the wait at once; one that is already asleep is
+         * woken; either way it re-reads quit before it would run a job */
         atomic_store(&b->quit, 1);
+        atomic_fetch_add_explicit(&b->generation, 1, memory_order_seq_cst);
         futex_wake_all(&b->generation);
         for (int t = 1; t < b->nthreads; ++t) pthread_join(b->threads[t], NULL);
         free(b->threads);

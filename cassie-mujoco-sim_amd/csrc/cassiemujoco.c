@@ -283,7 +283,7 @@ cassie_sim_t *cassie_sim_init(const char *modelfile, bool reinit)
     if (!library_initialized && !cassie_mujoco_init(modelfile)) return NULL;
     cassie_sim_t *c = sim_alloc();
     if (!c) return NULL;
-    if (reinit && !load_global_model(modelfile)) { free(c); return NULL; }
+    if (reinit && !load_global_model(modelfile)) { phys_host_free(c); return NULL; }
     c->m = phys_model_copy(initial_model);
     c->host = cassie_hostenv_alloc(); /* cassie_out_init + Agility block alloc/setup */
     if (!c->m || !c->host || !sim_attach_physics(c)) { cassie_sim_free(c); return NULL; }
@@ -1136,21 +1136,33 @@ void cassie_set_state(cassie_sim_t *c, const cassie_state_t *s)
 /* On-disk form of a cassie_state_t (the reference keeps states in memory only, :3380-3452):
  *   8 bytes magic "CASSIEST", u32 version, u32 sizeof(sim_data_t), u32 host image size, u32 reserved,
  *   the sim_data_t (time, qpos, qvel, qacc, warm start, ctrl, applied forces, sensordata, ...), the host image
- *   (cassie_out_t, encoder filters, torque delay lines, Agility block states).
- * Native byte order and layout: a checkpoint of this library for this library, like a memcpy of the struct would be. */
+ *   (cassie_out_t, encoder filters, torque delay lines, Agility block states), u64 FNV-1a checksum of everything before it.
+ * Native byte order and layout: a checkpoint of this library for this library, like a memcpy of the struct would be.  The
+ * Agility block states hold pointers into themselves; they are written as they are, together with the addresses the
+ * blocks lived at (so a loader can rebase them) -- the file therefore contains heap addresses of the writing process.
+ * A file that is shorter or longer than its header says, or whose checksum does not match, is rejected. */
 #define STATE_MAGIC "CASSIEST"
-#define STATE_VERSION 1u
+#define STATE_VERSION 2u
+static unsigned long long fnv1a(unsigned long long h, const void *data, size_t n)
+{
+    const unsigned char *p = data;
+    for (size_t i = 0; i < n; ++i) h = (h ^ p[i]) * 1099511628211ull;
+    return h;
+}
 int cassie_state_save(const cassie_state_t *s, const char *path)
 {
     if (!s || !path) return -1;
+    if (!cassie_hostenv_blocks_verified()) { fprintf(stderr, "cassie_state_save: Agility block sizes unverified, refusing\n"); return -1; }
     FILE *f = fopen(path, "wb");
     if (!f) return -1;
     const unsigned hdr[4] = {STATE_VERSION, (unsigned)sizeof(sim_data_t), (unsigned)cassie_hostenv_image_size(), 0u};
     void *img = malloc(hdr[2]);
     if (!img) { fclose(f); return -1; }
     cassie_hostenv_to_image(s->host, img);
+    unsigned long long sum = fnv1a(1469598103934665603ull, STATE_MAGIC, 8);
+    sum = fnv1a(sum, hdr, sizeof hdr); sum = fnv1a(sum, &s->d, sizeof s->d); sum = fnv1a(sum, img, hdr[2]);
     int ok = fwrite(STATE_MAGIC, 8, 1, f) == 1 && fwrite(hdr, sizeof hdr, 1, f) == 1 && fwrite(&s->d, sizeof s->d, 1, f) == 1 &&
-             fwrite(img, hdr[2], 1, f) == 1;
+             fwrite(img, hdr[2], 1, f) == 1 && fwrite(&sum, sizeof sum, 1, f) == 1;
     free(img);
     ok = fclose(f) == 0 && ok;
     return ok ? 0 : -1;
@@ -1158,6 +1170,7 @@ int cassie_state_save(const cassie_state_t *s, const char *path)
 int cassie_state_load(cassie_state_t *s, const char *path)
 {
     if (!s || !path) return -1;
+    if (!cassie_hostenv_blocks_verified()) { fprintf(stderr, "cassie_state_load: Agility block sizes unverified, refusing\n"); return -1; }
     FILE *f = fopen(path, "rb");
     if (!f) return -1;
     char magic[8];
@@ -1165,14 +1178,21 @@ int cassie_state_load(cassie_state_t *s, const char *path)
     int rc = -1;
     if (fread(magic, 8, 1, f) == 1 && memcmp(magic, STATE_MAGIC, 8) == 0 && fread(hdr, sizeof hdr, 1, f) == 1 &&
         hdr[0] == STATE_VERSION && hdr[1] == sizeof(sim_data_t) && hdr[2] == cassie_hostenv_image_size()) {
-        sim_data_t d;
+        sim_data_t *d = malloc(sizeof *d);
         void *img = malloc(hdr[2]);
-        if (img && fread(&d, sizeof d, 1, f) == 1 && fread(img, hdr[2], 1, f) == 1) {
-            s->d = d;
-            cassie_hostenv_from_image(s->host, img);
-            rc = 0;
+        unsigned long long sum = 0, want = fnv1a(1469598103934665603ull, STATE_MAGIC, 8);
+        char extra;
+        if (d && img && fread(d, sizeof *d, 1, f) == 1 && fread(img, hdr[2], 1, f) == 1 && fread(&sum, sizeof sum, 1, f) == 1 &&
+            fread(&extra, 1, 1, f) == 0 /* nothing may follow */) {
+            want = fnv1a(want, hdr, sizeof hdr); want = fnv1a(want, d, sizeof *d); want = fnv1a(want, img, hdr[2]);
+            if (want == sum) {
+                s->d = *d;
+                cassie_hostenv_from_image(s->host, img);
+                rc = 0;
+            }
         }
         free(img);
+        free(d);
     }
     fclose(f);
     return rc;

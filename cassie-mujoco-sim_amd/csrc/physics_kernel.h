@@ -85,7 +85,10 @@ struct PhysIO {
                                      sb = nbody.  qpos / qvel / sensordata have strides of their own so that the three can be
                                      columns of one caller-owned [nenv][nq + nv + nsensordata] observation block */
     double *qpos, *qvel, *qacc_warmstart, *time;
-    const double *ctrl, *qfrc_applied, *xfrc_applied; /* the last two may be null */
+    double *ctrl;               /* read in torque / exact-PD mode; in a drive mode the kernel WRITES the torque its last substep
+                                   applied (the delay line's output), so that a later forward pass -- mj_forward reads d->ctrl --
+                                   sees the motor torques of the state it evaluates */
+    const double *qfrc_applied, *xfrc_applied; /* may be null */
     double *qacc, *sensordata, *actuator_velocity;
     int *warn;                  /* [nenv] sticky warning bits */
     int *info;                  /* [nenv][4]: ncon, nefc, solver iterations, reserved (may be null) */
@@ -2538,7 +2541,10 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
     }
 
     /* ---------------- store state ---------------- */
-    if (io.integrate && io.drive_mode) drive_state_store(io, S, env, lane);
+    if (io.integrate && io.drive_mode) {
+        drive_state_store(io, S, env, lane);
+        if (lane < nu) io.ctrl[(size_t)env * io.su + lane] = S.ctrl[lane]; /* the applied torque: d->ctrl of the reference */
+    }
     if (io.integrate) {
         if (lane < nq) io.qpos[(size_t)env * io.sq + lane] = S.qpos[lane];
         if (lane < nv) {

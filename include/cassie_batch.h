@@ -69,6 +69,9 @@ void cassie_hostenv_set_drive_state(cassie_hostenv_t *e, const cm_drive_state_t 
 size_t cassie_hostenv_image_size(void);
 void cassie_hostenv_to_image(const cassie_hostenv_t *e, void *image);
 void cassie_hostenv_from_image(cassie_hostenv_t *e, const void *image);
+/* whether the closed library's block states have the sizes the flat image assumes (checked against the allocator when the
+ * first env is created); the image functions must not be used otherwise */
+bool cassie_hostenv_blocks_verified(void);
 
 /* cores this process may really use: min(affinity mask, cgroup CPU quota) */
 int cassie_host_cpu_count(void);

@@ -12,6 +12,33 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def _hip_device_count():
+    """Number of HIP devices visible to this process (0 when the runtime cannot be loaded)."""
+    import ctypes
+    for name in ("libamdhip64.so", "/opt/rocm/lib/libamdhip64.so"):
+        try:
+            hip = ctypes.CDLL(name)
+        except OSError:
+            continue
+        n = ctypes.c_int(0)
+        try:
+            return n.value if hip.hipGetDeviceCount(ctypes.byref(n)) == 0 else 0
+        except Exception:
+            return 0
+    return 0
+
+
+def pytest_collection_modifyitems(config, items):
+    """`pytest tests` on a box without a GPU: the gpu-marked tests are skipped (the product has no CPU fallback, so they
+    could only fail); with `-m gpu` on such a box they are skipped too, visibly."""
+    if not any("gpu" in it.keywords for it in items) or _hip_device_count() > 0:
+        return
+    skip = pytest.mark.skip(reason="no HIP device visible: the physics library has no CPU fallback")
+    for it in items:
+        if "gpu" in it.keywords:
+            it.add_marker(skip)
+
+
 @pytest.fixture(scope="session")
 def built():
     """Makes sure the product library, the oracle and the emulator are built (no-op when up to date)."""

@@ -178,7 +178,7 @@ extern "C" int emu_phys_run(const cm_model_t *model, int nenv, int nsub, int int
     g_io.nenv = nenv; g_io.nsub = nsub; g_io.integrate = integrate;
     g_io.sq = model->nq; g_io.sqv = model->nv; g_io.sv = model->nv; g_io.su = model->nu; g_io.ssd = model->nsensordata; g_io.sb = model->nbody;
     g_io.qpos = qpos; g_io.qvel = qvel; g_io.qacc_warmstart = qacc_warmstart; g_io.time = time;
-    g_io.ctrl = ctrl; g_io.qfrc_applied = qfrc_applied; g_io.xfrc_applied = xfrc_applied;
+    g_io.ctrl = (double *)ctrl; g_io.qfrc_applied = qfrc_applied; g_io.xfrc_applied = xfrc_applied;
     g_io.qacc = qacc; g_io.sensordata = sensordata; g_io.actuator_velocity = actuator_velocity;
     g_io.warn = warn; g_io.info = info; g_io.xpos_out = xpos_out; g_io.xquat_out = xquat_out;
     g_io.hfield = hfield;
@@ -205,7 +205,7 @@ extern "C" int emu_derive(const cm_model_t *model, int nenv, double *qpos, doubl
     memset(&g_io, 0, sizeof g_io);
     g_io.models = model; g_io.nenv = nenv; g_io.nsub = 1; g_io.integrate = 0;
     g_io.sq = model->nq; g_io.sqv = model->nv; g_io.sv = model->nv; g_io.su = model->nu; g_io.ssd = model->nsensordata; g_io.sb = model->nbody;
-    g_io.qpos = qpos; g_io.qvel = qvel; g_io.qacc_warmstart = qacc_warmstart; g_io.time = time; g_io.ctrl = ctrl;
+    g_io.qpos = qpos; g_io.qvel = qvel; g_io.qacc_warmstart = qacc_warmstart; g_io.time = time; g_io.ctrl = (double *)ctrl;
     g_io.qacc = qacc; g_io.sensordata = sensordata; g_io.actuator_velocity = actuator_velocity; g_io.warn = warn; g_io.info = info;
     g_io.xpos_out = xpos; g_io.xquat_out = xquat; g_io.hfield = hfield; g_io.ext = ext;
     memset(&g_dio, 0, sizeof g_dio);

@@ -131,6 +131,16 @@ def test_state_file_round_trip_and_rejection(L, tmp_path):
     assert L.cassie_state_load(t, path) == -1                       # foreign magic
     open(path, "wb").write(raw[:-100])
     assert L.cassie_state_load(t, path) == -1                       # truncated
+    open(path, "wb").write(raw + b"\0")
+    assert L.cassie_state_load(t, path) == -1                       # trailing bytes
+    flipped = bytearray(raw)
+    flipped[len(raw) // 2] ^= 0x10
+    open(path, "wb").write(bytes(flipped))
+    assert L.cassie_state_load(t, path) == -1                       # a flipped bit in the body: checksum mismatch
+    open(path, "wb").write(raw)
+    assert L.cassie_state_load(t, path) == 0                        # the intact file still loads
+    L.cassie_hostenv_blocks_verified.restype = ctypes.c_bool
+    assert L.cassie_hostenv_blocks_verified()                       # the closed library's block sizes are what the image assumes
     assert L.cassie_state_load(t, str(tmp_path / "missing.bin").encode()) == -1
     assert L.cassie_state_time(t)[0] == 1.2345                      # failed loads leave the state alone
     L.cassie_state_free(s)
