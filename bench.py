@@ -19,11 +19,16 @@ phase it happened to land in -- e.g. the contact-free first 3.7 mm of the drop).
 advanced 1000 untimed steps so that the mix is the stationary one.
 With N>1 envs shard across GPUs with no data-path exchange; the only collective is one RCCL all-gather of the
 observation block (qpos|qvel|sensordata, 96 doubles/env, ONE tensor the kernel writes in place) per 50 steps.
+Env counts: one GPU runs BASELINE configs[1] (4096 envs); N > 1 GPUs run configs[2]'s shard, 8192 envs per GPU = 65536
+at 8 GPUs (weak scaling); `--total-envs T` shards a fixed total instead (strong scaling).
+Timing: `--repeats` (10) fenced regions of exactly `--steps` steps each, one after the other on the stationary mix; every
+region is bracketed by barrier + torch.cuda.synchronize on both sides and counted at its slowest rank; `value` is the
+MEDIAN region, `value_min` / `value_max` the slowest / fastest.
 
 The JSON line carries, beside the contract's fields:
-  max_qpos_err    BASELINE.json's second half of the metric: after the timed region, sampled envs of the timed batch
-                  are replayed on the CPU reference (oracle/, the fp64 restatement of mj_step1 + mj_step2) through the
-                  same schedule (pre-roll, warm-up, timed steps, restarts) and the final qpos compared
+  max_qpos_err    BASELINE.json's second half of the metric: sampled envs of EVERY rank's shard of the timed batch are
+                  replayed on the CPU reference (oracle/, the fp64 restatement of mj_step1 + mj_step2) through the same
+                  schedule (pre-roll, warm-up, timed steps, restarts) and the qpos at a timed region's end compared
   value_exact_pd  (or value_drive_pd) a short run of the other device mode, with its own parity figure
   value_all_outputs_every_substep
                   `value` when every substep of a launch also forms the outputs nobody can read: a launch of 50 fused substeps
@@ -75,6 +80,47 @@ def shard_env_ids(rank, world, envs_per_rank):
     return np.arange(rank * envs_per_rank, (rank + 1) * envs_per_rank)
 
 
+ENVS_PER_GPU_SINGLE = 4096          # BASELINE configs[1]: the headline, one GPU
+ENVS_PER_GPU_SHARDED = 8192         # BASELINE configs[2]: 65536 envs sharded over 8 GPUs
+REPEATS = 10                        # fenced timed regions of exactly --steps steps each; `value` is their median
+REPLAY_BUDGET_STEPS = 2200          # the CPU replay follows the schedule up to the last region boundary within this many steps
+
+
+def resolve_envs(world, envs_per_gpu=None, total_envs=None):
+    """(envs per rank, scaling, which BASELINE config the shape is).  One GPU runs configs[1] (4096 envs); N > 1 GPUs run
+    configs[2]'s shard, 8192 envs per GPU = 65536 at 8 GPUs (weak scaling); --total-envs T shards a FIXED total T over
+    the ranks instead (strong scaling; 65536 envs fit one GPU, 0.3 GB); --envs-per-gpu overrides the per-rank count."""
+    if total_envs is not None:
+        if envs_per_gpu is not None:
+            raise SystemExit("--total-envs and --envs-per-gpu exclude each other")
+        if total_envs <= 0 or total_envs % world:
+            raise SystemExit("--total-envs must be a positive multiple of the number of GPUs")
+        n = total_envs // world
+        return n, "strong", ("BASELINE configs[2] (65536 envs)" if total_envs == 65536 else "%d envs in total" % total_envs)
+    if envs_per_gpu is not None:
+        n = envs_per_gpu
+    else:
+        n = ENVS_PER_GPU_SINGLE if world == 1 else ENVS_PER_GPU_SHARDED
+    what = ("BASELINE configs[1]" if (world, n) == (1, ENVS_PER_GPU_SINGLE) else
+            "BASELINE configs[2]" if world * n == 65536 else
+            "BASELINE configs[2]'s per-GPU shard" if n == ENVS_PER_GPU_SHARDED else "custom")
+    return n, "weak", what
+
+
+def parity_rows(n, world, parity_envs):
+    """Local rows of a rank's shard that are replayed on the CPU reference: the budget of `parity_envs` envs is spread
+    over ALL ranks (at least two per rank), evenly spaced over the shard, so a fault on any rank shows in max_qpos_err."""
+    k = max(1, min(n, max(2, parity_envs // world) if world > 1 else parity_envs))
+    return np.unique(np.linspace(0, n - 1, k).astype(int))
+
+
+def snapshot_region(steps, warmup, repeats):
+    """Index of the timed region after which the sampled envs are snapshotted for the CPU replay: the last one the replay
+    reaches within REPLAY_BUDGET_STEPS (the first one at least)."""
+    r = (REPLAY_BUDGET_STEPS - PREROLL - warmup) // max(1, steps) - 1
+    return int(min(repeats - 1, max(0, r)))
+
+
 def restart_group(policy_step):
     """The phase group whose envs restart from the init pose at this policy step."""
     return policy_step % NGROUP
@@ -88,6 +134,15 @@ def gather_observations(obs, world, out=None):
     if out is None:
         out = torch.empty((world * obs.shape[0], obs.shape[1]), dtype=obs.dtype, device=obs.device)
     dist.all_gather_into_tensor(out, obs)
+    return out
+
+
+def gather_rows(x, world):
+    """All-gather of equally shaped per-rank row blocks, rank-major (the sampled parity rows of every rank -> rank 0)."""
+    import torch
+    import torch.distributed as dist
+    out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+    dist.all_gather_into_tensor(out, x.contiguous())
     return out
 
 
@@ -338,8 +393,8 @@ class HostChainEnvs:
 
 
 def device_rollout(model, mode, n, steps, warmup, rank, world, local_rank, substeps_per_launch=HOLD, parity_envs=64, hfield=None, collect=None,
-                   all_outputs=False):
-    """One timed device-resident rollout of the workload in `mode`:
+                   all_outputs=False, repeats=1):
+    """One device-resident rollout of the workload in `mode`, timed as `repeats` fenced regions of exactly `steps` steps:
 
       "drive-pd"  CM_DRIVE_PD: every substep runs pd_input's motor PD on the ENCODER measurements of the
                   previous step (13 / 18-bit truncation, integer FIR / IIR velocity filters), the motor model with its
@@ -348,8 +403,9 @@ def device_rollout(model, mode, n, steps, warmup, rank, world, local_rank, subst
                   safety layer and estimator.  An episode restart is a fresh cassie_sim_t (init pose, zero filters / delays).
       "exact-pd"  the PD law on the exact joint state + the motor's speed-torque limit, no delay, no quantisation.
 
-    State and inputs are resident in HBM before the timed region.  Returns timings and, on rank 0, the comparison of
-    sampled envs with their replay on the CPU reference."""
+    State and inputs are resident in HBM before the timed regions.  Every region is bracketed by barrier +
+    torch.cuda.synchronize on both sides; a region's time is the maximum over the ranks.  Sampled envs of EVERY rank are
+    snapshotted at a region boundary and compared on rank 0 with their replay on the CPU reference."""
     import torch
     import torch.distributed as dist
     from cassie_amd import Batch
@@ -358,7 +414,9 @@ def device_rollout(model, mode, n, steps, warmup, rank, world, local_rank, subst
     drive = mode == "drive-pd"
     collect = world > 1 if collect is None else collect       # the observation all-gather, barriers, max-over-ranks reduction
     env_ids = shard_env_ids(rank, world, n)
-    total_steps = PREROLL + warmup + steps
+    snap_r = snapshot_region(steps, warmup, repeats)
+    total_steps = PREROLL + warmup + repeats * steps
+    replay_steps = PREROLL + warmup + (snap_r + 1) * steps
     npolicy = (total_steps + HOLD - 1) // HOLD + 1
     dev = torch.device("cuda", local_rank)
     b = Batch(model, n, device=local_rank)
@@ -447,37 +505,60 @@ def device_rollout(model, mode, n, steps, warmup, rank, world, local_rank, subst
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    sample = parity_rows(n, world, parity_envs)
+    sample_dev = torch.from_numpy(sample).to(dev)
     torch.cuda.synchronize(dev)
-    ev = [torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)]
+    region_s, region_ev, region_launches = [], [], []
+    q_sample = info_sample = None
     with torch.cuda.stream(launch_stream):
         sch.run(0, PREROLL + warmup)
-        elapsed = timed_region(sch, PREROLL + warmup, steps, fence, mark=lambda i: ev[i].record(launch_stream))
-    res = {"mode": mode, "n": n, "steps": steps, "warmup": warmup, "launches": sch.launches,
-           "kernel_ms": ev[0].elapsed_time(ev[1]) / sch.launches,   # mean stream time per launch (includes the rare restart / gather)
-           "elapsed": _reduce_max(elapsed, dev) if collect else elapsed}
+        for r in range(repeats):
+            ev = [torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)]
+            region_s.append(timed_region(sch, PREROLL + warmup + r * steps, steps, fence, mark=lambda i: ev[i].record(launch_stream)))
+            region_ev.append(ev[0].elapsed_time(ev[1]))
+            region_launches.append(sch.launches)
+            if r == snap_r:     # between two fenced regions: the sampled rows of this rank for the CPU replay
+                q_sample = obs[sample_dev, :nq].clone()
+                info_sample = torch.from_numpy(b.warnings()[1][sample][:, :3].astype(np.int64)).to(dev)
+    if collect:   # a region's time is the slowest rank's
+        t = torch.tensor(region_s, dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        region_s = [float(x) for x in t.cpu()]
+    launches = int(sum(region_launches))
+    res = {"mode": mode, "n": n, "steps": steps, "warmup": warmup, "repeats": repeats, "launches": launches,
+           "kernel_ms": float(sum(region_ev)) / launches,   # mean stream time per launch (includes the rare restart / gather)
+           "region_s": region_s, "elapsed": float(np.median(region_s))}
     if collect and rank == 0:
         # the gathered block of the last policy boundary must hold this rank's rows (global env order, rank-major)
         res["gather_ok"] = bool(sch.gathers > 0 and torch.equal(obs_all[rank * n:(rank + 1) * n], snap))
     w, info = b.warnings()
-    res["envs_with_warnings"] = int(np.count_nonzero(w))
-    res["mean_constraint_rows"], res["mean_pgs_iterations"], res["mean_pgs_guarded_sweeps"] = (float(info[:, k].mean()) for k in (1, 2, 3))
+    stats = torch.tensor([float(np.count_nonzero(w))] + [float(info[:, k].sum()) for k in (1, 2, 3)], dtype=torch.float64, device=dev)
+    if collect:
+        dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+    stats = stats.cpu().numpy()
+    res["envs_with_warnings"] = int(stats[0])
+    res["mean_constraint_rows"], res["mean_pgs_iterations"], res["mean_pgs_guarded_sweeps"] = (float(stats[k] / (world * n)) for k in (1, 2, 3))
+    # ---- the metric's second half: sampled envs of EVERY rank against the CPU reference, same schedule ----
+    ids_sample = torch.from_numpy(env_ids[sample].astype(np.int64)).to(dev)
+    if collect and world > 1:
+        q_sample, info_sample, ids_sample = (gather_rows(x, world) for x in (q_sample, info_sample, ids_sample))
     if rank == 0:
-        # ---- the metric's second half: sampled envs of the timed batch against the CPU reference, same schedule ----
-        nsample = max(1, min(parity_envs, n))
-        sample = np.unique(np.linspace(0, n - 1, nsample).astype(int))
-        q_gpu = obs[:, :nq].cpu().numpy()[sample]
+        q_gpu, counts_gpu, ids = q_sample.cpu().numpy(), info_sample.cpu().numpy(), ids_sample.cpu().numpy()
         from cassie_amd._lib import lib
         threads = lib().cassie_host_cpu_count()
-        orc = replay_on_oracle(model, env_ids[sample], lambda p: targets_host[p][sample], total_steps, hfield, threads,
+        tg_replay = pd_targets(ids, (replay_steps + HOLD - 1) // HOLD + 1)      # seeds depend on the global env id only
+        orc = replay_on_oracle(model, ids, lambda p: tg_replay[p], replay_steps, hfield, threads,
                                envs=HostChainEnvs if drive else OracleEnvs)
         q_ref = orc.qpos()
         err_abs = np.abs(q_gpu - q_ref)
         err_rel = err_abs / np.maximum(1.0, np.abs(q_ref))
+        per_rank = {int(r): float(err_abs[ids // n == r].max()) for r in np.unique(ids // n)}
         res["parity"] = {"reference": "oracle/cassie_oracle.c (fp64 CPU restatement of mj_step1 + mj_step2; parity with genuine MuJoCo unpinned)"
                                       + (" + the host chain csrc/cassie_hostpath.c (encoder / motor arithmetic pinned bit-exactly to the reference's code)" if drive else ""),
-                         "envs_compared": int(len(sample)), "steps_replayed": int(total_steps),
+                         "envs_compared": int(len(ids)), "ranks_compared": int(len(per_rank)), "max_qpos_err_per_rank": per_rank,
+                         "steps_replayed": int(replay_steps), "after_timed_region": int(snap_r),
                          "max_qpos_err": float(err_abs.max()), "max_qpos_rel_err": float(err_rel.max()),
-                         "frac_envs_with_equal_ncon_nefc_iters": float(np.mean(np.all(info[sample][:, :3] == orc.counts(), axis=1))),
+                         "frac_envs_with_equal_ncon_nefc_iters": float(np.mean(np.all(counts_gpu == orc.counts(), axis=1))),
                          "tolerance_rel": 1e-6, "ok": bool(err_rel.max() <= 1e-6)}
         if drive:
             res["parity"]["note"] = ("an encoder count that truncates differently on a last-bit physics difference moves a motor torque by "
@@ -507,12 +588,18 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=100)
-    ap.add_argument("--envs-per-gpu", type=int, default=4096)
+    ap.add_argument("--envs-per-gpu", type=int, default=None,
+                    help="default: %d with one GPU (BASELINE configs[1]), %d with more (configs[2]: 65536 envs at 8 GPUs)"
+                         % (ENVS_PER_GPU_SINGLE, ENVS_PER_GPU_SHARDED))
+    ap.add_argument("--total-envs", type=int, default=None,
+                    help="shard a FIXED total over the GPUs instead (strong scaling), e.g. 65536 at 1 / 2 / 4 / 8 GPUs")
+    ap.add_argument("--repeats", type=int, default=REPEATS,
+                    help="fenced timed regions of exactly --steps steps each; `value` is the median region, value_min / value_max the extremes")
     ap.add_argument("--substeps-per-launch", type=int, default=HOLD,
                     help="physics steps fused into one kernel launch (at most up to the next PD-target re-draw)")
     ap.add_argument("--model", default="cassie", choices=["cassie", "cassie_hfield", "cassie_tray_box"],
                     help="cassie = BASELINE configs[1] (the headline); the other two are configs[3] / configs[4], for the record")
-    ap.add_argument("--parity-envs", type=int, default=64, help="envs of the timed batch replayed on the CPU reference")
+    ap.add_argument("--parity-envs", type=int, default=64, help="envs of the timed batch replayed on the CPU reference (spread over all ranks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-step-pd", action="store_true")
     ap.add_argument("--no-other-mode", action="store_true", help="skip the short run of the other device mode")
@@ -544,22 +631,24 @@ def main():
 
     model = Model(args.model)
     pod = model.pod
-    n = args.envs_per_gpu
+    n, scaling, shape = resolve_envs(world, args.envs_per_gpu, args.total_envs)
+    repeats = max(1, args.repeats)
     hfield = None
     if args.model == "cassie_hfield":   # terrain of reference example/test_hfield.py:39-41, shared by all envs
         hfield = np.random.default_rng(99).random((200, 200)).astype(np.float32)
         hfield[95:105, 95:105] = 0
     r = device_rollout(model, args.mode, n, args.steps, args.warmup, rank, world, local_rank, args.substeps_per_launch, args.parity_envs, hfield,
-                       collect=collect)
+                       collect=collect, repeats=repeats)
 
     if rank == 0:
         elapsed, kern_ms, timed_launches = r["elapsed"], r["kernel_ms"], r["launches"]
-        steps_per_launch = args.steps / timed_launches
+        steps_per_launch = repeats * args.steps / timed_launches
         # read qpos+qvel+qacc_warmstart+ctrl, write qpos+qvel+qacc+sensordata+actuator_velocity (1976 B for cassie)
         algo_bytes = 8 * ((pod.nq + 2 * pod.nv + pod.nu) + (pod.nq + 2 * pod.nv + pod.nsensordata + pod.nu))
         assert args.model != "cassie" or algo_bytes == ALGO_BYTES_PER_ENV_STEP
         achieved = algo_bytes * n * steps_per_launch / (kern_ms * 1e-3) / 1e9
-        value = world * n * args.steps / elapsed
+        rate = lambda sec: world * n * args.steps / sec
+        value = rate(elapsed)
         traffic, traffic_src = pmc_traffic(n * steps_per_launch, args.model)
         api = {"drive-pd": "phys_batch_step in CM_DRIVE_PD mode (device-resident, include/cassie_phys.h): pd_input's motor PD on the encoder "
                            "measurements + motor model with torque delay + physics in one kernel -- cassie_sim_step_pd's drive-level semantics "
@@ -568,50 +657,57 @@ def main():
                            "limit + physics in one kernel (no encoder quantisation, no torque delay)"}[args.mode]
         out = {
             "metric": "env-steps/sec (whole node) at N envs; max |qpos_err| vs CPU ref", "value": value, "unit": "env-steps/s",
+            "value_min": rate(max(r["region_s"])), "value_max": rate(min(r["region_s"])),
             "max_qpos_err": r["parity"]["max_qpos_err"], "max_qpos_rel_err": r["parity"]["max_qpos_rel_err"],
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%d envs/GPU, %s.xml, %d-step episodes from the cassie_sim_init pose restarted at staggered phases "
-                                   "(untimed pre-roll of %d steps), random joint-PD targets re-drawn every %d steps; `value` is the "
-                                   "device-resident API; `value_step_pd` is cassie_sim_step_pd itself, batched (Agility blocks on host threads)"
-                                   % (n, args.model, EPISODE, PREROLL, HOLD),
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%d envs/GPU x %d GPU = %d envs (%s), %s.xml, %d-step episodes from the cassie_sim_init pose restarted at "
+                                   "staggered phases (untimed pre-roll of %d steps), random joint-PD targets re-drawn every %d steps; `value` is "
+                                   "the device-resident API, the MEDIAN of %d fenced timed regions of %d steps each (value_min / value_max: the "
+                                   "slowest / fastest region); `value_step_pd` is cassie_sim_step_pd itself, batched (Agility blocks on host "
+                                   "threads); `value_all_outputs_every_substep` is the every-P-row-every-substep figure"
+                                   % (n, world, world * n, shape, args.model, EPISODE, PREROLL, HOLD, repeats, args.steps),
                        "api_of_value": api, "mode": args.mode,
-                       "envs_total": world * n, "parallelism": "env-sharded x%d" % world,
+                       "envs_per_gpu": n, "envs_total": world * n, "baseline_config": shape, "parallelism": "env-sharded x%d" % world,
                        "obs_allgather_every_steps": HOLD if collect else None,
+                       "timed_regions": repeats, "region_ms": [1e3 * x for x in r["region_s"]],
                        "substeps_per_launch": steps_per_launch, "launches_timed": timed_launches,
                        "outputs_of_a_launch": "its last substep's (sensordata, measurement block, xpos / xquat, solver statistics); IMU words and "
                                               "body quaternions of the substeps in between, which nobody can read, are not formed -- "
-                                              "`all_outputs_every_substep` is the rate with them formed anyway",
+                                              "`value_all_outputs_every_substep` is the rate with every output of every P-row formed by every substep",
                        "preroll_steps": PREROLL, "episode_steps": EPISODE},
             "parity": r["parity"],
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic_note": "PMC bytes per env-step of the profiled 50-substep launch x this run's env-steps per launch; the state-in / "
+                                         "state-out part of it does not shrink with fewer substeps per launch, so short launches move more than this",
                          "kernel": "cassie_step_kernel<%d>" % (32 if pod.nv <= 32 else 40), "kernel_ms": kern_ms, "algorithmic_bytes_per_env_step": algo_bytes, "env_steps_per_launch": n * steps_per_launch,
                          "note": "latency-bound by design: ~2 KB of state vs ~0.22 MFLOP of serially dependent fp64 per env-step"},
             # the more telling bound: ~0.22 MFLOP of algorithmic fp64 work per env-step against the fp64 vector peak
-            "roofline_fp64": {"bound": "fp64-valu", "achieved": value * 0.22e6 / 1e12, "peak": 78.6, "unit": "TFLOP/s",
-                              "frac": value * 0.22e6 / 1e12 / 78.6,
+            "roofline_fp64": {"bound": "fp64-valu", "achieved": value * 0.22e6 / 1e12, "peak": 78.6 * world, "unit": "TFLOP/s",
+                              "frac": value * 0.22e6 / 1e12 / (78.6 * world),
                               "note": "algorithmic flops (SURVEY.md 8a estimate), not counting lanes that idle or recompute"},
             "envs_with_warnings": r["envs_with_warnings"],
             **({"obs_allgather_ok": r.get("gather_ok")} if collect else {}),   # rank 0's rows of the last gathered block = its snapshot
             "mean_constraint_rows": r["mean_constraint_rows"], "mean_pgs_iterations": r["mean_pgs_iterations"], "mean_pgs_guarded_sweeps": r["mean_pgs_guarded_sweeps"],
         }
-        if world == 1 and args.model == "cassie":
+        if world == 1 and args.model == "cassie" and args.total_envs is None:
             # the GPU legs first, back to back with the timed region; the CPU legs (tens of seconds with an idle GPU) last
             if not args.no_other_mode:
                 other = "exact-pd" if args.mode == "drive-pd" else "drive-pd"
-                o = device_rollout(model, other, n, min(args.steps, 400), min(args.warmup, 50), 0, 1, local_rank, args.substeps_per_launch, 16, hfield)
+                side = dict(steps=min(args.steps, 400), warmup=min(args.warmup, 50), repeats=min(repeats, 5))
+                o = device_rollout(model, other, n, side["steps"], side["warmup"], 0, 1, local_rank, args.substeps_per_launch, 16, hfield, repeats=side["repeats"])
                 out[other.replace("-", "_")] = {"value": n * o["steps"] / o["elapsed"], "unit": "env-steps/s", "steps": o["steps"], "warmup": o["warmup"],
-                                                "kernel_ms": o["kernel_ms"], "parity": o["parity"], "mean_constraint_rows": o["mean_constraint_rows"],
-                                                "mean_pgs_iterations": o["mean_pgs_iterations"]}
+                                                "timed_regions": o["repeats"], "kernel_ms": o["kernel_ms"], "parity": o["parity"],
+                                                "mean_constraint_rows": o["mean_constraint_rows"], "mean_pgs_iterations": o["mean_pgs_iterations"]}
                 out["value_" + other.replace("-", "_")] = out[other.replace("-", "_")]["value"]
                 # `value` with every output evaluated by every substep: a fused launch returns its last substep's outputs, so by
                 # default the IMU sensor words and body quaternions of the substeps in between -- values nobody can read -- are
                 # not formed; this is what forming them anyway costs
-                a = device_rollout(model, args.mode, n, min(args.steps, 400), min(args.warmup, 50), 0, 1, local_rank, args.substeps_per_launch, 4, hfield,
-                                   all_outputs=True)
+                a = device_rollout(model, args.mode, n, side["steps"], side["warmup"], 0, 1, local_rank, args.substeps_per_launch, 4, hfield,
+                                   all_outputs=True, repeats=side["repeats"])
                 out["all_outputs_every_substep"] = {"value": n * a["steps"] / a["elapsed"], "unit": "env-steps/s", "steps": a["steps"],
-                                                    "kernel_ms": a["kernel_ms"], "max_qpos_err": a["parity"]["max_qpos_err"]}
+                                                    "timed_regions": a["repeats"], "kernel_ms": a["kernel_ms"], "max_qpos_err": a["parity"]["max_qpos_err"]}
                 out["value_all_outputs_every_substep"] = out["all_outputs_every_substep"]["value"]
             if not args.no_step_pd:
                 sp = step_pd_host_api(n)

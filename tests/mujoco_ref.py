@@ -5,8 +5,9 @@ mj_step1 + mj_step2 (reference :1130-1134).  Neither that binary nor a `mujoco` 
 on the GPU box image, so everything here degrades to "unavailable"; on a machine that does have one, `find()` returns a
 backend that runs the genuine step on the inputs the oracle and the HIP kernel get:
 
-  1. a mujoco210 directory with bin/libmujoco210.so and include/mujoco.h (searched: $MUJOCO_DIR, ~/.mujoco/mujoco210,
-     /opt/mujoco210) -- oracle/mj_harness.c is compiled against it into oracle/_ref/ and driven through ctypes;
+  1. a mujoco210 directory with bin/libmujoco210.so and include/mujoco.h (searched: $MUJOCO_DIR, $MUJOCO_PATH, $MUJOCO_PY_MUJOCO_PATH,
+     ~/.mujoco/mujoco210, /opt/mujoco210, /usr/local/mujoco210, and the parent of any LD_LIBRARY_PATH entry that holds
+     libmujoco210*.so) -- oracle/mj_harness.c is compiled against it into oracle/_ref/ and driven through ctypes;
   2. an importable `mujoco` Python wheel (a later MuJoCo: its version is reported next to every number).
 
 Both need the reference's MJCF files: $CASSIE_MJCF_DIR, /root/reference/model, or oracle/_ref/model (staged by
@@ -32,10 +33,17 @@ def mjcf_path(model_name):
 
 
 def _find_mujoco210():
-    cands = [os.environ.get("MUJOCO_DIR"), os.path.expanduser("~/.mujoco/mujoco210"), "/opt/mujoco210"]
+    cands = [os.environ.get("MUJOCO_DIR"), os.environ.get("MUJOCO_PATH"), os.environ.get("MUJOCO_PY_MUJOCO_PATH"),
+             os.path.expanduser("~/.mujoco/mujoco210"), "/opt/mujoco210", "/usr/local/mujoco210"]
+    # a driver-side install that is only on the loader path: .../mujoco210/bin in LD_LIBRARY_PATH
+    for entry in os.environ.get("LD_LIBRARY_PATH", "").split(os.pathsep):
+        if entry and glob.glob(os.path.join(entry, "libmujoco210*.so")):
+            cands.append(os.path.dirname(entry.rstrip("/")))
+    seen = set()
     for d in cands:
-        if not d:
+        if not d or d in seen:
             continue
+        seen.add(d)
         libs = glob.glob(os.path.join(d, "bin", "libmujoco210*.so"))
         libs = [p for p in libs if "nogl" in p] + [p for p in libs if "nogl" not in p]   # the headless build first
         if libs and os.path.exists(os.path.join(d, "include", "mujoco.h")):

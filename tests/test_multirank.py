@@ -124,6 +124,66 @@ def test_two_rank_schedule_gathers_every_policy_step_and_reduces_the_time():
         assert np.array_equal(own[:, 1], np.where(grp[r * n:(r + 1) * n] <= 4, 250.0 - 50.0 * grp[r * n:(r + 1) * n], 250.0))
 
 
+def _parity_worker(rank, world, port, n, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+    ids = bench.shard_env_ids(rank, world, n)
+    rows = bench.parity_rows(n, world, 8)
+    q = torch.from_numpy(np.outer(ids[rows] + 1.0, np.arange(1.0, 4.0)))     # a rank's "qpos" rows carry its global env ids
+    gathered_ids = bench.gather_rows(torch.from_numpy(ids[rows].astype(np.int64)), world)
+    gathered_q = bench.gather_rows(q, world)
+    ret[rank] = (gathered_ids.numpy().copy(), gathered_q.numpy().copy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_parity_rows_of_every_rank_reach_rank_zero():
+    """max_qpos_err must cover ranks 1..N-1: every rank contributes sampled rows of its own shard, and what rank 0 receives
+    is labelled with the right global env ids (a sharding bug on another rank cannot hide)."""
+    import bench
+    world, n = 2, 16
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 33500 + os.getpid() % 2000
+    mp.spawn(_parity_worker, args=(world, port, n, ret), nprocs=world, join=True)
+    ids0, q0 = ret[0]
+    rows = bench.parity_rows(n, world, 8)
+    assert len(rows) == 4 and rows[0] == 0 and rows[-1] == n - 1            # 8 envs over 2 ranks, spread over the shard
+    assert np.array_equal(ids0, np.concatenate([rows, n + rows]))           # rank-major, both ranks present
+    assert np.array_equal(q0, np.outer(ids0 + 1.0, np.arange(1.0, 4.0)))
+    assert set(ids0 // n) == {0, 1}
+
+
+def test_env_count_defaults_follow_the_baseline_configs():
+    import bench
+    assert bench.resolve_envs(1) == (4096, "weak", "BASELINE configs[1]")                        # the headline, agrees with BENCH
+    assert bench.resolve_envs(8)[:2] == (8192, "weak") and bench.resolve_envs(8)[2] == "BASELINE configs[2]"   # 65536 at 8 GPUs
+    for w in (2, 4):
+        assert bench.resolve_envs(w)[0] == 8192                                                   # configs[2]'s per-GPU shard
+    for w in (1, 2, 4, 8):
+        n, scaling, what = bench.resolve_envs(w, total_envs=65536)                                # the same 65536 envs at every N
+        assert (n * w, scaling) == (65536, "strong") and "configs[2]" in what
+    assert bench.resolve_envs(2, envs_per_gpu=4096)[0] == 4096
+    with pytest.raises(SystemExit):
+        bench.resolve_envs(3, total_envs=65536)
+    with pytest.raises(SystemExit):
+        bench.resolve_envs(2, envs_per_gpu=10, total_envs=20)
+
+
+def test_parity_sample_and_snapshot_region():
+    import bench
+    assert len(bench.parity_rows(4096, 1, 64)) == 64
+    assert len(bench.parity_rows(8192, 8, 64)) == 8 and len(bench.parity_rows(8192, 64, 64)) == 2   # never fewer than two per rank
+    assert len(bench.parity_rows(3, 1, 64)) == 3
+    # the driver's run (--steps 20 --warmup 5, 10 regions): the replay reaches the end of the last region
+    assert bench.snapshot_region(20, 5, 10) == 9
+    # the default run (--steps 1000 --warmup 100): the replay stops after the first region (2100 steps)
+    assert bench.snapshot_region(1000, 100, 10) == 0
+    assert bench.snapshot_region(5000, 100, 3) == 0 and bench.snapshot_region(100, 0, 10) == 9
+
+
 def test_shards_partition_the_env_range():
     import bench
     ids = np.concatenate([bench.shard_env_ids(r, 8, 8192) for r in range(8)])
