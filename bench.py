@@ -358,6 +358,13 @@ class HostChainEnvs:
         self.orcs = [None] * len(self.ids)
         self.chains = [HostChain(model) for _ in self.ids]
         self.meas = np.zeros((len(self.ids), P.MEAS_DIM))
+        # Flip watch.  The encoder models truncate sensor / (2 pi) * 2^bits to an integer count; a device trajectory that
+        # differs from this replay in the last bits can only truncate differently if the replay's own value sits that close
+        # to a count boundary (a non-zero integer: truncation is continuous at zero).  flip_margin[i] is the smallest such
+        # distance, in counts, env i has seen: an env whose margin stayed above ~1e-9 cannot have flipped a count.
+        self.enc_slots = np.array([0, 1, 2, 3, 4, 8, 9, 10, 11, 12, 5, 6, 7, 13, 14, 15])
+        self.enc_scale = np.array([float(1 << model.pod.sensor_bits[int(k)]) for k in self.enc_slots]) / (2 * np.pi)
+        self.flip_margin = np.full(len(self.ids), np.inf)
         for i in range(len(self.ids)):
             self.reset(i, fresh_chain=False)
 
@@ -378,6 +385,11 @@ class HostChainEnvs:
         from hostchain_py import pd_command
         for i, (o, hc) in enumerate(zip(self.orcs, self.chains)):
             for _ in range(nsub):
+                v = o.sensordata[self.enc_slots] * self.enc_scale
+                k = np.rint(v)
+                near = np.abs(v - k)[k != 0]
+                if near.size:
+                    self.flip_margin[i] = min(self.flip_margin[i], float(near.min()))
                 ctrl, self.meas[i], _y = hc.ethercat(pd_command(self.meas[i], targets[i], PD_KP, PD_KD), False, o.sensordata.copy(), o.actuator_velocity.copy())
                 o.ctrl[:] = ctrl
                 o.step()

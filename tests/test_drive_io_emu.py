@@ -82,3 +82,47 @@ def test_pd_mode_on_measurements_against_host_chain_and_oracle(cassie):
         assert np.max(np.abs(emu.meas[0][:10] - meas[:10])) <= 2 * np.pi / (1 << 13) / 16 + 1e-12, t
     assert o.qpos[2] > 0.9                         # PD on quantised, delayed measurements still holds the robot up
     hc.close()
+
+
+def test_forward_after_a_drive_mode_step_uses_the_applied_torques(cassie):
+    """mj_forward reads d->ctrl, the torque last applied (reference src/cassiemujoco.c:971, :1223 after :1120-1134).  In
+    the device's drive modes the applied torque is the delay line's output and lives in LDS during a launch: the launch
+    must leave it in the ctrl field, or a later forward pass / phys_batch_derive (reward getters: foot forces, qacc)
+    evaluates the state under stale motor torques -- zeros in a device-resident rollout."""
+    import bench
+    from test_derive_emu import _ids
+    pod = cassie.pod
+    ids = np.array([3])
+    emu = EmuBatch(pod, 1)
+    emu.qpos[:] = cassie.qpos_init()
+    emu.forward()
+    emu.drive_mode = P.DRIVE_PD
+    emu.pd_kp, emu.pd_kd = bench.PD_KP[None].copy(), bench.PD_KD[None].copy()
+    ref = bench.HostChainEnvs(cassie, ids)
+    tg = bench.pd_targets(ids, 8)
+    for p in range(7):                              # 350 steps: the robot has landed and stands on its PD controller
+        emu.pd_ptarget = np.ascontiguousarray(tg[p])
+        emu.step(50)
+        ref.step(50, tg[p])
+    o = ref.orcs[0]
+    assert o.d.ncon >= 2 and np.abs(o.ctrl).max() > 1.0                 # standing, motors loaded
+    assert np.max(np.abs(emu.ctrl[0] - o.ctrl)) < 1e-9                  # the launch left the applied torques in the ctrl field
+    emu.drive_mode = P.DRIVE_OFF
+    D, _ = emu.derive(_ids(cassie))
+    o.forward()                                                          # the reference: forward on the applied torques
+    assert np.max(np.abs(emu.qacc[0] - o.qacc)) < 1e-6 * max(1.0, np.abs(o.qacc).max())
+    fz = D[0, P.DRV_FOOT_FORCE + 2] + D[0, P.DRV_FOOT_FORCE + 8]
+    ftot = 0.0
+    for c in range(o.d.ncon):
+        con = o.d.contact[c]
+        a = con.efc_address
+        ftot += sum(o.d.efc_force[a + i] for i in range(4)) * con.frame[2]
+    assert abs(fz - ftot) < 1e-6 * max(1.0, abs(ftot)) and fz > 100     # the feet carry the robot
+    # with stale (zero) torques the same state gives a visibly different answer: the check above is not vacuous
+    z = o.ctrl.copy()
+    o.ctrl[:] = 0
+    o.forward()
+    assert np.max(np.abs(emu.qacc[0] - o.qacc)) > 1.0
+    o.ctrl[:] = z
+    for hc in ref.chains:
+        hc.close()

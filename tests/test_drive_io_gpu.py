@@ -94,40 +94,52 @@ def test_fused_substeps_equal_single_steps(cassie):
 def test_pd_on_measurements_mode_against_host_chain_and_oracle(cassie):
     """CM_DRIVE_PD, the device-resident form of cassie_sim_step_pd's motor-PD path (pd_input's PD law on the encoder
     measurements of the previous step -> motor model with delay -> physics), 50 fused substeps per launch, 1000 steps,
-    against numpy PD + host chain + oracle physics run free."""
-    pod = cassie.pod
+    against numpy PD + host chain + oracle physics run free (bench.HostChainEnvs).  Agreement is to ROUNDING (1e-9
+    relative asserted) for every env whose encoder inputs stayed clear of a count boundary -- the replay watches that, see
+    tests/test_drive_parity_gpu.py -- and to the encoder quantisation (2e-4) only for an env that did not."""
     n = 12
-    tg = bench.pd_targets(np.arange(n), 20)
+    ids = np.arange(n)
+    tg = bench.pd_targets(ids, 20)
     b = Batch(cassie, n)
     b.set(P.F_QPOS, np.tile(cassie.qpos_init(), (n, 1)))
     b.forward()
     b.set(P.F_PD_KP, np.tile(bench.PD_KP, (n, 1)))
     b.set(P.F_PD_KD, np.tile(bench.PD_KD, (n, 1)))
     b.set_drive_mode(P.DRIVE_PD)
-    orcs = [Oracle(pod, cassie.qpos_init()) for _ in range(n)]
-    chains = [HostChain(cassie) for _ in range(n)]
-    meas = np.zeros((n, P.MEAS_DIM))
-    for o in orcs:
-        o.forward()
+    ref = bench.HostChainEnvs(cassie, ids)
     for p in range(20):
         b.set(P.F_PD_PTARGET, tg[p])
         b.step(50)
-        for e, (o, hc) in enumerate(zip(orcs, chains)):
-            for _ in range(50):
-                ctrl, meas[e], _ = hc.ethercat(pd_command(meas[e], tg[p][e], bench.PD_KP, bench.PD_KD), False, o.sensordata.copy(), o.actuator_velocity.copy())
-                o.ctrl[:] = ctrl
-                o.step()
-        q = b.get(P.F_QPOS)
+        ref.step(50, tg[p])
+        q, qr = b.get(P.F_QPOS), ref.qpos()
         w, info = b.warnings()
-        for e, o in enumerate(orcs):
-            assert (info[e, 0], info[e, 1]) == (o.d.ncon, o.d.nefc), (p, e)
-            # an encoder count that flips on a 1e-13 difference moves a motor torque by kp * 2 pi / 2^13 / gear: the
-            # trajectories agree to that quantisation, not to rounding
-            assert np.max(np.abs(q[e] - o.qpos)) < 2e-4, (p, e, np.max(np.abs(q[e] - o.qpos)))
+        assert np.array_equal(info[:, :3], ref.counts()), p
+        safe = ref.flip_margin > 1e-6
+        err = np.max(np.abs(q - qr) / np.maximum(1.0, np.abs(qr)), axis=1)
+        assert np.all(err[safe] <= 1e-9), (p, float(err[safe].max()))
+        assert np.all(np.max(np.abs(q - qr), axis=1)[~safe] < 2e-4), p
+    assert safe.sum() >= n - 1                      # a count-boundary graze is a ~1e-5 event per env
     assert not w.any()
     assert np.all(b.get(P.F_QPOS)[:, 2] > 0.6)
+    # the launch left the torques its last substep applied in the ctrl field (mj_forward reads d->ctrl): a forward pass /
+    # phys_batch_derive after a drive-mode step must evaluate the state under THOSE torques (ADVICE round 2)
+    applied = np.array([o.ctrl.copy() for o in ref.orcs])
+    assert np.max(np.abs(b.get(P.F_CTRL) - applied)) < 1e-9 and np.abs(applied).max() > 1.0
+    ids6 = [cassie.name2id(1, "left-foot"), cassie.name2id(1, "right-foot"), cassie.name2id(6, "left-heel"), cassie.name2id(6, "right-heel"),
+            cassie.name2id(6, "left-toe"), cassie.name2id(6, "right-toe")]
+    b.set_drive_mode(P.DRIVE_OFF)
+    b.derive(ids6)
+    b.sync()
+    D = b.get(P.F_DERIVED)
+    qacc = b.get(P.F_QACC)
+    for e, o in enumerate(ref.orcs):
+        o.forward()
+        assert np.max(np.abs(qacc[e] - o.qacc)) < 1e-6 * max(1.0, np.abs(o.qacc).max()), e
+        ftot = sum(sum(o.d.efc_force[o.d.contact[c].efc_address + i] for i in range(4)) * o.d.contact[c].frame[2] for c in range(o.d.ncon))
+        fz = D[e, P.DRV_FOOT_FORCE + 2] + D[e, P.DRV_FOOT_FORCE + 8]
+        assert abs(fz - ftot) < 1e-6 * max(1.0, abs(ftot)) and fz > 100, e
     b.close()
-    for hc in chains:
+    for hc in ref.chains:
         hc.close()
 
 

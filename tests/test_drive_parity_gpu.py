@@ -1,0 +1,209 @@
+"""GPU parity of the BENCHMARKED device mode (CM_DRIVE_PD: pd_input's motor PD on the encoder measurements + motor model
+with torque delay + physics in one kernel; reference src/cassiemujoco.c:1147-1157 minus the closed Agility blocks) at the
+benchmark's scale, on all three in-scope models, plus the shapes of BASELINE config 3 and the +-10 rad stress variant of
+reference example/cassietest_jac.py:106 (task 1).
+
+Reference side: oracle physics + the host chain of csrc/cassie_hostpath.c (the reference's own encoder / motor arithmetic,
+bit-exact by tests/test_hostpath.py) + pd_input's PD law -- bench.HostChainEnvs.
+
+Tolerance.  The device and the replay differ in floating-point operation order only, so they agree to rounding (<= 1e-9
+relative is asserted; 1e-14 is typical) -- unless an encoder COUNT truncates differently on such a last-bit difference,
+which moves one motor torque by kp * 2 pi / 2^bits / gear for a step.  The replay watches how close every encoder input
+ever came to a count boundary (HostChainEnvs.flip_margin, in counts): envs that stayed further than 1e-6 counts away
+cannot have flipped and are held to 1e-9; the others (none is expected: the chance is ~1e-5 per env per 1000 steps) to
+2e-4 absolute.  (ncon, nefc, solver iterations) must be EQUAL at every policy step either way."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import bench
+import golden_physics as G
+import oracle_py
+from cassie_amd import Batch, Model
+from cassie_amd import phys as P
+from hostchain_py import device_state_bytes
+
+pytestmark = pytest.mark.gpu
+REL_TOL = 1e-9
+FLIP_SAFE_COUNTS = 1e-6
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _drive_pd_rollout(model, name, n, nsteps, nsample=64, spread_on_terrain=False):
+    """n envs in CM_DRIVE_PD mode under the benchmark's PD workload, HOLD fused substeps per launch; `nsample` of them replayed
+    through HostChainEnvs and compared at EVERY policy step.  Returns (worst relative error, smallest flip margin, rows seen)."""
+    pod = model.pod
+    hf = G.terrain(name)
+    sample = np.unique(np.linspace(0, n - 1, nsample).astype(int))
+    npol = nsteps // bench.HOLD
+    tg = bench.pd_targets(sample, npol)                  # seeds depend on the env id only ...
+    q0 = np.tile(model.qpos_init(), (n, 1))
+    if spread_on_terrain:
+        for i, e in enumerate(sample):
+            q0[e, 0], q0[e, 1] = G.start_xy(name, i)
+    tg_all = np.tile(bench.PD_OFFSET, (npol, n, 1))      # ... the other envs get targets too (cheaply: a per-env phase of one stream)
+    rng = np.random.default_rng(77)
+    tg_all += rng.uniform(-0.3, 0.3, (npol, n, 10))
+    tg_all[:, sample, :] = tg
+    ref = bench.HostChainEnvs(model, sample, hf)
+    for i, e in enumerate(sample):
+        ref.orcs[i].qpos[:] = q0[e]
+        ref.orcs[i].forward()
+    b = Batch(model, n)
+    try:
+        if hf is not None:
+            b.set_hfield(hf)
+        b.set(P.F_QPOS, q0)
+        b.forward()                                      # what cassie_sim_init leaves: the init pose's sensordata
+        b.set(P.F_PD_KP, np.tile(bench.PD_KP, (n, 1)))
+        b.set(P.F_PD_KD, np.tile(bench.PD_KD, (n, 1)))
+        b.set_drive_mode(P.DRIVE_PD)
+        worst, rows = 0.0, 0
+        for p in range(npol):
+            b.set(P.F_PD_PTARGET, tg_all[p])
+            b.step(bench.HOLD)
+            ref.step(bench.HOLD, tg[p])
+            q = b.get(P.F_QPOS)[sample]
+            w, info = b.warnings()
+            qr, cnt = ref.qpos(), ref.counts()
+            bad = np.nonzero(np.any(info[sample][:, :3] != cnt, axis=1))[0]
+            assert bad.size == 0, (name, p, sample[bad][:8].tolist(), info[sample][bad][:8].tolist(), cnt[bad][:8].tolist())
+            err_abs = np.max(np.abs(q - qr), axis=1)
+            err_rel = np.max(np.abs(q - qr) / np.maximum(1.0, np.abs(qr)), axis=1)
+            safe = ref.flip_margin > FLIP_SAFE_COUNTS
+            assert np.all(err_rel[safe] <= REL_TOL), (name, p, float(err_rel[safe].max()), sample[safe][np.argmax(err_rel[safe])])
+            assert np.all(err_abs[~safe] < 2e-4), (name, p, float(err_abs.max()))
+            worst = max(worst, float(err_rel[safe].max()) if safe.any() else 0.0)
+            rows = max(rows, int(cnt[:, 1].max()))
+        assert not w.any(), "warning bits raised: %s" % np.unique(w)
+        assert np.all(np.isfinite(b.get(P.F_QPOS)))
+        # the integer FIR histories, IIR histories and torque delay lines of the sampled envs: bit for bit the host chain's
+        # wherever no count can have flipped
+        states = b.get_drive_state()
+        for i, e in enumerate(sample):
+            if ref.flip_margin[i] > FLIP_SAFE_COUNTS:
+                dev, host = device_state_bytes(states[int(e)]), ref.chains[i].state_bytes()
+                assert dev[0] == host[0], (name, "drive FIR history (int32 counts)", int(e))
+        return worst, float(ref.flip_margin.min()), rows
+    finally:
+        b.close()
+        for hc in ref.chains:
+            hc.close()
+        oracle_py.set_hfield(None)
+
+
+@pytest.mark.parametrize("name", ["cassie", "cassie_hfield", "cassie_tray_box"])
+def test_drive_pd_4096_envs_1000_steps(built, name):
+    """BASELINE configs 2 / 4 / 5 in the mode bench.py's `value` is measured in."""
+    worst, margin, rows = _drive_pd_rollout(Model(name), name, 4096, 1000, 64, spread_on_terrain=(name == "cassie_hfield"))
+    print("drive-pd %s: worst rel err %.2e over 64 envs x 20 policy steps, closest encoder input to a count boundary %.2e counts, up to %d rows"
+          % (name, worst, margin, rows))
+    assert rows >= 20
+
+
+def test_config3_per_rank_shape_8192_envs(cassie):
+    """BASELINE config 3's per-rank shape (8 x 8192 = 65536): one rank's batch, 1000 steps, sampled envs replayed."""
+    _drive_pd_rollout(cassie, "cassie", 8192, 1000, 32)
+
+
+def test_config3_whole_batch_65536_envs_in_one_launch(cassie):
+    """All 65536 envs of config 3 in ONE batch (it fits one GPU: 0.3 GB): two policy steps, sampled envs replayed."""
+    _drive_pd_rollout(cassie, "cassie", 65536, 100, 64)
+
+
+def _stress_targets(env_ids, npolicy):
+    """reference example/cassietest_jac.py:106: pTarget = offset + U(-10, 10) -- slams every joint into its limit."""
+    out = np.empty((npolicy, len(env_ids), 10))
+    for i, e in enumerate(env_ids):
+        out[:, i, :] = bench.PD_OFFSET + np.random.default_rng(4321 + int(e)).uniform(-10, 10, (npolicy, 10))
+    return out
+
+
+@pytest.mark.parametrize("name", ["cassie", "cassie_hfield"])
+def test_stress_variant_pm10_rad_targets(built, name):
+    """The +-10 rad stress variant: 4096 envs x 2000 steps (the robots end up on the ground) with targets held for 50 steps (harsher than the demo's per-step
+    re-draw).  The robots fall, joints sit in their limits (16 limit rows + 12 equality rows + 4 per contact approaches the
+    63-row cap; the height-field model can pass the 16-contact cap).  Every policy step the sampled envs are re-synchronised
+    to the device state, so each 50-step window is compared from identical inputs (the motion is chaotic: free-running
+    trajectories separate exponentially); envs whose window raised a cap warning are counted, the rest must agree.  The
+    cap-hit fractions go to gpurun_out/stress_caps_<model>.json (quoted in DESIGN.md)."""
+    import ctypes
+    model = Model(name)
+    pod = model.pod
+    n, npol = 4096, 40
+    hf = G.terrain(name)
+    sample = np.unique(np.linspace(0, n - 1, 128).astype(int))
+    tg = _stress_targets(np.arange(n), npol)
+    q0 = np.tile(model.qpos_init(), (n, 1))
+    if name == "cassie_hfield":
+        for e in range(n):
+            q0[e, 0], q0[e, 1] = G.start_xy(name, e)
+    if hf is not None:
+        oracle_py.set_hfield(hf)
+    L = oracle_py.lib()
+    buf = (oracle_py.CoData * len(sample))()
+    for i in range(len(sample)):
+        L.co_reset(ctypes.byref(pod), ctypes.byref(buf[i]))
+    kp, kd = np.tile(bench.PD_KP, (len(sample), 1)), np.tile(bench.PD_KD, (len(sample), 1))
+    b = Batch(model, n)
+    try:
+        if hf is not None:
+            b.set_hfield(hf)
+        b.set(P.F_QPOS, q0)
+        b.set(P.F_PD_KP, np.tile(bench.PD_KP, (n, 1)))
+        b.set(P.F_PD_KD, np.tile(bench.PD_KD, (n, 1)))
+        b.set_pd_mode(True)
+        hits = {"contact_full": 0, "constraint_full": 0, "diverged": 0, "unsupported": 0}
+        compared = excluded = 0
+        worst, max_rows, max_con = 0.0, 0, 0
+        for p in range(npol):
+            qs, vs, ws = b.get(P.F_QPOS)[sample], b.get(P.F_QVEL)[sample], b.get(P.F_QACC_WARMSTART)[sample]
+            for i in range(len(sample)):                # same inputs for the window
+                oracle_py.arr(buf[i].qpos)[: pod.nq] = qs[i]
+                oracle_py.arr(buf[i].qvel)[: pod.nv] = vs[i]
+                oracle_py.arr(buf[i].qacc_warmstart)[: pod.nv] = ws[i]
+                # the oracle's flags are sticky like the device's: both are cleared per window here
+                buf[i].warn_contact_full = buf[i].warn_constraint_full = buf[i].warn_unsupported_pair = buf[i].diverged = 0
+            b.clear_warnings()
+            b.set(P.F_PD_PTARGET, tg[p])
+            b.step(bench.HOLD)
+            w, info = b.warnings()
+            hits["contact_full"] += int(np.count_nonzero(w & P.WARN_CONTACT_FULL))
+            hits["constraint_full"] += int(np.count_nonzero(w & P.WARN_CONSTRAINT_FULL))
+            hits["diverged"] += int(np.count_nonzero(w & P.WARN_DIVERGED))
+            hits["unsupported"] += int(np.count_nonzero(w & P.WARN_UNSUPPORTED_PAIR))
+            max_rows, max_con = max(max_rows, int(info[:, 1].max())), max(max_con, int(info[:, 0].max()))
+            pt = np.ascontiguousarray(tg[p][sample])
+            L.co_step_batch(ctypes.byref(pod), ctypes.byref(buf), len(sample), bench.HOLD, pt.ctypes.data, kp.ctypes.data, kd.ctypes.data, 0)
+            capped = np.array([bool(d.warn_contact_full or d.warn_constraint_full or d.diverged) for d in buf])
+            q = b.get(P.F_QPOS)[sample]
+            qo = np.array([oracle_py.arr(d.qpos)[: pod.nq] for d in buf])
+            cnt = np.array([(d.ncon, d.nefc, d.solver_iter) for d in buf])
+            dev_capped = (w[sample] & (P.WARN_CONTACT_FULL | P.WARN_CONSTRAINT_FULL | P.WARN_DIVERGED)) != 0
+            assert np.array_equal(capped, dev_capped), (name, p, "oracle and kernel disagree on WHICH envs hit a cap")
+            ok = ~capped
+            excluded += int(capped.sum())
+            compared += int(ok.sum())
+            assert np.all(np.isfinite(q[ok]))
+            err = np.max(np.abs(q[ok] - qo[ok]) / np.maximum(1.0, np.abs(qo[ok])), axis=1) if ok.any() else np.zeros(0)
+            worst = max(worst, float(err.max()) if err.size else 0.0)
+            assert np.all(err <= 1e-6), (name, p, float(err.max()), sample[ok][np.argmax(err)])
+            assert np.array_equal(info[sample][ok][:, :2], cnt[ok][:, :2]), (name, p, "ncon / nefc differ on envs below the caps")
+        total = n * npol
+        report = {"model": name, "envs": n, "steps": npol * bench.HOLD, "targets": "offset + U(-10, 10) rad held for %d steps" % bench.HOLD,
+                  "env_windows": total, "frac_windows_contact_cap": hits["contact_full"] / total,
+                  "frac_windows_constraint_cap": hits["constraint_full"] / total, "frac_windows_diverged": hits["diverged"] / total,
+                  "unsupported_pair_warnings": hits["unsupported"], "max_rows_last_step": max_rows, "max_contacts_last_step": max_con,
+                  "sampled_env_windows_compared": compared, "sampled_env_windows_excluded_for_a_cap": excluded,
+                  "worst_rel_qpos_err_over_a_window": worst, "caps": {"CM_MAXCON": 16, "CM_MAXEFC": 63}}
+        print(json.dumps(report))
+        os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(REPO, "gpurun_out", "stress_caps_%s.json" % name), "w") as f:
+            json.dump(report, f, indent=1)
+        assert hits["unsupported"] == 0
+        assert compared > 0.5 * len(sample) * npol       # the assertion above covered most sampled env-windows
+    finally:
+        b.close()
+        oracle_py.set_hfield(None)
