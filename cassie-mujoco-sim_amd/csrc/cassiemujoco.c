@@ -58,7 +58,9 @@ struct cassie_sim {
     cassie_hostmodel_t hm;
     int left_foot_body, right_foot_body, left_heel, right_heel, left_toe, right_toe;
     unsigned long long hfield_hash; /* of the samples last uploaded (callers write through cassie_sim_hfielddata) */
+    unsigned long long model_print; /* phys_model_fingerprint of m when pod was compiled from it */
     bool applied_in_use;      /* qfrc_applied / xfrc_applied have been non-zero at some point */
+    bool ext_stale;           /* the last launch left a newer read-out in HBM than `ext` holds */
 };
 
 struct cassie_state {
@@ -76,9 +78,11 @@ static float zero_scratch_f[8];
 
 static int nsize(const cassie_sim_t *c, int what) { return phys_model_size(c->m, what); }
 
-/* A cassie_sim_t lives in pinned host memory: its mirrors of the physics state (d, ext) are the source / target of the
- * asynchronous copies around every step, which then run as true DMA transfers queued behind one another on the stream
- * with a single host synchronisation per step instead of one per array. */
+/* A cassie_sim_t lives in pinned, device-mapped host memory, and the batch-of-one's state fields are BOUND to its
+ * mirrors (sim_attach_physics): the step kernel loads qpos / qvel / ctrl / warm start straight from `d` over PCIe and
+ * stores the new state, qacc, sensordata, actuator_velocity, xpos and xquat straight back -- a step is one kernel launch
+ * and one stream synchronisation, with no copy engine in between (round 2 queued ~15 small copies per step).  The 20 KB
+ * derived read-out (`ext`) stays in HBM and is fetched when a getter asks for it. */
 static cassie_sim_t *sim_alloc(void)
 {
     cassie_sim_t *c = phys_host_alloc(sizeof(cassie_sim_t));
@@ -137,8 +141,14 @@ void cassie_cleanup(void)
 bool cassie_reload_xml(const char *modelfile) { return load_global_model(modelfile); }
 
 /* ------------------------------------------------------ host <-> HBM sync --- */
+/* The caller may have edited model arrays through the accessors or through the raw pointers they return (reference
+ * :1303-1584): a fingerprint of everything reachable that way is compared before every launch, and only a change costs a
+ * model compile + upload (round 2 recompiled and memcmp'ed the whole model every step). */
 static void sim_recompile(cassie_sim_t *c)
 {
+    const unsigned long long print = phys_model_fingerprint(c->m);
+    if (print == c->model_print) return;
+    c->model_print = print;
     cm_model_t pod;
     char err[256];
     if (phys_model_compile(c->m, &pod, err, sizeof err) != 0) {
@@ -158,21 +168,16 @@ static void sim_push_hfield(cassie_sim_t *c)
     const float *hf = phys_model_hfield_data(c->m);
     if (!hf) return;
     int n = phys_model_size(c->m, PHYS_NHFIELDDATA);
-    unsigned long long h = 1469598103934665603ull;
-    const unsigned *w = (const unsigned *)hf;
-    for (int i = 0; i < n; ++i) h = (h ^ w[i]) * 1099511628211ull;
+    const unsigned long long h = phys_hash_floats(hf, (size_t)n);
     if (h != c->hfield_hash) { phys_batch_set_hfield(c->b, hf, n); c->hfield_hash = h; }
 }
 
+/* what still has to travel before a launch: model / terrain edits, and the perturbation arrays once they are in use
+ * (they stay in HBM: the kernel walks them body by body, which is no access pattern for PCIe) */
 static void sim_push(cassie_sim_t *c)
 {
-    sim_recompile(c); /* the caller may have edited model arrays through the accessors */
+    sim_recompile(c);
     sim_push_hfield(c);
-    phys_batch_upload_async(c->b, PHYS_F_QPOS, c->d.qpos, 0, 1);
-    phys_batch_upload_async(c->b, PHYS_F_QVEL, c->d.qvel, 0, 1);
-    phys_batch_upload_async(c->b, PHYS_F_CTRL, c->d.ctrl, 0, 1);
-    phys_batch_upload_async(c->b, PHYS_F_TIME, &c->d.time, 0, 1);
-    /* perturbations reach the device (and switch the kernel's applied-force path on) only once some are set */
     if (!c->applied_in_use) {
         for (size_t i = 0; i < sizeof c->d.qfrc_applied / sizeof(double) && !c->applied_in_use; ++i) c->applied_in_use = c->d.qfrc_applied[i] != 0;
         for (size_t i = 0; i < sizeof c->d.xfrc_applied / sizeof(double) && !c->applied_in_use; ++i) c->applied_in_use = c->d.xfrc_applied[i] != 0;
@@ -181,38 +186,25 @@ static void sim_push(cassie_sim_t *c)
         phys_batch_upload_async(c->b, PHYS_F_QFRC_APPLIED, c->d.qfrc_applied, 0, 1);
         phys_batch_upload_async(c->b, PHYS_F_XFRC_APPLIED, c->d.xfrc_applied, 0, 1);
     }
-    if (c->d.warmstart_dirty) {
-        phys_batch_upload_async(c->b, PHYS_F_QACC_WARMSTART, c->d.qacc_warmstart, 0, 1);
-        c->d.warmstart_dirty = 0;
-    }
 }
 
-/* queued behind the kernel; sim_finish waits for everything and unpacks */
-static void sim_pull_kinematics(cassie_sim_t *c)
+static void sim_unpack_ext(cassie_sim_t *c)
 {
-    phys_batch_download_async(c->b, PHYS_F_XPOS, c->d.xpos, 0, 1);
-    phys_batch_download_async(c->b, PHYS_F_XQUAT, c->d.xquat, 0, 1);
-    phys_batch_download_ext_async(c->b, &c->ext, 0, 1);
-}
-
-static void sim_pull_all(cassie_sim_t *c)
-{
-    phys_batch_download_async(c->b, PHYS_F_QPOS, c->d.qpos, 0, 1);
-    phys_batch_download_async(c->b, PHYS_F_QVEL, c->d.qvel, 0, 1);
-    phys_batch_download_async(c->b, PHYS_F_QACC, c->d.qacc, 0, 1);
-    phys_batch_download_async(c->b, PHYS_F_QACC_WARMSTART, c->d.qacc_warmstart, 0, 1);
-    phys_batch_download_async(c->b, PHYS_F_TIME, &c->d.time, 0, 1);
-    phys_batch_download_async(c->b, PHYS_F_SENSORDATA, c->d.sensordata, 0, 1);
-    phys_batch_download_async(c->b, PHYS_F_ACTUATOR_VELOCITY, c->d.actuator_velocity, 0, 1);
-    sim_pull_kinematics(c);
-}
-
-static void sim_finish(cassie_sim_t *c)
-{
-    phys_batch_sync(c->b);
     int ns = nsize(c, PHYS_NSITE);
     for (int s = 0; s < ns && s < CM_MAXSITE; ++s)
         for (int i = 0; i < 3; ++i) c->d.site_xpos[3 * s + i] = c->ext.site_xpos[s][i];
+    c->ext_stale = false;
+}
+
+/* the derived read-out of the last launch, fetched from HBM on first use */
+static const cm_ext_t *sim_ext(const cassie_sim_t *cc)
+{
+    cassie_sim_t *c = (cassie_sim_t *)cc;
+    if (c->ext_stale) {
+        phys_batch_download_ext(c->b, &c->ext, 0, 1);
+        sim_unpack_ext(c);
+    }
+    return &c->ext;
 }
 
 /* mj_step1 + mj_step2 (reference :1130-1134) */
@@ -220,8 +212,8 @@ static void physics_step(cassie_sim_t *c, int nsteps)
 {
     sim_push(c);
     phys_batch_step(c->b, nsteps, NULL);
-    sim_pull_all(c);
-    sim_finish(c);
+    phys_batch_sync(c->b);
+    c->ext_stale = true;
 }
 
 /* mj_forward (reference :971, :1029, :1223) */
@@ -229,23 +221,21 @@ static void physics_forward(cassie_sim_t *c)
 {
     sim_push(c);
     phys_batch_forward(c->b, NULL);
-    phys_batch_download_async(c->b, PHYS_F_QACC, c->d.qacc, 0, 1);
-    phys_batch_download_async(c->b, PHYS_F_SENSORDATA, c->d.sensordata, 0, 1);
-    phys_batch_download_async(c->b, PHYS_F_ACTUATOR_VELOCITY, c->d.actuator_velocity, 0, 1);
-    sim_pull_kinematics(c);
-    sim_finish(c);
+    phys_batch_sync(c->b);
+    c->ext_stale = true;
 }
 
 /* position-dependent quantities only (the mj_kinematics / mj_fwdPosition / mj_comVel calls the
- * reference's getters make): refreshes xpos / ext but leaves qacc and sensordata mirrors alone,
+ * reference's getters make): refreshes xpos / xquat / ext but leaves qacc, sensordata and actuator_velocity alone,
  * because the encoder models read the sensordata of the last *step* */
 static void refresh_derived(const cassie_sim_t *cc)
 {
     cassie_sim_t *c = (cassie_sim_t *)cc;
     sim_push(c);
-    phys_batch_forward(c->b, NULL);
-    sim_pull_kinematics(c);
-    sim_finish(c);
+    phys_batch_forward_kinematics(c->b, NULL);
+    phys_batch_download_ext_async(c->b, &c->ext, 0, 1);
+    phys_batch_sync(c->b);
+    sim_unpack_ext(c);
 }
 
 /* --------------------------------------------------------------- instances --- */
@@ -272,8 +262,21 @@ static bool sim_attach_physics(cassie_sim_t *c)
         return false;
     }
     phys_batch_enable_ext(c->b, 1);
+    /* zero-copy: the kernel reads and writes the host mirrors in place (c is pinned and device-mapped) */
+    struct { int field; double *host; } bound[] = {
+        {PHYS_F_QPOS, c->d.qpos}, {PHYS_F_QVEL, c->d.qvel}, {PHYS_F_QACC_WARMSTART, c->d.qacc_warmstart}, {PHYS_F_TIME, &c->d.time},
+        {PHYS_F_CTRL, c->d.ctrl}, {PHYS_F_QACC, c->d.qacc}, {PHYS_F_SENSORDATA, c->d.sensordata},
+        {PHYS_F_ACTUATOR_VELOCITY, c->d.actuator_velocity}, {PHYS_F_XPOS, c->d.xpos}, {PHYS_F_XQUAT, c->d.xquat}};
+    for (size_t i = 0; i < sizeof bound / sizeof bound[0]; ++i)
+        if (phys_batch_bind(c->b, bound[i].field, bound[i].host) != 0) {
+            fprintf(stderr, "cassiemujoco: cannot bind the simulator's state to the GPU batch: %s\n", phys_last_error());
+            return false;
+        }
     const float *hf = phys_model_hfield_data(c->m);
     if (hf) phys_batch_set_hfield(c->b, hf, phys_model_size(c->m, PHYS_NHFIELDDATA));
+    c->hfield_hash = hf ? phys_hash_floats(hf, (size_t)phys_model_size(c->m, PHYS_NHFIELDDATA)) : 0;
+    c->model_print = phys_model_fingerprint(c->m);
+    c->ext_stale = true;
     lookup_ids(c);
     return true;
 }
@@ -300,9 +303,10 @@ void cassie_sim_copy_just_sim(cassie_sim_t *dst, const cassie_sim_t *src)
     /* model + data (mj_copyModel + mj_copyData, reference :1093-1100) and the three block states */
     phys_model_free(dst->m);
     dst->m = phys_model_copy(src->m);
+    dst->model_print = 0; /* another model object: compare its compiled form with what the batch holds before the next launch */
     dst->d = src->d;
     dst->d.warmstart_dirty = 1;
-    dst->ext = src->ext;
+    dst->ext = *sim_ext(src); dst->ext_stale = false;
     lookup_ids(dst);
     cassie_core_sim_copy(cassie_hostenv_core(dst->host), cassie_hostenv_core(src->host));
     state_output_copy(cassie_hostenv_estimator(dst->host), cassie_hostenv_estimator(src->host));
@@ -494,6 +498,7 @@ double *cassie_sim_xquat(cassie_sim_t *c, const char *name)
 double *cassie_sim_site_xpos(cassie_sim_t *c, const char *name)
 {
     int s = site_id(c, name);
+    (void)sim_ext(c); /* the site positions come with the derived read-out */
     return (s < 0 || s >= CM_MAXSITE) ? zero_scratch : &c->d.site_xpos[3 * s];
 }
 
@@ -510,7 +515,7 @@ void cassie_sim_site_xquat(cassie_sim_t *c, const char *name, double *xquat)
 {
     int s = site_id(c, name);
     if (s < 0 || s >= CM_MAXSITE) { xquat[0] = 1; xquat[1] = xquat[2] = xquat[3] = 0; return; }
-    mat2quat(xquat, c->ext.site_xmat[s]);
+    mat2quat(xquat, sim_ext(c)->site_xmat[s]);
 }
 
 void cassie_sim_read_rangefinder(cassie_sim_t *c, double ranges[6]) { memcpy(ranges, &c->d.sensordata[29], 6 * sizeof(double)); }
@@ -680,15 +685,15 @@ static void point_jacobian(const cassie_sim_t *c, int body, const double *point,
     if (jacp) memset(jacp, 0, 3 * nv * sizeof(double));
     if (jacr) memset(jacr, 0, 3 * nv * sizeof(double));
     if (body <= 0) return;
-    const double *com = c->ext.subtree_com[c->pod.body_rootid[body]];
+    const double *com = sim_ext(c)->subtree_com[c->pod.body_rootid[body]];
     double off[3] = {point[0] - com[0], point[1] - com[1], point[2] - com[2]};
     for (int k = 0; k < nv; ++k) {
         if (!((c->pod.body_dofmask[body] >> k) & 1ull)) continue;
         double t[3];
-        cross3(t, c->ext.cdof[k], off);
+        cross3(t, sim_ext(c)->cdof[k], off);
         for (int i = 0; i < 3; ++i) {
-            if (jacp) jacp[i * nv + k] = c->ext.cdof[k][3 + i] + t[i];
-            if (jacr) jacr[i * nv + k] = c->ext.cdof[k][i];
+            if (jacp) jacp[i * nv + k] = sim_ext(c)->cdof[k][3 + i] + t[i];
+            if (jacr) jacr[i * nv + k] = sim_ext(c)->cdof[k][i];
         }
     }
 }
@@ -710,7 +715,7 @@ void cassie_sim_get_jacobian_full_site(cassie_sim_t *c, double *jac, double *jac
     refresh_derived(c);
     int s = site_id(c, name);
     if (s < 0 || s >= CM_MAXSITE) { point_jacobian(c, 0, zero_scratch, jac, jac_rot); return; }
-    point_jacobian(c, c->pod.site_bodyid[s], c->ext.site_xpos[s], jac, jac_rot);
+    point_jacobian(c, c->pod.site_bodyid[s], sim_ext(c)->site_xpos[s], jac, jac_rot);
 }
 
 static int contact_body(const cassie_sim_t *c, int fullgeom) { return phys_model_iarray(c->m, PHYS_MI_GEOM_BODYID)[fullgeom]; }
@@ -720,8 +725,8 @@ bool cassie_sim_check_obstacle_collision(const cassie_sim_t *c)
     const double *user = phys_model_array(c->m, PHYS_M_GEOM_USER);
     int nug = nsize(c, PHYS_NUSER_GEOM);
     if (!user || nug < 1) return false;
-    for (int i = 0; i < c->ext.ncon; ++i)
-        if (user[nug * c->ext.con_geom1[i]] == 1 || user[nug * c->ext.con_geom2[i]] == 1) return true;
+    for (int i = 0; i < sim_ext(c)->ncon; ++i)
+        if (user[nug * sim_ext(c)->con_geom1[i]] == 1 || user[nug * sim_ext(c)->con_geom2[i]] == 1) return true;
     return false;
 }
 bool cassie_sim_check_self_collision(const cassie_sim_t *c)
@@ -729,15 +734,15 @@ bool cassie_sim_check_self_collision(const cassie_sim_t *c)
     const double *user = phys_model_array(c->m, PHYS_M_GEOM_USER);
     int nug = nsize(c, PHYS_NUSER_GEOM);
     if (!user || nug < 1) return false;
-    for (int i = 0; i < c->ext.ncon; ++i)
-        if (user[nug * c->ext.con_geom1[i]] == 2 && user[nug * c->ext.con_geom2[i]] == 2) return true;
+    for (int i = 0; i < sim_ext(c)->ncon; ++i)
+        if (user[nug * sim_ext(c)->con_geom1[i]] == 2 && user[nug * sim_ext(c)->con_geom2[i]] == 2) return true;
     return false;
 }
 bool cassie_sim_geom_collision(const cassie_sim_t *c, int geom_group)
 {
     const int *grp = phys_model_iarray(c->m, PHYS_MI_GEOM_GROUP);
-    for (int i = 0; i < c->ext.ncon; ++i) {
-        int g1 = grp[c->ext.con_geom1[i]], g2 = grp[c->ext.con_geom2[i]];
+    for (int i = 0; i < sim_ext(c)->ncon; ++i) {
+        int g1 = grp[sim_ext(c)->con_geom1[i]], g2 = grp[sim_ext(c)->con_geom2[i]];
         if ((g1 == 1 && g2 == geom_group) || (g2 == 1 && g1 == geom_group)) return true;
     }
     return false;
@@ -746,15 +751,15 @@ bool cassie_sim_geom_collision(const cassie_sim_t *c, int geom_group)
 /* contact force in world axes: frame^T * [normal, tangent1, tangent2] (mj_contactForce + mju_rotVecMatT) */
 static void contact_force_world(const cassie_sim_t *c, int i, double *fw)
 {
-    const double *fr = c->ext.con_frame[i], *f = c->ext.con_force[i];
+    const double *fr = sim_ext(c)->con_frame[i], *f = sim_ext(c)->con_force[i];
     for (int k = 0; k < 3; ++k) fw[k] = fr[k] * f[0] + fr[3 + k] * f[1] + fr[6 + k] * f[2];
 }
 
 void cassie_sim_foot_forces(const cassie_sim_t *c, double cfrc[12])
 {
     memset(cfrc, 0, 12 * sizeof(double));
-    for (int i = 0; i < c->ext.ncon; ++i) {
-        int b1 = contact_body(c, c->ext.con_geom1[i]), b2 = contact_body(c, c->ext.con_geom2[i]);
+    for (int i = 0; i < sim_ext(c)->ncon; ++i) {
+        int b1 = contact_body(c, sim_ext(c)->con_geom1[i]), b2 = contact_body(c, sim_ext(c)->con_geom2[i]);
         double fw[3];
         contact_force_world(c, i, fw);
         for (int side = 0; side < 2; ++side) {
@@ -771,8 +776,8 @@ void cassie_sim_heeltoe_forces(const cassie_sim_t *c, double toe_force[6], doubl
     memset(toe_force, 0, 6 * sizeof(double));
     memset(heel_force, 0, 6 * sizeof(double));
     const int heel[2] = {c->left_heel, c->right_heel}, toe[2] = {c->left_toe, c->right_toe};
-    for (int i = 0; i < c->ext.ncon; ++i) {
-        int b1 = contact_body(c, c->ext.con_geom1[i]), b2 = contact_body(c, c->ext.con_geom2[i]);
+    for (int i = 0; i < sim_ext(c)->ncon; ++i) {
+        int b1 = contact_body(c, sim_ext(c)->con_geom1[i]), b2 = contact_body(c, sim_ext(c)->con_geom2[i]);
         bool left = b1 == c->left_foot_body || b2 == c->left_foot_body;
         bool right = b1 == c->right_foot_body || b2 == c->right_foot_body;
         if (!left && !right) continue;
@@ -781,7 +786,7 @@ void cassie_sim_heeltoe_forces(const cassie_sim_t *c, double toe_force[6], doubl
         if (heel[id] < 0 || toe[id] < 0 || heel[id] >= CM_MAXSITE || toe[id] >= CM_MAXSITE) continue; /* model without heel/toe sites */
         double fw[3];
         contact_force_world(c, i, fw);
-        const double *p = c->ext.con_pos[i], *tp = c->ext.site_xpos[toe[id]], *hp = c->ext.site_xpos[heel[id]];
+        const double *p = sim_ext(c)->con_pos[i], *tp = sim_ext(c)->site_xpos[toe[id]], *hp = sim_ext(c)->site_xpos[heel[id]];
         double td = hypot(tp[0] - p[0], tp[1] - p[1]), hd = hypot(hp[0] - p[0], hp[1] - p[1]);
         double *dst = td < hd ? toe_force : heel_force;
         for (int j = 0; j < 3; ++j) dst[j + 3 * id] += sign * fw[j];
@@ -801,8 +806,8 @@ void cassie_sim_foot_positions(const cassie_sim_t *c, double cpos[6])
 void cassie_sim_foot_velocities(const cassie_sim_t *c, double cvel[12])
 {
     refresh_derived(c);
-    memcpy(cvel, c->ext.cvel[c->left_foot_body], 6 * sizeof(double));
-    memcpy(&cvel[6], c->ext.cvel[c->right_foot_body], 6 * sizeof(double));
+    memcpy(cvel, sim_ext(c)->cvel[c->left_foot_body], 6 * sizeof(double));
+    memcpy(&cvel[6], sim_ext(c)->cvel[c->right_foot_body], 6 * sizeof(double));
 }
 
 void cassie_sim_body_velocities(const cassie_sim_t *c, double cvel[6], const char *name)
@@ -810,14 +815,14 @@ void cassie_sim_body_velocities(const cassie_sim_t *c, double cvel[6], const cha
     refresh_derived(c);
     memset(cvel, 0, 6 * sizeof(double));
     int b = body_id(c, name);
-    if (b >= 0) memcpy(cvel, c->ext.cvel[b], 6 * sizeof(double));
+    if (b >= 0) memcpy(cvel, sim_ext(c)->cvel[b], 6 * sizeof(double));
 }
 
 void cassie_sim_foot_orient(const cassie_sim_t *c, double corient[4])
 {
     int s = site_id(c, "right-foot-middle"); /* not defined by the shipped models; identity then */
     if (s < 0 || s >= CM_MAXSITE) { corient[0] = 1; corient[1] = corient[2] = corient[3] = 0; return; }
-    mat2quat(corient, c->ext.site_xmat[s]);
+    mat2quat(corient, sim_ext(c)->site_xmat[s]);
 }
 
 /* whole-model centre of mass and its velocity / angular momentum from the kernel's read-out */
@@ -829,15 +834,15 @@ static double total_mass_com(const cassie_sim_t *c, double com[3])
     com[0] = com[1] = com[2] = 0;
     for (int b = 1; b < nb; ++b) {
         M += mass[b];
-        for (int i = 0; i < 3; ++i) com[i] += mass[b] * c->ext.xipos[b][i];
+        for (int i = 0; i < 3; ++i) com[i] += mass[b] * sim_ext(c)->xipos[b][i];
     }
     if (M > 0) for (int i = 0; i < 3; ++i) com[i] /= M;
     return M;
 }
 static void body_com_velocity(const cassie_sim_t *c, int b, double v[3])
 {
-    const double *cv = c->ext.cvel[b], *rc = c->ext.subtree_com[c->pod.body_rootid[b]];
-    double off[3] = {c->ext.xipos[b][0] - rc[0], c->ext.xipos[b][1] - rc[1], c->ext.xipos[b][2] - rc[2]}, t[3];
+    const double *cv = sim_ext(c)->cvel[b], *rc = sim_ext(c)->subtree_com[c->pod.body_rootid[b]];
+    double off[3] = {sim_ext(c)->xipos[b][0] - rc[0], sim_ext(c)->xipos[b][1] - rc[1], sim_ext(c)->xipos[b][2] - rc[2]}, t[3];
     cross3(t, cv, off);
     for (int i = 0; i < 3; ++i) v[i] = cv[3 + i] + t[i];
 }
@@ -890,14 +895,14 @@ void cassie_sim_angular_momentum(const cassie_sim_t *c, double Lcm[3])
         q[2] = xq[0] * iq[2] - xq[1] * iq[3] + xq[2] * iq[0] + xq[3] * iq[1];
         q[3] = xq[0] * iq[3] + xq[1] * iq[2] - xq[2] * iq[1] + xq[3] * iq[0];
         quat2mat(R, q);
-        const double *w = c->ext.cvel[b], *I = c->pod.body_inertia[b];
+        const double *w = sim_ext(c)->cvel[b], *I = c->pod.body_inertia[b];
         double wl[3] = {R[0] * w[0] + R[3] * w[1] + R[6] * w[2], R[1] * w[0] + R[4] * w[1] + R[7] * w[2], R[2] * w[0] + R[5] * w[1] + R[8] * w[2]};
         for (int i = 0; i < 3; ++i) wl[i] *= I[i];
         for (int i = 0; i < 3; ++i) Lcm[i] += R[3 * i] * wl[0] + R[3 * i + 1] * wl[1] + R[3 * i + 2] * wl[2];
         /* orbital part about the whole-model com */
         double v[3], r[3], t[3];
         body_com_velocity(c, b, v);
-        for (int i = 0; i < 3; ++i) { r[i] = c->ext.xipos[b][i] - com[i]; v[i] = mass[b] * (v[i] - vcom[i]); }
+        for (int i = 0; i < 3; ++i) { r[i] = sim_ext(c)->xipos[b][i] - com[i]; v[i] = mass[b] * (v[i] - vcom[i]); }
         cross3(t, r, v);
         for (int i = 0; i < 3; ++i) Lcm[i] += t[i];
     }
@@ -906,14 +911,14 @@ void cassie_sim_angular_momentum(const cassie_sim_t *c, double Lcm[3])
 void cassie_sim_full_mass_matrix(const cassie_sim_t *c, double M[1024])
 {
     refresh_derived(c);
-    for (int i = 0; i < 32; ++i) for (int j = 0; j < 32; ++j) M[i * 32 + j] = c->ext.qM[i][j];
+    for (int i = 0; i < 32; ++i) for (int j = 0; j < 32; ++j) M[i * 32 + j] = sim_ext(c)->qM[i][j];
 }
 
 void cassie_sim_minimal_mass_matrix(const cassie_sim_t *c, double M[256])
 {
     static const int IND[16] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 12, 18, 19, 20, 21, 25, 31}; /* base + 10 motors */
     refresh_derived(c);
-    for (int i = 0; i < 16; ++i) for (int j = 0; j < 16; ++j) M[i * 16 + j] = c->ext.qM[IND[i]][IND[j]];
+    for (int i = 0; i < 16; ++i) for (int j = 0; j < 16; ++j) M[i * 16 + j] = sim_ext(c)->qM[IND[i]][IND[j]];
 }
 
 void cassie_sim_centroid_inertia(const cassie_sim_t *cc, double Icm[9])
@@ -924,11 +929,11 @@ void cassie_sim_centroid_inertia(const cassie_sim_t *cc, double Icm[9])
     for (int i = 0; i < 4; ++i) { stored[i] = c->d.qpos[i + 3]; c->d.qpos[i + 3] = 0; }
     c->d.qpos[4] = 1;
     refresh_derived(c);
-    double m = c->ext.qM[0][0], rcm[3];
+    double m = sim_ext(c)->qM[0][0], rcm[3];
     total_mass_com(c, rcm);
     for (int i = 0; i < 3; ++i) rcm[i] -= c->d.qpos[i];
     double Ip[3][3], Ic[3][3];
-    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Ip[i][j] = c->ext.qM[i + 3][j + 3];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Ip[i][j] = sim_ext(c)->qM[i + 3][j + 3];
     Ic[0][0] = Ip[0][0] - m * (rcm[1] * rcm[1] + rcm[2] * rcm[2]);
     Ic[1][1] = Ip[1][1] - m * (rcm[2] * rcm[2] + rcm[0] * rcm[0]);
     Ic[2][2] = Ip[2][2] - m * (rcm[0] * rcm[0] + rcm[1] * rcm[1]);
@@ -944,11 +949,11 @@ void cassie_sim_loop_constraint_info(const cassie_sim_t *c, double J_cl[192], do
 {
     refresh_derived(c);
     int idx = 0;
-    for (int r = 0; r < c->ext.ne && r < CM_MAXEQROW && idx < 6; ++r) {
-        const char *nm = phys_model_id2name(c->m, OBJ_EQUALITY, c->ext.eq_id[r]);
+    for (int r = 0; r < sim_ext(c)->ne && r < CM_MAXEQROW && idx < 6; ++r) {
+        const char *nm = phys_model_id2name(c->m, OBJ_EQUALITY, sim_ext(c)->eq_id[r]);
         if (!nm || (strcmp(nm, "left-achilles-rod-eq") != 0 && strcmp(nm, "right-achilles-rod-eq") != 0)) continue;
-        for (int j = 0; j < 32; ++j) J_cl[idx * 32 + j] = c->ext.eq_J[r][j];
-        err_cl[idx] = c->ext.eq_pos[r];
+        for (int j = 0; j < 32; ++j) J_cl[idx * 32 + j] = sim_ext(c)->eq_J[r][j];
+        err_cl[idx] = sim_ext(c)->eq_pos[r];
         ++idx;
     }
 }
@@ -963,7 +968,7 @@ void cassie_sim_body_acceleration(const cassie_sim_t *c, double accel[6], const 
     for (int i = 0; i < 3; ++i) accel[3 + i] = -c->pod.gravity[i];
     for (int k = 0; k < nsize(c, PHYS_NV); ++k) {
         if (!((c->pod.body_dofmask[b] >> k) & 1ull)) continue;
-        for (int i = 0; i < 6; ++i) accel[i] += c->ext.cdof_dot[k][i] * c->d.qvel[k] + c->ext.cdof[k][i] * c->d.qacc[k];
+        for (int i = 0; i < 6; ++i) accel[i] += sim_ext(c)->cdof_dot[k][i] * c->d.qvel[k] + sim_ext(c)->cdof[k][i] * c->d.qacc[k];
     }
 }
 
@@ -977,8 +982,8 @@ void cassie_sim_body_contact_force(const cassie_sim_t *c, double cfrc[6], const 
     memset(cfrc, 0, 6 * sizeof(double));
     int b = body_id(c, name);
     if (b < 0) return;
-    for (int i = 0; i < c->ext.ncon; ++i) {
-        int b1 = contact_body(c, c->ext.con_geom1[i]), b2 = contact_body(c, c->ext.con_geom2[i]);
+    for (int i = 0; i < sim_ext(c)->ncon; ++i) {
+        int b1 = contact_body(c, sim_ext(c)->con_geom1[i]), b2 = contact_body(c, sim_ext(c)->con_geom2[i]);
         if (b != b1 && b != b2) continue;
         double fw[3];
         contact_force_world(c, i, fw);
@@ -1054,7 +1059,7 @@ void reset_state_est(cassie_sim_t *c, state_out_t *y)
 
 cassie_out_t cassie_sim_get_cassie_out(cassie_sim_t *c) { return *cassie_hostenv_cassie_out(c->host); }
 void cassie_sim_copy_cassie_out(cassie_sim_t *dst, cassie_out_t *y) { memcpy(cassie_hostenv_cassie_out(dst->host), y, sizeof(cassie_out_t)); }
-void cassie_sim_copy_mjd(cassie_sim_t *dst, cassie_sim_t *src) { dst->d = src->d; dst->d.warmstart_dirty = 1; dst->ext = src->ext; }
+void cassie_sim_copy_mjd(cassie_sim_t *dst, cassie_sim_t *src) { dst->d = src->d; dst->d.warmstart_dirty = 1; dst->ext = *sim_ext(src); dst->ext_stale = false; }
 void cassie_sim_copy_state_est(cassie_sim_t *dst, cassie_sim_t *src) { state_output_copy(cassie_hostenv_estimator(dst->host), cassie_hostenv_estimator(src->host)); }
 void cassie_sim_run_state_est(cassie_sim_t *c, cassie_out_t *cassie_out, state_out_t *y) { state_output_step(cassie_hostenv_estimator(c->host), cassie_out, y); }
 void state_out_free(state_out_t *out) { free(out); }

@@ -50,6 +50,7 @@ struct phys_batch {
     int *d_order = nullptr;
     int launches_since_order = 0;
     cm_ext_t *d_ext = nullptr;
+    double *d_scratch_out = nullptr; /* [nenv][nv + nsensordata + nu]: where phys_batch_forward_kinematics sends qacc / sensordata / actuator_velocity */
 };
 
 static bool hip_ok(hipError_t e, const char *what) {
@@ -109,8 +110,16 @@ static bool quiesce(phys_batch *b) {
     return ok;
 }
 
-static int launch(phys_batch *b, int nsub, int integrate, hipStream_t s) {
+static int launch(phys_batch *b, int nsub, int integrate, hipStream_t s, bool scratch_outputs = false) {
     ck::PhysIO io = make_io(b, nsub, integrate);
+    if (scratch_outputs) {
+        /* a read-out pass: the step outputs the caller's fields hold (sensordata and actuator_velocity of the last STEP feed
+         * the encoder / motor models of the next one; qacc) stay as they are */
+        const cm_model_t &m = b->host_model;
+        io.qacc = b->d_scratch_out; io.sv = m.nv;
+        io.sensordata = b->d_scratch_out + (size_t)b->nenv * m.nv; io.ssd = m.nsensordata;
+        io.actuator_velocity = io.sensordata + (size_t)b->nenv * m.nsensordata;
+    }
     b->last_stream = s;
     const dim3 grid(b->nenv), block(WV_WAVE);
     /* the compile-time-topology instantiations are used only when the model's dof tree is exactly theirs */
@@ -231,6 +240,7 @@ void phys_batch_free(phys_batch_t *b) {
     if (b->d_info) (void)hipFree(b->d_info);
     if (b->d_hfield) (void)hipFree(b->d_hfield);
     if (b->d_ext) (void)hipFree(b->d_ext);
+    if (b->d_scratch_out) (void)hipFree(b->d_scratch_out);
     if (b->d_drive) (void)hipFree(b->d_drive);
     if (b->d_order) (void)hipFree(b->d_order);
     if (b->d_cost) (void)hipFree(b->d_cost);
@@ -412,6 +422,18 @@ int phys_batch_forward(phys_batch_t *b, void *stream) {
     if (!b) return -1;
     (void)hipSetDevice(b->device);
     return launch(b, 1, 0, stream ? (hipStream_t)stream : b->stream);
+}
+
+int phys_batch_forward_kinematics(phys_batch_t *b, void *stream) {
+    if (!b) return -1;
+    (void)hipSetDevice(b->device);
+    if (b->drive_mode != CM_DRIVE_OFF) { phys_set_last_error("phys_batch_forward_kinematics: not in a drive mode (the pass reads the sensordata field)"); return -1; }
+    if (!b->d_scratch_out) {
+        const cm_model_t &m = b->host_model;
+        const size_t bytes = sizeof(double) * (size_t)b->nenv * (size_t)(m.nv + m.nsensordata + m.nu);
+        if (!hip_ok(hipMalloc((void **)&b->d_scratch_out, bytes), "hipMalloc(scratch outputs)")) return -1;
+    }
+    return launch(b, 1, 0, stream ? (hipStream_t)stream : b->stream, true);
 }
 
 int phys_batch_set_pd_mode(phys_batch_t *b, int on) {

@@ -10,6 +10,7 @@
 
 #include <cstring>
 #include <string>
+#include <vector>
 
 struct phys_model {
     cm::HostModel h;
@@ -24,6 +25,33 @@ static void set_err(char *err, int errlen, const std::string &s) {
     }
 }
 void phys_set_last_error(const char *s) { g_err = s ? s : ""; }
+
+/* 64-bit fingerprint of everything a caller can change through the read-write views below (and the options), four
+ * independent multiply-xor lanes so that the words stream at memory speed: a few microseconds for a Cassie model.  The
+ * single-simulator glue compares it before every step instead of recompiling the model: the reference hands out raw
+ * mjModel pointers (reference src/cassiemujoco.c:1303-1584), so a write can happen at any time without a call to notice. */
+namespace {
+struct Fingerprint {
+    unsigned long long h[4] = {0x9e3779b97f4a7c15ull, 0xc2b2ae3d27d4eb4full, 0x165667b19e3779f9ull, 0x27d4eb2f165667c5ull};
+    void words(const void *data, size_t bytes) {
+        const unsigned char *p = (const unsigned char *)data;
+        size_t i = 0;
+        for (; i + 32 <= bytes; i += 32) {
+            unsigned long long w[4];
+            memcpy(w, p + i, 32);
+            for (int k = 0; k < 4; ++k) h[k] = (h[k] ^ w[k]) * 0x100000001b3ull + 0x632be59bd9b4e019ull;
+        }
+        unsigned long long tail[4] = {0, 0, 0, 0};
+        if (i < bytes) { memcpy(tail, p + i, bytes - i); for (int k = 0; k < 4; ++k) h[k] = (h[k] ^ tail[k]) * 0x100000001b3ull + bytes; }
+    }
+    template <class T> void vec(const std::vector<T> &v) { if (!v.empty()) words(v.data(), v.size() * sizeof(T)); }
+    unsigned long long value() const {
+        unsigned long long x = h[0];
+        for (int k = 1; k < 4; ++k) x = (x ^ (h[k] >> 29) ^ (h[k] << 35)) * 0x9fb21c651e98df25ull;
+        return x ^ (x >> 32);
+    }
+};
+}  // namespace
 
 extern "C" {
 
@@ -61,6 +89,38 @@ int phys_model_compile(const phys_model_t *m, cm_model_t *out, char *err, int er
         return -1;
     }
     return 0;
+}
+
+unsigned long long phys_model_fingerprint(const phys_model_t *m) {
+    if (!m) return 0;
+    const cm::HostModel &h = m->h;
+    Fingerprint f;
+    const double opt[] = {h.timestep, h.tolerance, h.impratio, h.gravity[0], h.gravity[1], h.gravity[2], h.magnetic[0], h.magnetic[1],
+                          h.magnetic[2], (double)h.iterations, (double)h.solver_pgs, (double)h.flags, h.meaninertia,
+                          h.hfield_size[0], h.hfield_size[1], h.hfield_size[2], h.hfield_size[3], (double)h.hfield_nrow, (double)h.hfield_ncol};
+    f.words(opt, sizeof opt);
+    f.vec(h.body_pos); f.vec(h.body_quat); f.vec(h.body_ipos); f.vec(h.body_iquat); f.vec(h.body_mass); f.vec(h.body_inertia);
+    f.vec(h.body_invweight0); f.vec(h.body_subtreemass);
+    f.vec(h.jnt_pos); f.vec(h.jnt_axis); f.vec(h.jnt_range); f.vec(h.jnt_stiffness); f.vec(h.jnt_margin); f.vec(h.jnt_solref); f.vec(h.jnt_solimp);
+    f.vec(h.jnt_limited); f.vec(h.qpos0); f.vec(h.qpos_spring); f.vec(h.dof_armature); f.vec(h.dof_damping); f.vec(h.dof_invweight0);
+    f.vec(h.geom_type); f.vec(h.geom_contype); f.vec(h.geom_conaffinity); f.vec(h.geom_condim); f.vec(h.geom_priority); f.vec(h.geom_group);
+    f.vec(h.geom_pos); f.vec(h.geom_quat); f.vec(h.geom_size); f.vec(h.geom_friction); f.vec(h.geom_solref); f.vec(h.geom_solimp);
+    f.vec(h.geom_solmix); f.vec(h.geom_margin); f.vec(h.geom_gap); f.vec(h.geom_rbound); f.vec(h.geom_user);
+    f.vec(h.site_pos); f.vec(h.site_quat);
+    /* the integer arrays phys_model_iarray hands out as raw pointers */
+    f.vec(h.jnt_type); f.vec(h.jnt_qposadr); f.vec(h.jnt_dofadr); f.vec(h.geom_bodyid); f.vec(h.body_parentid); f.vec(h.body_jntadr);
+    f.vec(h.body_jntnum); f.vec(h.body_dofadr); f.vec(h.body_dofnum);
+    f.vec(h.eq_active); f.vec(h.eq_data); f.vec(h.eq_solref); f.vec(h.eq_solimp);
+    f.vec(h.act_ctrllimited); f.vec(h.act_gear); f.vec(h.act_ctrlrange); f.vec(h.act_user);
+    f.vec(h.sensor_type); f.vec(h.sensor_objid); f.vec(h.sensor_adr); f.vec(h.sensor_dim); f.vec(h.sensor_cutoff); f.vec(h.sensor_noise); f.vec(h.sensor_user);
+    return f.value();
+}
+
+/* the same hash over a block of 32-bit samples (the height field, which callers also write through a raw pointer) */
+unsigned long long phys_hash_floats(const float *data, size_t n) {
+    Fingerprint f;
+    if (data && n) f.words(data, n * sizeof(float));
+    return f.value();
 }
 
 int phys_model_name2id(const phys_model_t *m, int objtype, const char *name) {

@@ -62,11 +62,7 @@ constexpr int NSTAMP = 48;   /* 0..15 stage boundaries, 16..47 sub-stage stamps 
 #define CK_TRI(k, i) ((k) * ((k) + 1) / 2 + (i))
 #define CK_STAMP(i) do { if (io.prof && lane == 0) io.prof[(size_t)env * NSTAMP + (i)] = wv::clock(); CK_FRESH(); } while (0)
 /* stage boundary: re-derive the lane index and its aliases (see wv::fresh_lane) */
-#ifdef CK_FRESH_MODEL
-#define CK_FRESH() do { lane = wv::fresh_lane(); b = lane; k_ = lane; isbody = b < nbody; isdof = k_ < nv; m = wv::opaque_ptr(m_launch); } while (0)
-#else
 #define CK_FRESH() do { lane = wv::fresh_lane(); b = lane; k_ = lane; isbody = b < nbody; isdof = k_ < nv; } while (0)
-#endif
 
 /* warning bits reported per env */
 enum { WARN_CONTACT_FULL = 1, WARN_CONSTRAINT_FULL = 2, WARN_UNSUPPORTED_PAIR = 4, WARN_DIVERGED = 8 };
@@ -759,11 +755,7 @@ WV_DEVICE void factor_pair_by_height(ModelPtr m, double h, SH &S, double (&col)[
     /* The trunk dofs (the floating base: each one's ancestors are all the lower ones) come last and one to a height: a
      * round through LDS for a single dof is all latency.  They are eliminated in registers instead (below), with
      * v_readlane multipliers whose round trips overlap, so the height rounds stop where the trunk begins. */
-#ifndef CK_TRUNK_BY_HEIGHT
     constexpr int first_trunk_height = TOPO::height[TOPO::trunk - 1];
-#else
-    constexpr int first_trunk_height = TOPO::nheight;
-#endif
 #pragma unroll
     for (int s = 0; s < TOPO::nheight; ++s) {
         if (s >= first_trunk_height) continue;
@@ -801,7 +793,6 @@ WV_DEVICE void factor_pair_by_height(ModelPtr m, double h, SH &S, double (&col)[
             wv::sched_fence();
         }
     }
-#ifndef CK_TRUNK_BY_HEIGHT
     /* trunk: same arithmetic (multiplier = entry * 1/D, rounded once; update = one FMA), multipliers by v_readlane */
 #pragma unroll
     for (int k = TOPO::trunk - 1; k >= 0; --k) {
@@ -817,7 +808,6 @@ WV_DEVICE void factor_pair_by_height(ModelPtr m, double h, SH &S, double (&col)[
 #pragma unroll
         for (int i = k - 1; i >= 0; --i) { col[i] -= t[i] * col[k]; colh[i] -= th[i] * colh[k]; }
     }
-#endif
     wv::sync();
     if (lane < TOPO::nv) S.rsd[lane] = sqrt(S.dinv[lane]);
 }
@@ -934,12 +924,7 @@ WV_DEVICE int joint_sensor_slot(int j) { return j < 3 ? j + 5 : j + 10; } /* 5 6
  * identical sensordata / actuator_velocity in, the measurement block, the filter histories, the delay lines and the
  * ctrl values are bit for bit those of the host chain (csrc/cassie_hostpath.c, itself pinned to the reference's own
  * compiled code by tests/test_hostpath.py). */
-/* CK_DRIVE_NOINLINE keeps the drive-level pass out of the step kernel's register allocation (an experiment knob) */
-#if defined(CK_DRIVE_NOINLINE) && !defined(CK_EMULATED)
-#define WV_DRIVE_FN __device__ __noinline__
-#else
 #define WV_DRIVE_FN WV_DEVICE
-#endif
 /* the env's drive-level state between HBM (cm_drive_state_t + the measurement block) and the launch's LDS copy */
 template <class SH>
 WV_DEVICE void drive_state_load(const PhysIO &io, SH &S, int env, int lane) {
@@ -1078,9 +1063,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
     /* centres of mass are computed for tree roots only, but rows of the static world (body 0: the floor's side of every
      * contact) are read too -- multiplied by an empty dof mask, which is harmless only if the value is finite.  LDS is
      * not initialised: give every row a value once per launch. */
-#ifndef CK_NO_COM_INIT /* (test knob: reinstates the round-2 bug so the poison checks can be seen to catch it) */
-    if (lane < NB) { S.com[lane][0] = 0.0; S.com[lane][1] = 0.0; S.com[lane][2] = 0.0; }
-#endif
+    if (lane < NB && !wv::test_skip_com_init()) { S.com[lane][0] = 0.0; S.com[lane][1] = 0.0; S.com[lane][2] = 0.0; }
     if (io.drive_mode) {
         /* what the last step (or forward) of an earlier launch measured: the inputs of this launch's first drive-level pass */
         if (lane < m->nsensordata) S.sens[lane] = io.sensordata[(size_t)env * io.ssd + lane];
@@ -1121,28 +1104,16 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
     for (int u = 0; u < nu; ++u) if (isdof && m->act_dofid[u] == k_) kact = u;
     wv::sync();
 
-#ifdef CK_SINGLE_STEP
-    for (int sub = 0; sub < 1; ++sub) {
-#else
     for (int sub = 0; sub < io.nsub; ++sub) {
-#endif
         /* Outputs that every substep recomputes (sensordata, qacc, actuator_velocity, xpos / xquat, the solver statistics)
          * are stored only by the LAST substep of a launch: the others' values would be overwritten anyway, and on this
          * hardware vector stores share the loads' completion counter (vmcnt), so a store that is still in flight holds up
          * the next stage's first model read. */
-#ifdef CK_STORE_EVERY_SUBSTEP
-        const bool lastsub = true;
-#else
         const bool lastsub = sub == io.nsub - 1 || !io.integrate;
-#endif
         /* Body quaternions feed only the IMU frame sensor, the site / body orientation read-outs and xquat_out -- all of
          * them values of the last substep (in a drive mode also of the one before it, see the sensors): the other
          * substeps carry rotation matrices only through the kinematic recursion. */
-#ifdef CK_QUAT_EVERY_SUBSTEP
-        const bool need_quat = true;
-#else
         const bool need_quat = lastsub || io.ext != nullptr || io.all_outputs_every_substep || (io.drive_mode && sub + 2 == io.nsub);
-#endif
         /* divergence guard (mj_checkPos/mj_checkVel role): sticky flag, state left alone */
         {
             bool badv = false;
@@ -1150,11 +1121,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
             if (lane < nv) { double v = S.qvel[lane]; badv |= !(v == v) || fabs(v) > 1e10; }
             if (wv::ballot(badv) != 0ull) { warn |= WARN_DIVERGED; break; }
         }
-#ifdef CK_NO_DRIVE
-        if (false) {
-#else
         if (io.drive_mode) {
-#endif
             if (io.integrate) drive_level_io(io, S, m, env, lane, lastsub); /* mj_forward leaves the drive-level state alone */
             wv::sync();
         } else if (io.pd_ptarget) {
@@ -1466,11 +1433,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
         CK_STAMP(3);
 
         /* ================= P3 factor M and M + hB in registers; park the factors in LDS ================= */
-#ifndef CK_FACTOR_IN_REGISTERS
         constexpr bool by_height = TOPO::is_static;
-#else
-        constexpr bool by_height = false;
-#endif
         if constexpr (by_height) {
             factor_pair_by_height<NVP, TOPO>(m, h, S, col, colh, lane);
         } else {
@@ -1853,7 +1816,6 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
                 S.qfrc_smooth[k_] = f;
             }
         }
-#ifndef CK_NO_XFRC
         if (io.xfrc_applied) {
             /* Cartesian perturbations: [force, torque] at the body's inertial origin, read straight from HBM (wave-uniform
              * addresses; the perturbation API is not a hot path and its 1.5 KB tile is better spent elsewhere) */
@@ -1874,7 +1836,6 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
                 S.qfrc_smooth[k_] += f;
             }
         }
-#endif
         wv::sync();
         CK_STAMP(7);
 
@@ -1888,12 +1849,10 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
             const int neq = m->neq;
             const bool eact = lane < neq && m->eq_active[lane < neq ? lane : 0] != 0;
             const unsigned long long eall = neq >= 64 ? ~0ull : (1ull << neq) - 1;
-#ifndef CK_ROWS_SERIAL
             if (wv::ballot(eact) == eall && 3 * neq <= CM_MAXEFC) {
                 if (r_ < 3 * neq) { rtype = CM_CNSTR_EQUALITY; rid = r_ / 3; rsub = r_ - 3 * rid; }
                 nefc = 3 * neq;
             } else
-#endif
             for (int e = 0; e < neq; ++e) {
                 if (!m->eq_active[e]) continue;
                 if (nefc + 3 > CM_MAXEFC) { warn |= WARN_CONSTRAINT_FULL; continue; }
@@ -1927,12 +1886,10 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
         const int nefc_before_contacts = nefc;
         /* every contact a friction pyramid of four rows and all of them within the cap (the usual case): closed form */
         const bool cpyr = lane < ncon && S.c_dim[lane < ncon ? lane : 0] == 3;
-#ifndef CK_ROWS_SERIAL
         if (wv::ballot(cpyr) == (ncon >= 64 ? ~0ull : (1ull << ncon) - 1) && nefc + 4 * ncon <= CM_MAXEFC) {
             if (r_ >= nefc && r_ < nefc + 4 * ncon) { rtype = CM_CNSTR_CONTACT_PYRAMIDAL; rid = (r_ - nefc) >> 2; rsub = (r_ - nefc) & 3; }
             nefc += 4 * ncon;
         } else
-#endif
         for (int c = 0; c < ncon; ++c) {
             const int dim = S.c_dim[c];
             if (dim != 1 && dim != 3) { warn |= WARN_UNSUPPORTED_PAIR; continue; }
@@ -2050,15 +2007,10 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
                 if (TOPO::is_static ? k < TOPO::nv : k < nv) {
                     if (rtype >= 0) {
                         const double ul = u3[0] * cc[kk][3] + u3[1] * cc[kk][4] + u3[2] * cc[kk][5];
-#ifndef CK_J_BRANCHY
                         /* the two body-chain predicates applied by multiplication (exact: the factors are 0.0 / 1.0) */
                         const double sp = bitf(maskp, k), sm = bitf(maskm, k);
                         v = sp * (ul + wp[0] * cc[kk][0] + wp[1] * cc[kk][1] + wp[2] * cc[kk][2]) -
                             sm * (ul + wm[0] * cc[kk][0] + wm[1] * cc[kk][1] + wm[2] * cc[kk][2]);
-#else
-                        if ((maskp >> k) & 1ull) v += ul + wp[0] * cc[kk][0] + wp[1] * cc[kk][1] + wp[2] * cc[kk][2];
-                        if ((maskm >> k) & 1ull) v -= ul + wm[0] * cc[kk][0] + wm[1] * cc[kk][1] + wm[2] * cc[kk][2];
-#endif
                         if (k == limdof) v = limsgn;
                         jvel += v * qv[kk];
                         jws += v * qw[kk];
@@ -2078,12 +2030,8 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
          * encoder models (the joint / actuator positions) and the measurement block the LAST substep's drive pass writes
          * (the IMU words of the substep before it).  The IMU sensors -- frame quaternion, gyro, magnetometer and the
          * accelerometer with its second part after the solve -- are therefore evaluated by the last two substeps only. */
-#ifdef CK_IMU_EVERY_SUBSTEP
-        const bool need_imu = true, need_pos = true;
-#else
         const bool need_imu = lastsub || io.all_outputs_every_substep || (io.drive_mode && sub + 2 == io.nsub);
         const bool need_pos = lastsub || io.drive_mode || io.all_outputs_every_substep;
-#endif
         const bool issens = lane < m->nsensor && need_pos;
         const int ls = issens ? lane : 0; /* every constant of the lane's sensor in one level of (unconditional) reads */
         const int stype = issens ? m->sensor_type[ls] : -1;
@@ -2348,14 +2296,12 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
                         if (est < 0.5f * tol) converged = true;
                         else if (est > 2.0f * tol) converged = false;
                         else {
-#ifndef CK_PGS_ORDERED_SUM_IN_BAND
                             /* inside the band a double-precision tree sum decides: the rows' changes are cost decreases (at
                              * most +1e-10 each, or the guard had fired), so it differs from the ordered sum by rounding only,
                              * and the ordered sum is formed just when the tree sum lands within 1e-9 of the tolerance */
                             const double tree = -wv::wave_sum(change) * scale, tolv = tolerance;
                             if (fabs(tree - tolv) > 1e-9 * tolv) converged = tree < tolv;
                             else
-#endif
                             {
                                 double improvement = 0;
                                 for (int t = 0; t < nrows; ++t) improvement -= wv::readlane(change, t);
@@ -2567,16 +2513,7 @@ WV_GLOBAL void __launch_bounds__(WV_WAVE) WV_OCC cassie_step_kernel(PhysIO io) {
     WV_SHARED EnvShared<NVP, LPack<TOPO, NVP>::count> S;
     const int slot = wv::env_id();
     if (slot >= io.nenv) return;
-#ifdef CK_EMULATED
-    /* test hook: LDS is not initialised on the device; fill it with NaN patterns so that a read-before-write shows */
-    if (wv::g_poison_lds) {
-        if (wv::lane() == 0) {
-            const size_t lo = wv::g_poison_lo < sizeof S ? wv::g_poison_lo : sizeof S, hi = wv::g_poison_hi < sizeof S ? wv::g_poison_hi : sizeof S;
-            if (hi > lo) memset((char *)&S + lo, 0xff, hi - lo);
-        }
-        wv::sync();
-    }
-#endif
+    wv::test_launch_hook(&S, sizeof S); /* CPU emulator only (poisons LDS so that a read-before-write shows); empty on the device */
     const int env = io.order ? io.order[slot] : slot;
     const long long t0 = io.cost ? wv::clock() : 0;
     env_step<NVP, TOPO, FEAT>(io, S, env);

@@ -126,8 +126,12 @@ template <class P> WV_DEVICE P opaque_ptr(P p) {
  * scheduler's appetite for early loads cannot push the register allocator into scratch. */
 WV_DEVICE void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 
-/* test hook of the CPU emulator (always false on the device): take the guarded PGS sweep every time */
+/* test hooks of the CPU emulator (tests/emu/wave.h gives them bodies); on the device they are constants the compiler folds
+ * away: take the guarded PGS sweep every time / skip the once-per-launch initialisation of the centre-of-mass rows (the
+ * bug the LDS-poison checks were written for) / fill the env's LDS block with NaN patterns at the start of a launch */
 WV_DEVICE constexpr bool debug_force_guarded() { return false; }
+WV_DEVICE constexpr bool test_skip_com_init() { return false; }
+template <class S> WV_DEVICE void test_launch_hook(S *, unsigned long) {}
 
 WV_DEVICE long long clock() { return (long long)__builtin_readcyclecounter(); }
 

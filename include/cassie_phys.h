@@ -36,6 +36,10 @@ int phys_model_save(const phys_model_t *m, const char *path);
 void phys_model_set_const(phys_model_t *m);
 /* derive the pointer-free kernel model; returns 0 on success */
 int phys_model_compile(const phys_model_t *m, cm_model_t *out, char *err, int errlen);
+/* a 64-bit fingerprint of every model array / option a caller can change through the views below: compared before a step
+ * instead of recompiling (the reference hands out raw mjModel pointers, so writes cannot be observed otherwise) */
+unsigned long long phys_model_fingerprint(const phys_model_t *m);
+unsigned long long phys_hash_floats(const float *data, size_t n);
 /* mj_name2id / mj_id2name (reference :861-866, :1244, ...); objtype uses mjtObj numbering */
 int phys_model_name2id(const phys_model_t *m, int objtype, const char *name);
 const char *phys_model_id2name(const phys_model_t *m, int objtype, int id);
@@ -119,6 +123,11 @@ int phys_batch_uses_applied(const phys_batch_t *b);
 int phys_batch_step(phys_batch_t *b, int nsub, void *stream);
 /* mj_forward (reference :971, :1029, :1223, :3293): no integration */
 int phys_batch_forward(phys_batch_t *b, void *stream);
+/* the read-out half of mj_forward -- what the reference's getters obtain from mj_kinematics / mj_comPos / mj_comVel /
+ * mj_fwdPosition (reference src/cassiemujoco.c:1223-1301, :1604-1770): xpos / xquat / the ext read-out / body_cfrc of the
+ * current state, while the fields qacc, sensordata and actuator_velocity keep what the last STEP left (the encoder and
+ * motor models of the next step read those) */
+int phys_batch_forward_kinematics(phys_batch_t *b, void *stream);
 int phys_batch_sync(phys_batch_t *b);
 /* on != 0: every substep computes ctrl on the device from PHYS_F_PD_{PTARGET,KP,KD} -- the motor PD law of
  * pd_input_step (reference include/pd_input.h:34) followed by the speed-torque limit of motor()

@@ -112,6 +112,7 @@ unsigned long long ballot(bool p) {
 }
 int g_force_guarded = 0;
 int g_poison_lds = 0;
+int g_skip_com_init = 0;
 unsigned long g_poison_lo = 0, g_poison_hi = ~0ul;
 double wave_sum(double v) { /* same association order as the device's DPP reduction (csrc/wave.h) */
     const int l = lane(), row = l >> 4;
@@ -138,6 +139,7 @@ float wave_sum_f32(float v) { /* same tree in single precision */
 static ck::PhysIO g_io;
 extern "C" void emu_force_guarded_pgs(int on) { wv::g_force_guarded = on; }
 extern "C" void emu_poison_lds(int on) { wv::g_poison_lds = on; }
+extern "C" void emu_skip_com_init(int on) { wv::g_skip_com_init = on; }
 extern "C" void emu_poison_range(unsigned long lo, unsigned long hi) { wv::g_poison_lo = lo; wv::g_poison_hi = hi; }
 extern "C" unsigned long emu_offsetof32(int which) {
     typedef ck::EnvShared<32> E;

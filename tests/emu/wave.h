@@ -43,7 +43,19 @@ inline void sched_fence() {}
 extern int g_force_guarded;
 extern int g_poison_lds;
 extern unsigned long g_poison_lo, g_poison_hi;
+extern int g_skip_com_init;
 inline bool debug_force_guarded() { return g_force_guarded != 0; }
+inline bool test_skip_com_init() { return g_skip_com_init != 0; }
+/* LDS is not initialised on the device: fill the env's block with NaN patterns so that a read-before-write shows */
+inline void test_launch_hook(void *shared, unsigned long size) {
+    if (g_poison_lds) {
+        if (lane() == 0) {
+            const unsigned long lo = g_poison_lo < size ? g_poison_lo : size, hi = g_poison_hi < size ? g_poison_hi : size;
+            if (hi > lo) memset((char *)shared + lo, 0xff, hi - lo);
+        }
+        sync();
+    }
+}
 inline int fresh_lane() { return lane(); }
 template <class P> inline P opaque_ptr(P p) { return p; }
 inline double rcp_estimate(double x) { return (double)(1.0f / (float)x); } /* deliberately low precision, like the hardware estimate */

@@ -233,6 +233,24 @@ def test_kernel_never_reads_lds_it_has_not_written(cassie):
     assert not out[1][3].any() and out[1][4][:, 0].max() >= 1          # no divergence flag, contacts happened
     for a, b in zip(out[0], out[1]):
         assert np.array_equal(a, b)
+    # the check is not vacuous: with the round-2 bug reinstated (the emulator's test hook skips the once-per-launch
+    # initialisation of the centre-of-mass rows) the poisoned run differs from the clean one or raises the divergence flag
+    def fifty(poison, skip):
+        emu_py.lib().emu_skip_com_init(skip)
+        emu_py.lib().emu_poison_lds(poison)
+        try:
+            emu = EmuBatch(pod, 2)
+            emu.qpos[:] = cassie.qpos_init()
+            emu.qpos[1, 2] -= 0.02
+            emu.pd_kp, emu.pd_kd = np.tile(bench.PD_KP, (2, 1)), np.tile(bench.PD_KD, (2, 1))
+            emu.pd_ptarget = np.ascontiguousarray(bench.pd_targets([3, 4], 1)[0])
+            emu.step(50)
+            return emu.qpos.copy(), emu.warn.copy()
+        finally:
+            emu_py.lib().emu_poison_lds(0)
+            emu_py.lib().emu_skip_com_init(0)
+    clean, buggy = fifty(0, 0), fifty(1, 1)
+    assert buggy[1].any() or not np.array_equal(clean[0], buggy[0])
 
 
 @pytest.mark.parametrize("name,steps,drive", [("cassie_tray_box", 260, False), ("cassie_hfield", 120, False), ("cassie", 90, True)])
