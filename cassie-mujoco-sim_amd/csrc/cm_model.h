@@ -36,7 +36,8 @@ extern "C" {
 #define CM_MAXSITE   16
 #define CM_MAXSENSOR 24
 #define CM_MAXSENSORDATA 40
-#define CM_MAXHFPAIR 10      /* height-field pairs whose samples fit one wave pass (more: tested in the pair loop itself) */
+#define CM_MAXHFPAIR 18      /* height-field pairs of a model (their results travel through an LDS table of this many records) */
+#define CM_HF_PASS   10      /* height-field pairs whose samples fit one wave pass: CM_HF_PASS * CM_HF_SLOTS <= 64 lanes */
 #define CM_HF_SLOTS  6       /* sample spheres per height-field pair: two ends + at most four interior ones */
 #define CM_MAXCON    16      /* contacts kept per env-step */
 #define CM_MAXEFC    63      /* constraint rows per env-step (lane 63 is the qfrc_smooth column) */

@@ -1224,8 +1224,9 @@ bool HostModel::compile(cm_model_t *o, std::string *err) const {
         o->pair_type[i] = o->geom_type[g1] | (o->geom_type[g2] << 8);
         if (o->geom_type[g1] == CM_GEOM_HFIELD && i < o->npair_simple &&
             (o->geom_type[g2] == CM_GEOM_SPHERE || o->geom_type[g2] == CM_GEOM_CAPSULE)) {
-            if (o->nhfpair < CM_MAXHFPAIR) { o->pair_hfslot[i] = o->nhfpair; o->hfpair[o->nhfpair] = i; }
-            o->nhfpair++;                 /* beyond CM_MAXHFPAIR the kernel tests every height-field pair in the pair loop */
+            if (o->nhfpair >= CM_MAXHFPAIR) return fail("too many height-field collision pairs (CM_MAXHFPAIR)");
+            o->pair_hfslot[i] = o->nhfpair; o->hfpair[o->nhfpair] = i;
+            o->nhfpair++;
         }
         o->pair_margin[i] = std::max(o->geom_margin[g1], o->geom_margin[g2]);
         o->pair_includemargin[i] = o->pair_margin[i] - std::max(o->geom_gap[g1], o->geom_gap[g2]);

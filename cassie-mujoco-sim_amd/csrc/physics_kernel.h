@@ -353,31 +353,42 @@ WV_DEVICE int capsule_box(RawContact &c0, RawContact &c1, const double *pc, cons
  * candidate vertex of the clipped polygon: 0-3 incident vertices, 4-7 rectangle corners, 8-23 edge crossings; at most
  * the 4 deepest are kept, in candidate order -- or one edge-edge contact (lane 0).  Everything up to the candidates is
  * wave-uniform and computed redundantly by every lane.  Returns whether this lane holds a contact. ---- */
+/* run-time picks out of three / four register values by compare-and-select: an array indexed by a run-time value would be
+ * placed in scratch memory (box_box_lane used to keep ~200 bytes of such arrays there: 13 scratch stores and 15 loads per
+ * box pair, 1.9 GB of HBM writes per 4096-env launch of the tray model) */
+WV_DEVICE double sel3(int i, double a0, double a1, double a2) { return i == 0 ? a0 : (i == 1 ? a1 : a2); }
+WV_DEVICE double sel4(int i, double a0, double a1, double a2, double a3) { return i == 0 ? a0 : (i == 1 ? a1 : (i == 2 ? a2 : a3)); }
+WV_DEVICE void row3(double (&r)[3], const double (&M)[3][3], int i) {
+    for (int x = 0; x < 3; ++x) r[x] = sel3(i, M[0][x], M[1][x], M[2][x]);
+}
+
 WV_DEVICE bool box_box_lane(RawContact &rc, int lane, const double *p1, const double *m1, const double *s1, const double *p2, const double *m2,
                             const double *s2, double margin) {
     const double BB_TIE = 1e-10;
     double A[3][3], B[3][3], d[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]}, ta[3], tb[3], C[3][3], Q[3][3];
+    const double sa[3] = {s1[0], s1[1], s1[2]}, sb[3] = {s2[0], s2[1], s2[2]};
     for (int i = 0; i < 3; ++i) for (int k = 0; k < 3; ++k) { A[i][k] = m1[3 * k + i]; B[i][k] = m2[3 * k + i]; }
     for (int i = 0; i < 3; ++i) { ta[i] = dot3(d, A[i]); tb[i] = dot3(d, B[i]); }
     for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { C[i][j] = dot3(A[i], B[j]); Q[i][j] = fabs(C[i][j]); }
     int best = -1;
     double bestscore = 0;
     bool separated = false;
-    for (int k = 0; k < 15; ++k) {
+#pragma unroll
+    for (int k = 0; k < 15; ++k) { /* fully unrolled: every index below is a compile-time constant */
         double sep, sc;
         if (k < 3) {
-            sep = fabs(ta[k]) - (s1[k] + (s2[0] * Q[k][0] + s2[1] * Q[k][1] + s2[2] * Q[k][2]));
+            sep = fabs(ta[k]) - (sa[k] + (sb[0] * Q[k][0] + sb[1] * Q[k][1] + sb[2] * Q[k][2]));
             sc = sep;
         } else if (k < 6) {
             const int j = k - 3;
-            sep = fabs(tb[j]) - (s2[j] + (s1[0] * Q[0][j] + s1[1] * Q[1][j] + s1[2] * Q[2][j]));
+            sep = fabs(tb[j]) - (sb[j] + (sa[0] * Q[0][j] + sa[1] * Q[1][j] + sa[2] * Q[2][j]));
             sc = sep - BB_TIE;
         } else {
             const int i = (k - 6) / 3, j = (k - 6) % 3, i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
             const double len2 = 1.0 - C[i][j] * C[i][j];
             if (len2 < 1e-6) continue;
             const double proj = ta[i2] * C[i1][j] - ta[i1] * C[i2][j];
-            const double ra = s1[i1] * Q[i2][j] + s1[i2] * Q[i1][j], rb = s2[j1] * Q[i][j2] + s2[j2] * Q[i][j1];
+            const double ra = sa[i1] * Q[i2][j] + sa[i2] * Q[i1][j], rb = sb[j1] * Q[i][j2] + sb[j2] * Q[i][j1];
             sep = (fabs(proj) - (ra + rb)) / sqrt(len2);
             sc = (sep < 0 ? 1.05 * sep : sep) - 2 * BB_TIE;
         }
@@ -388,19 +399,25 @@ WV_DEVICE bool box_box_lane(RawContact &rc, int lane, const double *p1, const do
 
     if (best >= 6) {
         const int i = (best - 6) / 3, j = (best - 6) % 3;
+        double Ai[3], Bj[3];
+        row3(Ai, A, i); row3(Bj, B, j);
         double n[3], pa[3] = {p1[0], p1[1], p1[2]}, pb[3] = {p2[0], p2[1], p2[2]};
-        cross3(n, A[i], B[j]);
+        cross3(n, Ai, Bj);
         normalize3(n);
         if (dot3(n, d) < 0) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; }
+#pragma unroll
         for (int k = 0; k < 3; ++k) {
-            if (k != i) { const double sg = dot3(n, A[k]) > 0 ? 1.0 : -1.0; for (int x = 0; x < 3; ++x) pa[x] += sg * s1[k] * A[k][x]; }
-            if (k != j) { const double sg = dot3(n, B[k]) > 0 ? -1.0 : 1.0; for (int x = 0; x < 3; ++x) pb[x] += sg * s2[k] * B[k][x]; }
+            if (k != i) { const double sg = dot3(n, A[k]) > 0 ? 1.0 : -1.0; for (int x = 0; x < 3; ++x) pa[x] += sg * sa[k] * A[k][x]; }
+            if (k != j) { const double sg = dot3(n, B[k]) > 0 ? -1.0 : 1.0; for (int x = 0; x < 3; ++x) pb[x] += sg * sb[k] * B[k][x]; }
         }
         const double ab[3] = {pb[0] - pa[0], pb[1] - pa[1], pb[2] - pa[2]};
-        const double uaub = C[i][j], q1 = dot3(A[i], ab), q2 = -dot3(B[j], ab), den = 1.0 - uaub * uaub;
-        const double al = clampd((q1 + uaub * q2) / den, -s1[i], s1[i]), be = clampd((uaub * q1 + q2) / den, -s2[j], s2[j]);
+        double Ci[3];
+        row3(Ci, C, i);
+        const double uaub = sel3(j, Ci[0], Ci[1], Ci[2]), q1 = dot3(Ai, ab), q2 = -dot3(Bj, ab), den = 1.0 - uaub * uaub;
+        const double s1i = sel3(i, sa[0], sa[1], sa[2]), s2j = sel3(j, sb[0], sb[1], sb[2]);
+        const double al = clampd((q1 + uaub * q2) / den, -s1i, s1i), be = clampd((uaub * q1 + q2) / den, -s2j, s2j);
         double ca[3], cb[3];
-        for (int x = 0; x < 3; ++x) { ca[x] = pa[x] + al * A[i][x]; cb[x] = pb[x] + be * B[j][x]; }
+        for (int x = 0; x < 3; ++x) { ca[x] = pa[x] + al * Ai[x]; cb[x] = pb[x] + be * Bj[x]; }
         const double cd[3] = {cb[0] - ca[0], cb[1] - ca[1], cb[2] - ca[2]};
         rc.dist = dot3(cd, n);
         for (int x = 0; x < 3; ++x) { rc.normal[x] = n[x]; rc.tangent[x] = 0; rc.pos[x] = 0.5 * (ca[x] + cb[x]); }
@@ -411,24 +428,34 @@ WV_DEVICE bool box_box_lane(RawContact &rc, int lane, const double *p1, const do
     const int a = best % 3, a1 = (a + 1) % 3, a2 = (a + 2) % 3;
     double R[3][3], I[3][3];
     for (int i = 0; i < 3; ++i) for (int k = 0; k < 3; ++k) { R[i][k] = refA ? A[i][k] : B[i][k]; I[i][k] = refA ? B[i][k] : A[i][k]; }
-    const double *pr = refA ? p1 : p2, *pi = refA ? p2 : p1, *sr = refA ? s1 : s2, *si = refA ? s2 : s1;
+    double pr[3], pi[3], sr[3], si[3];
+    for (int x = 0; x < 3; ++x) { pr[x] = refA ? p1[x] : p2[x]; pi[x] = refA ? p2[x] : p1[x]; sr[x] = refA ? sa[x] : sb[x]; si[x] = refA ? sb[x] : sa[x]; }
+    /* the reference face's normal axis and its two in-plane axes, picked once (Ra, Ra1, Ra2) */
+    double Ra[3], Ra1[3], Ra2[3];
+    row3(Ra, R, a); row3(Ra1, R, a1); row3(Ra2, R, a2);
+    const double sra = sel3(a, sr[0], sr[1], sr[2]);
     const double dri[3] = {pi[0] - pr[0], pi[1] - pr[1], pi[2] - pr[2]};
-    const double sgn = dot3(dri, R[a]) >= 0 ? 1.0 : -1.0;
-    double n[3] = {sgn * R[a][0], sgn * R[a][1], sgn * R[a][2]};
+    const double sgn = dot3(dri, Ra) >= 0 ? 1.0 : -1.0;
+    double n[3] = {sgn * Ra[0], sgn * Ra[1], sgn * Ra[2]};
     int kf = 0;
     double kbest = fabs(dot3(n, I[0]));
+#pragma unroll
     for (int k = 1; k < 3; ++k) { const double v = fabs(dot3(n, I[k])); if (v > kbest + 1e-9) { kbest = v; kf = k; } }
     const int k1 = (kf + 1) % 3, k2 = (kf + 2) % 3;
-    const double isg = dot3(n, I[kf]) > 0 ? -1.0 : 1.0;
+    double If[3], I1[3], I2[3];
+    row3(If, I, kf); row3(I1, I, k1); row3(I2, I, k2);
+    const double sif = sel3(kf, si[0], si[1], si[2]), si1 = sel3(k1, si[0], si[1], si[2]), si2 = sel3(k2, si[0], si[1], si[2]);
+    const double isg = dot3(n, If) > 0 ? -1.0 : 1.0;
     double cr[3], ci[3];
-    for (int x = 0; x < 3; ++x) { cr[x] = pr[x] + sgn * sr[a] * R[a][x]; ci[x] = pi[x] + isg * si[kf] * I[kf][x]; }
-    const double h1 = sr[a1], h2 = sr[a2];
+    for (int x = 0; x < 3; ++x) { cr[x] = pr[x] + sgn * sra * Ra[x]; ci[x] = pi[x] + isg * sif * If[x]; }
+    const double h1 = sel3(a1, sr[0], sr[1], sr[2]), h2 = sel3(a2, sr[0], sr[1], sr[2]);
     const double su[4] = {1, -1, -1, 1}, sv[4] = {1, 1, -1, -1};
     double pu[4], pv[4], pw[4];
+#pragma unroll
     for (int q = 0; q < 4; ++q) {
         double x[3];
-        for (int t = 0; t < 3; ++t) x[t] = ci[t] + su[q] * si[k1] * I[k1][t] + sv[q] * si[k2] * I[k2][t] - cr[t];
-        pu[q] = dot3(x, R[a1]); pv[q] = dot3(x, R[a2]); pw[q] = dot3(x, n);
+        for (int t = 0; t < 3; ++t) x[t] = ci[t] + su[q] * si1 * I1[t] + sv[q] * si2 * I2[t] - cr[t];
+        pu[q] = dot3(x, Ra1); pv[q] = dot3(x, Ra2); pw[q] = dot3(x, n);
     }
     const double tol = 1e-12;
     /* lane = candidate */
@@ -436,15 +463,16 @@ WV_DEVICE bool box_box_lane(RawContact &rc, int lane, const double *p1, const do
     bool valid = false;
     if (lane < 4) {
         const int q = lane;
-        cu = pu[q]; cv = pv[q]; cw = pw[q];
+        cu = sel4(q, pu[0], pu[1], pu[2], pu[3]); cv = sel4(q, pv[0], pv[1], pv[2], pv[3]); cw = sel4(q, pw[0], pw[1], pw[2], pw[3]);
         valid = fabs(cu) <= h1 + tol && fabs(cv) <= h2 + tol;
     } else if (lane < 8) {
         const int q = lane - 4;
         const double e1u = pu[1] - pu[0], e1v = pv[1] - pv[0], e1w = pw[1] - pw[0], e2u = pu[3] - pu[0], e2v = pv[3] - pv[0], e2w = pw[3] - pw[0];
         const double det = e1u * e2v - e1v * e2u;
         const double gu = (e1w * e2v - e1v * e2w) / det, gv = (e1u * e2w - e1w * e2u) / det;
-        const double u = su[q] * h1, v = sv[q] * h2;
+        const double u = sel4(q, 1.0, -1.0, -1.0, 1.0) * h1, v = sel4(q, 1.0, 1.0, -1.0, -1.0) * h2;
         int pos = 0, neg = 0;
+#pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int f = (e + 1) & 3;
             const double cr2 = (pu[f] - pu[e]) * (v - pv[e]) - (pv[f] - pv[e]) * (u - pu[e]);
@@ -455,16 +483,19 @@ WV_DEVICE bool box_box_lane(RawContact &rc, int lane, const double *p1, const do
     } else if (lane < 24) {
         const int e = (lane - 8) >> 2, l = (lane - 8) & 3, f = (e + 1) & 3;
         const bool along_u = l < 2;
+        const double pue = sel4(e, pu[0], pu[1], pu[2], pu[3]), puf = sel4(f, pu[0], pu[1], pu[2], pu[3]);
+        const double pve = sel4(e, pv[0], pv[1], pv[2], pv[3]), pvf = sel4(f, pv[0], pv[1], pv[2], pv[3]);
+        const double pwe = sel4(e, pw[0], pw[1], pw[2], pw[3]), pwf = sel4(f, pw[0], pw[1], pw[2], pw[3]);
         const double lim = (l & 1) ? -(along_u ? h1 : h2) : (along_u ? h1 : h2);
-        const double x0 = along_u ? pu[e] : pv[e], x1 = along_u ? pu[f] : pv[f];
-        const double y0 = along_u ? pv[e] : pu[e], y1 = along_u ? pv[f] : pu[f], hy = along_u ? h2 : h1;
+        const double x0 = along_u ? pue : pve, x1 = along_u ? puf : pvf;
+        const double y0 = along_u ? pve : pue, y1 = along_u ? pvf : puf, hy = along_u ? h2 : h1;
         const double dx = x1 - x0;
         if (!(fabs(dx) < 1e-14)) {
             const double sp = (lim - x0) / dx;
             if (sp > 0 && sp < 1) {
                 const double y = y0 + sp * (y1 - y0);
                 if (!(fabs(y) > hy)) {
-                    cu = along_u ? lim : y; cv = along_u ? y : lim; cw = pw[e] + sp * (pw[f] - pw[e]);
+                    cu = along_u ? lim : y; cv = along_u ? y : lim; cw = pwe + sp * (pwf - pwe);
                     valid = true;
                 }
             }
@@ -485,7 +516,7 @@ WV_DEVICE bool box_box_lane(RawContact &rc, int lane, const double *p1, const do
     if (keep) {
         rc.dist = cw;
         for (int x = 0; x < 3; ++x) {
-            const double px = cr[x] + cu * R[a1][x] + cv * R[a2][x] + cw * n[x];
+            const double px = cr[x] + cu * Ra1[x] + cv * Ra2[x] + cw * n[x];
             rc.pos[x] = px - 0.5 * cw * n[x];
             rc.normal[x] = refA ? n[x] : -n[x];
             rc.tangent[x] = 0;
@@ -1471,90 +1502,97 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
         }
         CK_STAMP(21);
         /* Height-field pairs ahead of the pair loop: their sample spheres -- the sphere itself, or a capsule's two ends and
-         * up to four interior samples -- go one to a lane (CM_HF_SLOTS lanes per pair), so the walks over the grid cells
-         * under the samples run side by side instead of one after the other in the pair's lane; the lanes of a pair then
-         * apply the capsule rule (oracle hfield_capsule) to the samples' results, and the pair loop below picks the
-         * result up from the pair's first lane. */
-        const bool hf_spread = (FEAT & FEAT_HFIELD) != 0 && env_hfield != nullptr && m->nhfpair > 0 && m->nhfpair <= CM_MAXHFPAIR;
-        int hf_n = 0;
-        RawContact hf0, hf1;
-        if constexpr ((FEAT & FEAT_HFIELD) != 0) if (hf_spread) {
-            const int h = lane / CM_HF_SLOTS, k = lane % CM_HF_SLOTS;
-            const bool act = h < m->nhfpair;
-            const int p = m->hfpair[act ? h : 0];
-            const int g1 = m->pair_geom1[p], g2 = m->pair_geom2[p], t2 = m->pair_type[p] >> 8;
-            const double margin = m->pair_margin[p], s20 = m->pair_size[p][3], s21 = m->pair_size[p][4];
-            const double *p1 = S.x.s.geom_xpos[g1], *m1 = S.x.s.geom_xmat[g1], *p2 = S.x.s.geom_xpos[g2], *m2 = S.x.s.geom_xmat[g2];
-            const double axis[3] = {m2[2], m2[5], m2[8]};
-            const double cell = 2 * m->hfield_size[0] / (m->hfield_ncol > 1 ? m->hfield_ncol - 1 : 1);
-            int ni = 0;
-            bool mine = act && k == 0;
-            double t = 0;
-            if (t2 == CM_GEOM_CAPSULE) {
-                ni = (int)ceil(2 * s21 / cell) - 1;
-                if (ni < 0) ni = 0;
-                if (ni > 4) ni = 4;
-                mine = act && k < 2 + ni;
-                t = k == 0 ? s21 : (k == 1 ? -s21 : s21 * (1.0 - 2.0 * (k - 1) / (ni + 1)));
-            }
-            RawContact rcs;
-            rcs.dist = 1e300;
-            bool has = false;
-            if (mine) {
-                /* block cull as in the pair loop */
-                const double dif[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
-                (void)dif;
-                double e[3] = {p2[0] + t * axis[0], p2[1] + t * axis[1], p2[2] + t * axis[2]};
-                has = hfield_sphere(rcs, m, env_hfield, p1, m1, e, s20, margin) != 0;
-            }
-            /* the samples of this lane's pair: distances (1e300 = no contact) */
-            const int lead = lane - k;
-            double dk[CM_HF_SLOTS];
-            const double mydist = has ? rcs.dist : 1e300;
-#pragma unroll
-            for (int q = 0; q < CM_HF_SLOTS; ++q) dk[q] = wv::shfl(mydist, (lead + q) & 63);
-            int src0 = 0, src1 = 1;
-            bool have0 = dk[0] < 1e299, have1 = dk[1] < 1e299;
-            if (t2 == CM_GEOM_CAPSULE) {
-                int kmid = -1;
-                for (int q = 2; q < CM_HF_SLOTS; ++q) if (dk[q] < 1e299 && (kmid < 0 || dk[q] < dk[kmid])) kmid = q;
-                if (kmid >= 0 && (!have0 || dk[kmid] < dk[0]) && (!have1 || dk[kmid] < dk[1])) {
-                    const bool drop1 = !have0 ? false : (!have1 ? true : dk[0] <= dk[1]);
-                    if (drop1) { src1 = kmid; have1 = true; } else { src0 = kmid; have0 = true; }
+         * up to four interior samples -- go one to a lane (CM_HF_SLOTS lanes per pair, CM_HF_PASS pairs per pass), so the
+         * walks over the grid cells under the samples run side by side instead of one after the other in the pair's lane;
+         * the lanes of a pair then apply the capsule rule (oracle hfield_capsule) to the samples' results and the pair's
+         * first lane parks the outcome -- contact count and up to two contacts -- in an LDS table laid over the velocity
+         * tiles (unused until the velocity stage), where the pair loop below picks it up.  (Round 2 carried the outcome in
+         * registers and fetched it with 40 cross-lane moves per pair-loop pass, and kept a second copy of the terrain walk
+         * inside the pair loop for models with more pairs than one pass holds: both were what this instantiation spilled.) */
+        constexpr int HF_REC = 21; /* doubles per pair: count, then 2 x (dist, pos[3], normal[3], tangent[3]) */
+        static_assert(CM_MAXHFPAIR * HF_REC <= NB * 12, "the height-field result table must fit the cvel + cfrc tiles");
+        double *const hfres = &S.x.s.cvel[0][0];
+        const bool hf_on = (FEAT & FEAT_HFIELD) != 0 && env_hfield != nullptr && m->nhfpair > 0;
+        if constexpr ((FEAT & FEAT_HFIELD) != 0) if (hf_on) {
+            for (int h0 = 0; h0 < m->nhfpair; h0 += CM_HF_PASS) {
+                const int h = h0 + lane / CM_HF_SLOTS, k = lane % CM_HF_SLOTS;
+                const bool act = lane < CM_HF_PASS * CM_HF_SLOTS && h < m->nhfpair;
+                const int p = m->hfpair[act ? h : 0];
+                const int g1 = m->pair_geom1[p], g2 = m->pair_geom2[p], t2 = m->pair_type[p] >> 8;
+                const double margin = m->pair_margin[p], s20 = m->pair_size[p][3], s21 = m->pair_size[p][4];
+                const double *p1 = S.x.s.geom_xpos[g1], *m1 = S.x.s.geom_xmat[g1], *p2 = S.x.s.geom_xpos[g2], *m2 = S.x.s.geom_xmat[g2];
+                const double axis[3] = {m2[2], m2[5], m2[8]};
+                const double cell = 2 * m->hfield_size[0] / (m->hfield_ncol > 1 ? m->hfield_ncol - 1 : 1);
+                int ni = 0;
+                bool mine = act && k == 0;
+                double t = 0;
+                if (t2 == CM_GEOM_CAPSULE) {
+                    ni = (int)ceil(2 * s21 / cell) - 1;
+                    if (ni < 0) ni = 0;
+                    if (ni > 4) ni = 4;
+                    mine = act && k < 2 + ni;
+                    t = k == 0 ? s21 : (k == 1 ? -s21 : s21 * (1.0 - 2.0 * (k - 1) / (ni + 1)));
                 }
-            } else {
-                have1 = false;
+                RawContact rcs;
+                rcs.dist = 1e300;
+                bool has = false;
+                if (mine) {
+                    double e[3] = {p2[0] + t * axis[0], p2[1] + t * axis[1], p2[2] + t * axis[2]};
+                    has = hfield_sphere(rcs, m, env_hfield, p1, m1, e, s20, margin) != 0;
+                }
+                /* the samples of this lane's pair: distances (1e300 = no contact) */
+                const int lead = lane - k;
+                double dk[CM_HF_SLOTS];
+                const double mydist = has ? rcs.dist : 1e300;
+#pragma unroll
+                for (int q = 0; q < CM_HF_SLOTS; ++q) dk[q] = wv::shfl(mydist, (lead + q) & 63);
+                int src0 = 0, src1 = 1;
+                bool have0 = dk[0] < 1e299, have1 = dk[1] < 1e299;
+                if (t2 == CM_GEOM_CAPSULE) {
+                    int kmid = -1;
+                    double dmid = 1e300;
+#pragma unroll
+                    for (int q = 2; q < CM_HF_SLOTS; ++q) if (dk[q] < 1e299 && (kmid < 0 || dk[q] < dmid)) { kmid = q; dmid = dk[q]; }
+                    if (kmid >= 0 && (!have0 || dmid < dk[0]) && (!have1 || dmid < dk[1])) {
+                        const bool drop1 = !have0 ? false : (!have1 ? true : dk[0] <= dk[1]);
+                        if (drop1) { src1 = kmid; have1 = true; } else { src0 = kmid; have0 = true; }
+                    }
+                } else {
+                    have1 = false;
+                }
+                /* the lanes holding the chosen samples write them: first kept contact to record slot 0, second to slot 1 */
+                const int nkeep = (have0 ? 1 : 0) + (have1 ? 1 : 0);
+                double *rec = hfres + (size_t)(act ? h : 0) * HF_REC;
+                if (act && k == 0) rec[0] = (double)nkeep;
+                const int slot_of_me = (have0 && k == src0) ? 0 : ((have1 && k == src1) ? (have0 ? 1 : 0) : -1);
+                if (act && slot_of_me >= 0) {
+                    double *c = rec + 1 + 10 * slot_of_me;
+                    c[0] = rcs.dist;
+                    for (int i = 0; i < 3; ++i) { c[1 + i] = rcs.pos[i]; c[4 + i] = rcs.normal[i]; c[7 + i] = t2 == CM_GEOM_CAPSULE ? axis[i] : 0.0; }
+                }
             }
-            /* fetch the chosen samples' contacts (every lane of the pair ends up with the pair's result) */
-            const int la = (lead + src0) & 63, lb = (lead + src1) & 63;
-            hf0.dist = wv::shfl(rcs.dist, la); hf1.dist = wv::shfl(rcs.dist, lb);
-            for (int i = 0; i < 3; ++i) {
-                hf0.pos[i] = wv::shfl(rcs.pos[i], la); hf0.normal[i] = wv::shfl(rcs.normal[i], la);
-                hf1.pos[i] = wv::shfl(rcs.pos[i], lb); hf1.normal[i] = wv::shfl(rcs.normal[i], lb);
-                hf0.tangent[i] = t2 == CM_GEOM_CAPSULE ? axis[i] : 0.0; hf1.tangent[i] = hf0.tangent[i];
-            }
-            if (have0 && have1) hf_n = 2;
-            else if (have0) hf_n = 1;
-            else if (have1) { hf0 = hf1; hf_n = 1; }
-            if (!act) hf_n = 0;
+            wv::sync();
         }
         for (int p0 = 0; p0 < npass; p0 += WV_WAVE) {
             const int p = p0 + lane;
             int n = 0;
             RawContact rc0, rc1;
             bool from_spread = false;
-            if constexpr ((FEAT & FEAT_HFIELD) != 0) if (hf_spread) {
-                /* height-field pairs take their result from the first lane of their pair in the pre-pass */
+            if constexpr ((FEAT & FEAT_HFIELD) != 0) {
+                /* height-field pairs take their result from the table the pre-pass filled (no terrain bound: no contact) */
                 const int slot = p < npass ? m->pair_hfslot[p] : -1;
-                const int src = slot >= 0 ? slot * CM_HF_SLOTS : lane;
-                const int nn = wv::shfl_i(hf_n, src);
-                RawContact a, b2;
-                a.dist = wv::shfl(hf0.dist, src); b2.dist = wv::shfl(hf1.dist, src);
-                for (int i = 0; i < 3; ++i) {
-                    a.pos[i] = wv::shfl(hf0.pos[i], src); a.normal[i] = wv::shfl(hf0.normal[i], src); a.tangent[i] = wv::shfl(hf0.tangent[i], src);
-                    b2.pos[i] = wv::shfl(hf1.pos[i], src); b2.normal[i] = wv::shfl(hf1.normal[i], src); b2.tangent[i] = wv::shfl(hf1.tangent[i], src);
+                if (slot >= 0) {
+                    from_spread = true;
+                    if (hf_on) {
+                        const double *rec = hfres + (size_t)slot * HF_REC;
+                        n = (int)rec[0];
+                        rc0.dist = rec[1]; rc1.dist = rec[11];
+                        for (int i = 0; i < 3; ++i) {
+                            rc0.pos[i] = rec[2 + i]; rc0.normal[i] = rec[5 + i]; rc0.tangent[i] = rec[8 + i];
+                            rc1.pos[i] = rec[12 + i]; rc1.normal[i] = rec[15 + i]; rc1.tangent[i] = rec[18 + i];
+                        }
+                    }
                 }
-                if (slot >= 0) { n = nn; rc0 = a; rc1 = b2; from_spread = true; }
             }
             if (p < npass && !from_spread) {
                 const int g1 = m->pair_geom1[p], g2 = m->pair_geom2[p], tt = m->pair_type[p];
@@ -1601,39 +1639,6 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
                         double q1[3] = {p1[0] + a1[0] * x1, p1[1] + a1[1] * x1, p1[2] + a1[2] * x1};
                         double q2[3] = {p2[0] + a2[0] * x2, p2[1] + a2[1] * x2, p2[2] + a2[2] * x2};
                         n = sphere_sphere(rc0, q1, s10, q2, s20, margin);
-                    } else if ((FEAT & FEAT_HFIELD) != 0 && t1 == CM_GEOM_HFIELD && t2 == CM_GEOM_SPHERE) {
-                        n = hfield_sphere(rc0, m, env_hfield, p1, m1, p2, s20, margin);
-                    } else if ((FEAT & FEAT_HFIELD) != 0 && t1 == CM_GEOM_HFIELD && t2 == CM_GEOM_CAPSULE) {
-                        /* the two end spheres as against a plane, plus interior sample spheres no further apart than a grid
-                         * cell; an interior sample that is deeper than both ends replaces the shallower end (same rule and
-                         * order as the oracle's hfield_capsule) */
-                        double axis[3] = {m2[2], m2[5], m2[8]};
-                        const double cell = 2 * m->hfield_size[0] / (m->hfield_ncol > 1 ? m->hfield_ncol - 1 : 1);
-                        int ni = (int)ceil(2 * s21 / cell) - 1;
-                        if (ni < 0) ni = 0;
-                        if (ni > 4) ni = 4;
-                        RawContact mid;
-                        bool have0, have1, have_mid = false;
-                        {
-                            double e0[3] = {p2[0] + s21 * axis[0], p2[1] + s21 * axis[1], p2[2] + s21 * axis[2]};
-                            have0 = hfield_sphere(rc0, m, env_hfield, p1, m1, e0, s20, margin) != 0;
-                            double e1[3] = {p2[0] - s21 * axis[0], p2[1] - s21 * axis[1], p2[2] - s21 * axis[2]};
-                            have1 = hfield_sphere(rc1, m, env_hfield, p1, m1, e1, s20, margin) != 0;
-                        }
-                        for (int k = 1; k <= ni; ++k) {
-                            const double t = s21 * (1.0 - 2.0 * k / (ni + 1));
-                            double e[3] = {p2[0] + t * axis[0], p2[1] + t * axis[1], p2[2] + t * axis[2]};
-                            RawContact cur;
-                            if (hfield_sphere(cur, m, env_hfield, p1, m1, e, s20, margin) && (!have_mid || cur.dist < mid.dist)) { mid = cur; have_mid = true; }
-                        }
-                        if (have_mid && (!have0 || mid.dist < rc0.dist) && (!have1 || mid.dist < rc1.dist)) {
-                            const bool drop1 = !have0 ? false : (!have1 ? true : rc0.dist <= rc1.dist);
-                            if (drop1) { rc1 = mid; have1 = true; } else { rc0 = mid; have0 = true; }
-                        }
-                        if (have0 && have1) n = 2;
-                        else if (have0) n = 1;
-                        else if (have1) { rc0 = rc1; n = 1; }
-                        for (int i = 0; i < 3; ++i) { rc0.tangent[i] = axis[i]; rc1.tangent[i] = axis[i]; }
                     } else if (t1 == CM_GEOM_SPHERE && t2 == CM_GEOM_BOX) {
                         double sb[3] = {s20, s21, m->pair_size[p][5]};
                         n = sphere_box(rc0, p1, s10, p2, m2, sb, margin);
@@ -2180,11 +2185,14 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
              * hides behind the first row's FMAs (rows past the last constraint hold zeros and cost one wasted row at most) */
             double acc0 = 0, acc1 = 0;
             if (r < nefc) {
+                /* the 40-dof instantiation requests only the first half of the second row up front (its registers are what
+                 * the allocator otherwise spills in this stage) and the rest once the first row's products are under way */
+                constexpr int YB1 = NVP > 32 ? NVP / 2 : NVP;
                 double ya[NVP], yb[NVP];
 #pragma unroll
                 for (int k = 0; k < NVP; ++k) ya[k] = S.x.Yr[r][k];
 #pragma unroll
-                for (int k = 0; k < NVP; ++k) yb[k] = S.x.Yr[r + 1 < CM_MAXEFC ? r + 1 : r][k];
+                for (int k = 0; k < YB1; ++k) yb[k] = S.x.Yr[r + 1 < CM_MAXEFC ? r + 1 : r][k];
                 wv::sched_fence();
                 double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
 #pragma unroll
@@ -2193,6 +2201,11 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
                     a2 += ya[k + 2] * ycol[k + 2]; a3 += ya[k + 3] * ycol[k + 3];
                 }
                 acc0 = (a0 + a1) + (a2 + a3);
+                if constexpr (YB1 < NVP) {
+                    wv::sched_fence();
+#pragma unroll
+                    for (int k = YB1; k < NVP; ++k) yb[k] = S.x.Yr[r + 1 < CM_MAXEFC ? r + 1 : r][k];
+                }
                 if (r + 1 < CM_MAXEFC) {
                     double b0 = 0, b1 = 0, b2 = 0, b3 = 0;
 #pragma unroll
