@@ -30,7 +30,7 @@ HIPFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Iinclude -I$(CSRC) -ffp
 
 HOST_CPP := $(CSRC)/mjcf_loader.cpp $(CSRC)/phys_host.cpp
 HOST_C   := $(wildcard $(CSRC)/*.c)
-HIP_SRC  := $(CSRC)/phys_batch.hip
+HIP_SRC  := $(wildcard $(CSRC)/*.hip)   # phys_batch.hip + one kernels_*.hip per model family (they compile side by side)
 OBJS     := $(patsubst $(CSRC)/%.cpp,$(OBJD)/%.o,$(HOST_CPP)) $(patsubst $(CSRC)/%.c,$(OBJD)/%.o,$(HOST_C)) \
             $(patsubst $(CSRC)/%.hip,$(OBJD)/%.hip.o,$(HIP_SRC))
 
@@ -71,7 +71,7 @@ $(PKG)/bin/cassiesim: $(PKG)/apps/cassiesim.c $(PRODUCT)
 oracle/libcassie_oracle.so: oracle/cassie_oracle.c oracle/cassie_oracle.h $(CSRC)/cm_model.h
 	gcc -O2 -std=gnu11 -fPIC -shared -fopenmp -I$(CSRC) -Ioracle oracle/cassie_oracle.c -o $@ -lm
 
-tests/emu/libcassie_emu.so: tests/emu/emu_runtime.cpp tests/emu/wave.h $(CSRC)/physics_kernel.h $(CSRC)/cm_model.h
+tests/emu/libcassie_emu.so: tests/emu/emu_runtime.cpp tests/emu/wave.h $(CSRC)/physics_kernel.h $(CSRC)/small_kernels.h $(CSRC)/cm_model.h
 	g++ -O2 -std=c++17 -fPIC -shared -Wl,-Bsymbolic -Itests/emu -I$(CSRC) tests/emu/emu_runtime.cpp -o $@
 
 models: product

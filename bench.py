@@ -434,6 +434,8 @@ def device_rollout(model, mode, n, steps, warmup, rank, world, local_rank, subst
     b = Batch(model, n, device=local_rank)
     if all_outputs:
         b.set_all_outputs_every_substep(True)
+    if os.environ.get("CASSIE_NO_FAST_ROWS"):
+        b.set_fast_rows(False)          # A/B switch: the full step kernel alone (the row-capped fast kernel)
     if os.environ.get("CASSIE_NO_BALANCE"):
         b.set_balance(False)            # A/B switch for the longest-job-first launch order
     if hfield is not None:

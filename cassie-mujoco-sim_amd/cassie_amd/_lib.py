@@ -88,6 +88,7 @@ def _declare(L):
     L.phys_batch_mark.argtypes = [vp]
     L.phys_batch_debug_poison_lds.argtypes = [vp]
     L.phys_batch_set_balance.argtypes = [vp, c.c_int]
+    L.phys_batch_set_fast_rows.argtypes = [vp, c.c_int]
     L.phys_batch_set_all_outputs_every_substep.argtypes = [vp, c.c_int]
     L.phys_batch_derive.argtypes = [vp, c.POINTER(c.c_int), vp]
     L.phys_batch_clear_drive_state.argtypes = [vp, c.c_int, c.c_int, c.c_int, vp]

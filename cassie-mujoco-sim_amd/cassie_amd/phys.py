@@ -214,6 +214,10 @@ class Batch:
         """Longest-job-first launch order from the previous launch's per-env cost (default on for >= 2048 envs)."""
         lib().phys_batch_set_balance(self._h, 1 if on else 0)
 
+    def set_fast_rows(self, on=True):
+        """Row-capped fast kernel ahead of the full one (default on; results are bit for bit the same either way)."""
+        lib().phys_batch_set_fast_rows(self._h, 1 if on else 0)
+
     def set_all_outputs_every_substep(self, on=True):
         """Measurement aid: every substep of a fused launch evaluates every output (IMU sensors, body quaternions), not only
         the substeps whose values can be read."""

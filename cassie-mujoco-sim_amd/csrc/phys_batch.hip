@@ -17,7 +17,8 @@
 #include <vector>
 
 #include "cassie_phys.h"
-#include "physics_kernel.h"
+#include "small_kernels.h"
+#include "step_launch.h"
 
 void phys_set_last_error(const char *s);
 
@@ -50,6 +51,8 @@ struct phys_batch {
     int *d_order = nullptr;
     int launches_since_order = 0;
     cm_ext_t *d_ext = nullptr;
+    int *d_progress = nullptr;      /* [nenv] substeps completed by the row-capped fast instantiation (PhysIO::progress) */
+    bool fast_rows = true;          /* use the row-capped fast instantiation where one exists (phys_batch_set_fast_rows) */
     double *d_scratch_out = nullptr; /* [nenv][nv + nsensordata + nu]: where phys_batch_forward_kinematics sends qacc / sensordata / actuator_velocity */
 };
 
@@ -121,7 +124,7 @@ static int launch(phys_batch *b, int nsub, int integrate, hipStream_t s, bool sc
         io.actuator_velocity = io.sensordata + (size_t)b->nenv * m.nsensordata;
     }
     b->last_stream = s;
-    const dim3 grid(b->nenv), block(WV_WAVE);
+    const dim3 grid(b->nenv);
     /* the compile-time-topology instantiations are used only when the model's dof tree is exactly theirs */
     const cm_model_t &hm = b->host_model;
     auto matches = [&](const unsigned long long *table, int nv) {
@@ -132,17 +135,19 @@ static int launch(phys_batch *b, int nsub, int integrate, hipStream_t s, bool sc
     /* ... and the collision code of an instantiation is what the model's pair list needs (FEAT_*): plain cassie.xml has
      * neither height-field nor whole-wave (plane-box / box-box) pairs */
     const bool hf = hm.nhfpair > 0 || hm.hfield_geom >= 0, wp = hm.npair > hm.npair_simple;
+    bool launched;
     if (matches(ck::TopoCassie32::table, ck::TopoCassie32::nv)) {
-        if (!hf && !wp) hipLaunchKernelGGL((ck::cassie_step_kernel<32, ck::TopoCassie32, 0>), grid, block, 0, s, io);
-        else if (hf && !wp) hipLaunchKernelGGL((ck::cassie_step_kernel<32, ck::TopoCassie32, ck::FEAT_HFIELD>), grid, block, 0, s, io);
-        else hipLaunchKernelGGL((ck::cassie_step_kernel<32, ck::TopoCassie32, ck::FEAT_ALL>), grid, block, 0, s, io);
-    } else if (matches(ck::TopoCassieTray38::table, ck::TopoCassieTray38::nv)) {
-        if (!hf) hipLaunchKernelGGL((ck::cassie_step_kernel<40, ck::TopoCassieTray38, ck::FEAT_WAVEPAIRS>), grid, block, 0, s, io);
-        else hipLaunchKernelGGL((ck::cassie_step_kernel<40, ck::TopoCassieTray38, ck::FEAT_ALL>), grid, block, 0, s, io);
-    } else if (hm.nv <= 32)
-        hipLaunchKernelGGL((ck::cassie_step_kernel<32, ck::TopoRuntime, ck::FEAT_ALL>), grid, block, 0, s, io);
-    else
-        hipLaunchKernelGGL((ck::cassie_step_kernel<40, ck::TopoRuntime, ck::FEAT_ALL>), grid, block, 0, s, io);
+        /* stepping launches of the two Cassie instantiations go through the row-capped fast instantiation first; the full one
+         * behind it finishes the envs that met a substep with more rows (and is the only one for forward / read-out /
+         * profiling passes) */
+        const bool fast = b->fast_rows && integrate && !wp && !io.ext && !io.prof && b->d_progress;
+        io.progress = fast ? b->d_progress : nullptr;
+        if (!hf && !wp) launched = ck::launch_step_cassie(grid, s, io, fast);
+        else if (hf && !wp) launched = ck::launch_step_cassie_hfield(grid, s, io, fast);
+        else launched = ck::launch_step_cassie_all(grid, s, io);
+    } else if (matches(ck::TopoCassieTray38::table, ck::TopoCassieTray38::nv)) launched = ck::launch_step_tray(grid, s, io, hf);
+    else launched = ck::launch_step_generic(grid, s, io, hm.nv > 32);
+    if (!launched) { (void)hip_ok(hipErrorLaunchFailure, "cassie_step_kernel launch"); return -1; }
     if (!hip_ok(hipGetLastError(), "cassie_step_kernel launch")) return -1;
     /* the next launch's order from this one's per-env cost: after every long launch, now and then after short ones */
     if (io.order && integrate && (nsub >= 8 || ++b->launches_since_order >= 16)) {
@@ -216,6 +221,8 @@ phys_batch_t *phys_batch_create(const cm_model_t *model, int nenv, int device) {
         ok = ok && hip_ok(hipMalloc((void **)&b->d_cost, sizeof(unsigned) * (size_t)nenv), "hipMalloc(cost)");
         ok = ok && hip_ok(hipMemset(b->d_cost, 0, sizeof(unsigned) * (size_t)nenv), "hipMemset(cost)");
     }
+    ok = ok && hip_ok(hipMalloc((void **)&b->d_progress, sizeof(int) * (size_t)nenv), "hipMalloc(progress)");
+    ok = ok && hip_ok(hipMemset(b->d_progress, 0, sizeof(int) * (size_t)nenv), "hipMemset(progress)");
     ok = ok && hip_ok(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking), "hipStreamCreate");
     ok = ok && hip_ok(hipEventCreate(&b->ev0), "hipEventCreate") && hip_ok(hipEventCreate(&b->ev1), "hipEventCreate");
     ok = ok && hip_ok(hipEventCreateWithFlags(&b->ev_mark, hipEventDisableTiming), "hipEventCreate");
@@ -241,6 +248,7 @@ void phys_batch_free(phys_batch_t *b) {
     if (b->d_hfield) (void)hipFree(b->d_hfield);
     if (b->d_ext) (void)hipFree(b->d_ext);
     if (b->d_scratch_out) (void)hipFree(b->d_scratch_out);
+    if (b->d_progress) (void)hipFree(b->d_progress);
     if (b->d_drive) (void)hipFree(b->d_drive);
     if (b->d_order) (void)hipFree(b->d_order);
     if (b->d_cost) (void)hipFree(b->d_cost);
@@ -580,6 +588,12 @@ int phys_batch_derive(phys_batch_t *b, const int ids[6], void *stream) {
 int phys_batch_set_all_outputs_every_substep(phys_batch_t *b, int on) {
     if (!b) return -1;
     b->all_outputs = on != 0;
+    return 0;
+}
+
+int phys_batch_set_fast_rows(phys_batch_t *b, int on) {
+    if (!b) return -1;
+    b->fast_rows = on != 0;
     return 0;
 }
 

@@ -58,6 +58,7 @@ namespace ck {
 constexpr int NB = CM_MAXBODY;
 constexpr int NG = CM_MAXGEOM;
 constexpr int NROW = 64;       /* rows 0..62 constraints, column 63 = qfrc_smooth */
+constexpr int FAST_ROWS = 31;  /* rows of the row-capped fast instantiation (+ the qfrc_smooth column: half of the full tile) */
 constexpr int NSTAMP = 48;   /* 0..15 stage boundaries, 16..47 sub-stage stamps (tools/stage_profile.py names them) */
 #define CK_TRI(k, i) ((k) * ((k) + 1) / 2 + (i))
 #define CK_STAMP(i) do { if (io.prof && lane == 0) io.prof[(size_t)env * NSTAMP + (i)] = wv::clock(); CK_FRESH(); } while (0)
@@ -115,9 +116,17 @@ struct PhysIO {
     /* non-zero: every substep of a launch evaluates every output (IMU sensors, body quaternions) although only the last
      * substep's can be read -- a measurement aid (bench.py reports the rate with it as a side figure) */
     int all_outputs_every_substep;
+    /* The row-capped fast instantiation (cassie_step_kernel<..., MAXR < CM_MAXEFC>) steps an env until a substep needs more
+     * constraint rows than it holds; it then stores the state as of the start of that substep and records how many substeps
+     * it completed in progress[env].  The full instantiation, launched behind it with resume != 0, finishes those envs from
+     * there (and returns at once for the others).  progress may be null (then resume must be 0). */
+    int *progress;
+    int resume;
 };
 
-template <int NVP, int NL = NVP * (NVP + 1) / 2>
+/* MAXR: constraint rows this instantiation can hold (CM_MAXEFC, or fewer in the row-capped fast instantiation, see
+ * cassie_step_kernel); the Y tile has one more row, the qfrc_smooth column */
+template <int NVP, int NL = NVP * (NVP + 1) / 2, int MAXR = CM_MAXEFC>
 struct EnvShared {
     static constexpr int YP = NVP + 2; /* leading dimension of the Y staging tile: 16-byte aligned rows, conflict-free */
     union {
@@ -129,7 +138,7 @@ struct EnvShared {
             double cdof_dot[NVP][6], buf[NVP][6];
             double geom_xpos[NG][3], geom_xmat[NG][9];
         } s;
-        double Yr[NROW][YP];        /* Y staged row-major by constraint row for broadcast reads */
+        double Yr[MAXR + 1][YP];    /* Y staged row-major by constraint row for broadcast reads; row MAXR = the qfrc_smooth column */
     } x;
     /* L^T D L factors of M and of M + hB, rows stored as LPack<TOPO, NVP> says (NL entries): a full lower triangle,
      * entry (k, i <= k) at k(k+1)/2 + i, or block-dense rows for a compile-time topology that asks for them */
@@ -616,8 +625,8 @@ WV_DEVICE int hfield_sphere(RawContact &c, ModelPtr m, const float *data, const 
 }
 
 /* parks one detected contact (geometry only) in the contact list; finish_contacts completes the entries */
-template <int NVP, int NL>
-WV_DEVICE void write_raw_contact(EnvShared<NVP, NL> &S, int slot, int pair, const RawContact &r) {
+template <class SH>
+WV_DEVICE void write_raw_contact(SH &S, int slot, int pair, const RawContact &r) {
     S.c_dist[slot] = r.dist;
     S.c_pair[slot] = pair;
     for (int i = 0; i < 3; ++i) { S.c_pos[slot][i] = r.pos[i]; S.c_frame[slot][i] = r.normal[i]; S.c_frame[slot][3 + i] = r.tangent[i]; }
@@ -625,8 +634,8 @@ WV_DEVICE void write_raw_contact(EnvShared<NVP, NL> &S, int slot, int pair, cons
 
 /* lane = contact: contact frame from (normal, tangent hint) and the pair's pre-mixed parameters (model compile
  * time, cm_model_t::pair_*), once per contact and outside the divergent pair loops */
-template <int NVP, int NL>
-WV_DEVICE void finish_contacts(EnvShared<NVP, NL> &S, ModelPtr m, int lane, int ncon) {
+template <class SH>
+WV_DEVICE void finish_contacts(SH &S, ModelPtr m, int lane, int ncon) {
     if (lane < ncon) {
         const int p = S.c_pair[lane];
         double fr[9];
@@ -850,10 +859,10 @@ WV_DEVICE void factor_pair_by_height(ModelPtr m, double h, SH &S, double (&col)[
  *
  * pgs_rows: the guarded sweep (MuJoCo's rule `never accept a cost increase`, evaluated row by row).  Nested so that
  * the first row index >= nrows ends the sweep with one wave-uniform branch. */
-template <int I>
-WV_DEVICE void pgs_rows(const double (&brow)[CM_MAXEFC], int nrows, int r_, double Aii, double halfAii, double flo, double &f,
+template <int I, int N>
+WV_DEVICE void pgs_rows(const double (&brow)[N], int nrows, int r_, double Aii, double halfAii, double flo, double &f,
                         double &sres, double &improvement) {
-    if constexpr (I < CM_MAXEFC) {
+    if constexpr (I < N) {
         if (I < nrows) {
             double delta = fmax(sres, flo - f); /* = max(f - res / Aii, flo) - f */
             double change = delta * (halfAii * delta - Aii * sres);
@@ -862,7 +871,7 @@ WV_DEVICE void pgs_rows(const double (&brow)[CM_MAXEFC], int nrows, int r_, doub
             if (r_ == I) f += dlt;
             improvement -= chg;
             sres += brow[I] * dlt;
-            pgs_rows<I + 1>(brow, nrows, r_, Aii, halfAii, flo, f, sres, improvement);
+            pgs_rows<I + 1, N>(brow, nrows, r_, Aii, halfAii, flo, f, sres, improvement);
         }
     }
 }
@@ -870,9 +879,9 @@ WV_DEVICE void pgs_rows(const double (&brow)[CM_MAXEFC], int nrows, int r_, doub
 /* The same sweep with the guard off the dependent chain: the row's own lane keeps the residual it started from
  * (its step follows from it), so every row's cost change -- hence the guard and the sweep's improvement -- can be
  * evaluated once, after the sweep.  The caller re-runs the sweep through pgs_rows when a guard would have fired. */
-template <int I>
-WV_DEVICE void pgs_row_fast(const double (&brow)[CM_MAXEFC], int r_, double lo_f, double &sres, double &mys) {
-    if constexpr (I < CM_MAXEFC) {
+template <int I, int N>
+WV_DEVICE void pgs_row_fast(const double (&brow)[N], int r_, double lo_f, double &sres, double &mys) {
+    if constexpr (I < N) {
         const double delta = wv::max_raw(sres, lo_f); /* one v_max_f64: fmax() adds a canonicalising self-max to the row chain after every branch */
         if (r_ == I) mys = sres; /* the residual this row started from: its step is recomputed from it after the sweep */
         sres += brow[I] * wv::readlane(delta, I);
@@ -880,15 +889,15 @@ WV_DEVICE void pgs_row_fast(const double (&brow)[CM_MAXEFC], int r_, double lo_f
 }
 /* rows go four to a (wave-uniform) branch: rows past the last one are inert -- their column of A is zero in every
  * lane and their own lane's step is finite -- so running up to three of them costs less than three more branches */
-template <int I>
-WV_DEVICE void pgs_rows_fast(const double (&brow)[CM_MAXEFC], int nrows, int r_, double lo_f, double &sres, double &mys) {
-    if constexpr (I < CM_MAXEFC) {
+template <int I, int N>
+WV_DEVICE void pgs_rows_fast(const double (&brow)[N], int nrows, int r_, double lo_f, double &sres, double &mys) {
+    if constexpr (I < N) {
         if (I < nrows) {
-            pgs_row_fast<I>(brow, r_, lo_f, sres, mys);
-            pgs_row_fast<I + 1>(brow, r_, lo_f, sres, mys);
-            pgs_row_fast<I + 2>(brow, r_, lo_f, sres, mys);
-            pgs_row_fast<I + 3>(brow, r_, lo_f, sres, mys);
-            pgs_rows_fast<I + 4>(brow, nrows, r_, lo_f, sres, mys);
+            pgs_row_fast<I, N>(brow, r_, lo_f, sres, mys);
+            pgs_row_fast<I + 1, N>(brow, r_, lo_f, sres, mys);
+            pgs_row_fast<I + 2, N>(brow, r_, lo_f, sres, mys);
+            pgs_row_fast<I + 3, N>(brow, r_, lo_f, sres, mys);
+            pgs_rows_fast<I + 4, N>(brow, nrows, r_, lo_f, sres, mys);
         }
     }
 }
@@ -1073,8 +1082,8 @@ WV_DRIVE_FN void drive_level_io(const PhysIO &io, SH &S, ModelPtr m, int env, in
  * pairs handled by the whole wave.  The launcher picks the instantiation from the model (phys_batch.hip). */
 enum { FEAT_HFIELD = 1, FEAT_WAVEPAIRS = 2, FEAT_ALL = 3 };
 
-template <int NVP, class TOPO, int FEAT>
-WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count> &S, int env) {
+template <int NVP, class TOPO, int FEAT, int MAXR>
+WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count, MAXR> &S, int env, int sub_start) {
     typedef LPack<TOPO, NVP> LP;
     static_assert(LP::covers() && LP::distinct(), "packed factor rows must hold every ancestor pair, each in its own slot");
     const ModelPtr m_launch = (ModelPtr)(io.models + (size_t)env * io.model_stride);
@@ -1135,7 +1144,9 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
     for (int u = 0; u < nu; ++u) if (isdof && m->act_dofid[u] == k_) kact = u;
     wv::sync();
 
-    for (int sub = 0; sub < io.nsub; ++sub) {
+    bool bailed = false;
+    int sub = sub_start;
+    for (; sub < io.nsub; ++sub) {
         /* Outputs that every substep recomputes (sensordata, qacc, actuator_velocity, xpos / xquat, the solver statistics)
          * are stored only by the LAST substep of a launch: the others' values would be overwritten anyway, and on this
          * hardware vector stores share the loads' completion counter (vmcnt), so a store that is still in flight holds up
@@ -1153,8 +1164,12 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
             if (wv::ballot(badv) != 0ull) { warn |= WARN_DIVERGED; break; }
         }
         if (io.drive_mode) {
-            if (io.integrate) drive_level_io(io, S, m, env, lane, lastsub); /* mj_forward leaves the drive-level state alone */
-            wv::sync();
+            /* (the row-capped instantiation runs this pass after it knows that the substep fits its rows, see below: a
+             * substep it hands over must not have advanced the filter histories and delay lines) */
+            if constexpr (MAXR == CM_MAXEFC) {
+                if (io.integrate) drive_level_io(io, S, m, env, lane, lastsub); /* mj_forward leaves the drive-level state alone */
+                wv::sync();
+            }
         } else if (io.pd_ptarget) {
             if (lane < nu) {
                 const size_t o = (size_t)env * io.su + lane;
@@ -1655,8 +1670,8 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
             const unsigned long long m1b = wv::ballot(n >= 1), m2b = wv::ballot(n >= 2);
             const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
             const int slot = ncon + wv::popc64(m1b & below) + wv::popc64(m2b & below);
-            if (n >= 1 && slot < CM_MAXCON) write_raw_contact<NVP>(S, slot, p, rc0);
-            if (n >= 2 && slot + 1 < CM_MAXCON) write_raw_contact<NVP>(S, slot + 1, p, rc1);
+            if (n >= 1 && slot < CM_MAXCON) write_raw_contact(S, slot, p, rc0);
+            if (n >= 2 && slot + 1 < CM_MAXCON) write_raw_contact(S, slot + 1, p, rc1);
             ncon += wv::popc64(m1b) + wv::popc64(m2b);
         }
         CK_STAMP(22);
@@ -1701,13 +1716,39 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
             const unsigned long long hb = wv::ballot(hit);
             const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
             const int rank = wv::popc64(hb & below);
-            if (hit && rank < 4 && ncon + rank < CM_MAXCON) write_raw_contact<NVP>(S, ncon + rank, p, rc);
+            if (hit && rank < 4 && ncon + rank < CM_MAXCON) write_raw_contact(S, ncon + rank, p, rc);
             const int nh = wv::popc64(hb);
             ncon += nh < 4 ? nh : 4;
         }
         if (ncon > CM_MAXCON) { ncon = CM_MAXCON; warn |= WARN_CONTACT_FULL; }
         wv::sync();
-        finish_contacts<NVP>(S, m, lane, ncon);
+        finish_contacts(S, m, lane, ncon);
+        /* joint limits: lane = joint evaluates its own violation (the ballots give the row slots in joint order below) */
+        unsigned long long lob, hib;
+        {
+            bool lo = false, hi = false;
+            if (lane < njnt && m->jnt_limited[lane]) {
+                const int jt = m->jnt_type[lane];
+                if (jt == CM_JNT_HINGE || jt == CM_JNT_SLIDE) {
+                    const double q = S.qpos[m->jnt_qposadr[lane]], mg = m->jnt_margin[lane];
+                    lo = q - m->jnt_range[lane][0] < mg;
+                    hi = m->jnt_range[lane][1] - q < mg;
+                }
+            }
+            lob = wv::ballot(lo); hib = wv::ballot(hi);
+        }
+        if constexpr (MAXR < CM_MAXEFC) {
+            /* an upper bound of the rows this substep needs (the caps of the row assignment can only lower it): past this
+             * instantiation's capacity the env is handed to the full instantiation, from the start of this substep */
+            const int neq = m->neq;
+            const bool eact = lane < neq && m->eq_active[lane < neq ? lane : 0] != 0;
+            const int need = 3 * wv::popc64(wv::ballot(eact)) + wv::popc64(lob) + wv::popc64(hib) + 4 * ncon;
+            if (need > MAXR) { bailed = true; break; }
+            if (io.drive_mode) {
+                if (io.integrate) drive_level_io(io, S, m, env, lane, lastsub);
+                wv::sync();
+            }
+        }
         CK_STAMP(5);
 
         /* ================= P6 velocities and bias forces ================= */
@@ -1866,18 +1907,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
             }
         }
         {
-            /* joint limits: lane = joint evaluates its own violation, ballots give the row slots in joint order */
-            bool lo = false, hi = false;
-            if (lane < njnt && m->jnt_limited[lane]) {
-                const int jt = m->jnt_type[lane];
-                if (jt == CM_JNT_HINGE || jt == CM_JNT_SLIDE) {
-                    const double q = S.qpos[m->jnt_qposadr[lane]], mg = m->jnt_margin[lane];
-                    lo = q - m->jnt_range[lane][0] < mg;
-                    hi = m->jnt_range[lane][1] - q < mg;
-                }
-            }
-            const unsigned long long lob = wv::ballot(lo), hib = wv::ballot(hi);
-            /* rows in joint order, lower side before upper side */
+            /* joint-limit rows in joint order, lower side before upper side (lob / hib: evaluated after the collision stage) */
             for (unsigned long long any = lob | hib; any; any &= any - 1) {
                 const int j = wv::popc64((any & (0ull - any)) - 1);
                 for (int side = 0; side < 2; ++side) {
@@ -2172,15 +2202,18 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
                 ycol[k] = xk * S.rsd[k];
             }
         }
+        if (r_ < MAXR || lastcol) { /* (lanes MAXR .. 62 of a row-capped instantiation hold no row) */
+            const int yrow = lastcol ? MAXR : r_;
 #pragma unroll
-        for (int k = 0; k < NVP; ++k) S.x.Yr[r_][k] = ycol[k];
+            for (int k = 0; k < NVP; ++k) S.x.Yr[yrow][k] = ycol[k];
+        }
         wv::sync();
         CK_STAMP(9);
 
         /* ================= P9: this lane's row of A = Y^T Y + diag(R), b = Y^T y63 - aref ================= */
-        double arow[CM_MAXEFC];
+        double arow[MAXR];
 #pragma unroll
-        for (int r = 0; r < CM_MAXEFC; r += 2) {
+        for (int r = 0; r < MAXR; r += 2) {
             /* rows in pairs: both broadcast rows are requested before the first product, so the second row's LDS latency
              * hides behind the first row's FMAs (rows past the last constraint hold zeros and cost one wasted row at most) */
             double acc0 = 0, acc1 = 0;
@@ -2192,7 +2225,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
 #pragma unroll
                 for (int k = 0; k < NVP; ++k) ya[k] = S.x.Yr[r][k];
 #pragma unroll
-                for (int k = 0; k < YB1; ++k) yb[k] = S.x.Yr[r + 1 < CM_MAXEFC ? r + 1 : r][k];
+                for (int k = 0; k < YB1; ++k) yb[k] = S.x.Yr[r + 1 < MAXR ? r + 1 : r][k];
                 wv::sched_fence();
                 double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
 #pragma unroll
@@ -2204,9 +2237,9 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
                 if constexpr (YB1 < NVP) {
                     wv::sched_fence();
 #pragma unroll
-                    for (int k = YB1; k < NVP; ++k) yb[k] = S.x.Yr[r + 1 < CM_MAXEFC ? r + 1 : r][k];
+                    for (int k = YB1; k < NVP; ++k) yb[k] = S.x.Yr[r + 1 < MAXR ? r + 1 : r][k];
                 }
-                if (r + 1 < CM_MAXEFC) {
+                if (r + 1 < MAXR) {
                     double b0 = 0, b1 = 0, b2 = 0, b3 = 0;
 #pragma unroll
                     for (int k = 0; k < NVP; k += 4) {
@@ -2217,13 +2250,13 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
                 }
             }
             arow[r] = acc0;
-            if (r + 1 < CM_MAXEFC) arow[r + 1] = acc1;
+            if (r + 1 < MAXR) arow[r + 1] = acc1;
         }
         double rb = 0;
         {
             double acc = 0;
 #pragma unroll
-            for (int k = 0; k < NVP; ++k) acc += S.x.Yr[NROW - 1][k] * ycol[k];
+            for (int k = 0; k < NVP; ++k) acc += S.x.Yr[MAXR][k] * ycol[k];
             rb = acc - raref;
         }
         CK_STAMP(10);
@@ -2258,12 +2291,12 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
                  * nothing: their column of A is zero and f is zero in lanes that are not rows) */
                 double af0 = 0, af1 = 0, af2 = 0, af3 = 0;
 #pragma unroll
-                for (int t = 0; t < CM_MAXEFC; t += 4) {
+                for (int t = 0; t < MAXR; t += 4) {
                     if (t < nefc) {
                         af0 += arow[t] * wv::readlane(f, t);
-                        if (t + 1 < CM_MAXEFC) af1 += arow[t + 1] * wv::readlane(f, t + 1);
-                        if (t + 2 < CM_MAXEFC) af2 += arow[t + 2] * wv::readlane(f, t + 2);
-                        if (t + 3 < CM_MAXEFC) af3 += arow[t + 3] * wv::readlane(f, t + 3);
+                        if (t + 1 < MAXR) af1 += arow[t + 1] * wv::readlane(f, t + 1);
+                        if (t + 2 < MAXR) af2 += arow[t + 2] * wv::readlane(f, t + 2);
+                        if (t + 3 < MAXR) af3 += arow[t + 3] * wv::readlane(f, t + 3);
                     }
                 }
                 const double af = ((af0 + af1) + (af2 + af3)) + (isrow ? rR * f : 0.0); /* + the diagonal's R */
@@ -2279,7 +2312,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
             const double ninvAii = -invAii;
             double sres = res * ninvAii;
 #pragma unroll
-            for (int t = 0; t < CM_MAXEFC; ++t) arow[t] *= ninvAii;
+            for (int t = 0; t < MAXR; ++t) arow[t] *= ninvAii;
             const double cdiag = isrow ? rR * ninvAii : 0.0; /* the R part of B_jj = -(Y Y^T + R)_jj / A_jj, see above */
             const int maxiter = m->iterations;
             const double tolerance = m->tolerance;
@@ -2290,7 +2323,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
                     const double f0 = f, s0 = sres;
                     double mys = 0;
                     const double lo_f = flo - f;
-                    pgs_rows_fast<0>(arow, nrows, r_, lo_f, sres, mys);
+                    pgs_rows_fast<0, MAXR>(arow, nrows, r_, lo_f, sres, mys);
                     const double mydelta = fmax(mys, lo_f);
                     const double change = (r_ < nrows) ? mydelta * (halfAii * mydelta - Aii * mys) : 0.0;
                     /* The guarded sweep adds the rows' cost changes in row order, and the sum only feeds the convergence test.
@@ -2301,7 +2334,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
                     if (wv::ballot(change > 1e-10) != 0ull || wv::debug_force_guarded()) { /* some row would have raised the cost: redo guarded */
                         double improvement = 0;
                         f = f0; sres = s0; ++nguarded;
-                        pgs_rows<0>(arow, nrows, r_, Aii, halfAii, flo, f, sres, improvement);
+                        pgs_rows<0, MAXR>(arow, nrows, r_, Aii, halfAii, flo, f, sres, improvement);
                         sres = fma(cdiag, f - f0, sres);
                         converged = improvement * scale < tolerance;
                     } else {
@@ -2368,7 +2401,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
         /* ================= qacc = L^-1 D^-1/2 (y63 + Y f)  (lane = dof) ================= */
         double qacc;
         {
-            double z = isdof ? S.x.Yr[NROW - 1][k_] : 0.0;
+            double z = isdof ? S.x.Yr[MAXR][k_] : 0.0;
             {
                 /* z += Y f : rows in groups of four so LDS reads and broadcasts overlap; rolled (row count is dynamic) */
                 double z1 = 0, z2 = 0, z3 = 0;
@@ -2500,9 +2533,20 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
     }
 
     /* ---------------- store state ---------------- */
+    if (io.progress && lane == 0) io.progress[env] = bailed ? sub : io.nsub;
     if (io.integrate && io.drive_mode) {
         drive_state_store(io, S, env, lane);
         if (lane < nu) io.ctrl[(size_t)env * io.su + lane] = S.ctrl[lane]; /* the applied torque: d->ctrl of the reference */
+        if (bailed) {
+            /* handed over in the middle of a launch: what the last completed substep measured is the next drive-level pass's
+             * input, and it lives in LDS only */
+            if (lane < m->nsensordata) io.sensordata[(size_t)env * io.ssd + lane] = S.sens[lane];
+            if (lane < nu) io.actuator_velocity[(size_t)env * io.su + lane] = S.actvel[lane];
+            if (lane < CM_NUM_DRIVES) { /* ... and the drive positions / velocities CM_DRIVE_PD's law reads come back from the measurement block */
+                double *meas = io.meas + (size_t)env * CM_MEAS_DIM;
+                meas[CM_MEAS_DRIVE_POS + lane] = S.drv_pos[lane]; meas[CM_MEAS_DRIVE_VEL + lane] = S.drv_vel[lane];
+            }
+        }
     }
     if (io.integrate) {
         if (lane < nq) io.qpos[(size_t)env * io.sq + lane] = S.qpos[lane];
@@ -2520,193 +2564,28 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
     }
 }
 
-/* one single-wave workgroup per environment */
-template <int NVP, class TOPO, int FEAT = FEAT_ALL>
+/* one single-wave workgroup per environment.
+ *
+ * MAXR < CM_MAXEFC is the row-capped FAST instantiation: the constraint stages hold MAXR rows (31: a Cassie on its feet uses
+ * 20 .. 28), which halves the register arrays of the solve (A's rows, the PGS row chain) -- 112 instead of 316 bytes of
+ * scratch per lane -- and shortens every unrolled row loop.  An env whose substep needs more rows is handed over to the full
+ * instantiation through PhysIO::progress (see there); results are bit for bit those of the full instantiation alone, because
+ * the arithmetic of a substep that fits is the same in both. */
+template <int NVP, class TOPO, int FEAT = FEAT_ALL, int MAXR = CM_MAXEFC>
 WV_GLOBAL void __launch_bounds__(WV_WAVE) WV_OCC cassie_step_kernel(PhysIO io) {
-    WV_SHARED EnvShared<NVP, LPack<TOPO, NVP>::count> S;
+    WV_SHARED EnvShared<NVP, LPack<TOPO, NVP>::count, MAXR> S;
     const int slot = wv::env_id();
     if (slot >= io.nenv) return;
     wv::test_launch_hook(&S, sizeof S); /* CPU emulator only (poisons LDS so that a read-before-write shows); empty on the device */
     const int env = io.order ? io.order[slot] : slot;
+    const int sub_start = io.resume ? io.progress[env] : 0;
+    if (sub_start >= io.nsub) return; /* resume pass: the fast instantiation finished this env */
     const long long t0 = io.cost ? wv::clock() : 0;
-    env_step<NVP, TOPO, FEAT>(io, S, env);
-    if (io.cost && wv::lane() == 0) io.cost[env] = (unsigned)((wv::clock() - t0) >> 6); /* 64-clock units: 32 bits hold minutes */
-}
-
-/* Longest-job-first launch order.  A launch is nenv independent jobs (one env x nsub substeps each) handed to the
- * chip's wave slots in workgroup order; with only a few jobs per slot -- 4096 envs on 1024 SIMDs -- the launch ends
- * when the unluckiest slot does, measured ~15 % after the average one.  An env's cost persists from launch to launch
- * (it is its contact situation), so the next launch starts the expensive envs first and lets the cheap ones fill the
- * tail.  One workgroup: counting sort of the envs by the cost of their last launch into NBIN bins, descending; the
- * order inside a bin is arbitrary, which is harmless -- envs are independent and every env is stepped exactly once. */
-constexpr int ORDER_THREADS = 1024, ORDER_NBIN = 256;
-WV_GLOBAL void __launch_bounds__(ORDER_THREADS) cassie_order_kernel(const unsigned *cost, int *order, int nenv) {
-#ifndef CK_EMULATED
-    __shared__ unsigned lo_s, hi_s, count[ORDER_NBIN], start[ORDER_NBIN];
-    const int t = threadIdx.x;
-    if (t == 0) { lo_s = 0xffffffffu; hi_s = 0; }
-    if (t < ORDER_NBIN) count[t] = 0;
-    __syncthreads();
-    unsigned lo = 0xffffffffu, hi = 0;
-    for (int e = t; e < nenv; e += ORDER_THREADS) { const unsigned c = cost[e]; lo = c < lo ? c : lo; hi = c > hi ? c : hi; }
-    atomicMin(&lo_s, lo); atomicMax(&hi_s, hi);
-    __syncthreads();
-    lo = lo_s; hi = hi_s;
-    const float scale = hi > lo ? (float)(ORDER_NBIN - 1) / (float)(hi - lo) : 0.0f;
-    auto bin_of = [&](unsigned c) { return ORDER_NBIN - 1 - (int)((float)(c - lo) * scale); }; /* bin 0 = most expensive */
-    for (int e = t; e < nenv; e += ORDER_THREADS) atomicAdd(&count[bin_of(cost[e])], 1u);
-    __syncthreads();
-    if (t == 0) { unsigned acc = 0; for (int b = 0; b < ORDER_NBIN; ++b) { start[b] = acc; acc += count[b]; } }
-    __syncthreads();
-    for (int e = t; e < nenv; e += ORDER_THREADS) order[atomicAdd(&start[bin_of(cost[e])], 1u)] = e;
-#endif
-}
-
-/* The drive-level pass on its own, one wave per env: cassie_motor_data + cassie_sensor_data for every env on the
- * sensordata / actuator_velocity the last physics step left in HBM; writes ctrl (for the next physics launch), the
- * measurement block and the drive state.  The batched host API launches it ahead of the physics kernel so that the
- * measurements reach the host -- and the state estimators start -- while the physics is still running. */
-struct DriveShared {
-    double sens[CM_MAXSENSORDATA], actvel[CM_MAXU], ctrl[CM_MAXU];
-    int drv_x[CM_NUM_DRIVES][CM_DRIVE_FILTER_NB];
-    double drv_jx[CM_NUM_JOINTS][CM_JOINT_FILTER_NB], drv_jy[CM_NUM_JOINTS][CM_JOINT_FILTER_NA];
-    double drv_delay[CM_NUM_DRIVES][CM_TORQUE_DELAY_CYCLES];
-    double drv_pos[CM_NUM_DRIVES], drv_vel[CM_NUM_DRIVES];
-};
-
-WV_GLOBAL void __launch_bounds__(WV_WAVE) cassie_drive_kernel(PhysIO io, double *ctrl_out) {
-    WV_SHARED DriveShared S;
-    const int env = wv::env_id();
-    if (env >= io.nenv) return;
-    const ModelPtr m = (ModelPtr)(io.models + (size_t)env * io.model_stride);
-    const int lane = wv::lane(), nu = m->nu;
-    if (lane < m->nsensordata) S.sens[lane] = io.sensordata[(size_t)env * io.ssd + lane];
-    if (lane < nu) S.actvel[lane] = io.actuator_velocity[(size_t)env * io.su + lane];
-    drive_state_load(io, S, env, lane);
-    wv::sync();
-    drive_level_io(io, S, m, env, lane, true);
-    wv::sync();
-    drive_state_store(io, S, env, lane);
-    if (lane < nu) ctrl_out[(size_t)env * io.su + lane] = S.ctrl[lane];
-}
-
-/* ------------------------------------------------ derived getters, batched ---- */
-/* What the reference's reward-side getters compute from mjData, for one env from the read-out (cm_ext_t) a forward
- * pass left in HBM: whole-model centre of mass, its velocity, angular momentum about it (reference
- * src/cassiemujoco.c:1632-1700), foot positions / velocities (:1604-1630, :1752-1770), foot and heel / toe contact
- * forces (:1812-1898), the feet's Jacobians (:1254-1301) and the dense mass matrix (:1702-1712).  Same arithmetic as
- * the single-simulator getters in csrc/cassiemujoco.c.  ids: left / right foot body, left / right heel site, left /
- * right toe site (-1 = the model has none). */
-struct DeriveIO {
-    const cm_model_t *models; int model_stride; int nenv;
-    const cm_ext_t *ext;
-    const double *xpos, *xquat;   /* [nenv][nbody][3], [nenv][nbody][4] */
-    double *derived;              /* [nenv][CM_DRV_DIM] */
-    double *qM;                   /* [nenv][nv][nv] or null */
-    int ids[6];
-};
-
-WV_DEVICE void derive_env(const DeriveIO &io, int env, int lane) {
-    const ModelPtr m = (ModelPtr)(io.models + (size_t)env * io.model_stride);
-    const cm_ext_t *ex = io.ext + env;
-    const int nb = m->nbody, nv = m->nv;
-    double *out = io.derived + (size_t)env * CM_DRV_DIM;
-    const double *xpos = io.xpos + (size_t)env * nb * 3, *xquat = io.xquat + (size_t)env * nb * 4;
-    /* lane = body: mass-weighted sums */
-    const bool isb = lane > 0 && lane < nb;
-    const int b = isb ? lane : 0;
-    const double mb = isb ? m->body_mass[b] : 0.0;
-    double xi[3], vb[3] = {0, 0, 0}, w[3] = {0, 0, 0};
-    for (int i = 0; i < 3; ++i) xi[i] = ex->xipos[b][i];
-    if (isb) {
-        const double *cv = ex->cvel[b], *rc = ex->subtree_com[m->body_rootid[b]];
-        double off[3] = {xi[0] - rc[0], xi[1] - rc[1], xi[2] - rc[2]}, t[3];
-        for (int i = 0; i < 3; ++i) w[i] = cv[i];
-        cross3(t, w, off);
-        for (int i = 0; i < 3; ++i) vb[i] = cv[3 + i] + t[i];
+    env_step<NVP, TOPO, FEAT, MAXR>(io, S, env, sub_start);
+    if (io.cost && wv::lane() == 0) { /* 64-clock units: 32 bits hold minutes */
+        const unsigned c = (unsigned)((wv::clock() - t0) >> 6);
+        io.cost[env] = io.resume ? io.cost[env] + c : c;
     }
-    const double M = wv::wave_sum(mb), Mi = M > 0 ? 1.0 / M : 0.0;
-    double com[3], vcom[3];
-    for (int i = 0; i < 3; ++i) { com[i] = wv::wave_sum(mb * xi[i]) * Mi; vcom[i] = wv::wave_sum(mb * vb[i]) * Mi; }
-    /* angular momentum about the whole-model com: spin R diag(I) R^T w + orbital r x m (v - vcom) */
-    double L[3] = {0, 0, 0};
-    if (isb) {
-        double q[4], R[9], iq[4] = {m->body_iquat[b][0], m->body_iquat[b][1], m->body_iquat[b][2], m->body_iquat[b][3]};
-        double xq[4] = {xquat[4 * b], xquat[4 * b + 1], xquat[4 * b + 2], xquat[4 * b + 3]};
-        mulquat(q, xq, iq);
-        quat2mat(R, q);
-        double wl[3];
-        mulmatTvec3(wl, R, w);
-        for (int i = 0; i < 3; ++i) wl[i] *= m->body_inertia[b][i];
-        mulmatvec3(L, R, wl);
-        double r[3], mv[3], t[3];
-        for (int i = 0; i < 3; ++i) { r[i] = xi[i] - com[i]; mv[i] = mb * (vb[i] - vcom[i]); }
-        cross3(t, r, mv);
-        for (int i = 0; i < 3; ++i) L[i] += t[i];
-    }
-    for (int i = 0; i < 3; ++i) L[i] = wv::wave_sum(L[i]);
-    if (lane == 0) {
-        for (int i = 0; i < 3; ++i) { out[CM_DRV_COM_POS + i] = com[i]; out[CM_DRV_COM_VEL + i] = vcom[i]; out[CM_DRV_ANGMOM + i] = L[i]; }
-        out[CM_DRV_MASS] = M;
-    }
-    /* lane = side: foot kinematics and contact forces */
-    if (lane < 2) {
-        const int side = lane, foot = io.ids[side], heel = io.ids[2 + side], toe = io.ids[4 + side];
-        const double off = sqrt(0.01762 * 0.01762 + 0.05219 * 0.05219); /* foot joint to mid-foot (reference :1612) */
-        for (int i = 0; i < 3; ++i) out[CM_DRV_FOOT_POS + 3 * side + i] = (foot > 0 ? xpos[3 * foot + i] : 0.0) - (i == 2 ? off : 0.0);
-        for (int i = 0; i < 6; ++i) out[CM_DRV_FOOT_VEL + 6 * side + i] = foot > 0 ? ex->cvel[foot][i] : 0.0;
-        double ff[3] = {0, 0, 0}, tf[3] = {0, 0, 0}, hf[3] = {0, 0, 0};
-        for (int c = 0; c < ex->ncon; ++c) {
-            const int b1 = ex->con_body1[c], b2 = ex->con_body2[c];
-            if (b1 != foot && b2 != foot) continue;
-            const double *fr = ex->con_frame[c], *f = ex->con_force[c];
-            const double sgn = (b1 == foot) ? -1.0 : 1.0;
-            double fw[3];
-            for (int k = 0; k < 3; ++k) fw[k] = fr[k] * f[0] + fr[3 + k] * f[1] + fr[6 + k] * f[2];
-            for (int k = 0; k < 3; ++k) ff[k] += sgn * fw[k];
-            if (heel >= 0 && toe >= 0 && heel < CM_MAXSITE && toe < CM_MAXSITE) {
-                const double *p = ex->con_pos[c], *tp = ex->site_xpos[toe], *hp = ex->site_xpos[heel];
-                const double td = sqrt((tp[0] - p[0]) * (tp[0] - p[0]) + (tp[1] - p[1]) * (tp[1] - p[1]));
-                const double hd = sqrt((hp[0] - p[0]) * (hp[0] - p[0]) + (hp[1] - p[1]) * (hp[1] - p[1]));
-                double *dst = td < hd ? tf : hf;
-                for (int k = 0; k < 3; ++k) dst[k] += sgn * fw[k];
-            }
-        }
-        for (int k = 0; k < 3; ++k) {
-            out[CM_DRV_FOOT_FORCE + 6 * side + k] = ff[k]; out[CM_DRV_FOOT_FORCE + 6 * side + 3 + k] = 0.0;
-            out[CM_DRV_TOE_FORCE + 3 * side + k] = tf[k]; out[CM_DRV_HEEL_FORCE + 3 * side + k] = hf[k];
-        }
-    }
-    /* lane = dof: Jacobian columns of the two foot origins, and this dof's column of the mass matrix */
-    if (lane < CM_MAXV) {
-        const int k = lane;
-        for (int side = 0; side < 2; ++side) {
-            const int foot = io.ids[side];
-            double jp[3] = {0, 0, 0}, jr[3] = {0, 0, 0};
-            if (k < nv && foot > 0 && ((m->body_dofmask[foot] >> k) & 1ull)) {
-                const double *cm = ex->subtree_com[m->body_rootid[foot]];
-                double off[3] = {xpos[3 * foot] - cm[0], xpos[3 * foot + 1] - cm[1], xpos[3 * foot + 2] - cm[2]}, t[3];
-                double cd[6];
-                for (int i = 0; i < 6; ++i) cd[i] = ex->cdof[k][i];
-                cross3(t, cd, off);
-                for (int i = 0; i < 3; ++i) { jp[i] = cd[3 + i] + t[i]; jr[i] = cd[i]; }
-            }
-            for (int i = 0; i < 3; ++i) {
-                out[CM_DRV_FOOT_JACP + (side * 3 + i) * CM_MAXV + k] = jp[i];
-                out[CM_DRV_FOOT_JACR + (side * 3 + i) * CM_MAXV + k] = jr[i];
-            }
-        }
-        if (io.qM && k < nv) {
-            double *Mo = io.qM + (size_t)env * nv * nv;
-            for (int i = 0; i < nv; ++i) Mo[(size_t)i * nv + k] = ex->qM[i][k];
-        }
-    }
-}
-
-WV_GLOBAL void __launch_bounds__(WV_WAVE) cassie_derive_kernel(DeriveIO io) {
-    const int env = wv::env_id();
-    if (env >= io.nenv) return;
-    derive_env(io, env, wv::lane());
 }
 
 }  // namespace ck

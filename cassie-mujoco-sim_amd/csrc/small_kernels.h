@@ -1,0 +1,190 @@
+/*
+ * small_kernels.h -- the kernels around the step kernel (physics_kernel.h): the longest-job-first launch order, the
+ * drive-level pass on its own, the batched derived getters.  Included by phys_batch.hip (which launches them) and by the
+ * CPU wave emulator; the step kernel's own translation units (kernels_*.hip) do not need them.
+ */
+#ifndef CASSIE_SMALL_KERNELS_H
+#define CASSIE_SMALL_KERNELS_H
+
+#include "physics_kernel.h"
+
+namespace ck {
+
+/* Longest-job-first launch order.  A launch is nenv independent jobs (one env x nsub substeps each) handed to the
+ * chip's wave slots in workgroup order; with only a few jobs per slot -- 4096 envs on 1024 SIMDs -- the launch ends
+ * when the unluckiest slot does, measured ~15 % after the average one.  An env's cost persists from launch to launch
+ * (it is its contact situation), so the next launch starts the expensive envs first and lets the cheap ones fill the
+ * tail.  One workgroup: counting sort of the envs by the cost of their last launch into NBIN bins, descending; the
+ * order inside a bin is arbitrary, which is harmless -- envs are independent and every env is stepped exactly once. */
+constexpr int ORDER_THREADS = 1024, ORDER_NBIN = 256;
+WV_GLOBAL void __launch_bounds__(ORDER_THREADS) cassie_order_kernel(const unsigned *cost, int *order, int nenv) {
+#ifndef CK_EMULATED
+    __shared__ unsigned lo_s, hi_s, count[ORDER_NBIN], start[ORDER_NBIN];
+    const int t = threadIdx.x;
+    if (t == 0) { lo_s = 0xffffffffu; hi_s = 0; }
+    if (t < ORDER_NBIN) count[t] = 0;
+    __syncthreads();
+    unsigned lo = 0xffffffffu, hi = 0;
+    for (int e = t; e < nenv; e += ORDER_THREADS) { const unsigned c = cost[e]; lo = c < lo ? c : lo; hi = c > hi ? c : hi; }
+    atomicMin(&lo_s, lo); atomicMax(&hi_s, hi);
+    __syncthreads();
+    lo = lo_s; hi = hi_s;
+    const float scale = hi > lo ? (float)(ORDER_NBIN - 1) / (float)(hi - lo) : 0.0f;
+    auto bin_of = [&](unsigned c) { return ORDER_NBIN - 1 - (int)((float)(c - lo) * scale); }; /* bin 0 = most expensive */
+    for (int e = t; e < nenv; e += ORDER_THREADS) atomicAdd(&count[bin_of(cost[e])], 1u);
+    __syncthreads();
+    if (t == 0) { unsigned acc = 0; for (int b = 0; b < ORDER_NBIN; ++b) { start[b] = acc; acc += count[b]; } }
+    __syncthreads();
+    for (int e = t; e < nenv; e += ORDER_THREADS) order[atomicAdd(&start[bin_of(cost[e])], 1u)] = e;
+#endif
+}
+
+/* The drive-level pass on its own, one wave per env: cassie_motor_data + cassie_sensor_data for every env on the
+ * sensordata / actuator_velocity the last physics step left in HBM; writes ctrl (for the next physics launch), the
+ * measurement block and the drive state.  The batched host API launches it ahead of the physics kernel so that the
+ * measurements reach the host -- and the state estimators start -- while the physics is still running. */
+struct DriveShared {
+    double sens[CM_MAXSENSORDATA], actvel[CM_MAXU], ctrl[CM_MAXU];
+    int drv_x[CM_NUM_DRIVES][CM_DRIVE_FILTER_NB];
+    double drv_jx[CM_NUM_JOINTS][CM_JOINT_FILTER_NB], drv_jy[CM_NUM_JOINTS][CM_JOINT_FILTER_NA];
+    double drv_delay[CM_NUM_DRIVES][CM_TORQUE_DELAY_CYCLES];
+    double drv_pos[CM_NUM_DRIVES], drv_vel[CM_NUM_DRIVES];
+};
+
+WV_GLOBAL void __launch_bounds__(WV_WAVE) cassie_drive_kernel(PhysIO io, double *ctrl_out) {
+    WV_SHARED DriveShared S;
+    const int env = wv::env_id();
+    if (env >= io.nenv) return;
+    const ModelPtr m = (ModelPtr)(io.models + (size_t)env * io.model_stride);
+    const int lane = wv::lane(), nu = m->nu;
+    if (lane < m->nsensordata) S.sens[lane] = io.sensordata[(size_t)env * io.ssd + lane];
+    if (lane < nu) S.actvel[lane] = io.actuator_velocity[(size_t)env * io.su + lane];
+    drive_state_load(io, S, env, lane);
+    wv::sync();
+    drive_level_io(io, S, m, env, lane, true);
+    wv::sync();
+    drive_state_store(io, S, env, lane);
+    if (lane < nu) ctrl_out[(size_t)env * io.su + lane] = S.ctrl[lane];
+}
+
+/* ------------------------------------------------ derived getters, batched ---- */
+/* What the reference's reward-side getters compute from mjData, for one env from the read-out (cm_ext_t) a forward
+ * pass left in HBM: whole-model centre of mass, its velocity, angular momentum about it (reference
+ * src/cassiemujoco.c:1632-1700), foot positions / velocities (:1604-1630, :1752-1770), foot and heel / toe contact
+ * forces (:1812-1898), the feet's Jacobians (:1254-1301) and the dense mass matrix (:1702-1712).  Same arithmetic as
+ * the single-simulator getters in csrc/cassiemujoco.c.  ids: left / right foot body, left / right heel site, left /
+ * right toe site (-1 = the model has none). */
+struct DeriveIO {
+    const cm_model_t *models; int model_stride; int nenv;
+    const cm_ext_t *ext;
+    const double *xpos, *xquat;   /* [nenv][nbody][3], [nenv][nbody][4] */
+    double *derived;              /* [nenv][CM_DRV_DIM] */
+    double *qM;                   /* [nenv][nv][nv] or null */
+    int ids[6];
+};
+
+WV_DEVICE void derive_env(const DeriveIO &io, int env, int lane) {
+    const ModelPtr m = (ModelPtr)(io.models + (size_t)env * io.model_stride);
+    const cm_ext_t *ex = io.ext + env;
+    const int nb = m->nbody, nv = m->nv;
+    double *out = io.derived + (size_t)env * CM_DRV_DIM;
+    const double *xpos = io.xpos + (size_t)env * nb * 3, *xquat = io.xquat + (size_t)env * nb * 4;
+    /* lane = body: mass-weighted sums */
+    const bool isb = lane > 0 && lane < nb;
+    const int b = isb ? lane : 0;
+    const double mb = isb ? m->body_mass[b] : 0.0;
+    double xi[3], vb[3] = {0, 0, 0}, w[3] = {0, 0, 0};
+    for (int i = 0; i < 3; ++i) xi[i] = ex->xipos[b][i];
+    if (isb) {
+        const double *cv = ex->cvel[b], *rc = ex->subtree_com[m->body_rootid[b]];
+        double off[3] = {xi[0] - rc[0], xi[1] - rc[1], xi[2] - rc[2]}, t[3];
+        for (int i = 0; i < 3; ++i) w[i] = cv[i];
+        cross3(t, w, off);
+        for (int i = 0; i < 3; ++i) vb[i] = cv[3 + i] + t[i];
+    }
+    const double M = wv::wave_sum(mb), Mi = M > 0 ? 1.0 / M : 0.0;
+    double com[3], vcom[3];
+    for (int i = 0; i < 3; ++i) { com[i] = wv::wave_sum(mb * xi[i]) * Mi; vcom[i] = wv::wave_sum(mb * vb[i]) * Mi; }
+    /* angular momentum about the whole-model com: spin R diag(I) R^T w + orbital r x m (v - vcom) */
+    double L[3] = {0, 0, 0};
+    if (isb) {
+        double q[4], R[9], iq[4] = {m->body_iquat[b][0], m->body_iquat[b][1], m->body_iquat[b][2], m->body_iquat[b][3]};
+        double xq[4] = {xquat[4 * b], xquat[4 * b + 1], xquat[4 * b + 2], xquat[4 * b + 3]};
+        mulquat(q, xq, iq);
+        quat2mat(R, q);
+        double wl[3];
+        mulmatTvec3(wl, R, w);
+        for (int i = 0; i < 3; ++i) wl[i] *= m->body_inertia[b][i];
+        mulmatvec3(L, R, wl);
+        double r[3], mv[3], t[3];
+        for (int i = 0; i < 3; ++i) { r[i] = xi[i] - com[i]; mv[i] = mb * (vb[i] - vcom[i]); }
+        cross3(t, r, mv);
+        for (int i = 0; i < 3; ++i) L[i] += t[i];
+    }
+    for (int i = 0; i < 3; ++i) L[i] = wv::wave_sum(L[i]);
+    if (lane == 0) {
+        for (int i = 0; i < 3; ++i) { out[CM_DRV_COM_POS + i] = com[i]; out[CM_DRV_COM_VEL + i] = vcom[i]; out[CM_DRV_ANGMOM + i] = L[i]; }
+        out[CM_DRV_MASS] = M;
+    }
+    /* lane = side: foot kinematics and contact forces */
+    if (lane < 2) {
+        const int side = lane, foot = io.ids[side], heel = io.ids[2 + side], toe = io.ids[4 + side];
+        const double off = sqrt(0.01762 * 0.01762 + 0.05219 * 0.05219); /* foot joint to mid-foot (reference :1612) */
+        for (int i = 0; i < 3; ++i) out[CM_DRV_FOOT_POS + 3 * side + i] = (foot > 0 ? xpos[3 * foot + i] : 0.0) - (i == 2 ? off : 0.0);
+        for (int i = 0; i < 6; ++i) out[CM_DRV_FOOT_VEL + 6 * side + i] = foot > 0 ? ex->cvel[foot][i] : 0.0;
+        double ff[3] = {0, 0, 0}, tf[3] = {0, 0, 0}, hf[3] = {0, 0, 0};
+        for (int c = 0; c < ex->ncon; ++c) {
+            const int b1 = ex->con_body1[c], b2 = ex->con_body2[c];
+            if (b1 != foot && b2 != foot) continue;
+            const double *fr = ex->con_frame[c], *f = ex->con_force[c];
+            const double sgn = (b1 == foot) ? -1.0 : 1.0;
+            double fw[3];
+            for (int k = 0; k < 3; ++k) fw[k] = fr[k] * f[0] + fr[3 + k] * f[1] + fr[6 + k] * f[2];
+            for (int k = 0; k < 3; ++k) ff[k] += sgn * fw[k];
+            if (heel >= 0 && toe >= 0 && heel < CM_MAXSITE && toe < CM_MAXSITE) {
+                const double *p = ex->con_pos[c], *tp = ex->site_xpos[toe], *hp = ex->site_xpos[heel];
+                const double td = sqrt((tp[0] - p[0]) * (tp[0] - p[0]) + (tp[1] - p[1]) * (tp[1] - p[1]));
+                const double hd = sqrt((hp[0] - p[0]) * (hp[0] - p[0]) + (hp[1] - p[1]) * (hp[1] - p[1]));
+                double *dst = td < hd ? tf : hf;
+                for (int k = 0; k < 3; ++k) dst[k] += sgn * fw[k];
+            }
+        }
+        for (int k = 0; k < 3; ++k) {
+            out[CM_DRV_FOOT_FORCE + 6 * side + k] = ff[k]; out[CM_DRV_FOOT_FORCE + 6 * side + 3 + k] = 0.0;
+            out[CM_DRV_TOE_FORCE + 3 * side + k] = tf[k]; out[CM_DRV_HEEL_FORCE + 3 * side + k] = hf[k];
+        }
+    }
+    /* lane = dof: Jacobian columns of the two foot origins, and this dof's column of the mass matrix */
+    if (lane < CM_MAXV) {
+        const int k = lane;
+        for (int side = 0; side < 2; ++side) {
+            const int foot = io.ids[side];
+            double jp[3] = {0, 0, 0}, jr[3] = {0, 0, 0};
+            if (k < nv && foot > 0 && ((m->body_dofmask[foot] >> k) & 1ull)) {
+                const double *cm = ex->subtree_com[m->body_rootid[foot]];
+                double off[3] = {xpos[3 * foot] - cm[0], xpos[3 * foot + 1] - cm[1], xpos[3 * foot + 2] - cm[2]}, t[3];
+                double cd[6];
+                for (int i = 0; i < 6; ++i) cd[i] = ex->cdof[k][i];
+                cross3(t, cd, off);
+                for (int i = 0; i < 3; ++i) { jp[i] = cd[3 + i] + t[i]; jr[i] = cd[i]; }
+            }
+            for (int i = 0; i < 3; ++i) {
+                out[CM_DRV_FOOT_JACP + (side * 3 + i) * CM_MAXV + k] = jp[i];
+                out[CM_DRV_FOOT_JACR + (side * 3 + i) * CM_MAXV + k] = jr[i];
+            }
+        }
+        if (io.qM && k < nv) {
+            double *Mo = io.qM + (size_t)env * nv * nv;
+            for (int i = 0; i < nv; ++i) Mo[(size_t)i * nv + k] = ex->qM[i][k];
+        }
+    }
+}
+
+WV_GLOBAL void __launch_bounds__(WV_WAVE) cassie_derive_kernel(DeriveIO io) {
+    const int env = wv::env_id();
+    if (env >= io.nenv) return;
+    derive_env(io, env, wv::lane());
+}
+
+}  // namespace ck
+#endif

@@ -1,0 +1,36 @@
+/*
+ * step_launch.h -- the step kernel's instantiations live in translation units of their own (kernels_*.hip), one per model
+ * family, so that they compile side by side (each takes about a minute of hipcc time); phys_batch.hip picks one per launch
+ * through these functions.  Every function launches the row-capped fast instantiation first where `fast` is set and one
+ * exists (see ck::cassie_step_kernel), then the full instantiation; returns false if a launch failed.
+ */
+#ifndef CASSIE_STEP_LAUNCH_H
+#define CASSIE_STEP_LAUNCH_H
+
+#include <hip/hip_runtime.h>
+
+#include "physics_kernel.h"
+
+namespace ck {
+/* io.progress must be set when fast is; io.resume is managed here */
+bool launch_step_cassie(dim3 grid, hipStream_t s, PhysIO io, bool fast);            /* <32, TopoCassie32, 0>: plain cassie.xml */
+bool launch_step_cassie_hfield(dim3 grid, hipStream_t s, PhysIO io, bool fast);     /* <32, TopoCassie32, FEAT_HFIELD> */
+bool launch_step_cassie_all(dim3 grid, hipStream_t s, PhysIO io);                   /* <32, TopoCassie32, FEAT_ALL> */
+bool launch_step_tray(dim3 grid, hipStream_t s, PhysIO io, bool hfield);            /* <40, TopoCassieTray38, FEAT_WAVEPAIRS | FEAT_ALL> */
+bool launch_step_generic(dim3 grid, hipStream_t s, PhysIO io, bool wide);           /* <32 | 40, TopoRuntime, FEAT_ALL> */
+
+template <int NVP, class TOPO, int FEAT>
+inline bool launch_fast_then_full(dim3 grid, hipStream_t s, PhysIO io, bool fast) {
+    if (fast) {
+        io.resume = 0;
+        hipLaunchKernelGGL((cassie_step_kernel<NVP, TOPO, FEAT, FAST_ROWS>), grid, dim3(WV_WAVE), 0, s, io);
+        if (hipGetLastError() != hipSuccess) return false;
+        io.resume = 1;
+    } else {
+        io.progress = nullptr; io.resume = 0;
+    }
+    hipLaunchKernelGGL((cassie_step_kernel<NVP, TOPO, FEAT>), grid, dim3(WV_WAVE), 0, s, io);
+    return hipGetLastError() == hipSuccess;
+}
+}  // namespace ck
+#endif

@@ -182,6 +182,10 @@ int phys_batch_set_all_outputs_every_substep(phys_batch_t *b, int on);
  * and the next launch starts the expensive envs first, so the wave slots finish together instead of the launch waiting
  * for whichever slot drew the slow envs last.  Results do not depend on it (envs are independent). */
 int phys_batch_set_balance(phys_batch_t *b, int on);
+/* on (default): stepping launches of the Cassie instantiations run the row-capped fast kernel first and the full kernel
+ * only finishes envs that needed more than 31 constraint rows in some substep; off: the full kernel alone (same results,
+ * bit for bit -- a validation / measurement aid) */
+int phys_batch_set_fast_rows(phys_batch_t *b, int on);
 
 /* validation aid: fills every CU's LDS with NaN bit patterns before the next launch (LDS is neither initialised nor
  * cleared between kernels) -- a step kernel that read LDS it had not written would then show it */

@@ -9,7 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 
-#include "physics_kernel.h"
+#include "small_kernels.h"
 
 namespace {
 constexpr int NL = 64;
@@ -152,6 +152,12 @@ extern "C" unsigned long emu_offsetof32(int which) {
 }
 static int g_force_runtime_topology = 0;
 static void body32s() { ck::cassie_step_kernel<32, ck::TopoCassie32>(g_io); }
+static void body32s_fast() { ck::cassie_step_kernel<32, ck::TopoCassie32, ck::FEAT_ALL, ck::FAST_ROWS>(g_io); }
+/* the row-capped fast instantiation ahead of the full one, as phys_batch.hip launches them (PhysIO::progress / resume);
+ * g_fast_bails counts the envs the fast instantiation handed over */
+static int g_fast_rows = 0, g_fast_bails = 0;
+extern "C" void emu_fast_rows(int on) { g_fast_rows = on; }
+extern "C" int emu_fast_bails(void) { return g_fast_bails; }
 static void body40s() { ck::cassie_step_kernel<40, ck::TopoCassieTray38>(g_io); }
 static void body32() { ck::cassie_step_kernel<32, ck::TopoRuntime>(g_io); }
 static void body40() { ck::cassie_step_kernel<40, ck::TopoRuntime>(g_io); }
@@ -190,7 +196,17 @@ extern "C" int emu_phys_run(const cm_model_t *model, int nenv, int nsub, int int
     g_io.pd_dtarget = g_pd_dtarget; g_io.pd_torque = g_pd_torque;
     for (int e = 0; e < nenv; ++e) {
         g_env = e;
-        if (!g_force_runtime_topology && topo_matches(model, ck::TopoCassie32::table, ck::TopoCassie32::nv)) run_block(body32s);
+        if (!g_force_runtime_topology && topo_matches(model, ck::TopoCassie32::table, ck::TopoCassie32::nv)) {
+            static int progress[1 << 16];
+            if (g_fast_rows && integrate && e < (1 << 16)) {
+                g_io.progress = progress; g_io.resume = 0;
+                run_block(body32s_fast);
+                if (progress[e] < nsub) ++g_fast_bails;
+                g_io.resume = 1;
+            }
+            run_block(body32s);
+            g_io.progress = nullptr; g_io.resume = 0;
+        }
         else if (!g_force_runtime_topology && topo_matches(model, ck::TopoCassieTray38::table, ck::TopoCassieTray38::nv)) run_block(body40s);
         else run_block(model->nv <= 32 ? body32 : body40);
     }

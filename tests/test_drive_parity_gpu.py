@@ -207,3 +207,51 @@ def test_stress_variant_pm10_rad_targets(built, name):
     finally:
         b.close()
         oracle_py.set_hfield(None)
+
+
+@pytest.mark.parametrize("name,mode", [("cassie", "exact"), ("cassie", "drive"), ("cassie_hfield", "drive")])
+def test_row_capped_fast_kernel_equals_the_full_kernel_bit_for_bit(built, name, mode):
+    """Stepping launches of the Cassie instantiations run the row-capped fast kernel (31 rows) first; the full kernel behind it
+    finishes the envs that met a substep with more rows (PhysIO::progress).  Under the +-10 rad stress targets thousands of
+    envs are handed over in the middle of a fused launch: state, outputs, solver statistics, measurement block and drive
+    state must be BIT FOR BIT what the full kernel alone produces."""
+    model = Model(name)
+    n, npol = 2048, 10
+    hf = G.terrain(name)
+    tg = _stress_targets(np.arange(n), npol)
+    q0 = np.tile(model.qpos_init(), (n, 1))
+    if name == "cassie_hfield":
+        for e in range(n):
+            q0[e, 0], q0[e, 1] = G.start_xy(name, e)
+    out = []
+    for fast in (False, True):
+        b = Batch(model, n)
+        try:
+            b.set_fast_rows(fast)
+            if hf is not None:
+                b.set_hfield(hf)
+            b.set(P.F_QPOS, q0)
+            b.set(P.F_PD_KP, np.tile(bench.PD_KP, (n, 1)))
+            b.set(P.F_PD_KD, np.tile(bench.PD_KD, (n, 1)))
+            if mode == "drive":
+                b.forward()
+                b.set_drive_mode(P.DRIVE_PD)
+            else:
+                b.set_pd_mode(True)
+            rows = []
+            for p in range(npol):
+                b.set(P.F_PD_PTARGET, tg[p])
+                b.step(bench.HOLD)
+                rows.append(b.warnings()[1][:, 1].copy())
+            w, info = b.warnings()
+            rec = [b.get(P.F_QPOS), b.get(P.F_QVEL), b.get(P.F_QACC_WARMSTART), b.get(P.F_SENSORDATA), b.get(P.F_TIME), w, info[:, :3].copy(), np.array(rows)]
+            if mode == "drive":
+                rec += [b.get(P.F_MEAS), b.get(P.F_CTRL)] + [np.frombuffer(b"".join(device_state_bytes(s)), dtype=np.uint8) for s in b.get_drive_state(0, 64)]
+            out.append(rec)
+        finally:
+            b.close()
+    rows = out[0][7]
+    assert rows.max() > 31 and np.count_nonzero(rows.max(axis=0) > 31) > 100      # many envs passed the fast kernel's capacity ...
+    assert np.count_nonzero(rows.max(axis=0) <= 31) > 100                          # ... and many never did
+    for a, c in zip(out[0], out[1]):
+        assert a.tobytes() == c.tobytes()

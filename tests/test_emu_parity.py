@@ -302,3 +302,50 @@ def test_packed_factor_rows_address_the_same_slots_from_every_side(built):
     assert lib.emu_lpack_check() == 0
     assert lib.emu_lpack_count(0) == 32 * 33 // 2          # cassie.xml keeps the full triangle (index = base + immediate)
     assert lib.emu_lpack_count(1) == 392                   # 15 trunk + 2 x 156 leg + 51 cube + 13 padding + 1 dump slot
+
+
+@pytest.mark.parametrize("drive", [False, True])
+def test_row_capped_fast_kernel_hands_over_mid_launch_and_changes_nothing(cassie, drive):
+    """The row-capped fast instantiation (31 rows) ahead of the full one, as phys_batch.hip launches them: an env that
+    meets a substep with more rows in the MIDDLE of a fused launch is handed over through PhysIO::progress and finished by
+    the full instantiation.  State, outputs, solver statistics and (drive mode) filter histories / delay lines must be bit
+    for bit those of the full instantiation alone.  Workload: the +-10 rad stress targets, which push joints into their
+    limits within the first launches (rows pass 31 while the robot is still on its feet)."""
+    import bench
+    import emu_py
+    from cassie_amd import phys as P
+    from hostchain_py import device_state_bytes
+    pod = cassie.pod
+    n = 3
+    tg = np.empty((6, n, 10))
+    for e in range(n):
+        tg[:, e, :] = bench.PD_OFFSET + np.random.default_rng(4321 + e).uniform(-10, 10, (6, 10))
+    out, bails = [], 0
+    for fast in (0, 1):
+        emu_py.lib().emu_fast_rows(fast)
+        try:
+            emu = EmuBatch(pod, n)
+            emu.qpos[:] = cassie.qpos_init()
+            emu.qpos[:, 2] -= 0.2                               # start in contact so that rows are plenty from the first step
+            emu.pd_kp, emu.pd_kd = np.tile(bench.PD_KP, (n, 1)), np.tile(bench.PD_KD, (n, 1))
+            if drive:
+                emu.forward()
+                emu.drive_mode = P.DRIVE_PD
+            rows = []
+            for p in range(6):
+                emu.pd_ptarget = np.ascontiguousarray(tg[p])
+                emu.step(25)
+                rows.append(emu.info[:, 1].copy())
+            out.append((emu.qpos.copy(), emu.qvel.copy(), emu.qacc_warmstart.copy(), emu.sensordata.copy(), emu.meas.copy(), emu.info.copy(),
+                        emu.warn.copy(), emu.time.copy(), [device_state_bytes(emu.drive_state[e]) for e in range(n)], np.array(rows)))
+            if fast:
+                bails = emu_py.lib().emu_fast_bails()
+        finally:
+            emu_py.lib().emu_fast_rows(0)
+    assert out[0][9].max() > 31 and out[0][9].min() <= 31          # launches on both sides of the fast kernel's capacity
+    assert bails > 0                                                # and the hand-over really happened
+    for a, b in zip(out[0], out[1]):
+        if isinstance(a, list):
+            assert a == b
+        else:
+            assert a.tobytes() == b.tobytes()
