@@ -218,6 +218,13 @@ class Batch:
         """Row-capped fast kernel ahead of the full one (default on; results are bit for bit the same either way)."""
         lib().phys_batch_set_fast_rows(self._h, 1 if on else 0)
 
+    def fast_rows_progress(self):
+        """Substeps of the last stepping launch the fast kernel completed per env (< the launch's count: handed over there)."""
+        out = np.zeros(self.nenv, dtype=np.int32)
+        if lib().phys_batch_download_progress(self._h, out.ctypes.data) != 0:
+            raise RuntimeError("progress download failed")
+        return out
+
     def set_all_outputs_every_substep(self, on=True):
         """Measurement aid: every substep of a fused launch evaluates every output (IMU sensors, body quaternions), not only
         the substeps whose values can be read."""

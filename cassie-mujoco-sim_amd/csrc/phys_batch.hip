@@ -591,6 +591,13 @@ int phys_batch_set_all_outputs_every_substep(phys_batch_t *b, int on) {
     return 0;
 }
 
+int phys_batch_download_progress(phys_batch_t *b, int *host) {
+    if (!b || !host || !b->d_progress) return -1;
+    (void)hipSetDevice(b->device);
+    if (!quiesce(b)) return -1;
+    return hip_ok(hipMemcpy(host, b->d_progress, sizeof(int) * (size_t)b->nenv, hipMemcpyDeviceToHost), "progress download") ? 0 : -1;
+}
+
 int phys_batch_set_fast_rows(phys_batch_t *b, int on) {
     if (!b) return -1;
     b->fast_rows = on != 0;

@@ -2212,6 +2212,52 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
 
         /* ================= P9: this lane's row of A = Y^T Y + diag(R), b = Y^T y63 - aref ================= */
         double arow[MAXR];
+        double diag_yy = 0; /* this lane's row of Y with itself (the split path below forms it with the rows) */
+        /* The row-capped instantiation has at most 31 rows, so lanes 32 .. 62 hold none: the two halves of the wave share
+         * every dot product.  Lane r takes the terms k = 0, 1 (mod 4), lane r + 32 the terms k = 2, 3 (mod 4) of row r's
+         * products -- exactly the accumulators a0 + a1 and a2 + a3 of the full instantiation below -- and the halves are
+         * exchanged once, for all rows together: half the broadcast LDS reads and half the FMAs per row, and the sums are
+         * associated exactly as below, so the results are the same bit for bit. */
+        constexpr bool split_rows = MAXR <= 31 && NVP % 4 == 0;
+        if constexpr (split_rows) {
+            const int half = lane >> 5, myrow = lane & 31; /* (lane 31 / 63 "work for" row 31 = the qfrc_smooth column: unused) */
+            constexpr int NJ = NVP / 4;
+            double yc[NJ][2];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) { yc[j][0] = S.x.Yr[myrow][4 * j + 2 * half]; yc[j][1] = S.x.Yr[myrow][4 * j + 2 * half + 1]; }
+            double part[MAXR + 1];
+#pragma unroll
+            for (int r = 0; r < MAXR; r += 2) {
+                double p0 = 0, p1 = 0;
+                if (r < nefc) {
+                    double ya[NJ][2], yb[NJ][2];
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) { ya[j][0] = S.x.Yr[r][4 * j + 2 * half]; ya[j][1] = S.x.Yr[r][4 * j + 2 * half + 1]; }
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) { yb[j][0] = S.x.Yr[r + 1 < MAXR ? r + 1 : r][4 * j + 2 * half]; yb[j][1] = S.x.Yr[r + 1 < MAXR ? r + 1 : r][4 * j + 2 * half + 1]; }
+                    wv::sched_fence();
+                    double a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) { a0 += ya[j][0] * yc[j][0]; a1 += ya[j][1] * yc[j][1]; }
+                    p0 = a0 + a1;
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) { b0 += yb[j][0] * yc[j][0]; b1 += yb[j][1] * yc[j][1]; }
+                    p1 = b0 + b1;
+                }
+                part[r] = p0;
+                if (r + 1 < MAXR) part[r + 1] = p1;
+            }
+            {
+                double d0 = 0, d1 = 0;
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) { d0 += yc[j][0] * yc[j][0]; d1 += yc[j][1] * yc[j][1]; }
+                part[MAXR] = d0 + d1;
+            }
+            /* one exchange for everything: lane r <-> lane r + 32 (IEEE addition commutes: both halves end up with the same sum) */
+#pragma unroll
+            for (int r = 0; r < MAXR; ++r) arow[r] = part[r] + wv::shfl_xor(part[r], 32);
+            diag_yy = part[MAXR] + wv::shfl_xor(part[MAXR], 32);
+        } else {
 #pragma unroll
         for (int r = 0; r < MAXR; r += 2) {
             /* rows in pairs: both broadcast rows are requested before the first product, so the second row's LDS latency
@@ -2252,6 +2298,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
             arow[r] = acc0;
             if (r + 1 < MAXR) arow[r + 1] = acc1;
         }
+        }
         double rb = 0;
         {
             double acc = 0;
@@ -2269,7 +2316,8 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
          * R part of a row's action on its own residual is applied once per sweep (cdiag below): a row's residual is not
          * read again between its own turn and the end of the sweep. */
         double Aii = 1.0;
-        if (isrow) {
+        if constexpr (split_rows) { if (isrow) Aii = diag_yy + rR; }
+        else if (isrow) {
             double d0 = 0, d1 = 0, d2 = 0, d3 = 0;
 #pragma unroll
             for (int k = 0; k < NVP; k += 4) {
@@ -2533,7 +2581,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
     }
 
     /* ---------------- store state ---------------- */
-    if (io.progress && lane == 0) io.progress[env] = bailed ? sub : io.nsub;
+    if (io.progress && !io.resume && lane == 0) io.progress[env] = bailed ? sub : io.nsub; /* (the resume pass leaves the record) */
     if (io.integrate && io.drive_mode) {
         drive_state_store(io, S, env, lane);
         if (lane < nu) io.ctrl[(size_t)env * io.su + lane] = S.ctrl[lane]; /* the applied torque: d->ctrl of the reference */

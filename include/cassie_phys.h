@@ -186,6 +186,9 @@ int phys_batch_set_balance(phys_batch_t *b, int on);
  * only finishes envs that needed more than 31 constraint rows in some substep; off: the full kernel alone (same results,
  * bit for bit -- a validation / measurement aid) */
 int phys_batch_set_fast_rows(phys_batch_t *b, int on);
+/* diagnostics: how many substeps of the last stepping launch the fast kernel completed for every env ([nenv] ints; less than
+ * the launch's substep count = the env was handed over to the full kernel there) */
+int phys_batch_download_progress(phys_batch_t *b, int *host);
 
 /* validation aid: fills every CU's LDS with NaN bit patterns before the next launch (LDS is neither initialised nor
  * cleared between kernels) -- a step kernel that read LDS it had not written would then show it */

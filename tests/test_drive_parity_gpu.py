@@ -216,7 +216,7 @@ def test_row_capped_fast_kernel_equals_the_full_kernel_bit_for_bit(built, name, 
     envs are handed over in the middle of a fused launch: state, outputs, solver statistics, measurement block and drive
     state must be BIT FOR BIT what the full kernel alone produces."""
     model = Model(name)
-    n, npol = 2048, 10
+    n, npol = 1024, 30
     hf = G.terrain(name)
     tg = _stress_targets(np.arange(n), npol)
     q0 = np.tile(model.qpos_init(), (n, 1))
@@ -238,11 +238,13 @@ def test_row_capped_fast_kernel_equals_the_full_kernel_bit_for_bit(built, name, 
                 b.set_drive_mode(P.DRIVE_PD)
             else:
                 b.set_pd_mode(True)
-            rows = []
+            rows, handed = [], 0
             for p in range(npol):
                 b.set(P.F_PD_PTARGET, tg[p])
                 b.step(bench.HOLD)
                 rows.append(b.warnings()[1][:, 1].copy())
+                if fast:
+                    handed += int(np.count_nonzero(b.fast_rows_progress() < bench.HOLD))
             w, info = b.warnings()
             rec = [b.get(P.F_QPOS), b.get(P.F_QVEL), b.get(P.F_QACC_WARMSTART), b.get(P.F_SENSORDATA), b.get(P.F_TIME), w, info[:, :3].copy(), np.array(rows)]
             if mode == "drive":
@@ -251,7 +253,7 @@ def test_row_capped_fast_kernel_equals_the_full_kernel_bit_for_bit(built, name, 
         finally:
             b.close()
     rows = out[0][7]
-    assert rows.max() > 31 and np.count_nonzero(rows.max(axis=0) > 31) > 100      # many envs passed the fast kernel's capacity ...
-    assert np.count_nonzero(rows.max(axis=0) <= 31) > 100                          # ... and many never did
+    print("%s %s: %d of %d env-launches were handed over to the full kernel; rows of a launch's last substep up to %d" % (name, mode, handed, n * npol, rows.max()))
+    assert 50 < handed < n * npol // 2                 # the hand-over happened often, and most launches stayed in the fast kernel
     for a, c in zip(out[0], out[1]):
         assert a.tobytes() == c.tobytes()
