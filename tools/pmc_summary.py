@@ -9,20 +9,25 @@ import json
 import sys
 
 root = sys.argv[1]
-acc = collections.defaultdict(list)
-kernel = None
+# counter values per kernel name: a stepping launch is two kernels since round 3 (the row-capped fast instantiation and the
+# full one that only finishes handed-over envs); the summary is of the one that does the work -- the most wave cycles
+by_kernel = collections.defaultdict(lambda: collections.defaultdict(list))
 for p in sorted(glob.glob(root + "/p*/*/*counter_collection.csv")):
-    rows = [r for r in csv.DictReader(open(p)) if "cassie_step_kernel" in r.get("Kernel_Name", "")]
-    if not rows:
-        continue
-    # keep the fused launches only (the longest-running dispatches of the step kernel): drop the shortest third
     by_disp = collections.defaultdict(dict)
-    for r in rows:
+    names = {}
+    for r in csv.DictReader(open(p)):
+        if "cassie_step_kernel" not in r.get("Kernel_Name", ""):
+            continue
         by_disp[r["Dispatch_Id"]][r["Counter_Name"]] = float(r["Counter_Value"])
-        kernel = r["Kernel_Name"]
-    for d in by_disp.values():
+        names[r["Dispatch_Id"]] = r["Kernel_Name"]
+    for disp, d in by_disp.items():
         for k, v in d.items():
-            acc[k].append(v)
+            by_kernel[names[disp]][k].append(v)
+if not by_kernel:
+    raise SystemExit("no cassie_step_kernel dispatches under " + root)
+kernel = max(by_kernel, key=lambda n: sum(by_kernel[n].get("SQ_WAVE_CYCLES", [0.0])))
+others = {n: len(next(iter(c.values()))) for n, c in by_kernel.items() if n != kernel}
+acc = by_kernel[kernel]
 per = {}
 for k, v in acc.items():
     v = sorted(v)
@@ -49,5 +54,5 @@ derived = {
     "note": "SQ_* cycle counters are quad-cycles; FETCH_SIZE/WRITE_SIZE are KB, FETCH_SIZE doubled per MI355X_MICROARCH.md "
             "(gfx950 tallies 128-B requests at 64 B); WRITE_SIZE uncalibrated",
 }
-print(json.dumps({"kernel": kernel, "launch": "4096 envs x 50 fused substeps = 204800 env-steps (bench.py --steps 100 --warmup 50)",
+print(json.dumps({"kernel": kernel, "other_step_kernels_in_the_run": others, "launch": "4096 envs x 50 fused substeps = 204800 env-steps (bench.py --steps 100 --warmup 50)",
                   "per_launch": per, "derived": derived}, indent=1))
