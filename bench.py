@@ -470,23 +470,18 @@ def device_rollout(model, mode, n, steps, warmup, rank, world, local_rank, subst
     else:
         b.set_pd_mode(True)
     rows_of = [np.nonzero(env_ids % NGROUP == g)[0] for g in range(NGROUP)]
-    group_rows = [torch.from_numpy(r).to(dev) for r in rows_of]
     obs_all = torch.empty((world * n, nobs), dtype=torch.float64, device=dev) if collect else None
     launch_stream = torch.cuda.Stream(device=dev)   # a real (non-null) stream: the kernel and the timing events share it
     stream = launch_stream.cuda_stream
 
     def restart(group):
-        rows = group_rows[group]
-        if not rows.numel():
+        """The envs of a phase group (rows first, first + NGROUP, ...) start a new episode: a fresh cassie_sim_t -- init pose,
+        zero velocities and warm start, zero filter histories / delay lines, the init pose's sensordata -- in one small launch
+        on the launch stream (phys_batch_reset_envs)."""
+        rows = rows_of[group]
+        if not len(rows):
             return
-        if drive:
-            obs[rows] = init_row
-            actvel[rows] = 0
-            meas[rows] = 0
-            b.clear_drive_state(int(rows_of[group][0]), NGROUP, int(rows.numel()), stream)
-        else:
-            obs[rows, : nq + nv] = init_row[: nq + nv]
-        warm[rows] = 0
+        b.reset_envs(int(rows[0]), NGROUP, len(rows), init_row.data_ptr(), init_row.data_ptr() + (nq + nv) * esz if drive else None, stream)
 
     # The all-gather runs beside the next launch: the observation block is snapshotted on the launch stream (3 MB, device
     # to device), RCCL sends the snapshot from a second stream, and the next snapshot waits for that gather to have read it.

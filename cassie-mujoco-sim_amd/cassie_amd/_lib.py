@@ -89,6 +89,8 @@ def _declare(L):
     L.phys_batch_debug_poison_lds.argtypes = [vp]
     L.phys_batch_set_balance.argtypes = [vp, c.c_int]
     L.phys_batch_set_fast_rows.argtypes = [vp, c.c_int]
+    if hasattr(L, "phys_batch_reset_envs"):
+        L.phys_batch_reset_envs.argtypes = [vp, c.c_int, c.c_int, c.c_int, vp, vp, vp]
     if hasattr(L, "phys_batch_download_progress"):   # (absent from older variant builds selected with CASSIE_LIB)
         L.phys_batch_download_progress.argtypes = [vp, vp]
     L.phys_batch_set_all_outputs_every_substep.argtypes = [vp, c.c_int]

@@ -188,6 +188,13 @@ class Batch:
         if lib().phys_batch_clear_drive_state(self._h, first, stride, count, stream) != 0:
             raise RuntimeError("clear_drive_state failed")
 
+    def reset_envs(self, first, stride, count, qpos_row_ptr, sens_row_ptr=None, stream=None):
+        """Episode restart of envs first, first + stride, ... on the device in one launch (phys_batch_reset_envs): qpos from
+        the device row `qpos_row_ptr`, velocities / warm start / ctrl / time zero, drive-level state and measurement block
+        zero, sensordata from `sens_row_ptr` if given."""
+        if lib().phys_batch_reset_envs(self._h, int(first), int(stride), int(count), qpos_row_ptr, sens_row_ptr, stream) != 0:
+            raise RuntimeError("reset_envs failed: " + (lib().phys_last_error() or b"").decode())
+
     def get_drive_state(self, env0=0, n=None):
         n = self.nenv - env0 if n is None else n
         out = (CmDriveState * n)()

@@ -520,6 +520,28 @@ int phys_batch_download_drive_state(phys_batch_t *b, cm_drive_state_t *host, int
                    hip_ok(hipStreamSynchronize(b->stream), "drive state sync") ? 0 : -1;
 }
 
+int phys_batch_reset_envs(phys_batch_t *b, int first, int stride, int count, const double *qpos_row, const double *sens_row, void *stream) {
+    if (!b || !qpos_row || first < 0 || stride < 1 || count < 0 || (count > 0 && first + (size_t)(count - 1) * stride >= (size_t)b->nenv)) return -1;
+    (void)hipSetDevice(b->device);
+    if (count == 0) return 0;
+    const cm_model_t &m = b->host_model;
+    ck::ResetIO io;
+    memset(&io, 0, sizeof io);
+    io.first = first; io.stride = stride; io.count = count;
+    io.nq = m.nq; io.nv = m.nv; io.nu = m.nu; io.nsd = m.nsensordata;
+    io.sq = b->stride[PHYS_F_QPOS]; io.sqv = b->stride[PHYS_F_QVEL]; io.ssd = b->stride[PHYS_F_SENSORDATA];
+    io.qpos = b->d_field[PHYS_F_QPOS]; io.qvel = b->d_field[PHYS_F_QVEL]; io.warm = b->d_field[PHYS_F_QACC_WARMSTART];
+    io.ctrl = b->d_field[PHYS_F_CTRL]; io.qacc = b->d_field[PHYS_F_QACC]; io.time = b->d_field[PHYS_F_TIME];
+    io.sens = b->d_field[PHYS_F_SENSORDATA]; io.actvel = b->d_field[PHYS_F_ACTUATOR_VELOCITY];
+    io.meas = b->d_drive ? b->d_field[PHYS_F_MEAS] : nullptr;
+    io.drive = b->d_drive;
+    io.qpos_row = qpos_row; io.sens_row = sens_row;
+    hipStream_t s = stream ? (hipStream_t)stream : b->stream;
+    b->last_stream = s;
+    hipLaunchKernelGGL(ck::cassie_reset_kernel, dim3(count), dim3(WV_WAVE), 0, s, io);
+    return hip_ok(hipGetLastError(), "cassie_reset_kernel launch") ? 0 : -1;
+}
+
 int phys_batch_sync(phys_batch_t *b) {
     if (!b) return -1;
     (void)hipSetDevice(b->device);

@@ -186,5 +186,35 @@ WV_GLOBAL void __launch_bounds__(WV_WAVE) cassie_derive_kernel(DeriveIO io) {
     derive_env(io, env, wv::lane());
 }
 
+/* Episode restarts on the device (the batched form of what a fresh cassie_sim_t / cassie_sim_full_reset leaves, reference
+ * src/cassiemujoco.c:1023-1029, :2008-2034): envs first, first + stride, ... (count of them) get qpos = qpos_row, zero
+ * qvel / qacc_warmstart / ctrl / qacc / actuator_velocity / time, optionally sensordata = sens_row (what the first drive-level
+ * pass of the new episode reads: the init pose's), a zero measurement block and zero drive-level state (encoder filter
+ * histories, torque delay lines) -- one launch instead of a scatter per field.  The sticky warning word is left alone. */
+struct ResetIO {
+    int first, stride, count;
+    int nq, nv, nu, nsd, sq, sqv, ssd;
+    double *qpos, *qvel, *warm, *ctrl, *qacc, *time, *sens, *actvel, *meas;
+    cm_drive_state_t *drive;    /* may be null */
+    const double *qpos_row;     /* [nq] */
+    const double *sens_row;     /* [nsensordata] or null: sensordata is left alone */
+};
+WV_GLOBAL void __launch_bounds__(WV_WAVE) cassie_reset_kernel(ResetIO io) {
+    const int i = wv::env_id();
+    if (i >= io.count) return;
+    const size_t env = (size_t)io.first + (size_t)i * io.stride;
+    const int lane = wv::lane();
+    if (lane < io.nq) io.qpos[env * io.sq + lane] = io.qpos_row[lane];
+    if (lane < io.nv) { io.qvel[env * io.sqv + lane] = 0.0; io.warm[env * io.nv + lane] = 0.0; io.qacc[env * io.nv + lane] = 0.0; }
+    if (lane < io.nu) { io.ctrl[env * io.nu + lane] = 0.0; io.actvel[env * io.nu + lane] = 0.0; }
+    if (io.sens_row && lane < io.nsd) io.sens[env * io.ssd + lane] = io.sens_row[lane];
+    if (io.meas && lane < CM_MEAS_DIM) io.meas[env * CM_MEAS_DIM + lane] = 0.0;
+    if (io.drive) {
+        int *w = (int *)(io.drive + env);
+        for (int k = lane; k < (int)(sizeof(cm_drive_state_t) / sizeof(int)); k += WV_WAVE) w[k] = 0;
+    }
+    if (lane == 0) io.time[env] = 0.0;
+}
+
 }  // namespace ck
 #endif

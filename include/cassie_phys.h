@@ -123,6 +123,13 @@ int phys_batch_uses_applied(const phys_batch_t *b);
 int phys_batch_step(phys_batch_t *b, int nsub, void *stream);
 /* mj_forward (reference :971, :1029, :1223, :3293): no integration */
 int phys_batch_forward(phys_batch_t *b, void *stream);
+/* Episode restarts without leaving the device -- the batched form of what a fresh cassie_sim_t / cassie_sim_full_reset
+ * leaves (reference src/cassiemujoco.c:1023-1029, :2008-2034): envs first, first + stride, ... (count of them) get
+ * qpos = qpos_row [nq] (DEVICE pointer), zero qvel / qacc_warmstart / ctrl / qacc / actuator_velocity / time and -- once a drive mode is in use -- a zero measurement block and zero drive-level state (encoder filter histories,
+ * torque delay lines); sens_row [nsensordata] (device pointer or NULL) becomes their sensordata: the init pose's, which the
+ * new episode's first drive-level pass reads.  The sticky warning word stays (phys_batch_clear_warn).  One small launch on
+ * `stream`, ordered with the step launches there. */
+int phys_batch_reset_envs(phys_batch_t *b, int first, int stride, int count, const double *qpos_row, const double *sens_row, void *stream);
 /* the read-out half of mj_forward -- what the reference's getters obtain from mj_kinematics / mj_comPos / mj_comVel /
  * mj_fwdPosition (reference src/cassiemujoco.c:1223-1301, :1604-1770): xpos / xquat / the ext read-out / body_cfrc of the
  * current state, while the fields qacc, sensordata and actuator_velocity keep what the last STEP left (the encoder and

@@ -257,3 +257,46 @@ def test_row_capped_fast_kernel_equals_the_full_kernel_bit_for_bit(built, name, 
     assert 50 < handed < n * npol // 2                 # the hand-over happened often, and most launches stayed in the fast kernel
     for a, c in zip(out[0], out[1]):
         assert a.tobytes() == c.tobytes()
+
+
+def test_device_reset_equals_a_fresh_batch(cassie):
+    """phys_batch_reset_envs: envs restarted on the device continue bit for bit like envs of a fresh batch (the benchmark's
+    episode restarts; reference src/cassiemujoco.c:1023-1029 / :2008-2034 role), in the drive mode whose state the reset also
+    has to clear (filter histories, delay lines, measurement block), and the other envs are untouched."""
+    import torch
+    n = 64
+    tg = bench.pd_targets(np.arange(n), 4)
+    dev = torch.device("cuda", 0)
+    q_init = cassie.qpos_init()
+    sens_init = bench.HostChainEnvs(cassie, [0]).init_sensordata()
+
+    def make():
+        b = Batch(cassie, n)
+        b.set(P.F_QPOS, np.tile(q_init, (n, 1)))
+        b.forward()
+        b.set(P.F_PD_KP, np.tile(bench.PD_KP, (n, 1)))
+        b.set(P.F_PD_KD, np.tile(bench.PD_KD, (n, 1)))
+        b.set_drive_mode(P.DRIVE_PD)
+        return b
+    a = make()
+    for p in range(2):                                    # 100 steps: every env is somewhere else, filters and delay lines are full
+        a.set(P.F_PD_PTARGET, tg[p]); a.step(50)
+    before = a.get(P.F_QPOS).copy()
+    rows = torch.from_numpy(np.concatenate([q_init, sens_init])).to(dev)
+    first, stride, count = 3, 5, 12                       # envs 3, 8, ..., 58 restart
+    a.reset_envs(first, stride, count, rows.data_ptr(), rows.data_ptr() + 8 * len(q_init))
+    a.sync()
+    restarted = np.arange(first, first + stride * count, stride)
+    others = np.setdiff1d(np.arange(n), restarted)
+    assert np.array_equal(a.get(P.F_QPOS)[others], before[others])
+    assert np.array_equal(a.get(P.F_QPOS)[restarted], np.tile(q_init, (count, 1))) and not a.get(P.F_QVEL)[restarted].any()
+    fresh = make()
+    for p in range(2, 4):                                 # the restarted envs now run episode step 0..99 with targets 2, 3 -- like a fresh batch given those targets
+        a.set(P.F_PD_PTARGET, tg[p]); a.step(50)
+        fresh.set(P.F_PD_PTARGET, tg[p]); fresh.step(50)
+    for f in (P.F_QPOS, P.F_QVEL, P.F_SENSORDATA, P.F_MEAS, P.F_QACC_WARMSTART):
+        assert a.get(f)[restarted].tobytes() == fresh.get(f)[restarted].tobytes(), f
+    sa, sf = a.get_drive_state(), fresh.get_drive_state()
+    for e in restarted:
+        assert device_state_bytes(sa[int(e)]) == device_state_bytes(sf[int(e)])
+    a.close(); fresh.close()
