@@ -82,6 +82,7 @@ def shard_env_ids(rank, world, envs_per_rank):
 
 ENVS_PER_GPU_SINGLE = 4096          # BASELINE configs[1]: the headline, one GPU
 ENVS_PER_GPU_SHARDED = 8192         # BASELINE configs[2]: 65536 envs sharded over 8 GPUs
+STREAMS = 2                         # env ranges per rank, each stepped on its own stream (see device_rollout)
 REPEATS = 10                        # fenced timed regions of exactly --steps steps each; `value` is their median
 REPLAY_BUDGET_STEPS = 2200          # the CPU replay follows the schedule up to the last region boundary within this many steps
 
@@ -404,8 +405,22 @@ class HostChainEnvs:
         return self.orcs[0].sensordata.copy()
 
 
+def half_ranges(n, nstreams):
+    """Contiguous env ranges [(first, count)] a rank's batch is stepped in, one per stream (the last takes the remainder)."""
+    k = max(1, min(int(nstreams), n))
+    base = n // k
+    return [(i * base, base if i < k - 1 else n - i * base) for i in range(k)]
+
+
+def rows_of_group_in_range(group, global_first, first, count):
+    """Rows of the range [first, first + count) whose global env id (global_first + row) is in phase group `group`:
+    (first row, number of rows), the rows being NGROUP apart."""
+    r0 = first + (group - (global_first + first)) % NGROUP
+    return r0, len(range(r0, first + count, NGROUP))
+
+
 def device_rollout(model, mode, n, steps, warmup, rank, world, local_rank, substeps_per_launch=HOLD, parity_envs=64, hfield=None, collect=None,
-                   all_outputs=False, repeats=1):
+                   all_outputs=False, repeats=1, nstreams=1):
     """One device-resident rollout of the workload in `mode`, timed as `repeats` fenced regions of exactly `steps` steps:
 
       "drive-pd"  CM_DRIVE_PD: every substep runs pd_input's motor PD on the ENCODER measurements of the
@@ -414,6 +429,11 @@ def device_rollout(model, mode, n, steps, warmup, rank, world, local_rank, subst
                   cassie_sim_step_pd, bit for bit the host chain of csrc/cassie_hostpath.c, minus the closed Agility blocks'
                   safety layer and estimator.  An episode restart is a fresh cassie_sim_t (init pose, zero filters / delays).
       "exact-pd"  the PD law on the exact joint state + the motor's speed-torque limit, no delay, no quantisation.
+
+    nstreams > 1: the rank's batch is stepped as that many contiguous env ranges, each on its own stream at its own pace
+    (phys_batch_step_range): the CPU issues policy step p of every range, then p + 1, ..., but nothing on the device joins the
+    ranges between policy steps, so one range's workgroups fill the wave slots the other leaves idle at the end and the
+    start of its launches.  Restarts, PD targets and (N > 1) the observation all-gather are per range.
 
     State and inputs are resident in HBM before the timed regions.  Every region is bracketed by barrier +
     torch.cuda.synchronize on both sides; a region's time is the maximum over the ranks.  Sampled envs of EVERY rank are
@@ -469,41 +489,48 @@ def device_rollout(model, mode, n, steps, warmup, rank, world, local_rank, subst
         b.set_drive_mode(P.DRIVE_PD)
     else:
         b.set_pd_mode(True)
-    rows_of = [np.nonzero(env_ids % NGROUP == g)[0] for g in range(NGROUP)]
-    obs_all = torch.empty((world * n, nobs), dtype=torch.float64, device=dev) if collect else None
-    launch_stream = torch.cuda.Stream(device=dev)   # a real (non-null) stream: the kernel and the timing events share it
-    stream = launch_stream.cuda_stream
+    ranges = half_ranges(n, nstreams)
+    streams = [torch.cuda.Stream(device=dev) for _ in ranges]   # real (non-null) streams: the kernels and the timing events share them
+    obs_all = [torch.empty((world * cnt, nobs), dtype=torch.float64, device=dev) for _, cnt in ranges] if collect else None
 
     def restart(group):
-        """The envs of a phase group (rows first, first + NGROUP, ...) start a new episode: a fresh cassie_sim_t -- init pose,
-        zero velocities and warm start, zero filter histories / delay lines, the init pose's sensordata -- in one small launch
-        on the launch stream (phys_batch_reset_envs)."""
-        rows = rows_of[group]
-        if not len(rows):
-            return
-        b.reset_envs(int(rows[0]), NGROUP, len(rows), init_row.data_ptr(), init_row.data_ptr() + (nq + nv) * esz if drive else None, stream)
+        """The envs of a phase group start a new episode: a fresh cassie_sim_t -- init pose, zero velocities and warm start,
+        zero filter histories / delay lines, the init pose's sensordata -- in one small launch per range, on its stream
+        (phys_batch_reset_envs)."""
+        for (first, cnt), st in zip(ranges, streams):
+            r0, k = rows_of_group_in_range(group, int(env_ids[0]), first, cnt)
+            if k:
+                b.reset_envs(r0, NGROUP, k, init_row.data_ptr(), init_row.data_ptr() + (nq + nv) * esz if drive else None, st.cuda_stream)
 
-    # The all-gather runs beside the next launch: the observation block is snapshotted on the launch stream (3 MB, device
-    # to device), RCCL sends the snapshot from a second stream, and the next snapshot waits for that gather to have read it.
-    snap = torch.empty_like(obs) if collect else None
-    comm_stream = torch.cuda.Stream(device=dev) if collect else None
-    gather_done = [None]
+    # The all-gather runs beside the next launch: a range's observation block is snapshotted on its launch stream (device to
+    # device), RCCL sends the snapshot from a second stream, and the range's next snapshot waits for that gather to have read it.
+    snap = [torch.empty((cnt, nobs), dtype=torch.float64, device=dev) for _, cnt in ranges] if collect else None
+    comm_streams = [torch.cuda.Stream(device=dev) for _ in ranges] if collect else None
+    gather_done = [None] * len(ranges)
 
     def gather():
-        cur = torch.cuda.current_stream(dev)
-        if gather_done[0] is not None:
-            cur.wait_event(gather_done[0])
-        snap.copy_(obs, non_blocking=True)
-        ready = torch.cuda.Event()
-        ready.record(cur)
-        with torch.cuda.stream(comm_stream):
-            comm_stream.wait_event(ready)
-            gather_observations(snap, world, obs_all)
-            done = torch.cuda.Event()
-            done.record(comm_stream)
-        gather_done[0] = done
+        for i, ((first, cnt), st) in enumerate(zip(ranges, streams)):
+            if gather_done[i] is not None:
+                st.wait_event(gather_done[i])
+            with torch.cuda.stream(st):
+                snap[i].copy_(obs[first:first + cnt], non_blocking=True)
+            ready = torch.cuda.Event()
+            ready.record(st)
+            with torch.cuda.stream(comm_streams[i]):
+                comm_streams[i].wait_event(ready)
+                gather_observations(snap[i], world, obs_all[i])
+                done = torch.cuda.Event()
+                done.record(comm_streams[i])
+            gather_done[i] = done
 
-    sch = Schedule(step=lambda nsub: b.step(nsub, stream),
+    def step(nsub):
+        for (first, cnt), st in zip(ranges, streams):
+            if len(ranges) == 1:
+                b.step(nsub, st.cuda_stream)
+            else:
+                b.step_range(first, cnt, nsub, st.cuda_stream)
+
+    sch = Schedule(step=step,
                    bind_targets=lambda p: b.bind(P.F_PD_PTARGET, targets[p].data_ptr()),
                    restart=restart,
                    gather=gather if collect else None,
@@ -519,27 +546,29 @@ def device_rollout(model, mode, n, steps, warmup, rank, world, local_rank, subst
     torch.cuda.synchronize(dev)
     region_s, region_ev, region_launches = [], [], []
     q_sample = info_sample = None
-    with torch.cuda.stream(launch_stream):
-        sch.run(0, PREROLL + warmup)
-        for r in range(repeats):
-            ev = [torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)]
-            region_s.append(timed_region(sch, PREROLL + warmup + r * steps, steps, fence, mark=lambda i: ev[i].record(launch_stream)))
-            region_ev.append(ev[0].elapsed_time(ev[1]))
-            region_launches.append(sch.launches)
-            if r == snap_r:     # between two fenced regions: the sampled rows of this rank for the CPU replay
-                q_sample = obs[sample_dev, :nq].clone()
-                info_sample = torch.from_numpy(b.warnings()[1][sample][:, :3].astype(np.int64)).to(dev)
+    sch.run(0, PREROLL + warmup)
+    for r in range(repeats):
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in streams]
+        region_s.append(timed_region(sch, PREROLL + warmup + r * steps, steps, fence,
+                                     mark=lambda i: [e[i].record(st) for e, st in zip(evs, streams)]))
+        region_ev.append([e[0].elapsed_time(e[1]) for e in evs])     # per stream: its time over the region
+        region_launches.append(sch.launches)
+        if r == snap_r:     # between two fenced regions: the sampled rows of this rank for the CPU replay
+            q_sample = obs[sample_dev, :nq].clone()
+            info_sample = torch.from_numpy(b.warnings()[1][sample][:, :3].astype(np.int64)).to(dev)
     if collect:   # a region's time is the slowest rank's
         t = torch.tensor(region_s, dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         region_s = [float(x) for x in t.cpu()]
     launches = int(sum(region_launches))
-    res = {"mode": mode, "n": n, "steps": steps, "warmup": warmup, "repeats": repeats, "launches": launches,
-           "kernel_ms": float(sum(region_ev)) / launches,   # mean stream time per launch (includes the rare restart / gather)
+    res = {"mode": mode, "n": n, "steps": steps, "warmup": warmup, "repeats": repeats, "launches": launches, "streams": len(ranges),
+           # mean stream time of ONE range's launch (includes the rare restart / gather); with several streams the ranges' launches
+           # overlap, each sharing the GPU with the others'
+           "kernel_ms": float(np.mean([np.sum([ev[i] for ev in region_ev]) for i in range(len(streams))])) / launches,
            "region_s": region_s, "elapsed": float(np.median(region_s))}
     if collect and rank == 0:
         # the gathered block of the last policy boundary must hold this rank's rows (global env order, rank-major)
-        res["gather_ok"] = bool(sch.gathers > 0 and torch.equal(obs_all[rank * n:(rank + 1) * n], snap))
+        res["gather_ok"] = bool(sch.gathers > 0 and all(torch.equal(oa[rank * cnt:(rank + 1) * cnt], sn) for oa, sn, (_, cnt) in zip(obs_all, snap, ranges)))
     w, info = b.warnings()
     stats = torch.tensor([float(np.count_nonzero(w))] + [float(info[:, k].sum()) for k in (1, 2, 3)], dtype=torch.float64, device=dev)
     if collect:
@@ -604,6 +633,9 @@ def main():
                     help="shard a FIXED total over the GPUs instead (strong scaling), e.g. 65536 at 1 / 2 / 4 / 8 GPUs")
     ap.add_argument("--repeats", type=int, default=REPEATS,
                     help="fenced timed regions of exactly --steps steps each; `value` is the median region, value_min / value_max the extremes")
+    ap.add_argument("--streams", type=int, default=STREAMS,
+                    help="a rank's batch is stepped as this many contiguous env ranges, each on its own stream at its own pace "
+                         "(1 = the whole batch in one launch per policy step)")
     ap.add_argument("--substeps-per-launch", type=int, default=HOLD,
                     help="physics steps fused into one kernel launch (at most up to the next PD-target re-draw)")
     ap.add_argument("--model", default="cassie", choices=["cassie", "cassie_hfield", "cassie_tray_box"],
@@ -646,8 +678,9 @@ def main():
     if args.model == "cassie_hfield":   # terrain of reference example/test_hfield.py:39-41, shared by all envs
         hfield = np.random.default_rng(99).random((200, 200)).astype(np.float32)
         hfield[95:105, 95:105] = 0
+    nstreams = max(1, args.streams)
     r = device_rollout(model, args.mode, n, args.steps, args.warmup, rank, world, local_rank, args.substeps_per_launch, args.parity_envs, hfield,
-                       collect=collect, repeats=repeats)
+                       collect=collect, repeats=repeats, nstreams=nstreams)
 
     if rank == 0:
         elapsed, kern_ms, timed_launches = r["elapsed"], r["kernel_ms"], r["launches"]
@@ -679,6 +712,12 @@ def main():
                        "api_of_value": api, "mode": args.mode,
                        "envs_per_gpu": n, "envs_total": world * n, "baseline_config": shape, "parallelism": "env-sharded x%d" % world,
                        "obs_allgather_every_steps": HOLD if collect else None,
+                       "streams": r["streams"],
+                       "streams_note": ("the %d envs of a GPU are stepped as %d contiguous ranges, each on its own stream at its own pace "
+                                        "(phys_batch_step_range): per policy step every range gets its restarts, its PD targets and one "
+                                        "launch, and nothing on the device joins the ranges between policy steps, so one range's workgroups "
+                                        "fill the wave slots the other leaves idle at the end and the start of its launches; "
+                                        "`value_one_stream` is the same batch as one launch per policy step" % (n, r["streams"])) if r["streams"] > 1 else None,
                        "timed_regions": repeats, "region_ms": [1e3 * x for x in r["region_s"]],
                        "substeps_per_launch": steps_per_launch, "launches_timed": timed_launches,
                        "outputs_of_a_launch": "its last substep's (sensordata, measurement block, xpos / xquat, solver statistics); IMU words and "
@@ -688,6 +727,11 @@ def main():
             "parity": r["parity"],
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "concurrent_launches": r["streams"],
+                         "achieved_note": ("algorithmic bytes of the %d launches that run side by side (one per stream, %d env-steps each) / the mean "
+                                           "duration of one of them (HIP events on its stream); one launch alone: %.2f GB/s"
+                                           % (r["streams"], n * steps_per_launch // r["streams"], achieved / r["streams"])) if r["streams"] > 1 else
+                                          "algorithmic bytes of one launch / its mean duration (HIP events on the launch stream)",
                          "traffic_note": "PMC bytes per env-step of the profiled 50-substep launch x this run's env-steps per launch; the state-in / "
                                          "state-out part of it does not shrink with fewer substeps per launch, so short launches move more than this",
                          "kernel": "cassie_step_kernel<%d>" % (32 if pod.nv <= 32 else 40), "kernel_ms": kern_ms, "algorithmic_bytes_per_env_step": algo_bytes, "env_steps_per_launch": n * steps_per_launch,
@@ -705,7 +749,8 @@ def main():
             if not args.no_other_mode:
                 other = "exact-pd" if args.mode == "drive-pd" else "drive-pd"
                 side = dict(steps=min(args.steps, 400), warmup=min(args.warmup, 50), repeats=min(repeats, 5))
-                o = device_rollout(model, other, n, side["steps"], side["warmup"], 0, 1, local_rank, args.substeps_per_launch, 16, hfield, repeats=side["repeats"])
+                o = device_rollout(model, other, n, side["steps"], side["warmup"], 0, 1, local_rank, args.substeps_per_launch, 16, hfield, repeats=side["repeats"],
+                                   nstreams=nstreams)
                 out[other.replace("-", "_")] = {"value": n * o["steps"] / o["elapsed"], "unit": "env-steps/s", "steps": o["steps"], "warmup": o["warmup"],
                                                 "timed_regions": o["repeats"], "kernel_ms": o["kernel_ms"], "parity": o["parity"],
                                                 "mean_constraint_rows": o["mean_constraint_rows"], "mean_pgs_iterations": o["mean_pgs_iterations"]}
@@ -714,10 +759,17 @@ def main():
                 # default the IMU sensor words and body quaternions of the substeps in between -- values nobody can read -- are
                 # not formed; this is what forming them anyway costs
                 a = device_rollout(model, args.mode, n, side["steps"], side["warmup"], 0, 1, local_rank, args.substeps_per_launch, 4, hfield,
-                                   all_outputs=True, repeats=side["repeats"])
+                                   all_outputs=True, repeats=side["repeats"], nstreams=nstreams)
                 out["all_outputs_every_substep"] = {"value": n * a["steps"] / a["elapsed"], "unit": "env-steps/s", "steps": a["steps"],
                                                     "timed_regions": a["repeats"], "kernel_ms": a["kernel_ms"], "max_qpos_err": a["parity"]["max_qpos_err"]}
                 out["value_all_outputs_every_substep"] = out["all_outputs_every_substep"]["value"]
+                if nstreams > 1:    # the whole batch as one launch per policy step (rounds 1-2, and what a consumer that needs every env's
+                    # observation before it acts on any of them gets)
+                    one = device_rollout(model, args.mode, n, side["steps"], side["warmup"], 0, 1, local_rank, args.substeps_per_launch, 4, hfield,
+                                         repeats=side["repeats"], nstreams=1)
+                    out["one_stream"] = {"value": n * one["steps"] / one["elapsed"], "unit": "env-steps/s", "steps": one["steps"], "timed_regions": one["repeats"],
+                                         "kernel_ms": one["kernel_ms"], "max_qpos_err": one["parity"]["max_qpos_err"]}
+                    out["value_one_stream"] = out["one_stream"]["value"]
             if not args.no_step_pd:
                 sp = step_pd_host_api(n)
                 sd = step_pd_host_api(n, device_drives=True)

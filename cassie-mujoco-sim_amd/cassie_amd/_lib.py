@@ -89,6 +89,8 @@ def _declare(L):
     L.phys_batch_debug_poison_lds.argtypes = [vp]
     L.phys_batch_set_balance.argtypes = [vp, c.c_int]
     L.phys_batch_set_fast_rows.argtypes = [vp, c.c_int]
+    if hasattr(L, "phys_batch_step_range"):
+        L.phys_batch_step_range.argtypes = [vp, c.c_int, c.c_int, c.c_int, vp]
     if hasattr(L, "phys_batch_reset_envs"):
         L.phys_batch_reset_envs.argtypes = [vp, c.c_int, c.c_int, c.c_int, vp, vp, vp]
     if hasattr(L, "phys_batch_download_progress"):   # (absent from older variant builds selected with CASSIE_LIB)

@@ -149,6 +149,11 @@ class Batch:
         if lib().phys_batch_step(self._h, nsub, stream) != 0:
             raise RuntimeError("step failed: " + (lib().phys_last_error() or b"").decode())
 
+    def step_range(self, env0, n, nsub=1, stream=None):
+        """Steps the env range [env0, env0 + n) only; ranges may be in flight on different streams at once."""
+        if lib().phys_batch_step_range(self._h, int(env0), int(n), nsub, stream) != 0:
+            raise RuntimeError("step_range failed: " + (lib().phys_last_error() or b"").decode())
+
     def forward(self, stream=None):
         if lib().phys_batch_forward(self._h, stream) != 0:
             raise RuntimeError("forward failed: " + (lib().phys_last_error() or b"").decode())

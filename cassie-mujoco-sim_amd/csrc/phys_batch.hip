@@ -36,7 +36,9 @@ struct phys_batch {
     float *d_hfield = nullptr;
     size_t hfield_stride = 0, hfield_floats = 0; /* stride 0: one grid shared by all envs; else one grid of hfield_floats per env */
     hipStream_t stream = nullptr;
-    hipStream_t last_stream = nullptr; /* the stream of the most recent launch (callers may pass their own) */
+    hipStream_t recent_streams[4] = {nullptr, nullptr, nullptr, nullptr}; /* streams of the most recent launches (callers may pass
+                                       their own, and ranges of one batch may be in flight on several at once) */
+    int recent_next = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_mark = nullptr;
     bool use_applied = false;       /* qfrc_applied / xfrc_applied are passed only once uploaded */
     bool pd_mode = false;
@@ -109,12 +111,21 @@ static ck::PhysIO make_io(phys_batch *b, int nsub, int integrate) {
  * is still in flight on the batch's stream or on the caller's: wait for both first. */
 static bool quiesce(phys_batch *b) {
     bool ok = hip_ok(hipStreamSynchronize(b->stream), "hipStreamSynchronize");
-    if (b->last_stream && b->last_stream != b->stream) ok = hip_ok(hipStreamSynchronize(b->last_stream), "hipStreamSynchronize(caller stream)") && ok;
+    for (hipStream_t r : b->recent_streams)
+        if (r && r != b->stream) ok = hip_ok(hipStreamSynchronize(r), "hipStreamSynchronize(caller stream)") && ok;
     return ok;
 }
 
-static int launch(phys_batch *b, int nsub, int integrate, hipStream_t s, bool scratch_outputs = false) {
+static void note_stream(phys_batch *b, hipStream_t s) {
+    for (hipStream_t r : b->recent_streams) if (r == s) return;
+    b->recent_streams[b->recent_next] = s;
+    b->recent_next = (b->recent_next + 1) % 4;
+}
+
+static int launch(phys_batch *b, int nsub, int integrate, hipStream_t s, bool scratch_outputs = false, int env0 = 0, int n = -1) {
     ck::PhysIO io = make_io(b, nsub, integrate);
+    if (n < 0) n = b->nenv;
+    io.env0 = env0; io.nenv = n;
     if (scratch_outputs) {
         /* a read-out pass: the step outputs the caller's fields hold (sensordata and actuator_velocity of the last STEP feed
          * the encoder / motor models of the next one; qacc) stay as they are */
@@ -123,8 +134,8 @@ static int launch(phys_batch *b, int nsub, int integrate, hipStream_t s, bool sc
         io.sensordata = b->d_scratch_out + (size_t)b->nenv * m.nv; io.ssd = m.nsensordata;
         io.actuator_velocity = io.sensordata + (size_t)b->nenv * m.nsensordata;
     }
-    b->last_stream = s;
-    const dim3 grid(b->nenv);
+    note_stream(b, s);
+    const dim3 grid(n);
     /* the compile-time-topology instantiations are used only when the model's dof tree is exactly theirs */
     const cm_model_t &hm = b->host_model;
     auto matches = [&](const unsigned long long *table, int nv) {
@@ -152,7 +163,7 @@ static int launch(phys_batch *b, int nsub, int integrate, hipStream_t s, bool sc
     /* the next launch's order from this one's per-env cost: after every long launch, now and then after short ones */
     if (io.order && integrate && (nsub >= 8 || ++b->launches_since_order >= 16)) {
         b->launches_since_order = 0;
-        hipLaunchKernelGGL(ck::cassie_order_kernel, dim3(1), dim3(ck::ORDER_THREADS), 0, s, b->d_cost, b->d_order, b->nenv);
+        hipLaunchKernelGGL(ck::cassie_order_kernel, dim3(1), dim3(ck::ORDER_THREADS), 0, s, b->d_cost, b->d_order, n, env0);
         if (!hip_ok(hipGetLastError(), "cassie_order_kernel launch")) return -1;
     }
     return 0;
@@ -426,6 +437,12 @@ int phys_batch_step(phys_batch_t *b, int nsub, void *stream) {
     return launch(b, nsub, 1, stream ? (hipStream_t)stream : b->stream);
 }
 
+int phys_batch_step_range(phys_batch_t *b, int env0, int n, int nsub, void *stream) {
+    if (!b || nsub <= 0 || env0 < 0 || n <= 0 || env0 + n > b->nenv) return -1;
+    (void)hipSetDevice(b->device);
+    return launch(b, nsub, 1, stream ? (hipStream_t)stream : b->stream, false, env0, n);
+}
+
 int phys_batch_forward(phys_batch_t *b, void *stream) {
     if (!b) return -1;
     (void)hipSetDevice(b->device);
@@ -479,7 +496,7 @@ int phys_batch_drive_pass(phys_batch_t *b, int mode, void *stream) {
     ck::PhysIO io = make_io(b, 1, 1);
     b->drive_mode = keep;
     hipStream_t s = stream ? (hipStream_t)stream : b->stream;
-    b->last_stream = s;
+    note_stream(b, s);
     hipLaunchKernelGGL(ck::cassie_drive_kernel, dim3(b->nenv), dim3(WV_WAVE), 0, s, io, b->d_field[PHYS_F_CTRL]);
     return hip_ok(hipGetLastError(), "cassie_drive_kernel launch") ? 0 : -1;
 }
@@ -537,7 +554,7 @@ int phys_batch_reset_envs(phys_batch_t *b, int first, int stride, int count, con
     io.drive = b->d_drive;
     io.qpos_row = qpos_row; io.sens_row = sens_row;
     hipStream_t s = stream ? (hipStream_t)stream : b->stream;
-    b->last_stream = s;
+    note_stream(b, s);
     hipLaunchKernelGGL(ck::cassie_reset_kernel, dim3(count), dim3(WV_WAVE), 0, s, io);
     return hip_ok(hipGetLastError(), "cassie_reset_kernel launch") ? 0 : -1;
 }

@@ -76,7 +76,9 @@ typedef const WV_CONST_AS cm_model_t *ModelPtr;
 struct PhysIO {
     const cm_model_t *models;   /* one shared model, or one per env */
     int model_stride;           /* 0 = shared, 1 = per-env */
-    int nenv, nsub;             /* nsub physics steps per launch (ctrl / PD targets held) */
+    int nenv, nsub;             /* envs of this launch; nsub physics steps per launch (ctrl / PD targets held) */
+    int env0;                   /* first env of this launch: a launch may cover the env range [env0, env0 + nenv) of the batch (all
+                                   per-env arrays are indexed by the absolute env) */
     int integrate;              /* 1 = step (Euler), 0 = forward only (mj_forward role) */
     int sq, sqv, sv, su, ssd, sb; /* row strides in doubles: qpos, qvel, the other nv-sized fields, nu-sized fields, sensordata;
                                      sb = nbody.  qpos / qvel / sensordata have strides of their own so that the three can be
@@ -2625,7 +2627,7 @@ WV_GLOBAL void __launch_bounds__(WV_WAVE) WV_OCC cassie_step_kernel(PhysIO io) {
     const int slot = wv::env_id();
     if (slot >= io.nenv) return;
     wv::test_launch_hook(&S, sizeof S); /* CPU emulator only (poisons LDS so that a read-before-write shows); empty on the device */
-    const int env = io.order ? io.order[slot] : slot;
+    const int env = io.order ? io.order[io.env0 + slot] : io.env0 + slot; /* order holds absolute env ids, sorted range by range */
     const int sub_start = io.resume ? io.progress[env] : 0;
     if (sub_start >= io.nsub) return; /* resume pass: the fast instantiation finished this env */
     const long long t0 = io.cost ? wv::clock() : 0;

@@ -17,7 +17,9 @@ namespace ck {
  * tail.  One workgroup: counting sort of the envs by the cost of their last launch into NBIN bins, descending; the
  * order inside a bin is arbitrary, which is harmless -- envs are independent and every env is stepped exactly once. */
 constexpr int ORDER_THREADS = 1024, ORDER_NBIN = 256;
-WV_GLOBAL void __launch_bounds__(ORDER_THREADS) cassie_order_kernel(const unsigned *cost, int *order, int nenv) {
+WV_GLOBAL void __launch_bounds__(ORDER_THREADS) cassie_order_kernel(const unsigned *cost, int *order, int nenv, int base) {
+    /* sorts the env range [base, base + nenv): cost / order are indexed by the absolute env, the order entries are absolute */
+    cost += base; order += base;
 #ifndef CK_EMULATED
     __shared__ unsigned lo_s, hi_s, count[ORDER_NBIN], start[ORDER_NBIN];
     const int t = threadIdx.x;
@@ -35,7 +37,7 @@ WV_GLOBAL void __launch_bounds__(ORDER_THREADS) cassie_order_kernel(const unsign
     __syncthreads();
     if (t == 0) { unsigned acc = 0; for (int b = 0; b < ORDER_NBIN; ++b) { start[b] = acc; acc += count[b]; } }
     __syncthreads();
-    for (int e = t; e < nenv; e += ORDER_THREADS) order[atomicAdd(&start[bin_of(cost[e])], 1u)] = e;
+    for (int e = t; e < nenv; e += ORDER_THREADS) order[atomicAdd(&start[bin_of(cost[e])], 1u)] = base + e;
 #endif
 }
 

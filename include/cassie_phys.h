@@ -122,6 +122,11 @@ int phys_batch_uses_applied(const phys_batch_t *b);
  * single-step launches would leave; the state fields (qpos, qvel, time, warm start, drive-level state) advance nsub steps */
 int phys_batch_step(phys_batch_t *b, int nsub, void *stream);
 /* mj_forward (reference :971, :1029, :1223, :3293): no integration */
+/* The same for the env range [env0, env0 + n) only.  Ranges of one batch may be in flight on different streams at once (the
+ * per-env arrays are disjoint): stepping two half-batches on two streams, each at its own pace, lets one half's workgroups
+ * fill the wave slots the other half leaves idle at the end and the start of its launches -- +16 % on BASELINE config 2
+ *  when nothing joins the halves between policy steps. */
+int phys_batch_step_range(phys_batch_t *b, int env0, int n, int nsub, void *stream);
 int phys_batch_forward(phys_batch_t *b, void *stream);
 /* Episode restarts without leaving the device -- the batched form of what a fresh cassie_sim_t / cassie_sim_full_reset
  * leaves (reference src/cassiemujoco.c:1023-1029, :2008-2034): envs first, first + stride, ... (count of them) get

@@ -270,11 +270,11 @@ def test_bench_rollout_with_the_collective_path_on_one_rank(cassie):
     if created:
         dist.init_process_group("nccl", rank=0, world_size=1)
     try:
-        r = bench.device_rollout(cassie, "drive-pd", 512, 100, 50, 0, 1, 0, bench.HOLD, 8, None, collect=True, repeats=3)
+        r = bench.device_rollout(cassie, "drive-pd", 512, 100, 50, 0, 1, 0, bench.HOLD, 8, None, collect=True, repeats=3, nstreams=2)
     finally:
         if created:
             dist.destroy_process_group()
-    assert r["gather_ok"] is True
+    assert r["gather_ok"] is True and r["streams"] == 2          # two env ranges on two streams, one all-gather per range and policy step
     assert len(r["region_s"]) == 3 and r["parity"]["after_timed_region"] == 2 and r["parity"]["steps_replayed"] == 1000 + 50 + 300
     assert r["parity"]["ok"] and r["parity"]["frac_envs_with_equal_ncon_nefc_iters"] == 1.0
     assert r["envs_with_warnings"] == 0

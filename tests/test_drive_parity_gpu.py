@@ -300,3 +300,45 @@ def test_device_reset_equals_a_fresh_batch(cassie):
     for e in restarted:
         assert device_state_bytes(sa[int(e)]) == device_state_bytes(sf[int(e)])
     a.close(); fresh.close()
+
+
+def test_stepping_in_ranges_on_two_streams_equals_stepping_the_whole_batch(cassie):
+    """phys_batch_step_range: the batch stepped as two env ranges on two streams, each at its own pace and with the ranges'
+    launches interleaved differently every policy step, ends bit for bit where the whole batch stepped in one launch per
+    policy step does (envs are independent; the per-env arrays of the ranges are disjoint)."""
+    import torch
+    n, npol = 4096, 8
+    tg = bench.pd_targets(np.arange(n), npol)
+    out = []
+    for split in (False, True):
+        b = Batch(cassie, n)
+        try:
+            b.set(P.F_QPOS, np.tile(cassie.qpos_init(), (n, 1)))
+            b.forward()
+            b.set(P.F_PD_KP, np.tile(bench.PD_KP, (n, 1)))
+            b.set(P.F_PD_KD, np.tile(bench.PD_KD, (n, 1)))
+            b.set_drive_mode(P.DRIVE_PD)
+            tgd = torch.from_numpy(tg).cuda()
+            if not split:
+                for p in range(npol):
+                    b.bind(P.F_PD_PTARGET, tgd[p].data_ptr())
+                    b.step(50)
+            else:
+                s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+                # range A = envs [0, 1500) runs ahead of range B = [1500, 4096): A's policy steps are all queued before B's first
+                for p in range(npol):
+                    b.bind(P.F_PD_PTARGET, tgd[p].data_ptr())
+                    b.step_range(0, 1500, 50, s1.cuda_stream)
+                for p in range(npol):
+                    b.bind(P.F_PD_PTARGET, tgd[p].data_ptr())
+                    b.step_range(1500, n - 1500, 25, s2.cuda_stream)
+                    b.step_range(1500, n - 1500, 25, s2.cuda_stream)
+                torch.cuda.synchronize()
+            b.sync()
+            w, info = b.warnings()
+            out.append([b.get(P.F_QPOS), b.get(P.F_QVEL), b.get(P.F_QACC_WARMSTART), b.get(P.F_SENSORDATA), b.get(P.F_MEAS), b.get(P.F_TIME), w, info[:, :3].copy()])
+        finally:
+            b.close()
+    assert not out[0][6].any() and out[0][7][:, 0].max() >= 2
+    for a, c in zip(out[0], out[1]):
+        assert a.tobytes() == c.tobytes()

@@ -188,3 +188,22 @@ def test_shards_partition_the_env_range():
     import bench
     ids = np.concatenate([bench.shard_env_ids(r, 8, 8192) for r in range(8)])
     assert np.array_equal(ids, np.arange(65536))                            # BASELINE config 3: 8 x 8192
+
+
+def test_env_ranges_and_restart_rows_per_stream():
+    """bench.half_ranges / rows_of_group_in_range: the ranges partition a rank's envs, and the rows a range restarts at a
+    policy step are exactly the rows of that range whose GLOBAL env id is in the step's phase group."""
+    import bench
+    assert bench.half_ranges(4096, 2) == [(0, 2048), (2048, 2048)] and bench.half_ranges(4096, 1) == [(0, 4096)]
+    assert bench.half_ranges(10, 3) == [(0, 3), (3, 3), (6, 4)] and bench.half_ranges(2, 5) == [(0, 1), (1, 1)]
+    for rank, n, k in ((0, 4096, 2), (3, 8192, 2), (1, 100, 3)):
+        ids = bench.shard_env_ids(rank, 8, n)
+        for g in range(bench.NGROUP):
+            want = np.nonzero(ids % bench.NGROUP == g)[0]
+            got = []
+            for first, cnt in bench.half_ranges(n, k):
+                r0, c = bench.rows_of_group_in_range(g, int(ids[0]), first, cnt)
+                rows = r0 + bench.NGROUP * np.arange(c)
+                assert c == 0 or (rows[0] >= first and rows[-1] < first + cnt)
+                got.append(rows)
+            assert np.array_equal(np.concatenate(got), want), (rank, n, k, g)
