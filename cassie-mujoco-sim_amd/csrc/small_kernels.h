@@ -16,7 +16,10 @@ namespace ck {
  * (it is its contact situation), so the next launch starts the expensive envs first and lets the cheap ones fill the
  * tail.  One workgroup: counting sort of the envs by the cost of their last launch into NBIN bins, descending; the
  * order inside a bin is arbitrary, which is harmless -- envs are independent and every env is stepped exactly once. */
-constexpr int ORDER_THREADS = 1024, ORDER_NBIN = 256;
+/* one wave: on a GPU saturated by another stream's step kernel (whose workgroups hold every register of their SIMD and all
+ * but 0.8 KB of a CU's LDS) a workgroup is dispatched only when a wave slot frees, and a 1024-thread workgroup only when a
+ * whole CU does -- which, measured, took milliseconds and stalled the launching stream (round 3, two-stream stepping) */
+constexpr int ORDER_THREADS = 64, ORDER_NBIN = 256;
 WV_GLOBAL void __launch_bounds__(ORDER_THREADS) cassie_order_kernel(const unsigned *cost, int *order, int nenv, int base) {
     /* sorts the env range [base, base + nenv): cost / order are indexed by the absolute env, the order entries are absolute */
     cost += base; order += base;
@@ -24,7 +27,7 @@ WV_GLOBAL void __launch_bounds__(ORDER_THREADS) cassie_order_kernel(const unsign
     __shared__ unsigned lo_s, hi_s, count[ORDER_NBIN], start[ORDER_NBIN];
     const int t = threadIdx.x;
     if (t == 0) { lo_s = 0xffffffffu; hi_s = 0; }
-    if (t < ORDER_NBIN) count[t] = 0;
+    for (int b = t; b < ORDER_NBIN; b += ORDER_THREADS) count[b] = 0;
     __syncthreads();
     unsigned lo = 0xffffffffu, hi = 0;
     for (int e = t; e < nenv; e += ORDER_THREADS) { const unsigned c = cost[e]; lo = c < lo ? c : lo; hi = c > hi ? c : hi; }

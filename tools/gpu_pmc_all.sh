@@ -2,7 +2,7 @@
 # tools/pmc_summary.py reduces the CSVs to gpurun_out/pmc_summary.json.  MODE=exact-pd|drive-pd (default drive-pd).
 mkdir -p gpurun_out/pmc; cd /tmp; export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-CMD="python $R/bench.py ${MODEL:+--model $MODEL} --mode ${MODE:-drive-pd} --steps 100 --warmup 50 --no-cpu-baseline --no-step-pd --no-other-mode --parity-envs 4"
+CMD="python $R/bench.py ${MODEL:+--model $MODEL} --mode ${MODE:-drive-pd} --streams 1 --steps 100 --warmup 50 --no-cpu-baseline --no-step-pd --no-other-mode --parity-envs 4"
 i=0
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU" \
            "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_IFETCH SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS" \
