@@ -149,9 +149,8 @@ static int launch(phys_batch *b, int nsub, int integrate, hipStream_t s, bool sc
     bool launched;
     if (matches(ck::TopoCassie32::table, ck::TopoCassie32::nv)) {
         /* stepping launches of the two Cassie instantiations go through the row-capped fast instantiation first; the full one
-         * behind it finishes the envs that met a substep with more rows (and is the only one for forward / read-out /
-         * profiling passes) */
-        const bool fast = b->fast_rows && integrate && !wp && !io.ext && !io.prof && b->d_progress;
+         * behind it finishes the envs that met a substep with more rows (and is the only one for forward / read-out passes) */
+        const bool fast = b->fast_rows && integrate && !wp && !io.ext && b->d_progress;
         io.progress = fast ? b->d_progress : nullptr;
         if (!hf && !wp) launched = ck::launch_step_cassie(grid, s, io, fast);
         else if (hf && !wp) launched = ck::launch_step_cassie_hfield(grid, s, io, fast);

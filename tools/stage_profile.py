@@ -12,6 +12,8 @@ m = Model("cassie")
 NSUB = int(os.environ.get("NSUB", "1"))   # substeps fused per launch (the bench uses 50)
 for n in (int(a) for a in (sys.argv[1:] or ["512", "4096"])):
     b = Batch(m, n)
+    if os.environ.get("FULL_KERNEL"):
+        b.set_fast_rows(False)      # the stamps of the full instantiation alone (default: the row-capped fast one, where an env fits it)
     b.set(P.F_QPOS, np.tile(m.qpos_init(), (n, 1)))
     rng = np.random.default_rng(0)
     b.set(P.F_PD_PTARGET, np.array([0.0045, 0, 0.4973, -1.1997, -1.5968] * 2) + rng.uniform(-0.3, 0.3, (n, 10)))
