@@ -570,12 +570,17 @@ def device_rollout(model, mode, n, steps, warmup, rank, world, local_rank, subst
         # the gathered block of the last policy boundary must hold this rank's rows (global env order, rank-major)
         res["gather_ok"] = bool(sch.gathers > 0 and all(torch.equal(oa[rank * cnt:(rank + 1) * cnt], sn) for oa, sn, (_, cnt) in zip(obs_all, snap, ranges)))
     w, info = b.warnings()
-    stats = torch.tensor([float(np.count_nonzero(w))] + [float(info[:, k].sum()) for k in (1, 2, 3)], dtype=torch.float64, device=dev)
+    try:    # envs the row-capped fast kernel handed over to the full kernel in the last launch
+        handed = float(np.count_nonzero(b.fast_rows_progress() < min(substeps_per_launch, HOLD)))
+    except Exception:
+        handed = float("nan")
+    stats = torch.tensor([float(np.count_nonzero(w))] + [float(info[:, k].sum()) for k in (1, 2, 3)] + [handed], dtype=torch.float64, device=dev)
     if collect:
         dist.all_reduce(stats, op=dist.ReduceOp.SUM)
     stats = stats.cpu().numpy()
     res["envs_with_warnings"] = int(stats[0])
     res["mean_constraint_rows"], res["mean_pgs_iterations"], res["mean_pgs_guarded_sweeps"] = (float(stats[k] / (world * n)) for k in (1, 2, 3))
+    res["frac_envs_handed_over_last_launch"] = float(stats[4] / (world * n))
     # ---- the metric's second half: sampled envs of EVERY rank against the CPU reference, same schedule ----
     ids_sample = torch.from_numpy(env_ids[sample].astype(np.int64)).to(dev)
     if collect and world > 1:
@@ -742,6 +747,7 @@ def main():
                               "note": "algorithmic flops (SURVEY.md 8a estimate), not counting lanes that idle or recompute"},
             "envs_with_warnings": r["envs_with_warnings"],
             **({"obs_allgather_ok": r.get("gather_ok")} if collect else {}),   # rank 0's rows of the last gathered block = its snapshot
+            "frac_envs_handed_over_to_the_full_kernel_in_the_last_launch": r["frac_envs_handed_over_last_launch"],
             "mean_constraint_rows": r["mean_constraint_rows"], "mean_pgs_iterations": r["mean_pgs_iterations"], "mean_pgs_guarded_sweeps": r["mean_pgs_guarded_sweeps"],
         }
         if world == 1 and args.model == "cassie" and args.total_envs is None:
