@@ -47,6 +47,10 @@ def _declare(L):
     L.phys_model_free.argtypes = [vp]
     L.phys_model_save.argtypes = [vp, c.c_char_p]
     L.phys_model_set_const.argtypes = [vp]
+    if hasattr(L, "phys_model_set_flag"):
+        L.phys_model_set_flag.argtypes = [vp, c.c_uint, c.c_int]
+        L.phys_model_flags.argtypes = [vp]
+        L.phys_model_flags.restype = c.c_uint
     L.phys_model_compile.argtypes = [vp, c.POINTER(CmModel), c.c_char_p, c.c_int]
     L.phys_model_name2id.argtypes = [vp, c.c_int, c.c_char_p]
     L.phys_model_id2name.restype = c.c_char_p

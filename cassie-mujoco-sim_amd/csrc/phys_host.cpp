@@ -123,6 +123,13 @@ unsigned long long phys_hash_floats(const float *data, size_t n) {
     return f.value();
 }
 
+unsigned phys_model_flags(const phys_model_t *m) { return m ? m->h.flags : 0u; }
+int phys_model_set_flag(phys_model_t *m, unsigned flag, int on) {
+    if (!m || (flag & ~(CM_FLAG_EULERDAMP | CM_FLAG_WARMSTART | CM_FLAG_REFSAFE | CM_FLAG_HFDENSE)) != 0) return -1;
+    if (on) m->h.flags |= flag; else m->h.flags &= ~flag;
+    return 0;
+}
+
 int phys_model_name2id(const phys_model_t *m, int objtype, const char *name) {
     return m ? m->h.name2id(objtype, name) : -1;
 }

@@ -1528,12 +1528,17 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
          * inside the pair loop for models with more pairs than one pass holds: both were what this instantiation spilled.) */
         constexpr int HF_REC = 21; /* doubles per pair: count, then 2 x (dist, pos[3], normal[3], tangent[3]) */
         static_assert(CM_MAXHFPAIR * HF_REC <= NB * 12, "the height-field result table must fit the cvel + cfrc tiles");
+        static_assert(CM_HF_PASS * CM_HF_SLOTS <= WV_WAVE && CM_HF_SLOTS_DENSE <= WV_WAVE, "a pass of the height-field pre-pass is one wave");
         double *const hfres = &S.x.s.cvel[0][0];
         const bool hf_on = (FEAT & FEAT_HFIELD) != 0 && env_hfield != nullptr && m->nhfpair > 0;
         if constexpr ((FEAT & FEAT_HFIELD) != 0) if (hf_on) {
-            for (int h0 = 0; h0 < m->nhfpair; h0 += CM_HF_PASS) {
-                const int h = h0 + lane / CM_HF_SLOTS, k = lane % CM_HF_SLOTS;
-                const bool act = lane < CM_HF_PASS * CM_HF_SLOTS && h < m->nhfpair;
+            /* CM_FLAG_HFDENSE: ten sample slots per pair (six pairs per pass) instead of six (ten pairs per pass) */
+            const bool dense = (m->flags & CM_FLAG_HFDENSE) != 0;
+            const int slots = dense ? CM_HF_SLOTS_DENSE : CM_HF_SLOTS, per_pass = dense ? WV_WAVE / CM_HF_SLOTS_DENSE : CM_HF_PASS;
+            for (int h0 = 0; h0 < m->nhfpair; h0 += per_pass) {
+                const int hl = dense ? lane / CM_HF_SLOTS_DENSE : lane / CM_HF_SLOTS;
+                const int h = h0 + hl, k = lane - hl * slots;
+                const bool act = hl < per_pass && h < m->nhfpair;
                 const int p = m->hfpair[act ? h : 0];
                 const int g1 = m->pair_geom1[p], g2 = m->pair_geom2[p], t2 = m->pair_type[p] >> 8;
                 const double margin = m->pair_margin[p], s20 = m->pair_size[p][3], s21 = m->pair_size[p][4];
@@ -1546,7 +1551,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
                 if (t2 == CM_GEOM_CAPSULE) {
                     ni = (int)ceil(2 * s21 / cell) - 1;
                     if (ni < 0) ni = 0;
-                    if (ni > 4) ni = 4;
+                    if (ni > slots - 2) ni = slots - 2;
                     mine = act && k < 2 + ni;
                     t = k == 0 ? s21 : (k == 1 ? -s21 : s21 * (1.0 - 2.0 * (k - 1) / (ni + 1)));
                 }
@@ -1559,17 +1564,21 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
                 }
                 /* the samples of this lane's pair: distances (1e300 = no contact) */
                 const int lead = lane - k;
-                double dk[CM_HF_SLOTS];
+                double dk[CM_HF_SLOTS_DENSE];
                 const double mydist = has ? rcs.dist : 1e300;
 #pragma unroll
-                for (int q = 0; q < CM_HF_SLOTS; ++q) dk[q] = wv::shfl(mydist, (lead + q) & 63);
+                for (int q = 0; q < CM_HF_SLOTS_DENSE; ++q) {
+                    if (q >= CM_HF_SLOTS && !dense) { dk[q] = 1e300; continue; } /* (wave-uniform) */
+                    const double v = wv::shfl(mydist, (lead + q) & 63);
+                    dk[q] = q < slots ? v : 1e300;
+                }
                 int src0 = 0, src1 = 1;
                 bool have0 = dk[0] < 1e299, have1 = dk[1] < 1e299;
                 if (t2 == CM_GEOM_CAPSULE) {
                     int kmid = -1;
                     double dmid = 1e300;
 #pragma unroll
-                    for (int q = 2; q < CM_HF_SLOTS; ++q) if (dk[q] < 1e299 && (kmid < 0 || dk[q] < dmid)) { kmid = q; dmid = dk[q]; }
+                    for (int q = 2; q < CM_HF_SLOTS_DENSE; ++q) if (dk[q] < 1e299 && (kmid < 0 || dk[q] < dmid)) { kmid = q; dmid = dk[q]; }
                     if (kmid >= 0 && (!have0 || dmid < dk[0]) && (!have1 || dmid < dk[1])) {
                         const bool drop1 = !have0 ? false : (!have1 ? true : dk[0] <= dk[1]);
                         if (drop1) { src1 = kmid; have1 = true; } else { src0 = kmid; have0 = true; }

@@ -36,6 +36,11 @@ int phys_model_save(const phys_model_t *m, const char *path);
 void phys_model_set_const(phys_model_t *m);
 /* derive the pointer-free kernel model; returns 0 on success */
 int phys_model_compile(const phys_model_t *m, cm_model_t *out, char *err, int errlen);
+/* option flags of the model (CM_FLAG_* in csrc/cm_model.h: implicit joint damping, warm start, refsafe -- the mjOption
+ * disable / enable bits the in-scope models use -- and CM_FLAG_HFDENSE, the denser capsule sampling against height fields);
+ * a change takes effect with the next compile / the next step of a cassie_sim_t */
+unsigned phys_model_flags(const phys_model_t *m);
+int phys_model_set_flag(phys_model_t *m, unsigned flag, int on);
 /* a 64-bit fingerprint of every model array / option a caller can change through the views below: compared before a step
  * instead of recompiling (the reference hands out raw mjModel pointers, so writes cannot be observed otherwise) */
 unsigned long long phys_model_fingerprint(const phys_model_t *m);

@@ -735,7 +735,7 @@ int co_test_hfield_sphere(const cm_model_t *m, const double *ps, double r, doubl
     return n;
 }
 /* capsule: the two end spheres as against a plane, plus sample spheres along the axis no further apart than one grid cell
- * (at most 4 interior ones).  An interior sample counts only when it is deeper than both ends -- a bump under the middle
+ * (at most 4 interior ones; 8 with CM_FLAG_HFDENSE).  An interior sample counts only when it is deeper than both ends -- a bump under the middle
  * of the capsule -- and then replaces the shallower end; on flat ground this is exactly plane_capsule.  Contacts are
  * reported in the order of their position along the axis, +h first. */
 static int hfield_capsule(raw_contact_t *c, const cm_model_t *m, const float *data, const double *ph, const double *mh, const double *pc,
@@ -744,7 +744,8 @@ static int hfield_capsule(raw_contact_t *c, const cm_model_t *m, const float *da
     const double cell = 2 * m->hfield_size[0] / (m->hfield_ncol > 1 ? m->hfield_ncol - 1 : 1);
     int ni = (int)ceil(2 * h / cell) - 1;  /* interior samples */
     if (ni < 0) ni = 0;
-    if (ni > 4) ni = 4;
+    const int nimax = ((m->flags & CM_FLAG_HFDENSE) ? CM_HF_SLOTS_DENSE : CM_HF_SLOTS) - 2;
+    if (ni > nimax) ni = nimax;
     raw_contact_t end[2], mid;
     int have_end[2] = {0, 0}, have_mid = 0;
     double tmid = 0;

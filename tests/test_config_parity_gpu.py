@@ -278,3 +278,20 @@ def test_bench_rollout_with_the_collective_path_on_one_rank(cassie):
     assert len(r["region_s"]) == 3 and r["parity"]["after_timed_region"] == 2 and r["parity"]["steps_replayed"] == 1000 + 50 + 300
     assert r["parity"]["ok"] and r["parity"]["frac_envs_with_equal_ncon_nefc_iters"] == 1.0
     assert r["envs_with_warnings"] == 0
+
+
+def test_dense_heightfield_sampling_flag_on_the_gpu(built):
+    """CM_FLAG_HFDENSE (optional: up to eight interior samples per capsule, ten lanes per pair and two passes of the
+    pre-pass): robots tipped over on the rough terrain, so that shins and tarsi -- the capsules the flag changes -- reach the
+    ground; GPU against the oracle with the same flag, 256 envs x 600 steps, counts equal at every policy step."""
+    hf = Model("cassie_hfield")
+    hf.set_flag(P.FLAG_HFDENSE, True)
+    h = np.random.default_rng(99).random((200, 200)).astype(np.float32)
+    h[95:105, 95:105] = 0
+
+    def place(e, q):
+        q[0], q[1], q[2] = 0.6 + 0.07 * (e % 16), 0.9 - 0.05 * (e // 16 % 16), 0.75
+        q[3:7] = [0.924, 0.0, 0.383, 0.0] if e % 2 else [0.924, 0.383, 0.0, 0.0]      # pitched / rolled 45 degrees
+        return q
+    worst, rows, q = _pd_rollout(hf, 256, np.arange(0, 256, 16), nsteps=600, hfield=h, q0_of=place)
+    assert rows >= 28

@@ -240,3 +240,68 @@ def test_sphere_distance_equals_brute_force_distance_to_the_triangulated_surface
         assert hits > 40
     finally:
         oracle_py.set_hfield(None)
+
+
+def _dense_model():
+    from cassie_amd import phys as P
+    m = Model("cassie_hfield")
+    m.set_flag(P.FLAG_HFDENSE, True)
+    assert m.pod.flags & P.FLAG_HFDENSE
+    return m
+
+
+def test_dense_sampling_flag_finds_a_spike_between_the_default_samples(hf):
+    """CM_FLAG_HFDENSE (extension, off by default): a shin-like capsule (radius 4 cm, 43 cm long) lying 7 cm above flat ground
+    over a 10 cm spike placed midway between two of its default sample spheres (which sit 8.7 cm apart on the 5 cm grid):
+    the default sampling passes over the spike (its nearest sample spheres clear the spike's flanks), the dense sampling
+    (4.8 cm apart) has a sample within 2.4 cm of the tip and reports the contact."""
+    import ctypes
+    L = oracle_py.lib()
+    L.co_test_hfield_capsule.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_void_p]
+    nc = 200
+    xs = -5 + 10.0 * np.arange(nc) / (nc - 1)
+    j, i = int(np.argmin(np.abs(xs - 1.0))), int(np.argmin(np.abs(xs - 0.5)))
+    h = np.zeros((200, 200), dtype=np.float32)
+    h[i, j] = 0.5                                    # 10 cm spike (size z = 0.2) at (xs[j], xs[i]); ground at world z = -0.1
+    mc = np.array([0.0, 0, 1, 0, 1, 0, -1, 0, 0])    # capsule axis along world x
+    half, r = 0.215, 0.04
+    spacing = 2 * half / 5                           # default: 4 interior samples -> 5 intervals of 8.6 cm
+    pc = np.array([xs[j] - half + 1.5 * spacing, xs[i], -0.1 + 0.07 + r])      # spike midway between interior samples 1 and 2
+    out = np.zeros(14)
+    dense = _dense_model()
+    oracle_py.set_hfield(h)
+    try:
+        n_default = L.co_test_hfield_capsule(ctypes.byref(hf.pod), pc.ctypes.data, mc.ctypes.data, r, half, 0.0, out.ctypes.data)
+        n_dense = L.co_test_hfield_capsule(ctypes.byref(dense.pod), pc.ctypes.data, mc.ctypes.data, r, half, 0.0, out.ctypes.data)
+        assert n_default == 0 and n_dense == 1
+        assert -0.04 < out[0] < 0 and abs(out[1] - xs[j]) < 0.03 and out[6] > 0.5       # at the spike, pushing up
+    finally:
+        oracle_py.set_hfield(None)
+
+
+def test_emulated_kernel_matches_oracle_with_dense_sampling(built):
+    """The dense-sampling pre-pass (ten lanes per pair, six pairs per wave pass, two passes for Cassie's nine height-field
+    pairs) against the oracle with the same flag, a robot falling over on the rough part of the terrain (shins and tarsi reach
+    the ground: the long capsules are what the flag changes)."""
+    m = _dense_model()
+    h = terrain()
+    oracle_py.set_hfield(h)
+    try:
+        pod = m.pod
+        q = m.qpos_init()
+        q[0], q[1], q[2] = 0.6, 0.9, 0.75                        # over the rough part, low, and tipped over:
+        q[3:7] = [0.924, 0.0, 0.383, 0.0]                        # pitched 45 degrees
+        o = Oracle(pod, q)
+        emu = EmuBatch(pod, 1)
+        emu.qpos[:] = q
+        emu.hfield = h.ravel().copy()
+        most = 0
+        for s in range(400):
+            emu.step()
+            o.step()
+            assert (emu.info[0, 0], emu.info[0, 1]) == (o.d.ncon, o.d.nefc), s
+            most = max(most, o.d.ncon)
+        assert most >= 4                                         # several capsules on the ground
+        assert np.max(np.abs(emu.qpos[0] - o.qpos) / np.maximum(1, np.abs(o.qpos))) < 1e-7
+    finally:
+        oracle_py.set_hfield(None)
