@@ -652,6 +652,7 @@ double *cassie_sim_get_hfield_size(cassie_sim_t *c) { return phys_model_array(c-
 void cassie_sim_set_hfield_size(cassie_sim_t *c, double size[4]) { memcpy(phys_model_array(c->m, PHYS_M_HFIELD_SIZE), size, 4 * sizeof(double)); }
 float *cassie_sim_hfielddata(cassie_sim_t *c) { return phys_model_hfield_data(c->m); }
 void cassie_sim_set_hfield_dense_sampling(cassie_sim_t *c, bool on) { if (c) phys_model_set_flag(c->m, CM_FLAG_HFDENSE, on ? 1 : 0); }
+void cassie_sim_set_hfield_multi_contact(cassie_sim_t *c, bool on) { if (c) phys_model_set_flag(c->m, CM_FLAG_HFMULTI, on ? 1 : 0); }
 void cassie_sim_set_hfielddata(cassie_sim_t *c, float *data)
 {
     float *a = phys_model_hfield_data(c->m);

@@ -39,6 +39,7 @@ extern "C" {
 #define CM_MAXHFPAIR 18      /* height-field pairs of a model (their results travel through an LDS table of this many records) */
 #define CM_HF_PASS   10      /* height-field pairs whose samples fit one wave pass: CM_HF_PASS * CM_HF_SLOTS <= 64 lanes */
 #define CM_HF_SLOTS  6       /* sample spheres per height-field pair: two ends + at most four interior ones */
+#define CM_HF_MAXC    4      /* contacts per capsule / height-field pair with CM_FLAG_HFMULTI */
 #define CM_HF_SLOTS_DENSE 10 /* the same with CM_FLAG_HFDENSE: two ends + at most eight interior ones (six pairs per wave pass) */
 #define CM_MAXCON    16      /* contacts kept per env-step */
 #define CM_MAXEFC    63      /* constraint rows per env-step (lane 63 is the qfrc_smooth column) */
@@ -59,6 +60,10 @@ enum { CM_CNSTR_EQUALITY = 0, CM_CNSTR_LIMIT_JOINT = 3, CM_CNSTR_CONTACT_FRICTIO
 #define CM_FLAG_EULERDAMP  1u   /* implicit joint damping in the Euler step (SURVEY App.B 11) */
 #define CM_FLAG_WARMSTART  2u
 #define CM_FLAG_REFSAFE    4u
+#define CM_FLAG_HFMULTI   16u   /* capsule vs height field: up to CM_HF_MAXC contacts per pair -- its deepest sample spheres, deepest first
+                                   (ties: lower sample index) -- instead of the two-contact rule; towards MuJoCo's one contact per
+                                   penetrated prism.  Off by default: a Cassie standing on both feet then needs 44 constraint rows
+                                   instead of 28 */
 #define CM_FLAG_HFDENSE    8u   /* capsule vs height field: up to CM_HF_SLOTS_DENSE - 2 interior samples instead of CM_HF_SLOTS - 2 (a grid
                                    cell apart along Cassie's 0.43 m shin on the 5 cm grid of example/test_hfield.py); off by default: -10 % on
                                    BASELINE config 4 */

@@ -1526,8 +1526,9 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
          * tiles (unused until the velocity stage), where the pair loop below picks it up.  (Round 2 carried the outcome in
          * registers and fetched it with 40 cross-lane moves per pair-loop pass, and kept a second copy of the terrain walk
          * inside the pair loop for models with more pairs than one pass holds: both were what this instantiation spilled.) */
-        constexpr int HF_REC = 21; /* doubles per pair: count, then 2 x (dist, pos[3], normal[3], tangent[3]) */
-        static_assert(CM_MAXHFPAIR * HF_REC <= NB * 12, "the height-field result table must fit the cvel + cfrc tiles");
+        constexpr int HF_REC = 1 + 10 * CM_HF_MAXC; /* doubles per pair: count, then up to CM_HF_MAXC x (dist, pos[3], normal[3], tangent[3]) */
+        static_assert(CM_MAXHFPAIR * HF_REC <= NB * 12 + NVP * 12, "the height-field result table must fit the cvel + cfrc + cdof_dot + buf tiles");
+        static_assert(offsetof(decltype(S.x.s), buf) - offsetof(decltype(S.x.s), cvel) == sizeof(double) * (NB * 12 + NVP * 6), "those four tiles are contiguous");
         static_assert(CM_HF_PASS * CM_HF_SLOTS <= WV_WAVE && CM_HF_SLOTS_DENSE <= WV_WAVE, "a pass of the height-field pre-pass is one wave");
         double *const hfres = &S.x.s.cvel[0][0];
         const bool hf_on = (FEAT & FEAT_HFIELD) != 0 && env_hfield != nullptr && m->nhfpair > 0;
@@ -1587,10 +1588,23 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
                     have1 = false;
                 }
                 /* the lanes holding the chosen samples write them: first kept contact to record slot 0, second to slot 1 */
-                const int nkeep = (have0 ? 1 : 0) + (have1 ? 1 : 0);
+                int nkeep = (have0 ? 1 : 0) + (have1 ? 1 : 0);
                 double *rec = hfres + (size_t)(act ? h : 0) * HF_REC;
+                int slot_of_me = (have0 && k == src0) ? 0 : ((have1 && k == src1) ? (have0 ? 1 : 0) : -1);
+                if ((m->flags & CM_FLAG_HFMULTI) && t2 == CM_GEOM_CAPSULE) {
+                    /* CM_FLAG_HFMULTI: up to CM_HF_MAXC contacts, the deepest samples first (ties: lower sample index): a
+                     * sample's record slot is its rank among the pair's samples */
+                    int rank = 0, cnt = 0;
+#pragma unroll
+                    for (int q = 0; q < CM_HF_SLOTS_DENSE; ++q) {
+                        const bool valid = dk[q] < 1e299;
+                        cnt += valid ? 1 : 0;
+                        rank += (valid && (dk[q] < mydist || (dk[q] == mydist && q < k))) ? 1 : 0;
+                    }
+                    nkeep = cnt < CM_HF_MAXC ? cnt : CM_HF_MAXC;
+                    slot_of_me = (has && rank < CM_HF_MAXC) ? rank : -1;
+                }
                 if (act && k == 0) rec[0] = (double)nkeep;
-                const int slot_of_me = (have0 && k == src0) ? 0 : ((have1 && k == src1) ? (have0 ? 1 : 0) : -1);
                 if (act && slot_of_me >= 0) {
                     double *c = rec + 1 + 10 * slot_of_me;
                     c[0] = rcs.dist;
@@ -1604,6 +1618,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
             int n = 0;
             RawContact rc0, rc1;
             bool from_spread = false;
+            int hfs = -1;
             if constexpr ((FEAT & FEAT_HFIELD) != 0) {
                 /* height-field pairs take their result from the table the pre-pass filled (no terrain bound: no contact) */
                 const int slot = p < npass ? m->pair_hfslot[p] : -1;
@@ -1612,6 +1627,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
                     if (hf_on) {
                         const double *rec = hfres + (size_t)slot * HF_REC;
                         n = (int)rec[0];
+                        hfs = slot;     /* (contacts 3 and 4 of a CM_FLAG_HFMULTI pair go from the table straight to the contact list) */
                         rc0.dist = rec[1]; rc1.dist = rec[11];
                         for (int i = 0; i < 3; ++i) {
                             rc0.pos[i] = rec[2 + i]; rc0.normal[i] = rec[5 + i]; rc0.tangent[i] = rec[8 + i];
@@ -1680,10 +1696,25 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
             /* ballot-compact in pair order */
             const unsigned long long m1b = wv::ballot(n >= 1), m2b = wv::ballot(n >= 2);
             const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-            const int slot = ncon + wv::popc64(m1b & below) + wv::popc64(m2b & below);
+            int slot = ncon + wv::popc64(m1b & below) + wv::popc64(m2b & below);
+            int more = 0;
+            if constexpr ((FEAT & FEAT_HFIELD) != 0) {
+                /* height-field pairs with CM_FLAG_HFMULTI can hold a third and a fourth contact */
+                const unsigned long long m3b = wv::ballot(n >= 3), m4b = wv::ballot(n >= 4);
+                slot += wv::popc64(m3b & below) + wv::popc64(m4b & below);
+                more = wv::popc64(m3b) + wv::popc64(m4b);
+                for (int extra = 2; extra < CM_HF_MAXC; ++extra)
+                    if (n > extra && slot + extra < CM_MAXCON) {
+                        const double *c = hfres + (size_t)hfs * HF_REC + 1 + 10 * extra;
+                        RawContact rx;
+                        rx.dist = c[0];
+                        for (int i = 0; i < 3; ++i) { rx.pos[i] = c[1 + i]; rx.normal[i] = c[4 + i]; rx.tangent[i] = c[7 + i]; }
+                        write_raw_contact(S, slot + extra, p, rx);
+                    }
+            }
             if (n >= 1 && slot < CM_MAXCON) write_raw_contact(S, slot, p, rc0);
             if (n >= 2 && slot + 1 < CM_MAXCON) write_raw_contact(S, slot + 1, p, rc1);
-            ncon += wv::popc64(m1b) + wv::popc64(m2b);
+            ncon += wv::popc64(m1b) + wv::popc64(m2b) + more;
         }
         CK_STAMP(22);
         /* pass 2, one pair at a time with the whole wave: lane = feature (box corner / vertex), first four hits kept */

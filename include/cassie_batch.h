@@ -77,6 +77,9 @@ bool cassie_hostenv_blocks_verified(void);
  * capsules as long as Cassie's shin (eight interior samples instead of four); costs about 10 % on cassie_hfield.xml */
 struct cassie_sim;
 void cassie_sim_set_hfield_dense_sampling(struct cassie_sim *c, bool on);
+/* extension: up to four contacts per capsule / height-field pair (its deepest sample spheres) instead of two -- towards
+ * MuJoCo's one contact per penetrated prism; a Cassie standing on both feet then needs 44 constraint rows instead of 28 */
+void cassie_sim_set_hfield_multi_contact(struct cassie_sim *c, bool on);
 
 /* cores this process may really use: min(affinity mask, cgroup CPU quota) */
 int cassie_host_cpu_count(void);

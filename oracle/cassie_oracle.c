@@ -746,6 +746,30 @@ static int hfield_capsule(raw_contact_t *c, const cm_model_t *m, const float *da
     if (ni < 0) ni = 0;
     const int nimax = ((m->flags & CM_FLAG_HFDENSE) ? CM_HF_SLOTS_DENSE : CM_HF_SLOTS) - 2;
     if (ni > nimax) ni = nimax;
+    if (m->flags & CM_FLAG_HFMULTI) {
+        /* up to CM_HF_MAXC contacts: the deepest sample spheres (ends = samples 0, 1; interior ones 2 ..), deepest first,
+         * ties to the lower sample index */
+        raw_contact_t smp[CM_HF_SLOTS_DENSE];
+        int have[CM_HF_SLOTS_DENSE], taken[CM_HF_SLOTS_DENSE];
+        const int ns = 2 + ni;
+        for (int k = 0; k < ns; ++k) {
+            const double t = k == 0 ? h : (k == 1 ? -h : h * (1.0 - 2.0 * (k - 1) / (ni + 1)));
+            double e[3] = {pc[0] + t * ax[0], pc[1] + t * ax[1], pc[2] + t * ax[2]};
+            have[k] = hfield_sphere(&smp[k], m, data, ph, mh, e, sc[0], margin);
+            taken[k] = 0;
+        }
+        int n = 0;
+        while (n < CM_HF_MAXC) {
+            int best = -1;
+            for (int k = 0; k < ns; ++k) if (have[k] && !taken[k] && (best < 0 || smp[k].dist < smp[best].dist)) best = k;
+            if (best < 0) break;
+            taken[best] = 1;
+            c[n] = smp[best];
+            for (int k = 0; k < 3; ++k) c[n].tangent[k] = ax[k];
+            ++n;
+        }
+        return n;
+    }
     raw_contact_t end[2], mid;
     int have_end[2] = {0, 0}, have_mid = 0;
     double tmid = 0;
@@ -774,10 +798,10 @@ static int hfield_capsule(raw_contact_t *c, const cm_model_t *m, const float *da
 }
 
 /* test hook: one capsule (world centre pc, rotation matrix mc with the axis in its third column, radius, half length) against
- * the height field geom; out[2][7] = dist, pos, normal per contact */
+ * the height field geom; out[CM_HF_MAXC][7] = dist, pos, normal per contact (two without CM_FLAG_HFMULTI) */
 int co_test_hfield_capsule(const cm_model_t *m, const double *pc, const double *mc, double radius, double halflen, double margin, double *out) {
     if (m->hfield_geom < 0) return 0;
-    raw_contact_t c[2];
+    raw_contact_t c[CM_HF_MAXC];
     double mh[9], sc[3] = {radius, halflen, 0};
     quat2mat(mh, m->geom_quat[m->hfield_geom]);
     int n = hfield_capsule(c, m, g_hfield, m->geom_pos[m->hfield_geom], mh, pc, mc, sc, margin);

@@ -295,3 +295,22 @@ def test_dense_heightfield_sampling_flag_on_the_gpu(built):
         return q
     worst, rows, q = _pd_rollout(hf, 256, np.arange(0, 256, 16), nsteps=600, hfield=h, q0_of=place)
     assert rows >= 28
+
+
+def test_multi_contact_heightfield_flag_on_the_gpu(built):
+    """CM_FLAG_HFMULTI (optional: up to four contacts per capsule / height-field pair, deepest samples first): robots
+    standing on the flat patch (four contacts per foot: 44 rows -- past the row-capped fast kernel, so every launch is handed
+    over to the full one) and robots tipped over on the rough part; GPU against the oracle with the same flags."""
+    hf = Model("cassie_hfield")
+    hf.set_flag(P.FLAG_HFMULTI, True)
+    hf.set_flag(P.FLAG_HFDENSE, True)
+    h = np.random.default_rng(99).random((200, 200)).astype(np.float32)
+    h[95:105, 95:105] = 0
+
+    def place(e, q):
+        if e % 2:
+            q[0], q[1], q[2] = 0.6 + 0.07 * (e % 16), 0.9 - 0.05 * (e // 16 % 16), 0.75
+            q[3:7] = [0.924, 0.0, 0.383, 0.0]
+        return q
+    worst, rows, q = _pd_rollout(hf, 256, np.arange(0, 256, 8), nsteps=600, hfield=h, q0_of=place)
+    assert rows >= 40

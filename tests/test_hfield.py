@@ -305,3 +305,75 @@ def test_emulated_kernel_matches_oracle_with_dense_sampling(built):
         assert np.max(np.abs(emu.qpos[0] - o.qpos) / np.maximum(1, np.abs(o.qpos))) < 1e-7
     finally:
         oracle_py.set_hfield(None)
+
+
+def _flag_model(*flags):
+    m = Model("cassie_hfield")
+    for f in flags:
+        m.set_flag(f, True)
+    return m
+
+
+def test_multi_contact_flag_reports_the_deepest_samples(hf):
+    """CM_FLAG_HFMULTI (extension, off by default): a foot-like capsule pressed flat into flat ground reports four contacts
+    instead of its two ends -- all at the same depth, so in sample order: +h end, -h end, then the interior samples from the
+    +h side; over a spike the spike's sample comes first (deepest first)."""
+    import ctypes
+    from cassie_amd import phys as P
+    L = oracle_py.lib()
+    L.co_test_hfield_capsule.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_void_p]
+    multi = _flag_model(P.FLAG_HFMULTI)
+    nc = 200
+    xs = -5 + 10.0 * np.arange(nc) / (nc - 1)
+    j, i = int(np.argmin(np.abs(xs - 1.0))), int(np.argmin(np.abs(xs - 0.5)))
+    mc = np.array([0.0, 0, 1, 0, 1, 0, -1, 0, 0])    # capsule axis along world x
+    out = np.zeros(28)
+    pc = np.array([xs[j], xs[i], -0.1 + 0.015])      # radius 2 cm, centre 1.5 cm above the ground: 5 mm deep
+    oracle_py.set_hfield(np.zeros((200, 200), dtype=np.float32))
+    try:
+        n = L.co_test_hfield_capsule(ctypes.byref(multi.pod), pc.ctypes.data, mc.ctypes.data, 0.02, 0.08, 0.0, out.ctypes.data)
+        c = out.reshape(4, 7)
+        assert n == 4 and np.allclose(c[:, 0], -0.005)
+        assert np.allclose(c[:, 1], [xs[j] + 0.08, xs[j] - 0.08, xs[j] + 0.04, xs[j]])      # 3 interior samples: +4 cm, 0, -4 cm; the first two make the cut
+        assert L.co_test_hfield_capsule(ctypes.byref(hf.pod), pc.ctypes.data, mc.ctypes.data, 0.02, 0.08, 0.0, out.ctypes.data) == 2
+        h = np.zeros((200, 200), dtype=np.float32)
+        h[i, j] = 0.25                               # 5 cm spike under the middle
+        oracle_py.set_hfield(h)
+        n = L.co_test_hfield_capsule(ctypes.byref(multi.pod), pc.ctypes.data, mc.ctypes.data, 0.02, 0.08, 0.0, out.ctypes.data)
+        c = out.reshape(4, 7)
+        assert n == 4 and c[0, 0] < -0.04 and abs(c[0, 1] - xs[j]) < 0.03 and np.all(np.diff(c[:, 0]) >= 0)    # deepest first
+    finally:
+        oracle_py.set_hfield(None)
+
+
+@pytest.mark.parametrize("dense", [False, True])
+def test_emulated_kernel_matches_oracle_with_multi_contact(built, dense):
+    """The multi-contact rule (rank of a sample among its pair's samples = its slot of the pair's record; third and fourth
+    contact straight from the LDS table to the contact list) against the oracle: a robot dropped on the flat patch (standing:
+    four contacts per foot) and one tipped over on the rough part."""
+    from cassie_amd import phys as P
+    m = _flag_model(*([P.FLAG_HFMULTI] + ([P.FLAG_HFDENSE] if dense else [])))
+    h = terrain()
+    oracle_py.set_hfield(h)
+    try:
+        pod = m.pod
+        q0 = m.qpos_init()
+        q1 = m.qpos_init()
+        q1[0], q1[1], q1[2] = 0.6, 0.9, 0.75
+        q1[3:7] = [0.924, 0.0, 0.383, 0.0]
+        orcs = [Oracle(pod, q0), Oracle(pod, q1)]
+        emu = EmuBatch(pod, 2)
+        emu.qpos[0], emu.qpos[1] = q0, q1
+        emu.hfield = h.ravel().copy()
+        most = [0, 0]
+        for s in range(350):
+            emu.step()
+            for e, o in enumerate(orcs):
+                o.step()
+                assert (emu.info[e, 0], emu.info[e, 1]) == (o.d.ncon, o.d.nefc), (s, e)
+                most[e] = max(most[e], o.d.ncon)
+        assert most[0] >= 6 and most[1] >= 5         # more than the two-per-capsule rule gives a standing / lying robot
+        for e, o in enumerate(orcs):
+            assert np.max(np.abs(emu.qpos[e] - o.qpos) / np.maximum(1, np.abs(o.qpos))) < 1e-7
+    finally:
+        oracle_py.set_hfield(None)
