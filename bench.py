@@ -547,12 +547,16 @@ def device_rollout(model, mode, n, steps, warmup, rank, world, local_rank, subst
     region_s, region_ev, region_launches = [], [], []
     q_sample = info_sample = None
     sch.run(0, PREROLL + warmup)
+    b.enable_kernel_timing(True)        # a HIP event pair around the work-doing kernel of every stepping launch from here on
+    kern_n, kern_ms_total = 0, 0.0
     for r in range(repeats):
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in streams]
         region_s.append(timed_region(sch, PREROLL + warmup + r * steps, steps, fence,
                                      mark=lambda i: [e[i].record(st) for e, st in zip(evs, streams)]))
         region_ev.append([e[0].elapsed_time(e[1]) for e in evs])     # per stream: its time over the region
         region_launches.append(sch.launches)
+        kn, kms = b.kernel_timing()       # (after the fence: the region's launches are complete)
+        kern_n, kern_ms_total = kern_n + kn, kern_ms_total + kms
         if r == snap_r:     # between two fenced regions: the sampled rows of this rank for the CPU replay
             q_sample = obs[sample_dev, :nq].clone()
             info_sample = torch.from_numpy(b.warnings()[1][sample][:, :3].astype(np.int64)).to(dev)
@@ -564,7 +568,10 @@ def device_rollout(model, mode, n, steps, warmup, rank, world, local_rank, subst
     res = {"mode": mode, "n": n, "steps": steps, "warmup": warmup, "repeats": repeats, "launches": launches, "streams": len(ranges),
            # mean stream time of ONE range's launch (includes the rare restart / gather); with several streams the ranges' launches
            # overlap, each sharing the GPU with the others'
-           "kernel_ms": float(np.mean([np.sum([ev[i] for ev in region_ev]) for i in range(len(streams))])) / launches,
+           "stream_ms": float(np.mean([np.sum([ev[i] for ev in region_ev]) for i in range(len(streams))])) / launches,
+           # the dominant kernel itself: mean duration over all its launches of the timed regions, from a HIP event pair around each
+           # on its launch stream (phys_batch_kernel_timing) -- the quantity rocprofv3 --kernel-trace --stats averages
+           "kernel_ms": kern_ms_total / max(1, kern_n), "kernel_launches": kern_n,
            "region_s": region_s, "elapsed": float(np.median(region_s))}
     if collect and rank == 0:
         # the gathered block of the last policy boundary must hold this rank's rows (global env order, rank-major)
@@ -693,7 +700,11 @@ def main():
         # read qpos+qvel+qacc_warmstart+ctrl, write qpos+qvel+qacc+sensordata+actuator_velocity (1976 B for cassie)
         algo_bytes = 8 * ((pod.nq + 2 * pod.nv + pod.nu) + (pod.nq + 2 * pod.nv + pod.nsensordata + pod.nu))
         assert args.model != "cassie" or algo_bytes == ALGO_BYTES_PER_ENV_STEP
-        achieved = algo_bytes * n * steps_per_launch / (kern_ms * 1e-3) / 1e9
+        # whole GPU: algorithmic bytes of every env-step of a timed region / the region's time (= value x bytes per env-step);
+        # one launch of the dominant kernel: its env-steps x bytes / its own mean duration
+        launch_env_steps = n * steps_per_launch / r["streams"]
+        achieved_one = algo_bytes * launch_env_steps / (kern_ms * 1e-3) / 1e9
+        achieved = algo_bytes * world * n * args.steps / elapsed / 1e9 / world
         rate = lambda sec: world * n * args.steps / sec
         value = rate(elapsed)
         traffic, traffic_src = pmc_traffic(n * steps_per_launch, args.model)
@@ -733,13 +744,16 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "concurrent_launches": r["streams"],
-                         "achieved_note": ("algorithmic bytes of the %d launches that run side by side (one per stream, %d env-steps each) / the mean "
-                                           "duration of one of them (HIP events on its stream); one launch alone: %.2f GB/s"
-                                           % (r["streams"], n * steps_per_launch // r["streams"], achieved / r["streams"])) if r["streams"] > 1 else
-                                          "algorithmic bytes of one launch / its mean duration (HIP events on the launch stream)",
-                         "traffic_note": "PMC bytes per env-step of the profiled 50-substep launch x this run's env-steps per launch; the state-in / "
-                                         "state-out part of it does not shrink with fewer substeps per launch, so short launches move more than this",
-                         "kernel": "cassie_step_kernel<%d>" % (32 if pod.nv <= 32 else 40), "kernel_ms": kern_ms, "algorithmic_bytes_per_env_step": algo_bytes, "env_steps_per_launch": n * steps_per_launch,
+                         "achieved_note": ("per GPU: algorithmic bytes of all env-steps of a timed region / the region's time.  The %d env ranges' launches "
+                                           "overlap; ONE launch of the dominant kernel (%d env-steps, `kernel_ms` = its mean duration from a HIP "
+                                           "event pair around every launch on its stream -- what rocprofv3 averages) moves %.2f GB/s, and a range "
+                                           "needs `stream_ms_per_policy_step` per policy step (that kernel + the resume pass waiting for wave "
+                                           "slots + order / restart kernels)" % (r["streams"], launch_env_steps, achieved_one)) if r["streams"] > 1 else
+                                          "algorithmic bytes of one launch / the dominant kernel's mean duration (a HIP event pair around every launch on the launch stream)",
+                         "achieved_one_launch": achieved_one, "stream_ms_per_policy_step": r["stream_ms"], "kernel_launches_timed": r["kernel_launches"],
+                         "kernel": {"cassie": "ck::cassie_step_kernel<32, ck::TopoCassie32, 0, 31> (row-capped fast instantiation; <..., 63> finishes handed-over envs)",
+                                    "cassie_hfield": "ck::cassie_step_kernel<32, ck::TopoCassie32, 1, 31> (row-capped fast instantiation; <..., 63> finishes handed-over envs)",
+                                    "cassie_tray_box": "ck::cassie_step_kernel<40, ck::TopoCassieTray38, 2, 63>"}[args.model], "kernel_ms": kern_ms, "algorithmic_bytes_per_env_step": algo_bytes, "env_steps_per_launch": launch_env_steps,
                          "note": "latency-bound by design: ~2 KB of state vs ~0.22 MFLOP of serially dependent fp64 per env-step"},
             # the more telling bound: ~0.22 MFLOP of algorithmic fp64 work per env-step against the fp64 vector peak
             "roofline_fp64": {"bound": "fp64-valu", "achieved": value * 0.22e6 / 1e12, "peak": 78.6 * world, "unit": "TFLOP/s",

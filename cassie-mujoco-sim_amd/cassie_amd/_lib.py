@@ -93,6 +93,9 @@ def _declare(L):
     L.phys_batch_debug_poison_lds.argtypes = [vp]
     L.phys_batch_set_balance.argtypes = [vp, c.c_int]
     L.phys_batch_set_fast_rows.argtypes = [vp, c.c_int]
+    if hasattr(L, "phys_batch_kernel_timing"):
+        L.phys_batch_enable_kernel_timing.argtypes = [vp, c.c_int]
+        L.phys_batch_kernel_timing.argtypes = [vp, c.POINTER(c.c_int), c.POINTER(c.c_double)]
     if hasattr(L, "phys_batch_step_range"):
         L.phys_batch_step_range.argtypes = [vp, c.c_int, c.c_int, c.c_int, vp]
     if hasattr(L, "phys_batch_reset_envs"):

@@ -233,6 +233,16 @@ class Batch:
         """Longest-job-first launch order from the previous launch's per-env cost (default on for >= 2048 envs)."""
         lib().phys_batch_set_balance(self._h, 1 if on else 0)
 
+    def enable_kernel_timing(self, on=True):
+        lib().phys_batch_enable_kernel_timing(self._h, 1 if on else 0)
+
+    def kernel_timing(self):
+        """(launches, total ms) of the work-doing kernel of every stepping launch since the last call (HIP event pairs)."""
+        n, ms = ctypes.c_int(0), ctypes.c_double(0.0)
+        if lib().phys_batch_kernel_timing(self._h, ctypes.byref(n), ctypes.byref(ms)) != 0:
+            raise RuntimeError("kernel timing failed")
+        return n.value, ms.value
+
     def set_fast_rows(self, on=True):
         """Row-capped fast kernel ahead of the full one (default on; results are bit for bit the same either way)."""
         lib().phys_batch_set_fast_rows(self._h, 1 if on else 0)

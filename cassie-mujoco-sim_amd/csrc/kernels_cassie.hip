@@ -1,5 +1,5 @@
 /* the step kernel for plain cassie.xml (BASELINE configs 1-3): 32 dofs, compile-time topology, no height-field / box code */
 #include "step_launch.h"
 namespace ck {
-bool launch_step_cassie(dim3 grid, hipStream_t s, PhysIO io, bool fast) { return launch_fast_then_full<32, TopoCassie32, 0>(grid, s, io, fast); }
+bool launch_step_cassie(dim3 grid, hipStream_t s, PhysIO io, bool fast, hipEvent_t after_first) { return launch_fast_then_full<32, TopoCassie32, 0>(grid, s, io, fast, after_first); }
 }  // namespace ck

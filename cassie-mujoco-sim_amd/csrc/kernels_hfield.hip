@@ -1,5 +1,5 @@
 /* the step kernel for cassie_hfield.xml (BASELINE config 4): 32 dofs, compile-time topology, height-field pairs */
 #include "step_launch.h"
 namespace ck {
-bool launch_step_cassie_hfield(dim3 grid, hipStream_t s, PhysIO io, bool fast) { return launch_fast_then_full<32, TopoCassie32, FEAT_HFIELD>(grid, s, io, fast); }
+bool launch_step_cassie_hfield(dim3 grid, hipStream_t s, PhysIO io, bool fast, hipEvent_t after_first) { return launch_fast_then_full<32, TopoCassie32, FEAT_HFIELD>(grid, s, io, fast, after_first); }
 }  // namespace ck

@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "cassie_phys.h"
@@ -53,6 +54,10 @@ struct phys_batch {
     int *d_order = nullptr;
     int launches_since_order = 0;
     cm_ext_t *d_ext = nullptr;
+    /* per-kernel timing (phys_batch_kernel_timing): event pairs around the kernel of every stepping launch that does the work */
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    size_t ev_used = 0;
     int *d_progress = nullptr;      /* [nenv] substeps completed by the row-capped fast instantiation (PhysIO::progress) */
     bool fast_rows = true;          /* use the row-capped fast instantiation where one exists (phys_batch_set_fast_rows) */
     double *d_scratch_out = nullptr; /* [nenv][nv + nsensordata + nu]: where phys_batch_forward_kinematics sends qacc / sensordata / actuator_velocity */
@@ -147,16 +152,29 @@ static int launch(phys_batch *b, int nsub, int integrate, hipStream_t s, bool sc
      * neither height-field nor whole-wave (plane-box / box-box) pairs */
     const bool hf = hm.nhfpair > 0 || hm.hfield_geom >= 0, wp = hm.npair > hm.npair_simple;
     bool launched;
+    hipEvent_t ev_after = nullptr;
+    if (b->timing && integrate) {
+        if (b->ev_used == b->ev_pool.size()) {
+            hipEvent_t a = nullptr, c = nullptr;
+            if (hipEventCreate(&a) == hipSuccess && hipEventCreate(&c) == hipSuccess) b->ev_pool.emplace_back(a, c);
+        }
+        if (b->ev_used < b->ev_pool.size()) {
+            (void)hipEventRecord(b->ev_pool[b->ev_used].first, s);
+            ev_after = b->ev_pool[b->ev_used].second;
+            ++b->ev_used;
+        }
+    }
     if (matches(ck::TopoCassie32::table, ck::TopoCassie32::nv)) {
         /* stepping launches of the two Cassie instantiations go through the row-capped fast instantiation first; the full one
          * behind it finishes the envs that met a substep with more rows (and is the only one for forward / read-out passes) */
         const bool fast = b->fast_rows && integrate && !wp && !io.ext && b->d_progress;
         io.progress = fast ? b->d_progress : nullptr;
-        if (!hf && !wp) launched = ck::launch_step_cassie(grid, s, io, fast);
-        else if (hf && !wp) launched = ck::launch_step_cassie_hfield(grid, s, io, fast);
+        if (!hf && !wp) { launched = ck::launch_step_cassie(grid, s, io, fast, ev_after); ev_after = nullptr; }
+        else if (hf && !wp) { launched = ck::launch_step_cassie_hfield(grid, s, io, fast, ev_after); ev_after = nullptr; }
         else launched = ck::launch_step_cassie_all(grid, s, io);
     } else if (matches(ck::TopoCassieTray38::table, ck::TopoCassieTray38::nv)) launched = ck::launch_step_tray(grid, s, io, hf);
     else launched = ck::launch_step_generic(grid, s, io, hm.nv > 32);
+    if (ev_after) (void)hipEventRecord(ev_after, s);
     if (!launched) { (void)hip_ok(hipErrorLaunchFailure, "cassie_step_kernel launch"); return -1; }
     if (!hip_ok(hipGetLastError(), "cassie_step_kernel launch")) return -1;
     /* the next launch's order from this one's per-env cost: after every long launch, now and then after short ones */
@@ -259,6 +277,7 @@ void phys_batch_free(phys_batch_t *b) {
     if (b->d_ext) (void)hipFree(b->d_ext);
     if (b->d_scratch_out) (void)hipFree(b->d_scratch_out);
     if (b->d_progress) (void)hipFree(b->d_progress);
+    for (auto &e : b->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (b->d_drive) (void)hipFree(b->d_drive);
     if (b->d_order) (void)hipFree(b->d_order);
     if (b->d_cost) (void)hipFree(b->d_cost);
@@ -634,6 +653,28 @@ int phys_batch_download_progress(phys_batch_t *b, int *host) {
     (void)hipSetDevice(b->device);
     if (!quiesce(b)) return -1;
     return hip_ok(hipMemcpy(host, b->d_progress, sizeof(int) * (size_t)b->nenv, hipMemcpyDeviceToHost), "progress download") ? 0 : -1;
+}
+
+int phys_batch_enable_kernel_timing(phys_batch_t *b, int on) {
+    if (!b) return -1;
+    b->timing = on != 0;
+    b->ev_used = 0;
+    return 0;
+}
+
+int phys_batch_kernel_timing(phys_batch_t *b, int *launches, double *total_ms) {
+    if (!b || !launches || !total_ms) return -1;
+    (void)hipSetDevice(b->device);
+    if (!quiesce(b)) return -1;
+    double sum = 0;
+    int n = 0;
+    for (size_t i = 0; i < b->ev_used; ++i) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, b->ev_pool[i].first, b->ev_pool[i].second) == hipSuccess) { sum += ms; ++n; }
+    }
+    b->ev_used = 0;
+    *launches = n; *total_ms = sum;
+    return 0;
 }
 
 int phys_batch_set_fast_rows(phys_batch_t *b, int on) {

@@ -13,23 +13,26 @@
 
 namespace ck {
 /* io.progress must be set when fast is; io.resume is managed here */
-bool launch_step_cassie(dim3 grid, hipStream_t s, PhysIO io, bool fast);            /* <32, TopoCassie32, 0>: plain cassie.xml */
-bool launch_step_cassie_hfield(dim3 grid, hipStream_t s, PhysIO io, bool fast);     /* <32, TopoCassie32, FEAT_HFIELD> */
+/* after_first (may be null): recorded behind the first kernel of the launch -- the one that does the work -- for per-kernel timing */
+bool launch_step_cassie(dim3 grid, hipStream_t s, PhysIO io, bool fast, hipEvent_t after_first);            /* <32, TopoCassie32, 0>: plain cassie.xml */
+bool launch_step_cassie_hfield(dim3 grid, hipStream_t s, PhysIO io, bool fast, hipEvent_t after_first);     /* <32, TopoCassie32, FEAT_HFIELD> */
 bool launch_step_cassie_all(dim3 grid, hipStream_t s, PhysIO io);                   /* <32, TopoCassie32, FEAT_ALL> */
 bool launch_step_tray(dim3 grid, hipStream_t s, PhysIO io, bool hfield);            /* <40, TopoCassieTray38, FEAT_WAVEPAIRS | FEAT_ALL> */
 bool launch_step_generic(dim3 grid, hipStream_t s, PhysIO io, bool wide);           /* <32 | 40, TopoRuntime, FEAT_ALL> */
 
 template <int NVP, class TOPO, int FEAT>
-inline bool launch_fast_then_full(dim3 grid, hipStream_t s, PhysIO io, bool fast) {
+inline bool launch_fast_then_full(dim3 grid, hipStream_t s, PhysIO io, bool fast, hipEvent_t after_first) {
     if (fast) {
         io.resume = 0;
         hipLaunchKernelGGL((cassie_step_kernel<NVP, TOPO, FEAT, FAST_ROWS>), grid, dim3(WV_WAVE), 0, s, io);
         if (hipGetLastError() != hipSuccess) return false;
+        if (after_first) { (void)hipEventRecord(after_first, s); after_first = nullptr; }
         io.resume = 1;
     } else {
         io.progress = nullptr; io.resume = 0;
     }
     hipLaunchKernelGGL((cassie_step_kernel<NVP, TOPO, FEAT>), grid, dim3(WV_WAVE), 0, s, io);
+    if (after_first) (void)hipEventRecord(after_first, s);
     return hipGetLastError() == hipSuccess;
 }
 }  // namespace ck

@@ -202,6 +202,12 @@ int phys_batch_set_balance(phys_batch_t *b, int on);
 /* on (default): stepping launches of the Cassie instantiations run the row-capped fast kernel first and the full kernel
  * only finishes envs that needed more than 31 constraint rows in some substep; off: the full kernel alone (same results,
  * bit for bit -- a validation / measurement aid) */
+/* measurement aid: with timing enabled every stepping launch records a HIP event pair around the kernel that does its work
+ * (the row-capped fast kernel where one exists, else the step kernel) on the launch's stream; phys_batch_kernel_timing waits
+ * for the batch's streams and returns the number of launches since the last call and the sum of their kernel durations -- the
+ * same quantity rocprofv3 --kernel-trace --stats averages, also when launches of several env ranges overlap */
+int phys_batch_enable_kernel_timing(phys_batch_t *b, int on);
+int phys_batch_kernel_timing(phys_batch_t *b, int *launches, double *total_ms);
 int phys_batch_set_fast_rows(phys_batch_t *b, int on);
 /* diagnostics: how many substeps of the last stepping launch the fast kernel completed for every env ([nenv] ints; less than
  * the launch's substep count = the env was handed over to the full kernel there) */

@@ -39,7 +39,7 @@ timeout 300 python tools/single_sim_profile.py > gpurun_out/single_sim_profile.t
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 for m in cassie cassie_hfield cassie_tray_box; do
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$m -- python $R/bench.py --model $m --steps 200 --warmup 50 --repeats 3 --no-cpu-baseline --no-step-pd --no-other-mode > $R/gpurun_out/prof_$m.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$m -- python $R/bench.py --model $m --no-cpu-baseline --no-step-pd --no-other-mode > $R/gpurun_out/prof_$m.log 2>&1
 done
 cd $R
 for m in cassie cassie_hfield cassie_tray_box; do f=$(ls -t gpurun_out/prof_$m/*/*kernel_stats.csv | head -1); cp $f gpurun_out/kernel_stats_$m.csv; echo "== $m"; head -3 $f | cut -c1-200; done
