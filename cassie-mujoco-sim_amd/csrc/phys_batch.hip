@@ -573,7 +573,7 @@ int phys_batch_reset_envs(phys_batch_t *b, int first, int stride, int count, con
     io.qpos_row = qpos_row; io.sens_row = sens_row;
     hipStream_t s = stream ? (hipStream_t)stream : b->stream;
     note_stream(b, s);
-    hipLaunchKernelGGL(ck::cassie_reset_kernel, dim3(count), dim3(WV_WAVE), 0, s, io);
+    hipLaunchKernelGGL(ck::cassie_reset_kernel, dim3(count < 4 ? count : 4), dim3(WV_WAVE), 0, s, io);
     return hip_ok(hipGetLastError(), "cassie_reset_kernel launch") ? 0 : -1;
 }
 

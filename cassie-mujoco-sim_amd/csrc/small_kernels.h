@@ -205,10 +205,12 @@ struct ResetIO {
     const double *sens_row;     /* [nsensordata] or null: sensordata is left alone */
 };
 WV_GLOBAL void __launch_bounds__(WV_WAVE) cassie_reset_kernel(ResetIO io) {
-    const int i = wv::env_id();
-    if (i >= io.count) return;
-    const size_t env = (size_t)io.first + (size_t)i * io.stride;
+#ifndef CK_EMULATED
+    /* a few workgroups walk all the envs: on a GPU saturated by another stream's step kernel every workgroup waits for a
+     * wave slot to free, and one workgroup per env made this kernel a 0.5 ms stall of its stream (rocprofv3, two-range stepping) */
     const int lane = wv::lane();
+    for (int i = (int)blockIdx.x; i < io.count; i += (int)gridDim.x) {
+    const size_t env = (size_t)io.first + (size_t)i * io.stride;
     if (lane < io.nq) io.qpos[env * io.sq + lane] = io.qpos_row[lane];
     if (lane < io.nv) { io.qvel[env * io.sqv + lane] = 0.0; io.warm[env * io.nv + lane] = 0.0; io.qacc[env * io.nv + lane] = 0.0; }
     if (lane < io.nu) { io.ctrl[env * io.nu + lane] = 0.0; io.actvel[env * io.nu + lane] = 0.0; }
@@ -219,6 +221,8 @@ WV_GLOBAL void __launch_bounds__(WV_WAVE) cassie_reset_kernel(ResetIO io) {
         for (int k = lane; k < (int)(sizeof(cm_drive_state_t) / sizeof(int)); k += WV_WAVE) w[k] = 0;
     }
     if (lane == 0) io.time[env] = 0.0;
+    }
+#endif
 }
 
 }  // namespace ck
