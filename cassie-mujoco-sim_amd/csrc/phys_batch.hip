@@ -154,7 +154,7 @@ static int launch(phys_batch *b, int nsub, int integrate, hipStream_t s, bool sc
     bool launched;
     hipEvent_t ev_after = nullptr;
     if (b->timing && integrate) {
-        if (b->ev_used == b->ev_pool.size()) {
+        if (b->ev_used == b->ev_pool.size() && b->ev_pool.size() < 65536) { /* (launches beyond that between two queries go untimed) */
             hipEvent_t a = nullptr, c = nullptr;
             if (hipEventCreate(&a) == hipSuccess && hipEventCreate(&c) == hipSuccess) b->ev_pool.emplace_back(a, c);
         }
