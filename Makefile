@@ -26,7 +26,12 @@ CXXFLAGS := -O2 -std=c++17 -fPIC -Iinclude -I$(CSRC)
 CFLAGS   := -O2 -std=gnu11 -fPIC -Iinclude -I$(CSRC)
 # -amdgpu-sched-strategy=iterative-ilp: the step kernel is one long latency-bound instruction stream at one wave per SIMD;
 # scheduling for ILP instead of for occupancy measured +1.8 % (exact-pd) / +2.7 % (drive-pd), profiles/round2/README.md
-HIPFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Iinclude -I$(CSRC) -ffp-contract=on -mllvm -amdgpu-sched-strategy=iterative-ilp
+# -disable-machine-licm: the substep loop is one 20 000-instruction body at the register limit; machine-level LICM hoists the
+# materialisation of every fp64 literal and every loop-invariant lane predicate out of it -- into registers the loop does not
+# have, i.e. into scratch and SGPR-spill lanes that the loop then reloads.  Without it: scratch 136 -> 0 B, 474 -> 392 SGPR
+# spills, and +1 % (profiles/round3/README.md)
+HIPFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Iinclude -I$(CSRC) -ffp-contract=on -mllvm -amdgpu-sched-strategy=iterative-ilp \
+            -mllvm -disable-machine-licm
 
 HOST_CPP := $(CSRC)/mjcf_loader.cpp $(CSRC)/phys_host.cpp
 HOST_C   := $(wildcard $(CSRC)/*.c)
@@ -75,7 +80,7 @@ tests/emu/libcassie_emu.so: tests/emu/emu_runtime.cpp tests/emu/wave.h $(CSRC)/p
 	g++ -O2 -std=c++17 -fPIC -shared -Wl,-Bsymbolic -Itests/emu -I$(CSRC) tests/emu/emu_runtime.cpp -o $@
 
 models: product
-	python3 tools/make_models.py $(REF)/model models
+	python3 tools/make_models.py $(REF)/model models tests/golden
 
 clean:
 	rm -rf $(OBJD) $(PRODUCT) oracle/libcassie_oracle.so tests/emu/libcassie_emu.so

@@ -10,7 +10,9 @@ REPO_DIR = os.path.dirname(PKG_DIR)
 LIB_PATH = os.environ.get("CASSIE_LIB") or os.path.join(PKG_DIR, "lib", "libcassiemujoco.so")
 MODEL_DIR = os.path.join(REPO_DIR, "models")
 
-with open(os.path.join(PKG_DIR, "csrc", "cm_model.h")) as _f:
+# (a variant built from an older source tree comes with its own header: <variant>.so.cm_model.h next to it)
+_variant_hdr = LIB_PATH + ".cm_model.h"
+with open(_variant_hdr if os.path.exists(_variant_hdr) else os.path.join(PKG_DIR, "csrc", "cm_model.h")) as _f:
     _hdr = _f.read()
 MACROS = cstruct.parse_defines(_hdr)
 _structs = cstruct.parse_structs(_hdr, MACROS)

@@ -42,6 +42,7 @@ extern "C" {
 #define CM_HF_MAXC    4      /* contacts per capsule / height-field pair with CM_FLAG_HFMULTI */
 #define CM_HF_SLOTS_DENSE 10 /* the same with CM_FLAG_HFDENSE: two ends + at most eight interior ones (six pairs per wave pass) */
 #define CM_MAXCON    16      /* contacts kept per env-step */
+#define CM_MAXSLIDE  3       /* slide joints ahead of a body's rotational joint (kin_simple) */
 #define CM_MAXEFC    63      /* constraint rows per env-step (lane 63 is the qfrc_smooth column) */
 
 /* joint types (same numbering as MuJoCo's mjtJoint) */
@@ -69,6 +70,21 @@ enum { CM_CNSTR_EQUALITY = 0, CM_CNSTR_LIMIT_JOINT = 3, CM_CNSTR_CONTACT_FRICTIO
                                    BASELINE config 4 */
 
 #define CM_MINVAL 1e-15
+
+/* Kinematics record of a body of a kin_simple model: everything its lane needs to build the body's transform relative
+ * to its parent, in ONE level of reads indexed by the body (no body -> joint -> parameter chains, no loop over joints).
+ * Axes and anchors of the slides and of the rotational joint are constants in the PARENT frame (*_p = mat * local value),
+ * because no rotation of the same body precedes them.  A body with a free joint has mat / quat = identity and pos unused
+ * (its frame is qpos itself); absent slides have zero axes (their arithmetic runs unpredicated), absent rotational joint:
+ * rot_type = rot_jnt = -1. */
+typedef struct cm_kinrec {
+    int nslide, jnt0, rot_jnt, rot_type;
+    int rot_qadr, slide_qadr[CM_MAXSLIDE];
+    double slide_ref[CM_MAXSLIDE], slide_axis_p[CM_MAXSLIDE][3], slide_pos_p[CM_MAXSLIDE][3];
+    double rot_ref, rot_axis[3], rot_pos[3];   /* local axis (hinge quaternion) and anchor (0 for free joints) */
+    double rot_axis_p[3], rot_pos_p[3];       /* (0, 0, 1) and 0 for free joints */
+    double mat[9], quat[4], pos[3];
+} cm_kinrec_t;
 
 typedef struct cm_model {
     /* sizes */
@@ -102,6 +118,11 @@ typedef struct cm_model {
     double body_ipos[CM_MAXBODY][3], body_iquat[CM_MAXBODY][4];
     double body_mass[CM_MAXBODY], body_inertia[CM_MAXBODY][3];
     double body_mat[CM_MAXBODY][9], body_imat[CM_MAXBODY][9]; /* rotation matrices of body_quat / body_iquat */
+    /* kin_simple: every body's joints are at most CM_MAXSLIDE slides followed by at most one rotational joint (hinge /
+     * ball / free) -- true of the three in-scope models (the pelvis of model/cassie.xml:81-84 is three slides and a
+     * ball); body_kin is meaningful only then, and the compile-time-topology kernels require it */
+    int kin_simple;
+    cm_kinrec_t body_kin[CM_MAXBODY];
     double body_invweight0[CM_MAXBODY][2];
     double body_reach[CM_MAXBODY];        /* for tree roots: radius around the root body's origin that contains every
                                            * collision geom of the tree in any configuration (1e30 = unbounded) */

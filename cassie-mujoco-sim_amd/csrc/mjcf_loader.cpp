@@ -1057,6 +1057,39 @@ bool HostModel::compile(cm_model_t *o, std::string *err) const {
         for (int i = 0; i < 5; ++i) o->jnt_solimp[j][i] = jnt_solimp[5 * j + i];
         o->jnt_stiffness[j] = jnt_stiffness[j]; o->jnt_margin[j] = jnt_margin[j];
     }
+    /* kinematics records: leading slides + one rotational joint per body (cm_model.h cm_kinrec_t) */
+    o->kin_simple = 1;
+    for (int b = 0; b < nbody; ++b) {
+        cm_kinrec_t &kr = o->body_kin[b];
+        memset(&kr, 0, sizeof kr);
+        const int j0 = body_jntadr[b], jn = body_jntnum[b];
+        int nsl = 0;
+        while (nsl < jn && jnt_type[j0 + nsl] == CM_JNT_SLIDE) ++nsl;
+        const int rest = jn - nsl;
+        const int rj = rest >= 1 ? j0 + nsl : -1;
+        const bool freebody = rj >= 0 && jnt_type[rj] == CM_JNT_FREE;
+        if (nsl > CM_MAXSLIDE || rest > 1 || (freebody && nsl > 0)) { o->kin_simple = 0; nsl = nsl > CM_MAXSLIDE ? CM_MAXSLIDE : nsl; }
+        kr.nslide = nsl; kr.jnt0 = jn > 0 ? j0 : 0; kr.rot_jnt = rj; kr.rot_type = rj >= 0 ? jnt_type[rj] : -1;
+        const double ident[4] = {1, 0, 0, 0};
+        for (int i = 0; i < 4; ++i) kr.quat[i] = freebody ? ident[i] : body_quat[4 * b + i];
+        quat2mat(kr.mat, kr.quat);
+        for (int i = 0; i < 3; ++i) kr.pos[i] = body_pos[3 * b + i];
+        for (int sl = 0; sl < nsl; ++sl) {
+            const int j = j0 + sl;
+            kr.slide_qadr[sl] = jnt_qposadr[j]; kr.slide_ref[sl] = qpos0[jnt_qposadr[j]];
+            rotvec(kr.slide_axis_p[sl], kr.mat, &jnt_axis[3 * j]);
+            rotvec(kr.slide_pos_p[sl], kr.mat, &jnt_pos[3 * j]);
+        }
+        if (rj >= 0) {
+            kr.rot_qadr = jnt_qposadr[rj]; kr.rot_ref = qpos0[jnt_qposadr[rj]];
+            if (freebody) kr.rot_axis[2] = kr.rot_axis_p[2] = 1.0;
+            else {
+                for (int i = 0; i < 3; ++i) { kr.rot_axis[i] = jnt_axis[3 * rj + i]; kr.rot_pos[i] = jnt_pos[3 * rj + i]; }
+                rotvec(kr.rot_axis_p, kr.mat, kr.rot_axis);
+                rotvec(kr.rot_pos_p, kr.mat, kr.rot_pos);
+            }
+        }
+    }
     for (int i = 0; i < nq; ++i) { o->qpos0[i] = qpos0[i]; o->qpos_spring[i] = qpos_spring[i]; }
     for (int d = 0; d < nv; ++d) {
         o->dof_bodyid[d] = dof_bodyid[d]; o->dof_jntid[d] = dof_jntid[d]; o->dof_parentid[d] = dof_parentid[d];

@@ -144,7 +144,7 @@ static int launch(phys_batch *b, int nsub, int integrate, hipStream_t s, bool sc
     /* the compile-time-topology instantiations are used only when the model's dof tree is exactly theirs */
     const cm_model_t &hm = b->host_model;
     auto matches = [&](const unsigned long long *table, int nv) {
-        if (b->generic_kernel || hm.nv != nv) return false;
+        if (b->generic_kernel || hm.nv != nv || !hm.kin_simple) return false; /* (kin_simple: their kinematics stage, cm_model.h) */
         for (int k = 0; k < nv; ++k) if (hm.dof_ancmask[k] != table[k]) return false;
         return true;
     };
@@ -316,6 +316,7 @@ int phys_batch_set_model(phys_batch_t *b, const cm_model_t *model, int env) {
     /* one launch serves every env with the kernel instantiation picked from the shared model: a per-env model may vary
      * parameters, not the dof tree or the kinds of collision pairs */
     if (memcmp(model->dof_ancmask, b->host_model.dof_ancmask, sizeof(model->dof_ancmask[0]) * (size_t)model->nv) != 0 ||
+        model->kin_simple != b->host_model.kin_simple ||
         (model->nhfpair > 0) != (b->host_model.nhfpair > 0) || (model->hfield_geom >= 0) != (b->host_model.hfield_geom >= 0) ||
         (model->npair > model->npair_simple) != (b->host_model.npair > b->host_model.npair_simple)) {
         phys_set_last_error("phys_batch_set_model: a per-env model must keep the shared model's dof tree and collision pair kinds");

@@ -184,6 +184,51 @@ WV_DEVICE void normalize4(double *q) {
     if (n < CM_MINVAL) { q[0] = 1; q[1] = q[2] = q[3] = 0; }
     else { double s = 1.0 / n; q[0] *= s; q[1] *= s; q[2] *= s; q[3] *= s; }
 }
+/* the same through the hardware reciprocal-square-root estimate and two Newton steps (kinematics of the
+ * compile-time-topology kernels: no IEEE square root + division sequence on the stage's chain) */
+WV_DEVICE void normalize4_fast(double *q) {
+    const double n2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+    if (n2 < CM_MINVAL * CM_MINVAL) { q[0] = 1; q[1] = q[2] = q[3] = 0; }
+    else {
+        double y = wv::rsq_estimate(n2);
+        y = fma(0.5 * y, fma(-n2 * y, y, 1.0), y);
+        y = fma(0.5 * y, fma(-n2 * y, y, 1.0), y);
+        q[0] *= y; q[1] *= y; q[2] *= y; q[3] *= y;
+    }
+}
+/* sin and cos of a joint's half angle.  |x| < 2^19: three-part Cody-Waite reduction by pi/2 (the first two parts carry
+ * 33 bits each, so k * part is exact for |k| < 2^20) and the classic degree-13 / degree-14 minimax polynomials on
+ * [-pi/4, pi/4] (the coefficients of fdlibm's __kernel_sin / __kernel_cos, evaluated as two interleaved chains): about 1 ulp,
+ * a third of the instructions of the library routine and no branch.  Beyond (a joint that has spun 80 000 turns) the
+ * library's sincos, taken by the whole wave. */
+WV_DEVICE void sincos_reduced(double x, double &sn, double &cs) { /* |x| < 2^19 */
+    const double k = rint(x * 6.36619772367581382433e-01);
+    double r = fma(-k, 1.57079632673412561417e+00, x);
+    r = fma(-k, 6.07710050630396597660e-11, r);
+    r = fma(-k, 2.02226624879595063154e-21, r);
+    const double z = r * r;
+    double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    ps = fma(z, ps, 2.75573137070700676789e-06);
+    pc = fma(z, pc, -2.75573143513906633035e-07);
+    ps = fma(z, ps, -1.98412698298579493134e-04);
+    pc = fma(z, pc, 2.48015872894767294178e-05);
+    ps = fma(z, ps, 8.33333333332248946124e-03);
+    pc = fma(z, pc, -1.38888888888741095749e-03);
+    ps = fma(z, ps, -1.66666666666666324348e-01);
+    pc = fma(z, pc, 4.16666666666666019037e-02);
+    const double s = fma(r * z, ps, r);
+    const double hz = 0.5 * z, w = 1.0 - hz;
+    const double c = w + fma(z * z, pc, (1.0 - w) - hz);
+    const int n = (int)k;
+    const double a = (n & 1) ? c : s, bq = (n & 1) ? s : c;
+    sn = (n & 2) ? -a : a;
+    cs = ((n + 1) & 2) ? -bq : bq;
+}
+WV_DEVICE void sincos_bounded(double x, double &sn, double &cs) {
+    if (wv::ballot(!(fabs(x) < 524288.0)) != 0ull) sincos(x, &sn, &cs);
+    else sincos_reduced(x, sn, cs);
+}
 WV_DEVICE void mulquat(double *r, const double *a, const double *b) {
     double t0 = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
     double t1 = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
@@ -1196,6 +1241,62 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
 #pragma unroll
         for (int r = 0; r < 4; ++r) kanc[r] = isbody ? m->body_anc[b][r] : 0;
         const bool isfree = bjt == CM_JNT_FREE;
+        if constexpr (TOPO::is_static) {
+            /* Compile-time topologies come with kin_simple models (cm_model.h): a body's joints are up to CM_MAXSLIDE slides
+             * and then at most ONE rotational joint, described by one record per body.  Every constant of the stage is one
+             * level of reads away (all requested together), the slides are unpredicated FMAs with zero axes where a body has
+             * none, the rotation is evaluated once, and no lane waits for another body's joint loop (the pelvis of
+             * model/cassie.xml:81-84 has four joints: in the general loop below its lane runs three iterations alone, each
+             * behind its own chain of body -> joint -> parameter reads). */
+            {
+                /* (lanes beyond the bodies read the world's record: no joints, identity frame -- what they hold anyway) */
+                const auto *kr = &m->body_kin[isbody ? b : 0];
+                const int nsl = kr->nslide, j0 = kr->jnt0, jr = kr->rot_jnt, jt = kr->rot_type, qa = kr->rot_qadr;
+                int sqa[CM_MAXSLIDE];
+                double sref[CM_MAXSLIDE], sax[CM_MAXSLIDE][3], spo[CM_MAXSLIDE][3];
+#pragma unroll
+                for (int sl = 0; sl < CM_MAXSLIDE; ++sl) {
+                    sqa[sl] = kr->slide_qadr[sl]; sref[sl] = kr->slide_ref[sl];
+                    for (int i = 0; i < 3; ++i) { sax[sl][i] = kr->slide_axis_p[sl][i]; spo[sl][i] = kr->slide_pos_p[sl][i]; }
+                }
+                const double jref = kr->rot_ref;
+                double jp[3], ja[3], jpp[3], xl[3], q0[4];
+                for (int i = 0; i < 3; ++i) { jp[i] = kr->rot_pos[i]; ja[i] = kr->rot_axis[i]; jpp[i] = kr->rot_pos_p[i]; xl[i] = kr->rot_axis_p[i]; }
+                for (int i = 0; i < 9; ++i) Rl[i] = kr->mat[i];
+                for (int i = 0; i < 3; ++i) pl[i] = kr->pos[i];
+                for (int i = 0; i < 4; ++i) q0[i] = kr->quat[i];
+#pragma unroll
+                for (int sl = 0; sl < CM_MAXSLIDE; ++sl) {
+                    const double d = S.qpos[sqa[sl]] - sref[sl];
+                    if (sl < nsl) for (int i = 0; i < 3; ++i) { S.x.s.xanchor[j0 + sl][i] = pl[i] + spo[sl][i]; S.x.s.xaxis[j0 + sl][i] = sax[sl][i]; }
+                    for (int i = 0; i < 3; ++i) pl[i] += sax[sl][i] * d;
+                }
+                for (int i = 0; i < 4; ++i) qlq[i] = q0[i];
+                double sn, cs; /* (evaluated by every lane: its range check is a wave vote) */
+                sincos_bounded(jt == CM_JNT_HINGE ? 0.5 * (S.qpos[qa] - jref) : 0.0, sn, cs);
+                if (jr >= 0) {
+                    double qj[4];
+                    if (jt == CM_JNT_HINGE) {
+                        qj[0] = cs; qj[1] = ja[0] * sn; qj[2] = ja[1] * sn; qj[3] = ja[2] * sn;
+                    } else { /* ball, or free: position + quaternion (the record's frame constants are the identity) */
+                        const int qo = jt == CM_JNT_FREE ? qa + 3 : qa;
+                        for (int i = 0; i < 4; ++i) qj[i] = S.qpos[qo + i];
+                        normalize4_fast(qj);
+                        if (jt == CM_JNT_FREE) for (int i = 0; i < 3; ++i) pl[i] = S.qpos[qa + i];
+                    }
+                    double al[3], Rq[9], Rn[9], r[3];
+                    for (int i = 0; i < 3; ++i) { al[i] = pl[i] + jpp[i]; S.x.s.xanchor[jr][i] = al[i]; S.x.s.xaxis[jr][i] = xl[i]; }
+                    quat2mat(Rq, qj);
+                    for (int i = 0; i < 3; ++i)
+                        for (int c = 0; c < 3; ++c) Rn[3 * i + c] = Rl[3 * i] * Rq[c] + Rl[3 * i + 1] * Rq[3 + c] + Rl[3 * i + 2] * Rq[6 + c];
+                    for (int i = 0; i < 9; ++i) Rl[i] = Rn[i];
+                    if (need_quat) mulquat(qlq, q0, qj);
+                    /* rotation about the anchor: the origin moves so that the anchor stays put */
+                    mulmatvec3(r, Rl, jp);
+                    for (int i = 0; i < 3; ++i) pl[i] = al[i] - r[i];
+                }
+            }
+        } else
         if (isbody && b > 0) {
             double bpos[3], bq[4];
             for (int i = 0; i < 3; ++i) bpos[i] = m->body_pos[b][i];

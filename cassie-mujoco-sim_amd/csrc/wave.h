@@ -110,6 +110,8 @@ WV_DEVICE double div_rn(double a, double b) { return __ddiv_rn(a, b); }
 
 /* hardware reciprocal estimate (v_rcp_f64) */
 WV_DEVICE double rcp_estimate(double x) { return __builtin_amdgcn_rcp(x); }
+/* hardware reciprocal-square-root estimate (v_rsq_f64) */
+WV_DEVICE double rsq_estimate(double x) { return __builtin_amdgcn_rsq(x); }
 
 /* value-preserving move the optimiser cannot see through (wave-uniform ints only) */
 WV_DEVICE int opaque(int x) { x = __builtin_amdgcn_readfirstlane(x); asm volatile("" : "+s"(x)); return x; }

@@ -163,7 +163,7 @@ static void body32() { ck::cassie_step_kernel<32, ck::TopoRuntime>(g_io); }
 static void body40() { ck::cassie_step_kernel<40, ck::TopoRuntime>(g_io); }
 extern "C" void emu_force_runtime_topology(int on) { g_force_runtime_topology = on; }
 static bool topo_matches(const cm_model_t *m, const unsigned long long *t, int nv) {
-    if (m->nv != nv) return false;
+    if (m->nv != nv || !m->kin_simple) return false;
     for (int k = 0; k < nv; ++k) if (m->dof_ancmask[k] != t[k]) return false;
     return true;
 }
@@ -239,6 +239,9 @@ extern "C" int emu_derive(const cm_model_t *model, int nenv, double *qpos, doubl
     free(ext); free(xpos); free(xquat);
     return 0;
 }
+/* the kinematics stage's own elementary functions, for direct accuracy tests */
+extern "C" void emu_sincos_reduced(double x, double *s, double *c) { ck::sincos_reduced(x, *s, *c); }
+extern "C" void emu_normalize4_fast(double *q) { ck::normalize4_fast(q); }
 extern "C" unsigned long emu_sizeof_shared32(void) { return sizeof(ck::EnvShared<32>); }
 
 /* packed factor rows (ck::LPack): the run-time-lane addressing agrees with the compile-time slots; returns the number of mismatches */

@@ -59,6 +59,7 @@ inline void test_launch_hook(void *shared, unsigned long size) {
 inline int fresh_lane() { return lane(); }
 template <class P> inline P opaque_ptr(P p) { return p; }
 inline double rcp_estimate(double x) { return (double)(1.0f / (float)x); } /* deliberately low precision, like the hardware estimate */
+inline double rsq_estimate(double x) { return (double)(1.0f / sqrtf((float)x)); }
 /* individually rounded double operations (the emulator is built without FMA contraction: baseline x86-64) */
 inline double mul_rn(double a, double b) { volatile double r = a * b; return r; }
 inline double add_rn(double a, double b) { volatile double r = a + b; return r; }

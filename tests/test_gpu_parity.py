@@ -234,6 +234,38 @@ def test_generic_kernel_agrees_with_the_compile_time_topology_one(cassie, built)
 
 
 @pytest.mark.gpu
+def test_model_that_is_not_kin_simple_runs_the_general_joint_loop(built):
+    """The compile-time-topology kernels build a body's local transform from one record (slides + one rotational joint,
+    cm_model.h cm_kinrec_t).  A body with two hinges is outside that form: the launcher must pick the run-time-topology kernel,
+    whose kinematics stage loops over a body's joints -- against the oracle, 16 envs x 300 steps."""
+    from cassie_amd import Model
+    from test_kinematics_records import TWO_HINGES, two_hinges_start
+    m = Model(TWO_HINGES)
+    pod = m.pod
+    q0, v0 = two_hinges_start(m)
+    n = 16
+    rng = np.random.default_rng(11)
+    V = np.tile(v0, (n, 1)) + rng.uniform(-0.1, 0.1, (n, pod.nv))
+    ctrl = rng.uniform(-2, 2, (n, pod.nu))
+    b = Batch(m, n)
+    b.set(P.F_QPOS, np.tile(q0, (n, 1)))
+    b.set(P.F_QVEL, V)
+    b.set(P.F_CTRL, ctrl)
+    b.step(300)
+    q, v = b.get(P.F_QPOS), b.get(P.F_QVEL)
+    w, _ = b.warnings()
+    b.close()
+    assert not w.any()
+    for e in (0, 7, 15):
+        o = Oracle(pod, q0)
+        o.qvel[:] = V[e]
+        o.ctrl[:] = ctrl[e]
+        for _ in range(300):
+            o.step()
+        assert np.abs(q[e] - o.qpos).max() < 1e-9 and np.abs(v[e] - o.qvel).max() < 1e-7
+
+
+@pytest.mark.gpu
 def test_contact_and_row_caps_on_the_gpu(cassie):
     """Poses that overflow the 16-contact and 63-row caps (tests/test_emu_parity.py has the emulator twin): same warning
     bits, counts and trajectory as the oracle."""

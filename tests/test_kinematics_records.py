@@ -1,0 +1,148 @@
+"""The kinematics records of kin_simple models (cm_model.h cm_kinrec_t), the elementary functions of the stage that
+uses them (physics_kernel.h sincos_reduced / normalize4_fast, through the emulator build of the same header), and the
+fallback: a body with two rotational joints makes the model not kin_simple, which sends it to the run-time-topology
+kernel with the general joint loop."""
+import ctypes
+import math
+import os
+
+import numpy as np
+import pytest
+
+from cassie_amd import Model
+from emu_py import EmuBatch, lib as emu_lib
+from oracle_py import Oracle
+
+REF_MODEL_DIR = "/root/reference/model"
+JNT_FREE, JNT_BALL, JNT_SLIDE, JNT_HINGE = 0, 1, 2, 3
+
+
+def _quat2mat(q):
+    w, x, y, z = q
+    return np.array([[w * w + x * x - y * y - z * z, 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                     [2 * (x * y + w * z), w * w - x * x + y * y - z * z, 2 * (y * z - w * x)],
+                     [2 * (x * z - w * y), 2 * (y * z + w * x), w * w - x * x - y * y + z * z]])
+
+
+@pytest.mark.parametrize("name", ["cassie", "cassie_hfield", "cassie_tray_box"])
+def test_records_of_the_in_scope_models(built, name):
+    p = Model(name).pod
+    assert p.kin_simple == 1
+    nfree = 0
+    for b in range(1, p.nbody):
+        kr, j0, jn = p.body_kin[b], p.body_jntadr[b], p.body_jntnum[b]
+        types = [p.jnt_type[j0 + i] for i in range(jn)]
+        assert types[:kr.nslide] == [JNT_SLIDE] * kr.nslide and len(types) - kr.nslide <= 1
+        free = bool(types) and types[-1] == JNT_FREE
+        nfree += free
+        R = np.eye(3) if free else _quat2mat(list(p.body_quat[b]))
+        assert np.allclose(np.array(kr.mat).reshape(3, 3), R, atol=1e-15)
+        assert list(kr.quat) == ([1, 0, 0, 0] if free else list(p.body_quat[b]))
+        assert list(kr.pos) == list(p.body_pos[b])
+        for s in range(kr.nslide):
+            j = j0 + s
+            assert kr.slide_qadr[s] == p.jnt_qposadr[j] and kr.slide_ref[s] == p.qpos0[p.jnt_qposadr[j]]
+            assert np.allclose(kr.slide_axis_p[s], R @ np.array(p.jnt_axis[j]), atol=1e-15)
+            assert np.allclose(kr.slide_pos_p[s], R @ np.array(p.jnt_pos[j]), atol=1e-15)
+        for s in range(kr.nslide, 3):  # absent slides run unpredicated: zero axes, a valid address
+            assert list(kr.slide_axis_p[s]) == [0, 0, 0] and kr.slide_qadr[s] == 0
+        if len(types) > kr.nslide:
+            j = j0 + kr.nslide
+            assert (kr.rot_jnt, kr.rot_type, kr.rot_qadr) == (j, types[-1], p.jnt_qposadr[j])
+            if free:
+                assert list(kr.rot_axis_p) == [0, 0, 1] and list(kr.rot_pos) == [0, 0, 0] and list(kr.rot_pos_p) == [0, 0, 0]
+            else:
+                assert kr.rot_ref == p.qpos0[p.jnt_qposadr[j]]
+                assert list(kr.rot_axis) == list(p.jnt_axis[j]) and list(kr.rot_pos) == list(p.jnt_pos[j])
+                assert np.allclose(kr.rot_axis_p, R @ np.array(p.jnt_axis[j]), atol=1e-15)
+                assert np.allclose(kr.rot_pos_p, R @ np.array(p.jnt_pos[j]), atol=1e-15)
+        else:
+            assert kr.rot_jnt == -1 and kr.rot_type == -1
+    # the pelvis of model/cassie.xml:81-84: three slides and a ball; the box of cassie_tray_box.xml: a free joint
+    pelvis = [b for b in range(p.nbody) if p.body_jntnum[b] == 4]
+    assert len(pelvis) == 1 and p.body_kin[pelvis[0]].nslide == 3 and p.body_kin[pelvis[0]].rot_type == JNT_BALL
+    assert nfree == (1 if name == "cassie_tray_box" else 0)
+
+
+def _ulps(got, want):
+    return abs(np.longdouble(got) - want) / np.spacing(abs(float(want)))
+
+
+def test_sincos_reduced_accuracy(built):
+    L = emu_lib()
+    L.emu_sincos_reduced.argtypes = [ctypes.c_double, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
+    rng = np.random.default_rng(5)
+    s, c = ctypes.c_double(), ctypes.c_double()
+    # joint half-angles live well inside +-10 rad; the routine is used up to 2^19 (beyond: the library's sincos)
+    for bound, tol, n in ((0.78, 0.8, 20000), (10.0, 1.6, 40000), (524287.0, 2.5, 40000)):
+        xs = np.concatenate([rng.uniform(-bound, bound, n), [0.0, bound, -bound, 1e-300, -3e-9]])
+        xl = np.longdouble(xs)
+        rs, rc = np.sin(xl), np.cos(xl)
+        worst = 0.0
+        for i, x in enumerate(xs):
+            L.emu_sincos_reduced(float(x), ctypes.byref(s), ctypes.byref(c))
+            worst = max(worst, float(_ulps(s.value, rs[i])) if rs[i] != 0 else abs(s.value), float(_ulps(c.value, rc[i])))
+        assert worst < tol, (bound, worst)
+    # multiples of pi/2 and their neighbourhoods: quadrant bookkeeping, both signs
+    for k in range(-41, 42):
+        for d in (0.0, 1e-9, -1e-9):
+            x = k * (math.pi / 2) + d
+            L.emu_sincos_reduced(x, ctypes.byref(s), ctypes.byref(c))
+            assert abs(s.value - math.sin(x)) < 4e-16 and abs(c.value - math.cos(x)) < 4e-16
+
+
+def test_normalize4_fast(built):
+    L = emu_lib()
+    L.emu_normalize4_fast.argtypes = [ctypes.POINTER(ctypes.c_double)]
+    rng = np.random.default_rng(6)
+    for scale in (1.0, 1e-6, 1e6, 1 + 1e-12):
+        for _ in range(2000):
+            q = rng.normal(size=4) * scale
+            want = np.longdouble(q) / np.sqrt(np.sum(np.longdouble(q) ** 2))
+            buf = (ctypes.c_double * 4)(*q)
+            L.emu_normalize4_fast(buf)
+            assert np.max(np.abs(np.array(buf) - np.float64(want))) < 4.5e-16
+    buf = (ctypes.c_double * 4)(1e-16, 0, 1e-17, 0)  # below mju_normalize4's threshold: the identity
+    L.emu_normalize4_fast(buf)
+    assert list(buf) == [1, 0, 0, 0]
+
+
+TWO_HINGES = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cassie_two_hinges.cmodel")
+
+
+def two_hinges_start(m):
+    """cassie.xml with a second hinge on the left plantar rod (tools/make_models.py): the model, a start pose with the
+    extra joint bent, start velocities."""
+    pod = m.pod
+    assert (pod.nv, pod.njnt, pod.kin_simple) == (33, 27, 0)
+    q0 = m.qpos_init()
+    extra = [jn for jn in range(1, pod.njnt) if pod.jnt_bodyid[jn] == pod.jnt_bodyid[jn - 1] and pod.jnt_type[jn] == JNT_HINGE and pod.jnt_type[jn - 1] == JNT_HINGE]
+    assert len(extra) == 1
+    q0[pod.jnt_qposadr[extra[0]]] = 0.3
+    return q0, np.random.default_rng(3).uniform(-0.3, 0.3, pod.nv)
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_MODEL_DIR), reason="needs the reference MJCF")
+def test_two_hinges_fixture_is_what_the_loader_makes_of_the_modified_xml(built, tmp_path):
+    import subprocess
+    import sys
+    subprocess.run([sys.executable, os.path.join(os.path.dirname(TWO_HINGES), "..", "..", "tools", "make_models.py"), REF_MODEL_DIR,
+                    str(tmp_path), str(tmp_path)], check=True, capture_output=True)
+    assert open(tmp_path / "cassie_two_hinges.cmodel").read() == open(TWO_HINGES).read()
+
+
+def test_two_hinges_on_one_body_take_the_general_joint_loop(built):
+    m = Model(TWO_HINGES)
+    pod = m.pod
+    q0, v0 = two_hinges_start(m)
+    o = Oracle(pod, q0)
+    emu = EmuBatch(pod, 1)
+    emu.qpos[:] = q0
+    emu.qvel[:] = v0
+    o.qvel[:] = v0
+    for _ in range(60):
+        emu.step()
+        o.step()
+        assert (emu.info[0, 0], emu.info[0, 1]) == (o.d.ncon, o.d.nefc)
+    assert not emu.warn.any()
+    assert np.max(np.abs(emu.qpos[0] - o.qpos)) < 1e-10 and np.max(np.abs(emu.qvel[0] - o.qvel)) < 1e-8

@@ -11,7 +11,7 @@ printf '%s\n' "$PREFIX" > build/variants/$NAME.h
 OBJS=$(ls build/*.o | grep -v '\.hip\.o')
 for src in cassie-mujoco-sim_amd/csrc/*.hip; do
   o=build/variants/$(basename $src .hip)_$NAME.o
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Iinclude -Icassie-mujoco-sim_amd/csrc -ffp-contract=on ${SCHED--mllvm -amdgpu-sched-strategy=iterative-ilp} $EXTRA \
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Iinclude -Icassie-mujoco-sim_amd/csrc -ffp-contract=on ${SCHED--mllvm -amdgpu-sched-strategy=iterative-ilp} ${LICM--mllvm -disable-machine-licm} $EXTRA \
       -include build/variants/$NAME.h -c $src -o $o 2> build/variants/${NAME}_$(basename $src .hip).log &
   OBJS="$OBJS $o"
 done

@@ -16,7 +16,7 @@ template __global__ void ck::cassie_step_kernel<${NVP:-32}, ck::${TOPO:-TopoCass
 EOS
 echo "cassie_step_kernel<${NVP:-32}, ${TOPO:-TopoCassie32}, FEAT=${FEAT:-0}, MAXR=$MAXR>:"
 /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 --offload-device-only -Iinclude -Icassie-mujoco-sim_amd/csrc \
-  -ffp-contract=on ${SCHED--mllvm -amdgpu-sched-strategy=iterative-ilp} $EXTRA -Rpass-analysis=kernel-resource-usage ${KEEP:+-save-temps=obj} -c $T/one.hip -o $T/one.o 2>&1 |
+  -ffp-contract=on ${SCHED--mllvm -amdgpu-sched-strategy=iterative-ilp} ${LICM--mllvm -disable-machine-licm} $EXTRA -Rpass-analysis=kernel-resource-usage ${KEEP:+-save-temps=obj} -c $T/one.hip -o $T/one.o 2>&1 |
   grep -E "VGPRs:|AGPRs|Spill|ScratchSize|Occupancy|LDS Size|SGPRs:" | sed 's/.*remark: *//; s/ \[-Rpass.*//' | tail -8 | sed 's/^/    /'
 [ -n "$KEEP" ] && cp $T/one-hip-amdgcn-amd-amdhsa-gfx950.s "$KEEP" || true
 rm -rf $T
