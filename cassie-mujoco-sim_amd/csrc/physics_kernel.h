@@ -1359,6 +1359,15 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
             }
         }
         CK_STAMP(16);
+        /* Model constants of the stages behind the recursion (inertial frames, joint anchors to the world frame, geoms, centres
+         * of mass, cinert) are requested before it: their round trips through the memory system then run under the
+         * recursion's four LDS rounds instead of in front of each of those stages. */
+        const int pf_b = isbody ? b : 0, pf_g = lane < m->ngeom ? lane : -1, pf_gs = pf_g >= 0 ? pf_g : 0;
+        const int pf_jpb = lane < njnt ? m->jnt_parentbody[lane] : -1, pf_gb = m->geom_bodyid[pf_gs];
+        const double pf_mass = m->body_mass[pf_b];
+        double pf_ipos[3], pf_imat[9], pf_iner[3], pf_gpos[3], pf_gmat[9];
+        for (int i = 0; i < 3; ++i) { pf_ipos[i] = m->body_ipos[pf_b][i]; pf_iner[i] = m->body_inertia[pf_b][i]; pf_gpos[i] = m->geom_pos[pf_gs][i]; }
+        for (int i = 0; i < 9; ++i) { pf_imat[i] = m->body_imat[pf_b][i]; pf_gmat[i] = m->geom_mat[pf_gs][i]; }
         /* recursion over the tree by pointer jumping: after round r every body holds the product of the local
          * transforms of its 2^(r+1) nearest ancestors-or-self; four rounds cover trees up to 16 levels deep.  The
          * partial products ping-pong between the pose tiles and a second buffer laid over the (still unused)
@@ -1419,14 +1428,14 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
         /* inertial frames, and joint anchors / axes from the parent frame to the world frame */
         double ximat[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
         if (isbody && b > 0) {
-            double ip[3] = {m->body_ipos[b][0], m->body_ipos[b][1], m->body_ipos[b][2]}, xi[3], im[9];
-            for (int i = 0; i < 9; ++i) im[i] = m->body_imat[b][i];
+            double xi[3];
+            const double *ip = pf_ipos, *im = pf_imat;
             mulmatvec3(xi, xm, ip);
             for (int i = 0; i < 3; ++i) S.x.s.xipos[b][i] = xp[i] + xi[i];
             for (int i = 0; i < 3; ++i)
                 for (int c = 0; c < 3; ++c) ximat[3 * i + c] = xm[3 * i] * im[c] + xm[3 * i + 1] * im[3 + c] + xm[3 * i + 2] * im[6 + c];
         }
-        const int jpb = lane < njnt ? m->jnt_parentbody[lane] : -1;
+        const int jpb = pf_jpb;
         if (jpb >= 0) {
             const int pb = jpb;
             double al[3] = {S.x.s.xanchor[lane][0], S.x.s.xanchor[lane][1], S.x.s.xanchor[lane][2]};
@@ -1438,10 +1447,10 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
         CK_STAMP(1);
 
         /* geoms (lane = collision geom) */
-        if (lane < m->ngeom) {
-            const int g = lane, gb = m->geom_bodyid[g];
-            double gp[3] = {m->geom_pos[g][0], m->geom_pos[g][1], m->geom_pos[g][2]}, gm[9], t[3];
-            for (int i = 0; i < 9; ++i) gm[i] = m->geom_mat[g][i];
+        if (pf_g >= 0) {
+            const int g = pf_g, gb = pf_gb;
+            const double *gp = pf_gpos, *gm = pf_gmat;
+            double t[3];
             const double *R = S.x.s.xmat[gb];
             mulmatvec3(t, R, gp);
             for (int i = 0; i < 3; ++i) S.x.s.geom_xpos[g][i] = t[i] + S.x.s.xpos[gb][i];
@@ -1451,7 +1460,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
 
         CK_STAMP(17);
         /* ================= com of every kinematic tree (wave reduction per root) ================= */
-        const double bmass = (isbody && b > 0) ? m->body_mass[b] : 0.0;
+        const double bmass = (isbody && b > 0) ? pf_mass : 0.0;
         {
             /* one masked DPP tree reduction per kinematic tree (wave_sum returns the total in every lane) */
             const double px = isbody ? S.x.s.xipos[b < NB ? b : 0][0] : 0.0, py = isbody ? S.x.s.xipos[b < NB ? b : 0][1] : 0.0,
@@ -1472,7 +1481,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
         if (lane < NB) {
             double ci[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
             if (isbody && b > 0) {
-                const double I0 = m->body_inertia[b][0], I1 = m->body_inertia[b][1], I2 = m->body_inertia[b][2];
+                const double I0 = pf_iner[0], I1 = pf_iner[1], I2 = pf_iner[2];
                 const double *c = S.com[broot];
                 double dif[3] = {S.x.s.xipos[b][0] - c[0], S.x.s.xipos[b][1] - c[1], S.x.s.xipos[b][2] - c[2]};
                 double d2 = dot3(dif, dif);
@@ -1598,6 +1607,39 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
         CK_STAMP(4);
 
         /* ================= P4 collision ================= */
+        /* Requested here, read behind the collision passes (joint limits; the dof-chain indices of the velocity stage): the
+         * constants' trip through the memory system runs under the pair loop. */
+        /* (unconditional reads at clamped indices; the lane predicates are applied where the values are used, behind
+         * wv::keep -- a predicate folded into the read would make the compiler wait for the value on the spot) */
+        int pf_jlim, pf_jtype, pf_jqadr, danc[5], blast, kvin;
+        double pf_jmargin, pf_jlo, pf_jhi;
+        auto request_behind_collision = [&](int lane_now) {
+            const int pf_lj = lane_now < njnt ? lane_now : 0, pf_kd = lane_now < nv ? lane_now : 0, pf_bb = lane_now < nbody ? lane_now : 0;
+            pf_jlim = m->jnt_limited[pf_lj]; pf_jtype = m->jnt_type[pf_lj]; pf_jqadr = m->jnt_qposadr[pf_lj];
+            pf_jmargin = m->jnt_margin[pf_lj]; pf_jlo = m->jnt_range[pf_lj][0]; pf_jhi = m->jnt_range[pf_lj][1];
+#pragma unroll
+            for (int r = 0; r < 5; ++r) danc[r] = m->dof_anc[pf_kd][r];
+            blast = m->body_lastdof[pf_bb]; kvin = m->dof_vinsrc[pf_kd];
+        };
+        /* (the instantiations with the height-field pre-pass have no registers to spare across it and the pair loop: they ask
+         * behind the loop) */
+        constexpr bool request_early = (FEAT & FEAT_HFIELD) == 0;
+        if constexpr (request_early) request_behind_collision(lane);
+        /* A pair's constants (one level of lane-coalesced reads of the denormalised pair_* arrays) are requested ahead of
+         * their pass: the first 64 pairs' here, the next 64 pairs' between a pass's narrow phase and its contact compaction
+         * (into the same registers, which the narrow phase has finished with), so that their trip through the memory system
+         * runs under the compaction. */
+        const int pair_bound = m->npair_simple;
+        struct PairConst { int g1, g2, tt; double margin, rb1, rb2, s10, s11, s20, s21, s22; };
+        auto request_pair = [&](int pp, PairConst &c) {
+            const int ps = pp < pair_bound ? pp : 0;
+            c.g1 = m->pair_geom1[ps]; c.g2 = m->pair_geom2[ps]; c.tt = m->pair_type[ps];
+            c.margin = m->pair_margin[ps]; c.rb1 = m->pair_rbound[ps][0]; c.rb2 = m->pair_rbound[ps][1];
+            c.s10 = m->pair_size[ps][0]; c.s11 = m->pair_size[ps][1];
+            c.s20 = m->pair_size[ps][3]; c.s21 = m->pair_size[ps][4]; c.s22 = m->pair_size[ps][5];
+        };
+        PairConst pc;
+        if constexpr (request_early) request_pair(lane, pc);
         /* pass 1, lane = candidate pair (pair types that give at most two contacts) */
         int ncon = 0;
         const float *const env_hfield = io.hfield ? io.hfield + (size_t)env * io.hfield_stride : nullptr;
@@ -1714,6 +1756,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
             }
             wv::sync();
         }
+        if constexpr (!request_early) request_pair(lane, pc);
         for (int p0 = 0; p0 < npass; p0 += WV_WAVE) {
             const int p = p0 + lane;
             int n = 0;
@@ -1738,12 +1781,15 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
                 }
             }
             if (p < npass && !from_spread) {
-                const int g1 = m->pair_geom1[p], g2 = m->pair_geom2[p], tt = m->pair_type[p];
+                const int g1 = pc.g1, g2 = pc.g2, tt = pc.tt;
                 const int t1 = tt & 255, t2 = tt >> 8;
-                const double margin = m->pair_margin[p];
+                const double margin = pc.margin;
                 const double *p1 = S.x.s.geom_xpos[g1], *p2 = S.x.s.geom_xpos[g2];
                 const double *m1 = S.x.s.geom_xmat[g1], *m2 = S.x.s.geom_xmat[g2];
-                const double rb1 = m->pair_rbound[p][0], rb2 = m->pair_rbound[p][1];
+                const double rb1 = pc.rb1, rb2 = pc.rb2;
+                /* (the sizes come with the pair's other constants, not behind the cull: a second trip to memory for the pairs
+                 * that survive it costs the whole wave more than five reads that most lanes do not use) */
+                const double s10 = pc.s10, s11 = pc.s11, s20 = pc.s20, s21 = pc.s21, s22 = pc.s22;
                 double dif[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
                 CK_STAMP(31);
                 bool cull = false;
@@ -1755,8 +1801,6 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
                     cull = dot3(dif, nn) > margin + rb2;
                 }
                 if (!cull) {
-                    const double s10 = m->pair_size[p][0], s11 = m->pair_size[p][1];
-                    const double s20 = m->pair_size[p][3], s21 = m->pair_size[p][4];
                     if (t1 == CM_GEOM_PLANE && t2 == CM_GEOM_SPHERE) {
                         n = plane_sphere(rc0, p1, m1, p2, s20, margin);
                     } else if (t1 == CM_GEOM_PLANE && t2 == CM_GEOM_CAPSULE) {
@@ -1783,10 +1827,10 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
                         double q2[3] = {p2[0] + a2[0] * x2, p2[1] + a2[1] * x2, p2[2] + a2[2] * x2};
                         n = sphere_sphere(rc0, q1, s10, q2, s20, margin);
                     } else if (t1 == CM_GEOM_SPHERE && t2 == CM_GEOM_BOX) {
-                        double sb[3] = {s20, s21, m->pair_size[p][5]};
+                        double sb[3] = {s20, s21, s22};
                         n = sphere_box(rc0, p1, s10, p2, m2, sb, margin);
                     } else if (t1 == CM_GEOM_CAPSULE && t2 == CM_GEOM_BOX) {
-                        double sb[3] = {s20, s21, m->pair_size[p][5]};
+                        double sb[3] = {s20, s21, s22};
                         n = capsule_box(rc0, rc1, p1, m1, s10, s11, p2, m2, sb, margin);
                     } else {
                         warn |= WARN_UNSUPPORTED_PAIR;
@@ -1794,6 +1838,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
                 }
             }
             CK_STAMP(32);
+            if (p0 + WV_WAVE < npass) request_pair(p + WV_WAVE, pc);
             /* ballot-compact in pair order */
             const unsigned long long m1b = wv::ballot(n >= 1), m2b = wv::ballot(n >= 2);
             const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -1818,6 +1863,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
             ncon += wv::popc64(m1b) + wv::popc64(m2b) + more;
         }
         CK_STAMP(22);
+        if constexpr (!request_early) request_behind_collision(lane);
         /* pass 2, one pair at a time with the whole wave: lane = feature (box corner / vertex), first four hits kept */
         if constexpr ((FEAT & FEAT_WAVEPAIRS) != 0) for (int p = m->npair_simple; p < m->npair; ++p) {
             const int g1 = m->pair_geom1[p], g2 = m->pair_geom2[p], tt = m->pair_type[p];
@@ -1870,13 +1916,11 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
         unsigned long long lob, hib;
         {
             bool lo = false, hi = false;
-            if (lane < njnt && m->jnt_limited[lane]) {
-                const int jt = m->jnt_type[lane];
-                if (jt == CM_JNT_HINGE || jt == CM_JNT_SLIDE) {
-                    const double q = S.qpos[m->jnt_qposadr[lane]], mg = m->jnt_margin[lane];
-                    lo = q - m->jnt_range[lane][0] < mg;
-                    hi = m->jnt_range[lane][1] - q < mg;
-                }
+            wv::keep(pf_jlim); wv::keep(pf_jtype);
+            if (lane < njnt && pf_jlim && (pf_jtype == CM_JNT_HINGE || pf_jtype == CM_JNT_SLIDE)) {
+                const double q = S.qpos[pf_jqadr];
+                lo = q - pf_jlo < pf_jmargin;
+                hi = pf_jhi - q < pf_jmargin;
             }
             lob = wv::ballot(lo); hib = wv::ballot(hi);
         }
@@ -1901,11 +1945,18 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
          * every lane's read of a round is issued before any lane's write).  A body's velocity is the sum at its last
          * dof; the velocity entering a joint is the sum at dof_vinsrc. */
         double mycvel[6], mycacc[6];
-        int danc[5];
+        /* (danc / blast / kvin: requested ahead of the collision stage)  The per-dof records of the passive / actuation stage
+         * behind this one (cm_model_t::dof_*: damping, the joint's spring, the actuator on the dof -- one level of
+         * unconditional reads; dofs without a spring / actuator carry zero stiffness / gear) are requested now. */
 #pragma unroll
-        for (int r = 0; r < 5; ++r) danc[r] = isdof ? m->dof_anc[k_][r] : -1;
-        const int blast = isbody ? m->body_lastdof[b] : -1;
-        const int kvin = isdof ? m->dof_vinsrc[k_] : -1;
+        for (int r = 0; r < 5; ++r) { wv::keep(danc[r]); if (!isdof) danc[r] = -1; }
+        wv::keep(blast); wv::keep(kvin);
+        if (!isbody) blast = -1;
+        if (!isdof) kvin = -1;
+        const int kd = isdof ? k_ : 0;
+        const double kdamp = m->dof_damping[kd], kstiff = m->dof_stiffness[kd], kref = m->dof_springref[kd];
+        const double kgear = m->dof_gear[kd], klo = m->dof_ctrl_lo[kd], khi = m->dof_ctrl_hi[kd];
+        const int kq = m->dof_qadr[kd], ka = m->dof_act[kd];
         auto chain_sums = [&](double (&acc)[6]) { /* acc: this dof's term in, its chain sum out; tile: buf */
             if (lane < NVP) for (int t = 0; t < 6; ++t) S.x.s.buf[lane][t] = acc[t];
             wv::sync();
@@ -1989,13 +2040,13 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
         CK_STAMP(6);
 
         /* ================= P6/P7/P8 passive + actuation -> qfrc_smooth (lane = dof) ================= */
+        /* The equality rows' constants are requested here, two stages ahead of the rows' geometry: with every equality active (the
+         * usual case, closed form in the row assignment below) row r belongs to equality r / 3 */
+        const int pf_eq = lane < 3 * m->neq ? lane / 3 : 0;
+        /* (only what the rows' LDS reads hang on: the bodies and their roots; the anchors, masks and solver parameters are read in place,
+         * where their trip to memory runs under those LDS reads -- carrying them too pushes launch-long values into scratch) */
+        int pf_eb1 = m->eq_body1[pf_eq], pf_eb2 = m->eq_body2[pf_eq], pf_er1 = m->eq_root[pf_eq][0], pf_er2 = m->eq_root[pf_eq][1];
         {
-            /* per-dof records (cm_model_t::dof_*): damping, the joint's spring, the actuator on the dof -- one level of
-             * unconditional reads; dofs without a spring / actuator carry zero stiffness / gear */
-            const int kd = isdof ? k_ : 0;
-            const double kdamp = m->dof_damping[kd], kstiff = m->dof_stiffness[kd], kref = m->dof_springref[kd];
-            const double kgear = m->dof_gear[kd], klo = m->dof_ctrl_lo[kd], khi = m->dof_ctrl_hi[kd];
-            const int kq = m->dof_qadr[kd], ka = m->dof_act[kd];
             if (isdof) {
                 double f = -kdamp * S.qvel[k_];
                 f -= kstiff * (S.qpos[kq] - kref);
@@ -2088,7 +2139,14 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
         double limsgn = 0, rpos = 0, rmargin = 0, rdiag = 0, imp_pos = 0, rRscale = 1.0;
         double solref0 = 0.02, solref1 = 1, solimp[5] = {0.9, 0.95, 0.001, 0.5, 2};
         if (rtype == CM_CNSTR_EQUALITY) {
-            const int b1 = m->eq_body1[rid], b2 = m->eq_body2[rid];
+            if (rid != pf_eq) { /* (an inactive equality ahead of this one: the constants requested in advance are another row's) */
+                pf_eb1 = m->eq_body1[rid]; pf_eb2 = m->eq_body2[rid]; pf_er1 = m->eq_root[rid][0]; pf_er2 = m->eq_root[rid][1];
+            }
+            maskp = m->eq_dofmask[rid][0]; maskm = m->eq_dofmask[rid][1];
+            rdiag = m->eq_invweight[rid];
+            solref0 = m->eq_solref[rid][0]; solref1 = m->eq_solref[rid][1];
+            for (int i = 0; i < 5; ++i) solimp[i] = m->eq_solimp[rid][i];
+            const int b1 = pf_eb1, b2 = pf_eb2;
             double l1[3] = {m->eq_data[rid][0], m->eq_data[rid][1], m->eq_data[rid][2]};
             double l2[3] = {m->eq_data[rid][3], m->eq_data[rid][4], m->eq_data[rid][5]};
             double a1[3], a2[3];
@@ -2096,18 +2154,16 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
             mulmatvec3(a2, S.x.s.xmat[b2], l2);
             for (int i = 0; i < 3; ++i) { a1[i] += S.x.s.xpos[b1][i]; a2[i] += S.x.s.xpos[b2][i]; }
             u3[0] = rsub == 0 ? 1.0 : 0.0; u3[1] = rsub == 1 ? 1.0 : 0.0; u3[2] = rsub == 2 ? 1.0 : 0.0;
-            const double *c1 = S.com[m->eq_root[rid][0]], *c2 = S.com[m->eq_root[rid][1]];
+            const double *c1 = S.com[pf_er1], *c2 = S.com[pf_er2];
             double o1[3] = {a1[0] - c1[0], a1[1] - c1[1], a1[2] - c1[2]};
             double o2[3] = {a2[0] - c2[0], a2[1] - c2[1], a2[2] - c2[2]};
             cross3(wp, o1, u3);
             cross3(wm, o2, u3);
-            maskp = m->eq_dofmask[rid][0]; maskm = m->eq_dofmask[rid][1];
+
             double res[3] = {a1[0] - a2[0], a1[1] - a2[1], a1[2] - a2[2]};
             rpos = rsub == 0 ? res[0] : (rsub == 1 ? res[1] : res[2]); rmargin = 0;
             imp_pos = sqrt(dot3(res, res));
-            rdiag = m->eq_invweight[rid];
-            solref0 = m->eq_solref[rid][0]; solref1 = m->eq_solref[rid][1];
-            for (int i = 0; i < 5; ++i) solimp[i] = m->eq_solimp[rid][i];
+
         } else if (rtype == CM_CNSTR_LIMIT_JOINT) {
             const double q = S.qpos[m->jnt_qposadr[rid]];
             rpos = rsub == 0 ? q - m->jnt_range[rid][0] : m->jnt_range[rid][1] - q;
@@ -2163,6 +2219,17 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
             }
         }
         CK_STAMP(27);
+        /* The constants of the sensor stage behind the Jacobian loop are requested here, every one of them in one level of
+         * unconditional reads (lane = sensor): their round trip through the memory system runs under the loop instead of
+         * in front of the sensors. */
+        const bool need_imu = lastsub || io.all_outputs_every_substep || (io.drive_mode && sub + 2 == io.nsub);
+        const bool need_pos = lastsub || io.drive_mode || io.all_outputs_every_substep;
+        const bool issens = lane < m->nsensor && need_pos;
+        const int ls = issens ? lane : 0;
+        int stype = m->sensor_type[ls], slot_ = m->sensor_slot[ls];
+        const int sqadr = m->sensor_qadr[ls], sb = m->sensor_body[ls], sroot = m->sensor_root[ls];
+        const int sdim = m->sensor_dim[ls], sadr = m->sensor_adr[ls];
+        const double sgain = m->sensor_gain[ls], scut = m->sensor_cutoff[ls];
         /* this lane's Jacobian row, one dof at a time, straight into registers; lane 63 carries qfrc_smooth */
         double ycol[NVP];
         double jvel = 0, jws = 0;
@@ -2208,14 +2275,9 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
          * encoder models (the joint / actuator positions) and the measurement block the LAST substep's drive pass writes
          * (the IMU words of the substep before it).  The IMU sensors -- frame quaternion, gyro, magnetometer and the
          * accelerometer with its second part after the solve -- are therefore evaluated by the last two substeps only. */
-        const bool need_imu = lastsub || io.all_outputs_every_substep || (io.drive_mode && sub + 2 == io.nsub);
-        const bool need_pos = lastsub || io.drive_mode || io.all_outputs_every_substep;
-        const bool issens = lane < m->nsensor && need_pos;
-        const int ls = issens ? lane : 0; /* every constant of the lane's sensor in one level of (unconditional) reads */
-        const int stype = issens ? m->sensor_type[ls] : -1;
-        const int aslot = (stype == CM_SENS_ACCELEROMETER) ? m->sensor_slot[ls] : -1; /* which accelerometer this lane is */
-        const int sqadr = m->sensor_qadr[ls], sb = m->sensor_body[ls], sroot = m->sensor_root[ls];
-        const double sgain = m->sensor_gain[ls];
+        wv::keep(stype); wv::keep(slot_);
+        if (!issens) stype = -1;
+        const int aslot = (stype == CM_SENS_ACCELEROMETER) ? slot_ : -1; /* which accelerometer this lane is */
         if (issens) {
             double sout[4] = {0, 0, 0, 0};
             if (sqadr >= 0) sout[0] = sgain * S.qpos[sqadr]; /* actuatorpos (gear * q) and jointpos */
@@ -2245,14 +2307,12 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
                 }
             }
             if (stype != CM_SENS_ACCELEROMETER && (need_imu || sqadr >= 0)) {
-                const double cut = m->sensor_cutoff[lane];
-                const int dim = m->sensor_dim[lane], adr = m->sensor_adr[lane];
                 for (int i = 0; i < 4; ++i) {
-                    if (i >= dim) continue;
+                    if (i >= sdim) continue;
                     double v = sout[i];
-                    if (cut > 0 && stype != CM_SENS_FRAMEQUAT) v = clampd(v, -cut, cut);
-                    if (lastsub) io.sensordata[(size_t)env * io.ssd + adr + i] = v;
-                    if (io.drive_mode) S.sens[adr + i] = v;
+                    if (scut > 0 && stype != CM_SENS_FRAMEQUAT) v = clampd(v, -scut, scut);
+                    if (lastsub) io.sensordata[(size_t)env * io.ssd + sadr + i] = v;
+                    if (io.drive_mode) S.sens[sadr + i] = v;
                 }
             }
         }
@@ -2590,6 +2650,10 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
         }
 
         /* ================= qacc = L^-1 D^-1/2 (y63 + Y f)  (lane = dof) ================= */
+        /* (constants of the stages behind the solves, requested ahead of them: actuator velocities, the Euler step) */
+        const int pf_u = lane < nu ? lane : 0, pf_ej = lane < njnt ? lane : 0;
+        const double pf_agear = m->act_gear[pf_u], pf_kdamp = m->dof_damping[isdof ? k_ : 0];
+        const int pf_adof = m->act_dofid[pf_u], pf_ejt = m->jnt_type[pf_ej], pf_eqa = m->jnt_qposadr[pf_ej], pf_eda = m->jnt_dofadr[pf_ej];
         double qacc;
         {
             double z = isdof ? S.x.Yr[MAXR][k_] : 0.0;
@@ -2655,7 +2719,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
             }
         }
         if (lane < nu) {
-            const double av = m->act_gear[lane] * S.qvel[m->act_dofid[lane]];
+            const double av = pf_agear * S.qvel[pf_adof];
             if (lastsub) io.actuator_velocity[(size_t)env * io.su + lane] = av;
             if (io.drive_mode) S.actvel[lane] = av;
         }
@@ -2671,7 +2735,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
         double qacc_int = qacc;
         if (m->flags & CM_FLAG_EULERDAMP) {
             /* (M + hB) x = M qacc  <=>  x = qacc - (M + hB)^-1 (hB qacc) */
-            double w = isdof ? h * m->dof_damping[k_] * qacc : 0.0;
+            double w = isdof ? h * pf_kdamp * qacc : 0.0;
             double lcol[NVP], lrowh[NVP]; /* this lane's column and row of the factor of M + hB, staged before the chains */
             const typename LP::Row myrow = LP::row_of(k_);
 #pragma unroll
@@ -2699,8 +2763,8 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
         }
         wv::sync();
         if (lane < njnt) {
-            const int j = lane, jt = m->jnt_type[j];
-            int qa = m->jnt_qposadr[j], da = m->jnt_dofadr[j];
+            const int jt = pf_ejt;
+            int qa = pf_eqa, da = pf_eda;
             if (jt == CM_JNT_HINGE || jt == CM_JNT_SLIDE) {
                 S.qpos[qa] += h * S.qvel[da];
             } else {

@@ -124,6 +124,11 @@ template <class P> WV_DEVICE P opaque_ptr(P p) {
     return (P)(((unsigned long long)hi << 32) | lo);
 }
 
+/* the value stays what it is, but the compiler must have it in a register HERE and may not have derived anything from it
+ * earlier: used where a constant is requested from memory well ahead of its use -- a compare or a select folded into the
+ * load would pull the wait for the value forward to the request */
+WV_DEVICE void keep(int &x) { asm volatile("" : "+v"(x)); }
+
 /* instruction-scheduling fence: nothing is moved across it.  Used between hand-staged load / compute groups so the
  * scheduler's appetite for early loads cannot push the register allocator into scratch. */
 WV_DEVICE void sched_fence() { __builtin_amdgcn_sched_barrier(0); }

@@ -40,6 +40,7 @@ inline long long clock() { return 0; }
 inline double max_raw(double a, double b) { return a > b ? a : b; }
 inline int opaque(int x) { return x; }
 inline void sched_fence() {}
+inline void keep(int &) {}
 extern int g_force_guarded;
 extern int g_poison_lds;
 extern unsigned long g_poison_lo, g_poison_hi;
