@@ -158,6 +158,9 @@ struct EnvShared {
     double drv_jx[CM_NUM_JOINTS][CM_JOINT_FILTER_NB], drv_jy[CM_NUM_JOINTS][CM_JOINT_FILTER_NA];
     double drv_delay[CM_NUM_DRIVES][CM_TORQUE_DELAY_CYCLES];
     double drv_pos[CM_NUM_DRIVES], drv_vel[CM_NUM_DRIVES];
+    /* what a launch's drive-level passes read and no substep changes (drive_consts_load): gear ratio, torque limit, no-load
+     * speed in rad/s, encoder counts and scale; the launch's command (torque + STO, or PD targets and gains) */
+    double drv_c[CM_NUM_DRIVES][10], drv_jc[CM_NUM_JOINTS][2];
     /* contacts */
     double c_dist[CM_MAXCON], c_pos[CM_MAXCON][3], c_frame[CM_MAXCON][9], c_fri[CM_MAXCON][3];
     double c_solref[CM_MAXCON][2], c_solimp[CM_MAXCON][5], c_margin[CM_MAXCON];
@@ -195,6 +198,17 @@ WV_DEVICE void normalize4_fast(double *q) {
         y = fma(0.5 * y, fma(-n2 * y, y, 1.0), y);
         q[0] *= y; q[1] *= y; q[2] *= y; q[3] *= y;
     }
+}
+/* normalize3 the same way; returns the norm */
+WV_DEVICE double normalize3_fast(double *a) {
+    const double n2 = dot3(a, a);
+    if (n2 < CM_MINVAL * CM_MINVAL) { a[0] = 1; a[1] = 0; a[2] = 0; return sqrt(n2); }
+    double y = wv::rsq_estimate(n2);
+    y = fma(0.5 * y, fma(-n2 * y, y, 1.0), y);
+    y = fma(0.5 * y, fma(-n2 * y, y, 1.0), y);
+    a[0] *= y; a[1] *= y; a[2] *= y;
+    const double n = n2 * y;
+    return fma(0.5 * y, fma(-n, n, n2), n); /* one Newton step on the norm itself: n2 * y carries y's rounding */
 }
 /* sin and cos of a joint's half angle.  |x| < 2^19: three-part Cody-Waite reduction by pi/2 (the first two parts carry
  * 33 bits each, so k * part is exact for |k| < 2^20) and the classic degree-13 / degree-14 minimax polynomials on
@@ -951,22 +965,34 @@ WV_DEVICE void pgs_rows_fast(const double (&brow)[N], int nrows, int r_, double 
 
 /* x := L^-1 x (forward) and x := L^-T x (backward) by substitution, lane = dof: lrow / lcol hold the lane's row /
  * column of the unit-triangular factor (zeros outside its ancestors / descendants) and every hop is a v_readlane round
- * trip (~40 clocks).  With a compile-time topology the two mutually independent dof ranges [trunk, split) and
- * [split, nv) -- Cassie's legs -- run as two interleaved chains in separate accumulators, which halves the number of
- * dependent hops; lanes outside a range carry zeros in its coefficients, so the other chain never touches them. */
+ * trip (~40 clocks).  With a compile-time topology the hops go LEVEL BY LEVEL of the dof tree (a dof's level = the number
+ * of its ancestors): dofs of one level are mutually unrelated, so their broadcasts are all read from the same state of
+ * the vector and their terms are summed before they touch it -- the dependent chain is as long as the tree is deep (13
+ * for Cassie: floating base, hip, knee, shin, tarsus, crank), not as long as the dof list (32), and the forward pass
+ * skips the dofs nobody descends from (their column of L is empty). */
+template <class TOPO>
+struct DofLevels {
+    static constexpr int level(int k) { int n = 0; for (int i = 0; i < TOPO::nv; ++i) n += (int)((TOPO::table[k] >> i) & 1ull); return n; }
+    static constexpr bool has_descendants(int j) { for (int k = 0; k < TOPO::nv; ++k) if ((TOPO::table[k] >> j) & 1ull) return true; return false; }
+    static constexpr int depth() { int d = 0; for (int k = 0; k < TOPO::nv; ++k) if (level(k) > d) d = level(k); return d; }
+};
 template <int NVP, class TOPO>
 WV_DEVICE double solve_forward(double z, const double (&lrow)[NVP], int lane, int nv) {
     if constexpr (TOPO::is_static) {
-        constexpr int T = TOPO::trunk, SP = TOPO::split, NV = TOPO::nv;
+        typedef DofLevels<TOPO> LV;
 #pragma unroll
-        for (int i = 0; i < T; ++i) z -= lrow[i] * wv::readlane(z, i);
-        double za = z, zb = z;
+        for (int d = 0; d < LV::depth(); ++d) {
+            double t0 = 0, t1 = 0;
+            int n = 0;
 #pragma unroll
-        for (int t = 0; t < NVP; ++t) {
-            if (T + t < SP) za -= lrow[T + t] * wv::readlane(za, T + t);
-            if (SP + t < NV - 1) zb -= lrow[SP + t] * wv::readlane(zb, SP + t);
+            for (int j = 0; j < TOPO::nv; ++j) {
+                if (LV::level(j) != d || !LV::has_descendants(j)) continue;
+                const double bj = wv::readlane(z, j);
+                if ((n++ & 1) == 0) t0 = fma(lrow[j], bj, t0); else t1 = fma(lrow[j], bj, t1);
+            }
+            z -= t0 + t1;
         }
-        return lane >= SP ? zb : za;
+        return z;
     } else {
 #pragma unroll
         for (int i = 0; i < NVP - 1; ++i) {
@@ -979,16 +1005,19 @@ WV_DEVICE double solve_forward(double z, const double (&lrow)[NVP], int lane, in
 template <int NVP, class TOPO>
 WV_DEVICE double solve_backward(double w, const double (&lcol)[NVP], int lane, int nv) {
     if constexpr (TOPO::is_static) {
-        constexpr int T = TOPO::trunk, SP = TOPO::split, NV = TOPO::nv;
-        double wa = w, wb = lane >= SP ? w : 0.0; /* lanes below the split collect the second range's terms from zero */
+        typedef DofLevels<TOPO> LV;
 #pragma unroll
-        for (int t = 0; t < NVP; ++t) {
-            if (SP - 1 - t >= T) wa -= lcol[SP - 1 - t] * wv::readlane(wa, SP - 1 - t);
-            if (NV - 1 - t >= SP) wb -= lcol[NV - 1 - t] * wv::readlane(wb, NV - 1 - t);
+        for (int d = LV::depth(); d >= 1; --d) {
+            double t0 = 0, t1 = 0;
+            int n = 0;
+#pragma unroll
+            for (int j = 0; j < TOPO::nv; ++j) {
+                if (LV::level(j) != d) continue;
+                const double bj = wv::readlane(w, j);
+                if ((n++ & 1) == 0) t0 = fma(lcol[j], bj, t0); else t1 = fma(lcol[j], bj, t1);
+            }
+            w -= t0 + t1;
         }
-        w = lane >= SP ? wb : wa + wb;
-#pragma unroll
-        for (int k = T - 1; k >= 1; --k) w -= lcol[k] * wv::readlane(w, k);
         return w;
     } else {
 #pragma unroll
@@ -1040,26 +1069,57 @@ WV_DEVICE void drive_state_store(const PhysIO &io, SH &S, int env, int lane) {
     }
 }
 
+/* Once per launch: the constants of the env's drive-level passes, into LDS.  The derived ones (no-load speed in rad/s, encoder
+ * scale) are computed here by the same individually rounded operations, in the same order, as the reference computes them on
+ * every call -- so the passes read the very bits they used to compute, without three divisions and a trip to the model and
+ * to the command arrays per substep. */
+enum { DRVC_RATIO = 0, DRVC_TMAX, DRVC_WMAX, DRVC_COUNTS, DRVC_SCALE, DRVC_U_OR_PT, DRVC_STO_OR_DT, DRVC_FF, DRVC_KP, DRVC_KD };
+template <class SH>
+WV_DEVICE void drive_consts_load(const PhysIO &io, SH &S, ModelPtr m, int env, int lane) {
+    const double TWO_PI = 2 * 3.14159265358979323846, PI = 3.14159265358979323846;
+    const int nu = m->nu;
+    if (lane < CM_NUM_DRIVES) {
+        const int i = lane, bits = m->sensor_bits[drive_sensor_slot(i)];
+        const double ratio = m->act_gear[i], counts = (double)(1 << bits);
+        double *c = S.drv_c[i];
+        c[DRVC_RATIO] = ratio; c[DRVC_TMAX] = m->act_ctrlrange[i][1];
+        c[DRVC_WMAX] = wv::div_rn(wv::mul_rn(wv::mul_rn(m->act_maxrpm[i], 2.0), PI), 60.0);
+        c[DRVC_COUNTS] = counts; c[DRVC_SCALE] = wv::div_rn(wv::div_rn(TWO_PI, counts), ratio);
+        if (io.drive_mode == CM_DRIVE_TORQUE) {
+            c[DRVC_U_OR_PT] = io.drive_cmd[(size_t)env * (nu + 1) + i];
+            c[DRVC_STO_OR_DT] = io.drive_cmd[(size_t)env * (nu + 1) + nu] != 0.0 ? 1.0 : 0.0;
+            c[DRVC_FF] = 0.0; c[DRVC_KP] = 0.0; c[DRVC_KD] = 0.0;
+        } else {
+            const size_t o = (size_t)env * nu + i;
+            c[DRVC_U_OR_PT] = io.pd_ptarget[o]; c[DRVC_STO_OR_DT] = io.pd_dtarget ? io.pd_dtarget[o] : 0.0;
+            c[DRVC_FF] = io.pd_torque ? io.pd_torque[o] : 0.0; c[DRVC_KP] = io.pd_kp[o]; c[DRVC_KD] = io.pd_kd[o];
+        }
+    } else if (lane < CM_NUM_DRIVES + CM_NUM_JOINTS) {
+        const int j = lane - CM_NUM_DRIVES, bits = m->sensor_bits[joint_sensor_slot(j)];
+        const double counts = (double)(1 << bits);
+        S.drv_jc[j][0] = counts; S.drv_jc[j][1] = wv::div_rn(TWO_PI, counts);
+    }
+}
+
 template <class SH>
 WV_DRIVE_FN void drive_level_io(const PhysIO &io, SH &S, ModelPtr m, int env, int lane, bool write_meas) {
     const double TWO_PI = 2 * 3.14159265358979323846, PI = 3.14159265358979323846;
     double *meas = io.meas + (size_t)env * CM_MEAS_DIM;
-    const int nu = m->nu;
     if (lane < CM_NUM_DRIVES) {
         const int i = lane;
-        const double ratio = m->act_gear[i], tmax = m->act_ctrlrange[i][1];
-        const double wmax = wv::div_rn(wv::mul_rn(wv::mul_rn(m->act_maxrpm[i], 2.0), PI), 60.0);
+        double cst[10];
+        for (int k = 0; k < 10; ++k) cst[k] = S.drv_c[i][k];
+        const double ratio = cst[DRVC_RATIO], tmax = cst[DRVC_TMAX], wmax = cst[DRVC_WMAX];
         /* the command: a drive torque from the caller, or pd_input's motor PD on the measurements of the previous step */
         double u;
         bool sto = false;
         if (io.drive_mode == CM_DRIVE_TORQUE) {
-            u = io.drive_cmd[(size_t)env * (nu + 1) + i];
-            sto = io.drive_cmd[(size_t)env * (nu + 1) + nu] != 0.0;
+            u = cst[DRVC_U_OR_PT];
+            sto = cst[DRVC_STO_OR_DT] != 0.0;
         } else {
-            const size_t o = (size_t)env * nu + i;
             const double p = S.drv_pos[i], v = S.drv_vel[i];
-            const double pt = io.pd_ptarget[o], dt = io.pd_dtarget ? io.pd_dtarget[o] : 0.0, ff = io.pd_torque ? io.pd_torque[o] : 0.0;
-            u = wv::add_rn(wv::add_rn(ff, wv::mul_rn(io.pd_kp[o], wv::sub_rn(pt, p))), wv::mul_rn(io.pd_kd[o], wv::sub_rn(dt, v)));
+            const double pt = cst[DRVC_U_OR_PT], dt = cst[DRVC_STO_OR_DT], ff = cst[DRVC_FF];
+            u = wv::add_rn(wv::add_rn(ff, wv::mul_rn(cst[DRVC_KP], wv::sub_rn(pt, p))), wv::mul_rn(cst[DRVC_KD], wv::sub_rn(dt, v)));
         }
         /* motor(): speed-torque curve, STO, delay line (reference :638-664) */
         const double w = S.actvel[i];
@@ -1074,10 +1134,9 @@ WV_DRIVE_FN void drive_level_io(const PhysIO &io, SH &S, ModelPtr m, int env, in
         S.drv_delay[i][0] = tau;
         S.ctrl[i] = ctrl_i;
         /* drive_encoder(): truncation to encoder counts, 9-tap integer FIR (reference :558-593) */
-        const int slot = drive_sensor_slot(i), bits = m->sensor_bits[slot];
-        const double counts = (double)(1 << bits);
+        const int slot = drive_sensor_slot(i);
+        const double counts = cst[DRVC_COUNTS], scale = cst[DRVC_SCALE];
         const int ev = (int)wv::mul_rn(wv::div_rn(S.sens[slot], TWO_PI), counts);
-        const double scale = wv::div_rn(wv::div_rn(TWO_PI, counts), ratio);
         const double pos = wv::mul_rn((double)ev, scale);
         int x[CM_DRIVE_FILTER_NB];
         bool allzero = true;
@@ -1096,10 +1155,9 @@ WV_DRIVE_FN void drive_level_io(const PhysIO &io, SH &S, ModelPtr m, int env, in
         }
     } else if (lane < CM_NUM_DRIVES + CM_NUM_JOINTS) {
         /* joint_encoder(): IIR on the quantised position (reference :596-635) */
-        const int j = lane - CM_NUM_DRIVES, slot = joint_sensor_slot(j), bits = m->sensor_bits[slot];
-        const double counts = (double)(1 << bits);
+        const int j = lane - CM_NUM_DRIVES, slot = joint_sensor_slot(j);
+        const double counts = S.drv_jc[j][0], scale = S.drv_jc[j][1];
         const int ev = (int)wv::mul_rn(wv::div_rn(S.sens[slot], TWO_PI), counts);
-        const double scale = wv::div_rn(TWO_PI, counts);
         const double pos = wv::mul_rn((double)ev, scale);
         double x[CM_JOINT_FILTER_NB], yv[CM_JOINT_FILTER_NA];
         bool allzero = true;
@@ -1156,6 +1214,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
         if (lane < m->nsensordata) S.sens[lane] = io.sensordata[(size_t)env * io.ssd + lane];
         if (lane < nu) S.actvel[lane] = io.actuator_velocity[(size_t)env * io.su + lane];
         drive_state_load(io, S, env, lane);
+        drive_consts_load(io, S, m, env, lane);
     }
     double time = io.time[env];
 
@@ -2762,22 +2821,30 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
             S.qacc_ws[k_] = qacc;
         }
         wv::sync();
-        if (lane < njnt) {
-            const int jt = pf_ejt;
+        {
+            /* lane = joint.  Hinges and slides are one FMA; a ball (or the rotation of a free joint) turns its quaternion by
+             * h * |w| about w -- through the stage's own bounded-range sincos and reciprocal-square-root normalisations (the
+             * library's sin + cos, a square root and two divisions, run for three lanes, were a tenth of this stage).  The
+             * sincos sits outside the lane branches: its range check is a wave vote. */
+            const int jt = lane < njnt ? pf_ejt : -1;
             int qa = pf_eqa, da = pf_eda;
-            if (jt == CM_JNT_HINGE || jt == CM_JNT_SLIDE) {
-                S.qpos[qa] += h * S.qvel[da];
-            } else {
-                if (jt == CM_JNT_FREE) {
-                    for (int i = 0; i < 3; ++i) S.qpos[qa + i] += h * S.qvel[da + i];
-                    qa += 3; da += 3;
-                }
-                double ax[3] = {S.qvel[da], S.qvel[da + 1], S.qvel[da + 2]};
-                const double ang = h * normalize3(ax);
-                const double sn = sin(0.5 * ang);
-                double qr[4] = {cos(0.5 * ang), ax[0] * sn, ax[1] * sn, ax[2] * sn};
+            if (jt == CM_JNT_HINGE || jt == CM_JNT_SLIDE) S.qpos[qa] += h * S.qvel[da];
+            if (jt == CM_JNT_FREE) {
+                for (int i = 0; i < 3; ++i) S.qpos[qa + i] += h * S.qvel[da + i];
+                qa += 3; da += 3;
+            }
+            const bool turns = jt == CM_JNT_FREE || jt == CM_JNT_BALL;
+            double ax[3] = {1, 0, 0}, ang = 0;
+            if (turns) {
+                for (int i = 0; i < 3; ++i) ax[i] = S.qvel[da + i];
+                ang = h * normalize3_fast(ax);
+            }
+            double sn, cs;
+            sincos_bounded(0.5 * ang, sn, cs);
+            if (turns) {
+                double qr[4] = {cs, ax[0] * sn, ax[1] * sn, ax[2] * sn};
                 double q[4] = {S.qpos[qa], S.qpos[qa + 1], S.qpos[qa + 2], S.qpos[qa + 3]};
-                normalize4(q);
+                normalize4_fast(q);
                 mulquat(q, q, qr);
                 for (int i = 0; i < 4; ++i) S.qpos[qa + i] = q[i];
             }

@@ -54,6 +54,7 @@ struct DriveShared {
     double drv_jx[CM_NUM_JOINTS][CM_JOINT_FILTER_NB], drv_jy[CM_NUM_JOINTS][CM_JOINT_FILTER_NA];
     double drv_delay[CM_NUM_DRIVES][CM_TORQUE_DELAY_CYCLES];
     double drv_pos[CM_NUM_DRIVES], drv_vel[CM_NUM_DRIVES];
+    double drv_c[CM_NUM_DRIVES][10], drv_jc[CM_NUM_JOINTS][2];
 };
 
 WV_GLOBAL void __launch_bounds__(WV_WAVE) cassie_drive_kernel(PhysIO io, double *ctrl_out) {
@@ -65,6 +66,7 @@ WV_GLOBAL void __launch_bounds__(WV_WAVE) cassie_drive_kernel(PhysIO io, double 
     if (lane < m->nsensordata) S.sens[lane] = io.sensordata[(size_t)env * io.ssd + lane];
     if (lane < nu) S.actvel[lane] = io.actuator_velocity[(size_t)env * io.su + lane];
     drive_state_load(io, S, env, lane);
+    drive_consts_load(io, S, m, env, lane);
     wv::sync();
     drive_level_io(io, S, m, env, lane, true);
     wv::sync();

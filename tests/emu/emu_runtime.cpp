@@ -242,6 +242,7 @@ extern "C" int emu_derive(const cm_model_t *model, int nenv, double *qpos, doubl
 /* the kinematics stage's own elementary functions, for direct accuracy tests */
 extern "C" void emu_sincos_reduced(double x, double *s, double *c) { ck::sincos_reduced(x, *s, *c); }
 extern "C" void emu_normalize4_fast(double *q) { ck::normalize4_fast(q); }
+extern "C" double emu_normalize3_fast(double *a) { return ck::normalize3_fast(a); }
 extern "C" unsigned long emu_sizeof_shared32(void) { return sizeof(ck::EnvShared<32>); }
 
 /* packed factor rows (ck::LPack): the run-time-lane addressing agrees with the compile-time slots; returns the number of mismatches */

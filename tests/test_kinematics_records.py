@@ -102,6 +102,18 @@ def test_normalize4_fast(built):
             buf = (ctypes.c_double * 4)(*q)
             L.emu_normalize4_fast(buf)
             assert np.max(np.abs(np.array(buf) - np.float64(want))) < 4.5e-16
+    L.emu_normalize3_fast.argtypes = [ctypes.POINTER(ctypes.c_double)]
+    L.emu_normalize3_fast.restype = ctypes.c_double
+    for scale in (1.0, 1e-9, 1e4):
+        for _ in range(2000):
+            a = rng.normal(size=3) * scale
+            nl = np.sqrt(np.sum(np.longdouble(a) ** 2))
+            buf3 = (ctypes.c_double * 3)(*a)
+            n = L.emu_normalize3_fast(buf3)
+            assert abs(n - float(nl)) <= 1.01 * np.spacing(float(nl))
+            assert np.max(np.abs(np.array(buf3) - np.float64(np.longdouble(a) / nl))) < 4.5e-16
+    buf3 = (ctypes.c_double * 3)(3e-16, 0, -4e-16)  # below mju_normalize3's threshold: x axis, the true (tiny) norm
+    assert L.emu_normalize3_fast(buf3) == math.sqrt(3e-16 ** 2 + 4e-16 ** 2) and list(buf3) == [1, 0, 0]
     buf = (ctypes.c_double * 4)(1e-16, 0, 1e-17, 0)  # below mju_normalize4's threshold: the identity
     L.emu_normalize4_fast(buf)
     assert list(buf) == [1, 0, 0, 0]
