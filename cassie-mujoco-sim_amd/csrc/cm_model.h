@@ -112,7 +112,9 @@ typedef struct cm_model {
     int body_subtreeend[CM_MAXBODY];      /* bodies [b, end) form b's subtree (depth-first ids) */
     uint64_t body_dofmask[CM_MAXBODY];    /* bit k set <=> dof k moves this body */
     int body_nchild[CM_MAXBODY], body_child[CM_MAXBODY][4]; /* direct children (at most 4 in the supported models) */
-    int body_anc[CM_MAXBODY][4];          /* 1st, 2nd, 4th, 8th ancestor (0 = world) for pointer-jumping recursions */
+    int body_anc3[CM_MAXBODY][6];         /* ancestors at distance 1, 2 | 3, 6 | 9, 18 (0 = world): radix-3 pointer jumping for the
+                                           * kinematic recursion -- a round composes a body's partial transform with those of two
+                                           * ancestors, so two rounds cover trees 9 levels deep (Cassie), three rounds 27 */
     int nroot, root_body[4];              /* kinematic tree roots (children of the world that move) */
     double body_pos[CM_MAXBODY][3], body_quat[CM_MAXBODY][4];
     double body_ipos[CM_MAXBODY][3], body_iquat[CM_MAXBODY][4];
@@ -147,7 +149,9 @@ typedef struct cm_model {
      * dof's hinge / slide joint (stiffness 0 otherwise), and the actuator on the dof (gear 0, actuator 0 if none) */
     double dof_stiffness[CM_MAXV], dof_springref[CM_MAXV], dof_gear[CM_MAXV], dof_ctrl_lo[CM_MAXV], dof_ctrl_hi[CM_MAXV];
     int dof_qadr[CM_MAXV], dof_act[CM_MAXV];
-    int dof_anc[CM_MAXV][5];              /* 1st, 2nd, 4th, 8th, 16th ancestor dof (-1 = none) for pointer-jumping prefix sums */
+    int dof_anc4[CM_MAXV][9];             /* ancestor dofs at distance 1, 2, 3 | 4, 8, 12 | 16, 32, 48 (-1 = none): radix-4 pointer jumping
+                                           * for the prefix sums along the dof chains -- a round adds the partial sums of three
+                                           * ancestors, so two rounds cover chains of 16 dofs, three rounds chains of 64 */
     int dof_vinsrc[CM_MAXV];              /* dof whose chain sum is the velocity entering dof k's joint (-1 = none): the nearest
                                              ancestor of another joint; for the rotational dofs of a free joint its last translational dof */
     int body_lastdof[CM_MAXBODY];         /* last dof on the body's chain to the root (-1 = none) */

@@ -1095,16 +1095,14 @@ bool HostModel::compile(cm_model_t *o, std::string *err) const {
         o->dof_bodyid[d] = dof_bodyid[d]; o->dof_jntid[d] = dof_jntid[d]; o->dof_parentid[d] = dof_parentid[d];
         o->dof_armature[d] = dof_armature[d]; o->dof_damping[d] = dof_damping[d]; o->dof_invweight0[d] = dof_invweight0[d];
     }
-    if (o->maxdepth > 16) return fail("kinematic tree deeper than 16 levels");
-    for (int b = 0; b < nbody; ++b) {
-        int a = b;
-        for (int r = 0, hop = 1; r < 4; ++r, hop *= 2) {
-            int x = b;
-            for (int t = 0; t < hop; ++t) x = x > 0 ? body_parentid[x] : 0;
-            o->body_anc[b][r] = x;
-        }
-        (void)a;
-    }
+    if (o->maxdepth > 27) return fail("kinematic tree deeper than 27 levels");
+    for (int b = 0; b < nbody; ++b)
+        for (int r = 0, unit = 1; r < 3; ++r, unit *= 3)
+            for (int i = 1; i <= 2; ++i) {
+                int x = b;
+                for (int t = 0; t < i * unit; ++t) x = x > 0 ? body_parentid[x] : 0;
+                o->body_anc3[b][2 * r + i - 1] = x;
+            }
     o->nroot = 0;
     for (int b = 1; b < nbody; ++b) {
         o->body_nchild[b] = 0;
@@ -1133,11 +1131,12 @@ bool HostModel::compile(cm_model_t *o, std::string *err) const {
         int depth = 0;
         for (int a = dof_parentid[d]; a >= 0; a = dof_parentid[a]) ++depth;
         if (depth >= 32) return fail("dof chain deeper than 32");
-        for (int r = 0, hop = 1; r < 5; ++r, hop *= 2) {
-            int a = d;
-            for (int t = 0; t < hop && a >= 0; ++t) a = dof_parentid[a];
-            o->dof_anc[d][r] = a;
-        }
+        for (int r = 0, unit = 1; r < 3; ++r, unit *= 4)
+            for (int i = 1; i <= 3; ++i) {
+                int a = d;
+                for (int t = 0; t < i * unit && a >= 0; ++t) a = dof_parentid[a];
+                o->dof_anc4[d][3 * r + i - 1] = a;
+            }
         int src = dof_parentid[d];
         while (src >= 0 && dof_jntid[src] == dof_jntid[d]) src = dof_parentid[src];
         const int j = dof_jntid[d];

@@ -143,8 +143,10 @@ static int launch(phys_batch *b, int nsub, int integrate, hipStream_t s, bool sc
     const dim3 grid(n);
     /* the compile-time-topology instantiations are used only when the model's dof tree is exactly theirs */
     const cm_model_t &hm = b->host_model;
-    auto matches = [&](const unsigned long long *table, int nv) {
-        if (b->generic_kernel || hm.nv != nv || !hm.kin_simple) return false; /* (kin_simple: their kinematics stage, cm_model.h) */
+    auto matches = [&](const unsigned long long *table, int nv, int body_levels) {
+        /* (kin_simple, and a body tree no deeper than theirs: the record-based local transforms and the round count of the
+         * recursion in their kinematics stage) */
+        if (b->generic_kernel || hm.nv != nv || !hm.kin_simple || hm.maxdepth > body_levels) return false;
         for (int k = 0; k < nv; ++k) if (hm.dof_ancmask[k] != table[k]) return false;
         return true;
     };
@@ -164,7 +166,7 @@ static int launch(phys_batch *b, int nsub, int integrate, hipStream_t s, bool sc
             ++b->ev_used;
         }
     }
-    if (matches(ck::TopoCassie32::table, ck::TopoCassie32::nv)) {
+    if (matches(ck::TopoCassie32::table, ck::TopoCassie32::nv, ck::TopoCassie32::body_levels)) {
         /* stepping launches of the two Cassie instantiations go through the row-capped fast instantiation first; the full one
          * behind it finishes the envs that met a substep with more rows (and is the only one for forward / read-out passes) */
         const bool fast = b->fast_rows && integrate && !wp && !io.ext && b->d_progress;
@@ -172,7 +174,7 @@ static int launch(phys_batch *b, int nsub, int integrate, hipStream_t s, bool sc
         if (!hf && !wp) { launched = ck::launch_step_cassie(grid, s, io, fast, ev_after); ev_after = nullptr; }
         else if (hf && !wp) { launched = ck::launch_step_cassie_hfield(grid, s, io, fast, ev_after); ev_after = nullptr; }
         else launched = ck::launch_step_cassie_all(grid, s, io);
-    } else if (matches(ck::TopoCassieTray38::table, ck::TopoCassieTray38::nv)) launched = ck::launch_step_tray(grid, s, io, hf);
+    } else if (matches(ck::TopoCassieTray38::table, ck::TopoCassieTray38::nv, ck::TopoCassieTray38::body_levels)) launched = ck::launch_step_tray(grid, s, io, hf);
     else launched = ck::launch_step_generic(grid, s, io, hm.nv > 32);
     if (ev_after) (void)hipEventRecord(ev_after, s);
     if (!launched) { (void)hip_ok(hipErrorLaunchFailure, "cassie_step_kernel launch"); return -1; }
@@ -316,7 +318,7 @@ int phys_batch_set_model(phys_batch_t *b, const cm_model_t *model, int env) {
     /* one launch serves every env with the kernel instantiation picked from the shared model: a per-env model may vary
      * parameters, not the dof tree or the kinds of collision pairs */
     if (memcmp(model->dof_ancmask, b->host_model.dof_ancmask, sizeof(model->dof_ancmask[0]) * (size_t)model->nv) != 0 ||
-        model->kin_simple != b->host_model.kin_simple ||
+        model->kin_simple != b->host_model.kin_simple || model->maxdepth != b->host_model.maxdepth ||
         (model->nhfpair > 0) != (b->host_model.nhfpair > 0) || (model->hfield_geom >= 0) != (b->host_model.hfield_geom >= 0) ||
         (model->npair > model->npair_simple) != (b->host_model.npair > b->host_model.npair_simple)) {
         phys_set_last_error("phys_batch_set_model: a per-env model must keep the shared model's dof tree and collision pair kinds");

@@ -1296,9 +1296,15 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
          * over the tree levels is then just R = Rp Rl, p = pp + Rp pl -- no trigonometry, quaternions or square
          * roots on the dependent chain. */
         double Rl[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, pl[3] = {0, 0, 0}, qlq[4] = {1, 0, 0, 0};
-        int kanc[4]; /* the four jump ancestors in one 16-byte read, issued with the stage's other model reads */
+        /* rounds of the recursion over the tree below (radix-3 pointer jumping, cm_model_t::body_anc3): a compile-time
+         * topology knows how deep its tree is (Cassie: 9 levels -> two rounds) */
+        constexpr int kin_rounds = [] {
+            if constexpr (TOPO::is_static) { int r = 0, n = 1; while (n < TOPO::body_levels) { n *= 3; ++r; } return r < 1 ? 1 : r; }
+            else return 3;
+        }();
+        int kanc[2 * kin_rounds]; /* the jump ancestors, issued with the stage's other model reads */
 #pragma unroll
-        for (int r = 0; r < 4; ++r) kanc[r] = isbody ? m->body_anc[b][r] : 0;
+        for (int r = 0; r < 2 * kin_rounds; ++r) kanc[r] = isbody ? m->body_anc3[b][r] : 0;
         const bool isfree = bjt == CM_JNT_FREE;
         if constexpr (TOPO::is_static) {
             /* Compile-time topologies come with kin_simple models (cm_model.h): a body's joints are up to CM_MAXSLIDE slides
@@ -1427,10 +1433,11 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
         double pf_ipos[3], pf_imat[9], pf_iner[3], pf_gpos[3], pf_gmat[9];
         for (int i = 0; i < 3; ++i) { pf_ipos[i] = m->body_ipos[pf_b][i]; pf_iner[i] = m->body_inertia[pf_b][i]; pf_gpos[i] = m->geom_pos[pf_gs][i]; }
         for (int i = 0; i < 9; ++i) { pf_imat[i] = m->body_imat[pf_b][i]; pf_gmat[i] = m->geom_mat[pf_gs][i]; }
-        /* recursion over the tree by pointer jumping: after round r every body holds the product of the local
-         * transforms of its 2^(r+1) nearest ancestors-or-self; four rounds cover trees up to 16 levels deep.  The
-         * partial products ping-pong between the pose tiles and a second buffer laid over the (still unused)
-         * cinert / crb tiles. */
+        /* recursion over the tree by radix-3 pointer jumping: in round r every body composes its partial transform with
+         * those of its 3^r-th and 2 * 3^r-th ancestors, after which it holds the product of the local transforms of its
+         * 3^(r+1) nearest ancestors-or-self -- two LDS round trips for Cassie's nine levels where doubling needed four, for
+         * the same four compositions.  The partial products ping-pong between the pose tiles and a second buffer laid over the
+         * (still unused) cinert / crb tiles, arranged so that the last round lands in the pose tiles. */
         double xm[9], xp[3], xq[4];
         for (int i = 0; i < 9; ++i) xm[i] = Rl[i];
         for (int i = 0; i < 3; ++i) xp[i] = pl[i];
@@ -1438,49 +1445,51 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
         {
             double *bufB = &S.x.s.cinert[0][0]; /* 16 doubles per body, R(9) p(3) q(4), at a stride of 17: a 128-byte stride
                                                    would put all lanes on two LDS banks */
-            if (lane < NB) {
-                for (int i = 0; i < 9; ++i) S.x.s.xmat[lane][i] = xm[i];
-                for (int i = 0; i < 3; ++i) S.x.s.xpos[lane][i] = xp[i];
-                if (need_quat) for (int i = 0; i < 4; ++i) S.x.s.xquat[lane][i] = xq[i];
-            }
-            wv::sync();
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int a = kanc[r];
-                double Ra[9], pa[3], qa[4] = {1, 0, 0, 0};
-                if ((r & 1) == 0) {
-                    for (int i = 0; i < 9; ++i) Ra[i] = S.x.s.xmat[a][i];
-                    for (int i = 0; i < 3; ++i) pa[i] = S.x.s.xpos[a][i];
-                    if (need_quat) for (int i = 0; i < 4; ++i) qa[i] = S.x.s.xquat[a][i];
-                } else {
-                    for (int i = 0; i < 9; ++i) Ra[i] = bufB[a * 17 + i];
-                    for (int i = 0; i < 3; ++i) pa[i] = bufB[a * 17 + 9 + i];
-                    if (need_quat) for (int i = 0; i < 4; ++i) qa[i] = bufB[a * 17 + 12 + i];
-                }
-                if (a > 0 || r == 0) { /* the world's transform is the identity: nothing to compose beyond the root */
-                    double Rn[9], pn[3];
-                    for (int i = 0; i < 3; ++i) {
-                        for (int c = 0; c < 3; ++c) Rn[3 * i + c] = Ra[3 * i] * xm[c] + Ra[3 * i + 1] * xm[3 + c] + Ra[3 * i + 2] * xm[6 + c];
-                        pn[i] = pa[i] + (Ra[3 * i] * xp[0] + Ra[3 * i + 1] * xp[1] + Ra[3 * i + 2] * xp[2]);
-                    }
-                    if (a > 0) {
-                        for (int i = 0; i < 9; ++i) xm[i] = Rn[i];
-                        for (int i = 0; i < 3; ++i) xp[i] = pn[i];
-                        if (need_quat) mulquat(xq, qa, xq);
-                    }
-                }
+            auto park = [&](bool in_pose_tiles) {
                 if (lane < NB) {
-                    if ((r & 1) == 0) {
-                        for (int i = 0; i < 9; ++i) bufB[lane * 17 + i] = xm[i];
-                        for (int i = 0; i < 3; ++i) bufB[lane * 17 + 9 + i] = xp[i];
-                        if (need_quat) for (int i = 0; i < 4; ++i) bufB[lane * 17 + 12 + i] = xq[i];
-                    } else {
+                    if (in_pose_tiles) {
                         for (int i = 0; i < 9; ++i) S.x.s.xmat[lane][i] = xm[i];
                         for (int i = 0; i < 3; ++i) S.x.s.xpos[lane][i] = xp[i];
                         if (need_quat) for (int i = 0; i < 4; ++i) S.x.s.xquat[lane][i] = xq[i];
+                    } else {
+                        for (int i = 0; i < 9; ++i) bufB[lane * 17 + i] = xm[i];
+                        for (int i = 0; i < 3; ++i) bufB[lane * 17 + 9 + i] = xp[i];
+                        if (need_quat) for (int i = 0; i < 4; ++i) bufB[lane * 17 + 12 + i] = xq[i];
                     }
                 }
                 wv::sync();
+            };
+            /* compose an ancestor's partial transform (Ra, pa, qa) in front of this body's */
+            auto compose = [&](const double *Ra, const double *pa, const double *qa) {
+                double Rn[9], pn[3];
+                for (int i = 0; i < 3; ++i) {
+                    for (int c = 0; c < 3; ++c) Rn[3 * i + c] = Ra[3 * i] * xm[c] + Ra[3 * i + 1] * xm[3 + c] + Ra[3 * i + 2] * xm[6 + c];
+                    pn[i] = pa[i] + (Ra[3 * i] * xp[0] + Ra[3 * i + 1] * xp[1] + Ra[3 * i + 2] * xp[2]);
+                }
+                for (int i = 0; i < 9; ++i) xm[i] = Rn[i];
+                for (int i = 0; i < 3; ++i) xp[i] = pn[i];
+                if (need_quat) mulquat(xq, qa, xq);
+            };
+            constexpr bool first_in_pose_tiles = (kin_rounds & 1) == 0;
+            park(first_in_pose_tiles);
+#pragma unroll
+            for (int r = 0; r < kin_rounds; ++r) {
+                const bool from_pose_tiles = first_in_pose_tiles == ((r & 1) == 0);
+                const int a1 = kanc[2 * r], a2 = kanc[2 * r + 1];
+                double R1[9], p1[3], q1[4] = {1, 0, 0, 0}, R2[9], p2[3], q2[4] = {1, 0, 0, 0};
+                if (from_pose_tiles) {
+                    for (int i = 0; i < 9; ++i) { R1[i] = S.x.s.xmat[a1][i]; R2[i] = S.x.s.xmat[a2][i]; }
+                    for (int i = 0; i < 3; ++i) { p1[i] = S.x.s.xpos[a1][i]; p2[i] = S.x.s.xpos[a2][i]; }
+                    if (need_quat) for (int i = 0; i < 4; ++i) { q1[i] = S.x.s.xquat[a1][i]; q2[i] = S.x.s.xquat[a2][i]; }
+                } else {
+                    for (int i = 0; i < 9; ++i) { R1[i] = bufB[a1 * 17 + i]; R2[i] = bufB[a2 * 17 + i]; }
+                    for (int i = 0; i < 3; ++i) { p1[i] = bufB[a1 * 17 + 9 + i]; p2[i] = bufB[a2 * 17 + 9 + i]; }
+                    if (need_quat) for (int i = 0; i < 4; ++i) { q1[i] = bufB[a1 * 17 + 12 + i]; q2[i] = bufB[a2 * 17 + 12 + i]; }
+                }
+                /* the world's transform is the identity: nothing to compose beyond the root */
+                if (a1 > 0) compose(R1, p1, q1);
+                if (a2 > 0) compose(R2, p2, q2);
+                park(!from_pose_tiles);
             }
         }
         if (b == 0) for (int i = 0; i < 3; ++i) S.x.s.xipos[0][i] = 0;
@@ -1670,14 +1679,21 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
          * constants' trip through the memory system runs under the pair loop. */
         /* (unconditional reads at clamped indices; the lane predicates are applied where the values are used, behind
          * wv::keep -- a predicate folded into the read would make the compiler wait for the value on the spot) */
-        int pf_jlim, pf_jtype, pf_jqadr, danc[5], blast, kvin;
+        /* rounds of radix-4 pointer jumping along the dof chains (velocity stage, cm_model_t::dof_anc4): after round r a dof
+         * holds the sum over itself and its 4^(r+1) - 1 nearest ancestors; a compile-time topology knows how long its longest
+         * chain is (Cassie: 14 dofs -> two rounds) */
+        constexpr int chain_rounds = [] {
+            if constexpr (TOPO::is_static) { int r = 0, n = 1; while (n < DofLevels<TOPO>::depth() + 1) { n *= 4; ++r; } return r < 3 ? r : 3; }
+            else return 3;
+        }();
+        int pf_jlim, pf_jtype, pf_jqadr, danc[9], blast, kvin;
         double pf_jmargin, pf_jlo, pf_jhi;
         auto request_behind_collision = [&](int lane_now) {
             const int pf_lj = lane_now < njnt ? lane_now : 0, pf_kd = lane_now < nv ? lane_now : 0, pf_bb = lane_now < nbody ? lane_now : 0;
             pf_jlim = m->jnt_limited[pf_lj]; pf_jtype = m->jnt_type[pf_lj]; pf_jqadr = m->jnt_qposadr[pf_lj];
             pf_jmargin = m->jnt_margin[pf_lj]; pf_jlo = m->jnt_range[pf_lj][0]; pf_jhi = m->jnt_range[pf_lj][1];
 #pragma unroll
-            for (int r = 0; r < 5; ++r) danc[r] = m->dof_anc[pf_kd][r];
+            for (int r = 0; r < 3 * chain_rounds; ++r) danc[r] = m->dof_anc4[pf_kd][r];
             blast = m->body_lastdof[pf_bb]; kvin = m->dof_vinsrc[pf_kd];
         };
         /* (the instantiations with the height-field pre-pass have no registers to spare across it and the pair loop: they ask
@@ -2008,7 +2024,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
          * behind this one (cm_model_t::dof_*: damping, the joint's spring, the actuator on the dof -- one level of
          * unconditional reads; dofs without a spring / actuator carry zero stiffness / gear) are requested now. */
 #pragma unroll
-        for (int r = 0; r < 5; ++r) { wv::keep(danc[r]); if (!isdof) danc[r] = -1; }
+        for (int r = 0; r < 3 * chain_rounds; ++r) { wv::keep(danc[r]); if (!isdof) danc[r] = -1; }
         wv::keep(blast); wv::keep(kvin);
         if (!isbody) blast = -1;
         if (!isdof) kvin = -1;
@@ -2020,12 +2036,17 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
             if (lane < NVP) for (int t = 0; t < 6; ++t) S.x.s.buf[lane][t] = acc[t];
             wv::sync();
 #pragma unroll
-            for (int r = 0; r < 5; ++r) {
-                double up[6];
-                const int a = danc[r] >= 0 ? danc[r] : 0;
-                for (int t = 0; t < 6; ++t) up[t] = S.x.s.buf[a][t];
+            for (int r = 0; r < chain_rounds; ++r) {
+                double up[3][6];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const int a = danc[3 * r + i] >= 0 ? danc[3 * r + i] : 0;
+                    for (int t = 0; t < 6; ++t) up[i][t] = S.x.s.buf[a][t];
+                }
                 wv::sync();
-                if (danc[r] >= 0) for (int t = 0; t < 6; ++t) acc[t] += up[t];
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+                    if (danc[3 * r + i] >= 0) for (int t = 0; t < 6; ++t) acc[t] += up[i][t];
                 if (lane < NVP) for (int t = 0; t < 6; ++t) S.x.s.buf[lane][t] = acc[t];
                 wv::sync();
             }

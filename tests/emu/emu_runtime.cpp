@@ -162,8 +162,8 @@ static void body40s() { ck::cassie_step_kernel<40, ck::TopoCassieTray38>(g_io); 
 static void body32() { ck::cassie_step_kernel<32, ck::TopoRuntime>(g_io); }
 static void body40() { ck::cassie_step_kernel<40, ck::TopoRuntime>(g_io); }
 extern "C" void emu_force_runtime_topology(int on) { g_force_runtime_topology = on; }
-static bool topo_matches(const cm_model_t *m, const unsigned long long *t, int nv) {
-    if (m->nv != nv || !m->kin_simple) return false;
+static bool topo_matches(const cm_model_t *m, const unsigned long long *t, int nv, int body_levels) {
+    if (m->nv != nv || !m->kin_simple || m->maxdepth > body_levels) return false;
     for (int k = 0; k < nv; ++k) if (m->dof_ancmask[k] != t[k]) return false;
     return true;
 }
@@ -196,7 +196,7 @@ extern "C" int emu_phys_run(const cm_model_t *model, int nenv, int nsub, int int
     g_io.pd_dtarget = g_pd_dtarget; g_io.pd_torque = g_pd_torque;
     for (int e = 0; e < nenv; ++e) {
         g_env = e;
-        if (!g_force_runtime_topology && topo_matches(model, ck::TopoCassie32::table, ck::TopoCassie32::nv)) {
+        if (!g_force_runtime_topology && topo_matches(model, ck::TopoCassie32::table, ck::TopoCassie32::nv, ck::TopoCassie32::body_levels)) {
             static int progress[1 << 16];
             if (g_fast_rows && integrate && e < (1 << 16)) {
                 g_io.progress = progress; g_io.resume = 0;
@@ -207,7 +207,7 @@ extern "C" int emu_phys_run(const cm_model_t *model, int nenv, int nsub, int int
             run_block(body32s);
             g_io.progress = nullptr; g_io.resume = 0;
         }
-        else if (!g_force_runtime_topology && topo_matches(model, ck::TopoCassieTray38::table, ck::TopoCassieTray38::nv)) run_block(body40s);
+        else if (!g_force_runtime_topology && topo_matches(model, ck::TopoCassieTray38::table, ck::TopoCassieTray38::nv, ck::TopoCassieTray38::body_levels)) run_block(body40s);
         else run_block(model->nv <= 32 ? body32 : body40);
     }
     return 0;
@@ -231,8 +231,8 @@ extern "C" int emu_derive(const cm_model_t *model, int nenv, double *qpos, doubl
     for (int i = 0; i < 6; ++i) g_dio.ids[i] = ids[i];
     for (int e = 0; e < nenv; ++e) {
         g_env = e;
-        if (topo_matches(model, ck::TopoCassie32::table, ck::TopoCassie32::nv)) run_block(body32s);
-        else if (topo_matches(model, ck::TopoCassieTray38::table, ck::TopoCassieTray38::nv)) run_block(body40s);
+        if (topo_matches(model, ck::TopoCassie32::table, ck::TopoCassie32::nv, ck::TopoCassie32::body_levels)) run_block(body32s);
+        else if (topo_matches(model, ck::TopoCassieTray38::table, ck::TopoCassieTray38::nv, ck::TopoCassieTray38::body_levels)) run_block(body40s);
         else run_block(model->nv <= 32 ? body32 : body40);
         run_block(body_derive);
     }

@@ -18,7 +18,10 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        _lib = ctypes.CDLL(os.path.join(REPO_DIR, "oracle", "libcassie_oracle.so"))
+        # (a library variant built from an older source tree -- tools/build_variant.sh, CASSIE_LIB -- comes with the oracle
+        # of that tree next to it: the two share cm_model_t's layout)
+        variant = (os.environ.get("CASSIE_LIB") or "") + ".oracle.so"
+        _lib = ctypes.CDLL(variant if os.path.exists(variant) else os.path.join(REPO_DIR, "oracle", "libcassie_oracle.so"))
         _lib.co_sizeof_data.restype = ctypes.c_ulong
         assert _lib.co_sizeof_data() == ctypes.sizeof(CoData), "co_data_t layout mismatch"
         for fn in ("co_reset", "co_forward", "co_step", "co_kinematics", "co_com_pos", "co_crb", "co_factor_m",
