@@ -1597,23 +1597,30 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
         /* ================= P2 CRBA: composite inertias, then one COLUMN of M per lane ================= */
         /* composite inertias: crb_b = sum of cinert_c over the contiguous subtree range [b, bend): dense loop over all
          * bodies with a per-lane range predicate, operands staged four bodies at a time */
+        /* There are at most 32 bodies and 64 lanes: lanes l and l + 32 both work for body l, the lower one on bodies
+         * [0, NB / 2) of the loop, the upper one on [NB / 2, NB); the lower lane then takes the upper one's partial sum
+         * (wv::from_upper_half: one lane-swap instruction per dword).  Half the iterations for ten swaps and adds. */
         {
             double acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-            const unsigned bsub = (isbody && b > 0) ? (unsigned)(((1ull << bend) - 1ull) ^ ((1ull << b) - 1ull)) : 0u; /* bodies [b, bend) */
+            const int hb = lane & 31, hbend = wv::shfl_i(bend, hb), coff = lane < 32 ? 0 : NB / 2;
+            const unsigned bsub = (hb < nbody && hb > 0) ? (unsigned)(((1ull << hbend) - 1ull) ^ ((1ull << hb) - 1ull)) : 0u; /* bodies [hb, hbend) */
+            const double (*cin)[10] = &S.x.s.cinert[coff];
 #pragma unroll
-            for (int c0 = 0; c0 < NB; c0 += 4) {
+            for (int c0 = 0; c0 < NB / 2; c0 += 4) {
                 double ci4[4][10];
 #pragma unroll
                 for (int cc = 0; cc < 4; ++cc)
 #pragma unroll
-                    for (int t = 0; t < 10; ++t) ci4[cc][t] = S.x.s.cinert[c0 + cc][t];
+                    for (int t = 0; t < 10; ++t) ci4[cc][t] = cin[c0 + cc][t];
 #pragma unroll
                 for (int cc = 0; cc < 4; ++cc) {
-                    const double w = bitf(bsub, c0 + cc);
+                    const double w = bitf(bsub >> coff, c0 + cc);
 #pragma unroll
                     for (int t = 0; t < 10; ++t) acc[t] = fma(w, ci4[cc][t], acc[t]);
                 }
             }
+#pragma unroll
+            for (int t = 0; t < 10; ++t) acc[t] += wv::from_upper_half(acc[t]);
             if (isbody) for (int i = 0; i < 10; ++i) S.x.s.crb[b][i] = acc[i];
         }
         wv::sync();
@@ -1628,11 +1635,40 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
         CK_STAMP(20);
         double col[NVP], colh[NVP]; /* col[i] = M[i][lane] (i >= lane); colh: same for M + h*diag(damping) */
         double cdm[6]; /* this lane's motion axis, fetched where it is used rather than carried in registers */
-        for (int i = 0; i < 6; ++i) cdm[i] = S.cdof[lane < NVP ? lane : 0][i];
         /* armature and h * damping sit on the diagonal only: they are added where the pivots are read (wave-uniform
          * scalars there) instead of being selected into one lane-dependent entry of each column here */
         /* M[i][lane] = cdof_lane . (crb[body_i] cdof_i): the buf rows are broadcast reads, staged eight rows at a time so
          * the LDS latency is paid once per group instead of once per row */
+        if constexpr (NVP == 32) {
+            /* 32 columns on 64 lanes: lanes l and l + 32 both work for column l, on rows [0, 16) and [16, 32); the lower lane
+             * takes the upper one's sixteen entries through the lane swap */
+            const int hk = lane & 31, roff = lane < 32 ? 0 : 16;
+            const unsigned hdesc = (unsigned)wv::shfl_i((int)(unsigned)kdesc, hk) >> roff; /* (kdesc: no bit at or past nv <= 32) */
+            for (int i = 0; i < 6; ++i) cdm[i] = S.cdof[hk][i];
+            const double (*bufr)[6] = &S.x.s.buf[roff];
+            double part[16];
+#pragma unroll
+            for (int i0 = 0; i0 < 16; i0 += 8) {
+                double bb[8][6];
+#pragma unroll
+                for (int ii = 0; ii < 8; ++ii)
+#pragma unroll
+                    for (int t = 0; t < 6; ++t) bb[ii][t] = bufr[i0 + ii][t];
+                wv::sched_fence();
+#pragma unroll
+                for (int ii = 0; ii < 8; ++ii) {
+                    const double v = (cdm[0] * bb[ii][0] + cdm[1] * bb[ii][1]) + (cdm[2] * bb[ii][2] + cdm[3] * bb[ii][3]) + (cdm[4] * bb[ii][4] + cdm[5] * bb[ii][5]);
+                    part[i0 + ii] = ((hdesc >> (i0 + ii)) & 1u) ? v : 0.0;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const double up = wv::from_upper_half(part[i]);
+                col[i] = part[i]; colh[i] = part[i];
+                col[16 + i] = up; colh[16 + i] = up;
+            }
+        } else {
+        for (int i = 0; i < 6; ++i) cdm[i] = S.cdof[lane < NVP ? lane : 0][i];
 #pragma unroll
         for (int i0 = 0; i0 < NVP; i0 += 8) {
             double bb[8][6];
@@ -1650,6 +1686,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
                 col[i] = v;
                 colh[i] = v;
             }
+        }
         }
         if (io.ext && isdof) {
             cm_ext_t *ex = io.ext + env;
@@ -2097,7 +2134,29 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
         CK_STAMP(24);
         /* lane = dof: project the subtree's force on the motion axis; subtree = contiguous body range [kbody, kbend) */
         double qfrc_bias = 0;
-        {
+        if constexpr (NVP == 32) {
+            /* (32 dofs on 64 lanes: the two halves of the wave split the bodies of the loop, as in the composite-inertia sums) */
+            double acc[6] = {0, 0, 0, 0, 0, 0};
+            const int hk = lane & 31, hkbody = wv::shfl_i(kbody, hk), hkbend = wv::shfl_i(kbend, hk), coff = lane < 32 ? 0 : NB / 2;
+            const unsigned ksub = hk < nv ? (unsigned)(((1ull << hkbend) - 1ull) ^ ((1ull << hkbody) - 1ull)) >> coff : 0u; /* bodies [kbody, kbend) */
+            const double (*cfr)[6] = &S.x.s.cfrc[coff];
+#pragma unroll
+            for (int c0 = 0; c0 < NB / 2; c0 += 4) {
+                double ff[4][6];
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+                    for (int t = 0; t < 6; ++t) ff[cc][t] = cfr[c0 + cc][t];
+                wv::sched_fence();
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) {
+                    const double w = bitf(ksub, c0 + cc);
+#pragma unroll
+                    for (int t = 0; t < 6; ++t) acc[t] = fma(w, ff[cc][t], acc[t]);
+                }
+            }
+            for (int i = 0; i < 6; ++i) { acc[i] += wv::from_upper_half(acc[i]); qfrc_bias += S.cdof[lane < NVP ? lane : 0][i] * acc[i]; }
+        } else {
             double acc[6] = {0, 0, 0, 0, 0, 0};
             const unsigned ksub = isdof ? (unsigned)(((1ull << kbend) - 1ull) ^ ((1ull << kbody) - 1ull)) : 0u; /* bodies [kbody, kbend) */
 #pragma unroll

@@ -48,6 +48,16 @@ WV_DEVICE double shfl(double v, int src_lane) { return __shfl(v, src_lane, WV_WA
 WV_DEVICE double shfl_xor(double v, int mask) { return __shfl_xor(v, mask, WV_WAVE); }
 WV_DEVICE int shfl_i(int v, int src_lane) { return __shfl(v, src_lane, WV_WAVE); }
 
+/* for lanes 0..31: the value lane + 32 holds (the upper lanes get their own value back): one v_permlane32_swap_b32 per
+ * dword, no LDS crossbar.  Used where the two halves of the wave each do half of a lane's work (dense loops whose work
+ * items number at most 32) and the lower half collects the results. */
+WV_DEVICE double from_upper_half(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const auto rl = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto rh = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double((int)rh[1], (int)rl[1]);
+}
+
 /* broadcast lane `src` (wave-uniform index) of a per-lane double: two v_readlane_b32 */
 WV_DEVICE double readlane(double v, int src) {
     int lo = __double2loint(v), hi = __double2hiint(v);

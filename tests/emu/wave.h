@@ -30,6 +30,7 @@ void sync();
 double shfl(double v, int src_lane);
 double shfl_xor(double v, int mask);
 int shfl_i(int v, int src_lane);
+inline double from_upper_half(double v) { const double o = shfl_xor(v, 32); return lane() < 32 ? o : v; }
 double readlane(double v, int src);
 int lane();
 template <int DST> inline double writelane(double v, double s) { return lane() == DST ? s : v; } /* s is the same in every lane */
