@@ -2554,51 +2554,48 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
 
         /* ================= P9: this lane's row of A = Y^T Y + diag(R), b = Y^T y63 - aref ================= */
         double arow[MAXR];
-        double diag_yy = 0; /* this lane's row of Y with itself (the split path below forms it with the rows) */
-        /* The row-capped instantiation has at most 31 rows, so lanes 32 .. 62 hold none: the two halves of the wave share
-         * every dot product.  Lane r takes the terms k = 0, 1 (mod 4), lane r + 32 the terms k = 2, 3 (mod 4) of row r's
-         * products -- exactly the accumulators a0 + a1 and a2 + a3 of the full instantiation below -- and the halves are
-         * exchanged once, for all rows together: half the broadcast LDS reads and half the FMAs per row, and the sums are
-         * associated exactly as below, so the results are the same bit for bit. */
-        constexpr bool split_rows = MAXR <= 31 && NVP % 4 == 0;
-        if constexpr (split_rows) {
-            const int half = lane >> 5, myrow = lane & 31; /* (lane 31 / 63 "work for" row 31 = the qfrc_smooth column: unused) */
-            constexpr int NJ = NVP / 4;
-            double yc[NJ][2];
+        double diag_yy = 0; /* this lane's row of Y with itself */
+        double rb = 0;
+        /* Every product of two staged rows is ONE fused multiply-add chain over the dofs in index order, started from zero --
+         * in both instantiations, so that their results agree bit for bit:
+         *   - the row-capped instantiation (at most 31 rows + the qfrc_smooth row = a 32 x 32 Gram matrix of the staged tile)
+         *     forms it on the matrix core: v_mfma_f64_16x16x4_f64 is exactly that chain per element (wave.h),
+         *     three 16 x 16 tiles (the matrix is symmetric) x NVP / 4 blocks of dofs, operands straight from the staged
+         *     tile, 64 clocks each with nothing else on the wave's critical path; the tiles go through LDS (the part of the
+         *     body-stage region behind the staged tile) so that every lane ends up with its own row in registers;
+         *   - the full instantiation forms the same chains on the vector unit, two rows at a time. */
+        constexpr bool gram_on_matrix_core = MAXR == 31 && NVP % 4 == 0;
+        if constexpr (gram_on_matrix_core) {
+            constexpr int YP = EnvShared<NVP, LPack<TOPO, NVP>::count, MAXR>::YP;
+            static_assert(2 * (MAXR + 1) * YP * sizeof(double) <= sizeof(S.x), "the Gram matrix is parked behind the staged tile");
+            double (*Am)[YP] = (double (*)[YP])(&S.x.Yr[0][0] + (MAXR + 1) * YP);
+            const int mi = lane & 15, mk = lane >> 4;
+            double y0[NVP / 4], y1[NVP / 4];
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) { yc[j][0] = S.x.Yr[myrow][4 * j + 2 * half]; yc[j][1] = S.x.Yr[myrow][4 * j + 2 * half + 1]; }
-            double part[MAXR + 1];
+            for (int kb = 0; kb < NVP / 4; ++kb) { y0[kb] = S.x.Yr[mi][4 * kb + mk]; y1[kb] = S.x.Yr[16 + mi][4 * kb + mk]; }
+            wv::mfma_acc t00 = {{0, 0, 0, 0}}, t01 = {{0, 0, 0, 0}}, t11 = {{0, 0, 0, 0}};
 #pragma unroll
-            for (int r = 0; r < MAXR; r += 2) {
-                double p0 = 0, p1 = 0;
-                if (r < nefc) {
-                    double ya[NJ][2], yb[NJ][2];
+            for (int kb = 0; kb < NVP / 4; ++kb) wv::mfma_f64_16x16x4_x3(y0[kb], y0[kb], t00, y0[kb], y1[kb], t01, y1[kb], y1[kb], t11);
+            wv::mfma_f64_drain(t00, t01, t11);
 #pragma unroll
-                    for (int j = 0; j < NJ; ++j) { ya[j][0] = S.x.Yr[r][4 * j + 2 * half]; ya[j][1] = S.x.Yr[r][4 * j + 2 * half + 1]; }
-#pragma unroll
-                    for (int j = 0; j < NJ; ++j) { yb[j][0] = S.x.Yr[r + 1 < MAXR ? r + 1 : r][4 * j + 2 * half]; yb[j][1] = S.x.Yr[r + 1 < MAXR ? r + 1 : r][4 * j + 2 * half + 1]; }
-                    wv::sched_fence();
-                    double a0 = 0, a1 = 0, b0 = 0, b1 = 0;
-#pragma unroll
-                    for (int j = 0; j < NJ; ++j) { a0 += ya[j][0] * yc[j][0]; a1 += ya[j][1] * yc[j][1]; }
-                    p0 = a0 + a1;
-#pragma unroll
-                    for (int j = 0; j < NJ; ++j) { b0 += yb[j][0] * yc[j][0]; b1 += yb[j][1] * yc[j][1]; }
-                    p1 = b0 + b1;
-                }
-                part[r] = p0;
-                if (r + 1 < MAXR) part[r + 1] = p1;
+            for (int v = 0; v < 4; ++v) {
+                const int row = mk + 4 * v;
+                Am[row][mi] = t00.c[v];
+                Am[row][16 + mi] = t01.c[v];
+                Am[16 + mi][row] = t01.c[v];
+                Am[16 + row][16 + mi] = t11.c[v];
             }
-            {
-                double d0 = 0, d1 = 0;
+            wv::sync();
+            const int myrow = lane & 31; /* (lanes 32 .. 63 hold no row: they read a row's values and never use them) */
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) { d0 += yc[j][0] * yc[j][0]; d1 += yc[j][1] * yc[j][1]; }
-                part[MAXR] = d0 + d1;
-            }
-            /* one exchange for everything: lane r <-> lane r + 32 (IEEE addition commutes: both halves end up with the same sum) */
+            for (int t = 0; t < MAXR; ++t) arow[t] = Am[myrow][t];
+            rb = Am[myrow][MAXR] - raref;
+            /* (the register allocator's plan for the whole kernel depends on this lane's column of Y staying in registers up to
+             * here -- it did when the vector unit formed the products; released at the staging store, 600 values go to
+             * scratch all over the kernel.  No instruction is emitted.) */
 #pragma unroll
-            for (int r = 0; r < MAXR; ++r) arow[r] = part[r] + wv::shfl_xor(part[r], 32);
-            diag_yy = part[MAXR] + wv::shfl_xor(part[MAXR], 32);
+            for (int k = 0; k < NVP; ++k) wv::touch(ycol[k]);
+            diag_yy = Am[myrow][myrow];
         } else {
 #pragma unroll
         for (int r = 0; r < MAXR; r += 2) {
@@ -2615,6 +2612,11 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
 #pragma unroll
                 for (int k = 0; k < YB1; ++k) yb[k] = S.x.Yr[r + 1 < MAXR ? r + 1 : r][k];
                 wv::sched_fence();
+                if constexpr (NVP == 32) {
+                    /* (the instantiation with a row-capped twin: the chain of the matrix core, see above) */
+#pragma unroll
+                    for (int k = 0; k < NVP; ++k) { acc0 = fma(ya[k], ycol[k], acc0); if (r + 1 < MAXR) acc1 = fma(yb[k], ycol[k], acc1); }
+                } else {
                 double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
 #pragma unroll
                 for (int k = 0; k < NVP; k += 4) {
@@ -2636,17 +2638,17 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
                     }
                     acc1 = (b0 + b1) + (b2 + b3);
                 }
+                }
             }
             arow[r] = acc0;
             if (r + 1 < MAXR) arow[r + 1] = acc1;
         }
-        }
-        double rb = 0;
         {
             double acc = 0;
 #pragma unroll
-            for (int k = 0; k < NVP; ++k) acc += S.x.Yr[MAXR][k] * ycol[k];
+            for (int k = 0; k < NVP; ++k) acc = fma(S.x.Yr[MAXR][k], ycol[k], acc);
             rb = acc - raref;
+        }
         }
         CK_STAMP(10);
 
@@ -2658,15 +2660,22 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
          * R part of a row's action on its own residual is applied once per sweep (cdiag below): a row's residual is not
          * read again between its own turn and the end of the sweep. */
         double Aii = 1.0;
-        if constexpr (split_rows) { if (isrow) Aii = diag_yy + rR; }
+        if constexpr (gram_on_matrix_core) { if (isrow) Aii = diag_yy + rR; }
         else if (isrow) {
-            double d0 = 0, d1 = 0, d2 = 0, d3 = 0;
+            if constexpr (NVP == 32) { /* (the instantiation with a row-capped twin: the chain of the matrix core) */
+                double d = 0;
 #pragma unroll
-            for (int k = 0; k < NVP; k += 4) {
-                d0 += ycol[k] * ycol[k]; d1 += ycol[k + 1] * ycol[k + 1];
-                d2 += ycol[k + 2] * ycol[k + 2]; d3 += ycol[k + 3] * ycol[k + 3];
+                for (int k = 0; k < NVP; ++k) d = fma(ycol[k], ycol[k], d);
+                Aii = d + rR;
+            } else {
+                double d0 = 0, d1 = 0, d2 = 0, d3 = 0;
+#pragma unroll
+                for (int k = 0; k < NVP; k += 4) {
+                    d0 += ycol[k] * ycol[k]; d1 += ycol[k + 1] * ycol[k + 1];
+                    d2 += ycol[k + 2] * ycol[k + 2]; d3 += ycol[k + 3] * ycol[k + 3];
+                }
+                Aii = ((d0 + d1) + (d2 + d3)) + rR;
             }
-            Aii = ((d0 + d1) + (d2 + d3)) + rR;
         }
         const double invAii = 1.0 / Aii;
         double f = 0, res = isrow ? rb : 0.0;

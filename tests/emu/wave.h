@@ -30,6 +30,12 @@ void sync();
 double shfl(double v, int src_lane);
 double shfl_xor(double v, int mask);
 int shfl_i(int v, int src_lane);
+struct mfma_acc { double c[4]; };
+void mfma_f64_16x16x4(double a, double b, double (&c)[4]);
+inline void mfma_f64_16x16x4_x3(double a0, double b0, mfma_acc &c0, double a1, double b1, mfma_acc &c1, double a2, double b2, mfma_acc &c2) {
+    mfma_f64_16x16x4(a0, b0, c0.c); mfma_f64_16x16x4(a1, b1, c1.c); mfma_f64_16x16x4(a2, b2, c2.c);
+}
+inline void mfma_f64_drain(mfma_acc &, mfma_acc &, mfma_acc &) {}
 inline double from_upper_half(double v) { const double o = shfl_xor(v, 32); return lane() < 32 ? o : v; }
 double readlane(double v, int src);
 int lane();
@@ -42,6 +48,7 @@ inline double max_raw(double a, double b) { return a > b ? a : b; }
 inline int opaque(int x) { return x; }
 inline void sched_fence() {}
 inline void keep(int &) {}
+inline void touch(double) {}
 extern int g_force_guarded;
 extern int g_poison_lds;
 extern unsigned long g_poison_lo, g_poison_hi;
