@@ -50,7 +50,7 @@ WV_DEVICE int shfl_i(int v, int src_lane) { return __shfl(v, src_lane, WV_WAVE);
 
 /* v_mfma_f64_16x16x4_f64: D = A B + C on the matrix core, A 16 x 4, B 4 x 16, C / D 16 x 16 spread over the wave -- lane l
  * supplies A[l & 15][l >> 4] and B[l >> 4][l & 15] and holds C / D[(l >> 4) + 4 v][l & 15] in c[v], v = 0 .. 3.  Every
- * element is the plain FMA chain over k = 0 .. 3 on top of C, bit for bit (tools/micro/mfma_f64_probe.hip), at 64 clocks
+ * element is the plain FMA chain over k = 0 .. 3 on top of C, bit for bit (tools/mfma_f64_probe.hip), at 64 clocks
  * per instruction whether or not the next one depends on it.  All 64 lanes must be active.
  *
  * Written as inline assembly on VGPR operands, three independent accumulations to a block: the compiler stops lending the

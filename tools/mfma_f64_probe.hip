@@ -1,3 +1,4 @@
+// Build: hipcc -O3 --offload-arch=gfx950 tools/mfma_f64_probe.hip -o /tmp/mfma_f64_probe (output: profiles/round3/v27_mfma_f64_probe.txt)
 // Probe of v_mfma_f64_16x16x4_f64 on gfx950: (1) is a result element the plain FMA chain over k = 0..3 on top of C
 // (bit for bit)?  (2) issue interval of independent / dependent instructions in one wave per SIMD.
 #include <hip/hip_runtime.h>
