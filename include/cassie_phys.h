@@ -93,7 +93,10 @@ phys_batch_t *phys_batch_create(const cm_model_t *model, int nenv, int device);
 void phys_batch_free(phys_batch_t *b);                                  /* mj_deleteData (reference :452) */
 int phys_batch_nenv(const phys_batch_t *b);
 int phys_batch_field_dim(const phys_batch_t *b, int field);            /* doubles per env */
-/* replace the model of one env (env >= 0) or of all envs (env = -1): per-env domain randomisation */
+/* replace the model of one env (env >= 0) or of all envs (env = -1): per-env domain randomisation.  One launch serves every
+ * env with the kernel instantiation picked from the shared model, so a per-env model may vary parameters but must keep the
+ * shared model's sizes, dof tree, body-tree depth, joint make-up of the bodies (cm_model_t::kin_simple) and kinds of collision
+ * pairs (-1 + phys_last_error() otherwise) */
 int phys_batch_set_model(phys_batch_t *b, const cm_model_t *model, int env);
 /* height-field samples (nrow * ncol floats, MuJoCo's normalised 0..1 elevations): one grid shared by all envs, or --
  * per-env terrain randomisation -- a grid of its own for one env (the others keep what they had) */
