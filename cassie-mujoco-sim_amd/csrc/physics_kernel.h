@@ -1597,31 +1597,31 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
         /* ================= P2 CRBA: composite inertias, then one COLUMN of M per lane ================= */
         /* composite inertias: crb_b = sum of cinert_c over the contiguous subtree range [b, bend): dense loop over all
          * bodies with a per-lane range predicate, operands staged four bodies at a time */
-        /* There are at most 32 bodies and 64 lanes: lanes l and l + 32 both work for body l, the lower one on bodies
-         * [0, NB / 2) of the loop, the upper one on [NB / 2, NB); the lower lane then takes the upper one's partial sum
-         * (wv::from_upper_half: one lane-swap instruction per dword).  Half the iterations for ten swaps and adds. */
+        /* A 0/1-weighted sum over bodies is a matrix product, W (body x body: c in b's subtree) times cinert (body x 10), and its
+         * result layout on the matrix core -- lane l holds rows (l >> 4) + 4 v, column l & 15 -- is a layout the LDS tile can be
+         * written in directly: 16 v_mfma_f64_16x16x4_f64 (two blocks of 16 bodies x eight blocks of four summands, even and odd
+         * blocks in separate accumulators), the weights built from the subtree masks in registers, the summands single LDS reads.
+         * (fma(1, x, acc) is acc + x, fma(0, x, acc) is acc: the sums are plain sums, in body order.) */
         {
-            double acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-            const int hb = lane & 31, hbend = wv::shfl_i(bend, hb), coff = lane < 32 ? 0 : NB / 2;
-            const unsigned bsub = (hb < nbody && hb > 0) ? (unsigned)(((1ull << hbend) - 1ull) ^ ((1ull << hb) - 1ull)) : 0u; /* bodies [hb, hbend) */
-            const double (*cin)[10] = &S.x.s.cinert[coff];
+            const int mi = lane & 15, mk = lane >> 4;
+            const unsigned mine = (isbody && b > 0) ? (unsigned)(((1ull << bend) - 1ull) ^ ((1ull << b) - 1ull)) : 0u; /* bodies [b, bend) */
+            const unsigned w0 = (unsigned)wv::shfl_i((int)mine, mi) >> mk, w1 = (unsigned)wv::shfl_i((int)mine, 16 + mi) >> mk;
+            double bv[NB / 4];
 #pragma unroll
-            for (int c0 = 0; c0 < NB / 2; c0 += 4) {
-                double ci4[4][10];
+            for (int kb = 0; kb < NB / 4; ++kb) { const double v = S.x.s.cinert[4 * kb + mk][mi < 10 ? mi : 0]; bv[kb] = mi < 10 ? v : 0.0; }
+            wv::mfma_acc d0a = {{0, 0, 0, 0}}, d0b = {{0, 0, 0, 0}}, d1a = {{0, 0, 0, 0}}, d1b = {{0, 0, 0, 0}};
 #pragma unroll
-                for (int cc = 0; cc < 4; ++cc)
+            for (int kb = 0; kb < NB / 4; kb += 2)
+                wv::mfma_f64_16x16x4_x4((double)((w0 >> (4 * kb)) & 1u), bv[kb], d0a, (double)((w1 >> (4 * kb)) & 1u), bv[kb], d1a,
+                                        (double)((w0 >> (4 * kb + 4)) & 1u), bv[kb + 1], d0b, (double)((w1 >> (4 * kb + 4)) & 1u), bv[kb + 1], d1b);
+            wv::mfma_f64_drain4(d0a, d0b, d1a, d1b);
+            if (mi < 10) {
 #pragma unroll
-                    for (int t = 0; t < 10; ++t) ci4[cc][t] = cin[c0 + cc][t];
-#pragma unroll
-                for (int cc = 0; cc < 4; ++cc) {
-                    const double w = bitf(bsub >> coff, c0 + cc);
-#pragma unroll
-                    for (int t = 0; t < 10; ++t) acc[t] = fma(w, ci4[cc][t], acc[t]);
+                for (int v = 0; v < 4; ++v) {
+                    S.x.s.crb[mk + 4 * v][mi] = d0a.c[v] + d0b.c[v];
+                    S.x.s.crb[16 + mk + 4 * v][mi] = d1a.c[v] + d1b.c[v];
                 }
             }
-#pragma unroll
-            for (int t = 0; t < 10; ++t) acc[t] += wv::from_upper_half(acc[t]);
-            if (isbody) for (int i = 0; i < 10; ++i) S.x.s.crb[b][i] = acc[i];
         }
         wv::sync();
         CK_STAMP(19);

@@ -70,6 +70,27 @@ WV_DEVICE void mfma_f64_16x16x4_x3(double a0, double b0, mfma_acc &c0, double a1
                  : "+v"(x0), "+v"(x1), "+v"(x2) : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2));
     for (int v = 0; v < 4; ++v) { c0.c[v] = x0[v]; c1.c[v] = x1[v]; c2.c[v] = x2[v]; }
 }
+/* the same for four independent accumulations */
+WV_DEVICE void mfma_f64_16x16x4_x4(double a0, double b0, mfma_acc &c0, double a1, double b1, mfma_acc &c1, double a2, double b2, mfma_acc &c2,
+                                   double a3, double b3, mfma_acc &c3) {
+    typedef double d4 __attribute__((ext_vector_type(4)));
+    d4 x0 = {c0.c[0], c0.c[1], c0.c[2], c0.c[3]}, x1 = {c1.c[0], c1.c[1], c1.c[2], c1.c[3]}, x2 = {c2.c[0], c2.c[1], c2.c[2], c2.c[3]},
+       x3 = {c3.c[0], c3.c[1], c3.c[2], c3.c[3]};
+    asm volatile("s_nop 4\n\t"
+                 "v_mfma_f64_16x16x4_f64 %0, %4, %5, %0\n\t"
+                 "v_mfma_f64_16x16x4_f64 %1, %6, %7, %1\n\t"
+                 "v_mfma_f64_16x16x4_f64 %2, %8, %9, %2\n\t"
+                 "v_mfma_f64_16x16x4_f64 %3, %10, %11, %3"
+                 : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3));
+    for (int v = 0; v < 4; ++v) { c0.c[v] = x0[v]; c1.c[v] = x1[v]; c2.c[v] = x2[v]; c3.c[v] = x3[v]; }
+}
+WV_DEVICE void mfma_f64_drain4(mfma_acc &c0, mfma_acc &c1, mfma_acc &c2, mfma_acc &c3) {
+    typedef double d4 __attribute__((ext_vector_type(4)));
+    d4 x0 = {c0.c[0], c0.c[1], c0.c[2], c0.c[3]}, x1 = {c1.c[0], c1.c[1], c1.c[2], c1.c[3]}, x2 = {c2.c[0], c2.c[1], c2.c[2], c2.c[3]},
+       x3 = {c3.c[0], c3.c[1], c3.c[2], c3.c[3]};
+    asm volatile("s_nop 15\n\ts_nop 3" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));
+    for (int v = 0; v < 4; ++v) { c0.c[v] = x0[v]; c1.c[v] = x1[v]; c2.c[v] = x2[v]; c3.c[v] = x3[v]; }
+}
 WV_DEVICE void mfma_f64_drain(mfma_acc &c0, mfma_acc &c1, mfma_acc &c2) {
     typedef double d4 __attribute__((ext_vector_type(4)));
     d4 x0 = {c0.c[0], c0.c[1], c0.c[2], c0.c[3]}, x1 = {c1.c[0], c1.c[1], c1.c[2], c1.c[3]}, x2 = {c2.c[0], c2.c[1], c2.c[2], c2.c[3]};

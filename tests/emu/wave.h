@@ -36,6 +36,11 @@ inline void mfma_f64_16x16x4_x3(double a0, double b0, mfma_acc &c0, double a1, d
     mfma_f64_16x16x4(a0, b0, c0.c); mfma_f64_16x16x4(a1, b1, c1.c); mfma_f64_16x16x4(a2, b2, c2.c);
 }
 inline void mfma_f64_drain(mfma_acc &, mfma_acc &, mfma_acc &) {}
+inline void mfma_f64_16x16x4_x4(double a0, double b0, mfma_acc &c0, double a1, double b1, mfma_acc &c1, double a2, double b2, mfma_acc &c2,
+                                double a3, double b3, mfma_acc &c3) {
+    mfma_f64_16x16x4(a0, b0, c0.c); mfma_f64_16x16x4(a1, b1, c1.c); mfma_f64_16x16x4(a2, b2, c2.c); mfma_f64_16x16x4(a3, b3, c3.c);
+}
+inline void mfma_f64_drain4(mfma_acc &, mfma_acc &, mfma_acc &, mfma_acc &) {}
 inline double from_upper_half(double v) { const double o = shfl_xor(v, 32); return lane() < 32 ? o : v; }
 double readlane(double v, int src);
 int lane();
