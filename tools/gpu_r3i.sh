@@ -1,4 +1,4 @@
-# round 3, final measurement set (v27: record-based kinematics, no machine LICM, constants requested a stage ahead, radix-3 / 4
+# round 3, final measurement set (v28: record-based kinematics, no machine LICM, constants requested a stage ahead, radix-3 / 4
 # pointer jumping, A = Y Y^T on the matrix core).  Box clocks differ by up to 30 % between leases: the first bench line decides
 # whether this box is a normal one (>= 18 M env-steps/s on config 2); on a slow box only the suite and that line are kept.
 mkdir -p gpurun_out; nproc > gpurun_out/nproc.txt
