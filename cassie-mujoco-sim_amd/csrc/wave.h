@@ -51,52 +51,25 @@ WV_DEVICE int shfl_i(int v, int src_lane) { return __shfl(v, src_lane, WV_WAVE);
 /* v_mfma_f64_16x16x4_f64: D = A B + C on the matrix core, A 16 x 4, B 4 x 16, C / D 16 x 16 spread over the wave -- lane l
  * supplies A[l & 15][l >> 4] and B[l >> 4][l & 15] and holds C / D[(l >> 4) + 4 v][l & 15] in c[v], v = 0 .. 3.  Every
  * element is the plain FMA chain over k = 0 .. 3 on top of C, bit for bit (tools/mfma_f64_probe.hip), at 64 clocks
- * per instruction whether or not the next one depends on it.  All 64 lanes must be active.
- *
- * Written as inline assembly on VGPR operands, three independent accumulations to a block: the compiler stops lending the
- * accumulation registers to the register allocator as spill space in any kernel in which it sees a matrix instruction
- * (this kernel lives on them: 1204 bytes of scratch per lane with the builtin, none without), and three interleaved chains
- * are what the builtin's own schedule uses to cover the instruction's dependent-issue distance.  The no-ops in front cover
- * a vector write of an operand just ahead of the block; mfma_f64_drain() must stand between the last block and the first
- * read of a result (19 wait states, what the compiler's hazard recogniser inserts for this instruction). */
+ * per instruction whether or not the next one depends on it.  All 64 lanes must be active.  Callers keep three or four
+ * independent accumulations in flight (the _x3 / _x4 forms) so that a dependent instruction never follows directly;
+ * mfma_f64_drain is a no-op on the device (the compiler inserts the wait states in front of the first read of a result). */
 struct mfma_acc { double c[4]; };
-WV_DEVICE void mfma_f64_16x16x4_x3(double a0, double b0, mfma_acc &c0, double a1, double b1, mfma_acc &c1, double a2, double b2, mfma_acc &c2) {
+WV_DEVICE void mfma_f64_16x16x4(double a, double b, mfma_acc &c) {
     typedef double d4 __attribute__((ext_vector_type(4)));
-    d4 x0 = {c0.c[0], c0.c[1], c0.c[2], c0.c[3]}, x1 = {c1.c[0], c1.c[1], c1.c[2], c1.c[3]}, x2 = {c2.c[0], c2.c[1], c2.c[2], c2.c[3]};
-    asm volatile("s_nop 4\n\t"
-                 "v_mfma_f64_16x16x4_f64 %0, %3, %4, %0\n\t"
-                 "v_mfma_f64_16x16x4_f64 %1, %5, %6, %1\n\t"
-                 "v_mfma_f64_16x16x4_f64 %2, %7, %8, %2"
-                 : "+v"(x0), "+v"(x1), "+v"(x2) : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2));
-    for (int v = 0; v < 4; ++v) { c0.c[v] = x0[v]; c1.c[v] = x1[v]; c2.c[v] = x2[v]; }
+    d4 x = {c.c[0], c.c[1], c.c[2], c.c[3]};
+    x = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, x, 0, 0, 0);
+    c.c[0] = x[0]; c.c[1] = x[1]; c.c[2] = x[2]; c.c[3] = x[3];
 }
-/* the same for four independent accumulations */
+WV_DEVICE void mfma_f64_16x16x4_x3(double a0, double b0, mfma_acc &c0, double a1, double b1, mfma_acc &c1, double a2, double b2, mfma_acc &c2) {
+    mfma_f64_16x16x4(a0, b0, c0); mfma_f64_16x16x4(a1, b1, c1); mfma_f64_16x16x4(a2, b2, c2);
+}
 WV_DEVICE void mfma_f64_16x16x4_x4(double a0, double b0, mfma_acc &c0, double a1, double b1, mfma_acc &c1, double a2, double b2, mfma_acc &c2,
                                    double a3, double b3, mfma_acc &c3) {
-    typedef double d4 __attribute__((ext_vector_type(4)));
-    d4 x0 = {c0.c[0], c0.c[1], c0.c[2], c0.c[3]}, x1 = {c1.c[0], c1.c[1], c1.c[2], c1.c[3]}, x2 = {c2.c[0], c2.c[1], c2.c[2], c2.c[3]},
-       x3 = {c3.c[0], c3.c[1], c3.c[2], c3.c[3]};
-    asm volatile("s_nop 4\n\t"
-                 "v_mfma_f64_16x16x4_f64 %0, %4, %5, %0\n\t"
-                 "v_mfma_f64_16x16x4_f64 %1, %6, %7, %1\n\t"
-                 "v_mfma_f64_16x16x4_f64 %2, %8, %9, %2\n\t"
-                 "v_mfma_f64_16x16x4_f64 %3, %10, %11, %3"
-                 : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3) : "v"(a0), "v"(b0), "v"(a1), "v"(b1), "v"(a2), "v"(b2), "v"(a3), "v"(b3));
-    for (int v = 0; v < 4; ++v) { c0.c[v] = x0[v]; c1.c[v] = x1[v]; c2.c[v] = x2[v]; c3.c[v] = x3[v]; }
+    mfma_f64_16x16x4(a0, b0, c0); mfma_f64_16x16x4(a1, b1, c1); mfma_f64_16x16x4(a2, b2, c2); mfma_f64_16x16x4(a3, b3, c3);
 }
-WV_DEVICE void mfma_f64_drain4(mfma_acc &c0, mfma_acc &c1, mfma_acc &c2, mfma_acc &c3) {
-    typedef double d4 __attribute__((ext_vector_type(4)));
-    d4 x0 = {c0.c[0], c0.c[1], c0.c[2], c0.c[3]}, x1 = {c1.c[0], c1.c[1], c1.c[2], c1.c[3]}, x2 = {c2.c[0], c2.c[1], c2.c[2], c2.c[3]},
-       x3 = {c3.c[0], c3.c[1], c3.c[2], c3.c[3]};
-    asm volatile("s_nop 15\n\ts_nop 3" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));
-    for (int v = 0; v < 4; ++v) { c0.c[v] = x0[v]; c1.c[v] = x1[v]; c2.c[v] = x2[v]; c3.c[v] = x3[v]; }
-}
-WV_DEVICE void mfma_f64_drain(mfma_acc &c0, mfma_acc &c1, mfma_acc &c2) {
-    typedef double d4 __attribute__((ext_vector_type(4)));
-    d4 x0 = {c0.c[0], c0.c[1], c0.c[2], c0.c[3]}, x1 = {c1.c[0], c1.c[1], c1.c[2], c1.c[3]}, x2 = {c2.c[0], c2.c[1], c2.c[2], c2.c[3]};
-    asm volatile("s_nop 15\n\ts_nop 3" : "+v"(x0), "+v"(x1), "+v"(x2));
-    for (int v = 0; v < 4; ++v) { c0.c[v] = x0[v]; c1.c[v] = x1[v]; c2.c[v] = x2[v]; }
-}
+WV_DEVICE void mfma_f64_drain(mfma_acc &, mfma_acc &, mfma_acc &) {}
+WV_DEVICE void mfma_f64_drain4(mfma_acc &, mfma_acc &, mfma_acc &, mfma_acc &) {}
 
 /* for lanes 0..31: the value lane + 32 holds (the upper lanes get their own value back): one v_permlane32_swap_b32 per
  * dword, no LDS crossbar.  Used where the two halves of the wave each do half of a lane's work (dense loops whose work
