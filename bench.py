@@ -209,10 +209,35 @@ def max_over_ranks(seconds, world, device=None):
     return float(t.item())
 
 
-def pmc_traffic(env_steps_per_launch, model_name="cassie"):
+def has_fast_kernel(model_name):
+    """Models whose stepping launches start the row-capped fast instantiation (phys_batch.hip, launch)."""
+    return model_name in ("cassie", "cassie_hfield")
+
+
+def handed_over_in_last_launch(progress, nsub_of_last_launch):
+    """Envs the fast kernel handed over to the full kernel in the last launch: PhysIO::progress holds the substeps the fast
+    kernel completed, so an env was handed over iff that is short of the launch's OWN substep count (not of HOLD: the
+    driver's `--steps 20` regions end with a 20-substep launch)."""
+    return float(np.count_nonzero(np.asarray(progress) < int(nsub_of_last_launch)))
+
+
+def launch_io_bytes_per_env(pod, drive=True):
+    """What ONE launch moves per env whatever its substep count: the state it loads and the state + last-substep outputs it
+    stores (fields of csrc/physics_kernel.h env_step's load / store blocks, in doubles)."""
+    nq, nv, nu, nsd, nb = pod.nq, pod.nv, pod.nu, pod.nsensordata, pod.nbody
+    drv = 1240 // 8 if drive else 0                                   # cm_drive_state_t
+    load = nq + 2 * nv + nu + 1 + (nsd + nu + drv + 2 * 10 + 5 * 10 if drive else 3 * nu)
+    store = nq + 2 * nv + 1 + nv + nsd + nu + 7 * nb + 2 + (drv + 56 + nu if drive else 0)
+    return 8 * (load + store)
+
+
+def pmc_traffic(env_steps_per_launch, model_name="cassie", envs_per_launch=None, pod=None):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (tools/gpu_pmc.sh: FETCH_SIZE and WRITE_SIZE in
-    separate --pmc runs, corrected as MI355X_MICROARCH.md prescribes), scaled to this run's env-steps per launch.
-    The counters cannot be collected from inside the timed process, so this is the last measured figure, or None."""
+    separate --pmc runs, corrected as MI355X_MICROARCH.md prescribes), brought to this run's launch shape: the passes
+    profile 50-substep launches, and a launch's traffic is a per-env part that does not depend on the substep count (state
+    in, state and last-substep outputs out: launch_io_bytes_per_env) plus a per-env-step part (model constants, terrain,
+    spills) -- only the second scales with the substeps.  The counters cannot be collected from inside the timed process, so
+    this is the last measured figure, or None."""
     import glob
     import re
 
@@ -224,8 +249,13 @@ def pmc_traffic(env_steps_per_launch, model_name="cassie"):
     for path in reversed(files):
         try:
             d = json.load(open(path))["derived"]
-            per_env_step = (d["hbm_read_bytes_per_launch"] + d["hbm_write_bytes_per_launch"]) / d["env_steps_per_launch"]
-            return per_env_step * env_steps_per_launch, os.path.relpath(path, REPO)
+            total, es = d["hbm_read_bytes_per_launch"] + d["hbm_write_bytes_per_launch"], d["env_steps_per_launch"]
+            if envs_per_launch is None or pod is None:
+                return total / es * env_steps_per_launch, os.path.relpath(path, REPO)
+            envs_pmc = d.get("envs_per_launch", 4096)
+            fixed = launch_io_bytes_per_env(pod)
+            per_env_step = max(0.0, total - fixed * envs_pmc) / es
+            return fixed * envs_per_launch + per_env_step * env_steps_per_launch, os.path.relpath(path, REPO)
         except (KeyError, ValueError, OSError):
             continue
     return None, None
@@ -419,8 +449,47 @@ def rows_of_group_in_range(group, global_first, first, count):
     return r0, len(range(r0, first + count, NGROUP))
 
 
+class GpuRuntime:
+    """What device_rollout asks of the machine under it: the device, streams / events, the batch, the CPU reference for the
+    replay.  This is the real one (HIP through torch, RCCL); tests/bench_standin.py has a CPU stand-in (gloo, no physics)
+    through which tests/test_multirank.py drives main()'s N > 1 path on a box without GPUs (`--dry-run-cpu`)."""
+    backend = "nccl"
+    name = None
+
+    def __init__(self, local_rank):
+        import torch
+        self.torch, self.local_rank = torch, local_rank
+        self.device = torch.device("cuda", local_rank)
+
+    def Stream(self):
+        return self.torch.cuda.Stream(device=self.device)   # real (non-null) streams: the kernels and the timing events share them
+
+    def Event(self, enable_timing=False):
+        return self.torch.cuda.Event(enable_timing=enable_timing)
+
+    def use(self, stream):
+        return self.torch.cuda.stream(stream)
+
+    def synchronize(self):
+        self.torch.cuda.synchronize(self.device)
+
+    def make_batch(self, model, n):
+        from cassie_amd import Batch
+        return Batch(model, n, device=self.local_rank)
+
+    def init_sensordata(self, model, hfield):
+        return HostChainEnvs(model, [0], hfield).init_sensordata()
+
+    def replay_envs(self, drive):
+        return HostChainEnvs if drive else OracleEnvs
+
+    def host_threads(self):
+        from cassie_amd._lib import lib
+        return lib().cassie_host_cpu_count()
+
+
 def device_rollout(model, mode, n, steps, warmup, rank, world, local_rank, substeps_per_launch=HOLD, parity_envs=64, hfield=None, collect=None,
-                   all_outputs=False, repeats=1, nstreams=1):
+                   all_outputs=False, repeats=1, nstreams=1, rt=None):
     """One device-resident rollout of the workload in `mode`, timed as `repeats` fenced regions of exactly `steps` steps:
 
       "drive-pd"  CM_DRIVE_PD: every substep runs pd_input's motor PD on the ENCODER measurements of the
@@ -440,8 +509,8 @@ def device_rollout(model, mode, n, steps, warmup, rank, world, local_rank, subst
     snapshotted at a region boundary and compared on rank 0 with their replay on the CPU reference."""
     import torch
     import torch.distributed as dist
-    from cassie_amd import Batch
     from cassie_amd import phys as P
+    rt = rt or GpuRuntime(local_rank)
     pod = model.pod
     drive = mode == "drive-pd"
     collect = world > 1 if collect is None else collect       # the observation all-gather, barriers, max-over-ranks reduction
@@ -450,12 +519,14 @@ def device_rollout(model, mode, n, steps, warmup, rank, world, local_rank, subst
     total_steps = PREROLL + warmup + repeats * steps
     replay_steps = PREROLL + warmup + (snap_r + 1) * steps
     npolicy = (total_steps + HOLD - 1) // HOLD + 1
-    dev = torch.device("cuda", local_rank)
-    b = Batch(model, n, device=local_rank)
+    dev = rt.device
+    b = rt.make_batch(model, n)
     if all_outputs:
         b.set_all_outputs_every_substep(True)
     if os.environ.get("CASSIE_NO_FAST_ROWS"):
         b.set_fast_rows(False)          # A/B switch: the full step kernel alone (the row-capped fast kernel)
+    if os.environ.get("CASSIE_WAVES_PER_ENV"):
+        b.set_waves_per_env(int(os.environ["CASSIE_WAVES_PER_ENV"]))   # A/B switch: one wave per env instead of two
     if os.environ.get("CASSIE_NO_BALANCE"):
         b.set_balance(False)            # A/B switch for the longest-job-first launch order
     if hfield is not None:
@@ -467,7 +538,7 @@ def device_rollout(model, mode, n, steps, warmup, rank, world, local_rank, subst
     init_row = torch.zeros(nobs, dtype=torch.float64, device=dev)
     init_row[:nq] = torch.from_numpy(model.qpos_init()).to(dev)
     if drive:   # the drive-level models read the previous step's sensordata: a restarted env carries the init pose's
-        init_row[nq + nv:] = torch.from_numpy(HostChainEnvs(model, [0], hfield).init_sensordata()).to(dev)
+        init_row[nq + nv:] = torch.from_numpy(rt.init_sensordata(model, hfield)).to(dev)
     obs = init_row.repeat(n, 1).contiguous()
     warm = torch.zeros((n, nv), dtype=torch.float64, device=dev)
     esz = obs.element_size()
@@ -490,7 +561,7 @@ def device_rollout(model, mode, n, steps, warmup, rank, world, local_rank, subst
     else:
         b.set_pd_mode(True)
     ranges = half_ranges(n, nstreams)
-    streams = [torch.cuda.Stream(device=dev) for _ in ranges]   # real (non-null) streams: the kernels and the timing events share them
+    streams = [rt.Stream() for _ in ranges]
     obs_all = [torch.empty((world * cnt, nobs), dtype=torch.float64, device=dev) for _, cnt in ranges] if collect else None
 
     def restart(group):
@@ -505,25 +576,28 @@ def device_rollout(model, mode, n, steps, warmup, rank, world, local_rank, subst
     # The all-gather runs beside the next launch: a range's observation block is snapshotted on its launch stream (device to
     # device), RCCL sends the snapshot from a second stream, and the range's next snapshot waits for that gather to have read it.
     snap = [torch.empty((cnt, nobs), dtype=torch.float64, device=dev) for _, cnt in ranges] if collect else None
-    comm_streams = [torch.cuda.Stream(device=dev) for _ in ranges] if collect else None
+    comm_streams = [rt.Stream() for _ in ranges] if collect else None
     gather_done = [None] * len(ranges)
 
     def gather():
         for i, ((first, cnt), st) in enumerate(zip(ranges, streams)):
             if gather_done[i] is not None:
                 st.wait_event(gather_done[i])
-            with torch.cuda.stream(st):
+            with rt.use(st):
                 snap[i].copy_(obs[first:first + cnt], non_blocking=True)
-            ready = torch.cuda.Event()
+            ready = rt.Event()
             ready.record(st)
-            with torch.cuda.stream(comm_streams[i]):
+            with rt.use(comm_streams[i]):
                 comm_streams[i].wait_event(ready)
                 gather_observations(snap[i], world, obs_all[i])
-                done = torch.cuda.Event()
+                done = rt.Event()
                 done.record(comm_streams[i])
             gather_done[i] = done
 
+    last_launch = {"nsub": 0}
+
     def step(nsub):
+        last_launch["nsub"] = nsub
         for (first, cnt), st in zip(ranges, streams):
             if len(ranges) == 1:
                 b.step(nsub, st.cuda_stream)
@@ -539,18 +613,18 @@ def device_rollout(model, mode, n, steps, warmup, rank, world, local_rank, subst
     def fence():
         if collect:
             dist.barrier()
-        torch.cuda.synchronize(dev)
+        rt.synchronize()
 
     sample = parity_rows(n, world, parity_envs)
     sample_dev = torch.from_numpy(sample).to(dev)
-    torch.cuda.synchronize(dev)
+    rt.synchronize()
     region_s, region_ev, region_launches = [], [], []
     q_sample = info_sample = None
     sch.run(0, PREROLL + warmup)
     b.enable_kernel_timing(True)        # a HIP event pair around the work-doing kernel of every stepping launch from here on
     kern_n, kern_ms_total = 0, 0.0
     for r in range(repeats):
-        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in streams]
+        evs = [(rt.Event(enable_timing=True), rt.Event(enable_timing=True)) for _ in streams]
         region_s.append(timed_region(sch, PREROLL + warmup + r * steps, steps, fence,
                                      mark=lambda i: [e[i].record(st) for e, st in zip(evs, streams)]))
         region_ev.append([e[0].elapsed_time(e[1]) for e in evs])     # per stream: its time over the region
@@ -577,28 +651,26 @@ def device_rollout(model, mode, n, steps, warmup, rank, world, local_rank, subst
         # the gathered block of the last policy boundary must hold this rank's rows (global env order, rank-major)
         res["gather_ok"] = bool(sch.gathers > 0 and all(torch.equal(oa[rank * cnt:(rank + 1) * cnt], sn) for oa, sn, (_, cnt) in zip(obs_all, snap, ranges)))
     w, info = b.warnings()
-    try:    # envs the row-capped fast kernel handed over to the full kernel in the last launch
-        handed = float(np.count_nonzero(b.fast_rows_progress() < min(substeps_per_launch, HOLD)))
-    except Exception:
-        handed = float("nan")
+    # envs the row-capped fast kernel handed over to the full kernel in the last launch: those whose record of
+    # completed substeps is short of THAT launch's substep count; NaN (-> null in the line) for a model without a fast kernel
+    handed = handed_over_in_last_launch(b.fast_rows_progress(), last_launch["nsub"]) if has_fast_kernel(model.name) else float("nan")
     stats = torch.tensor([float(np.count_nonzero(w))] + [float(info[:, k].sum()) for k in (1, 2, 3)] + [handed], dtype=torch.float64, device=dev)
     if collect:
         dist.all_reduce(stats, op=dist.ReduceOp.SUM)
     stats = stats.cpu().numpy()
     res["envs_with_warnings"] = int(stats[0])
     res["mean_constraint_rows"], res["mean_pgs_iterations"], res["mean_pgs_guarded_sweeps"] = (float(stats[k] / (world * n)) for k in (1, 2, 3))
-    res["frac_envs_handed_over_last_launch"] = float(stats[4] / (world * n))
+    res["frac_envs_handed_over_last_launch"] = None if np.isnan(stats[4]) else float(stats[4] / (world * n))
     # ---- the metric's second half: sampled envs of EVERY rank against the CPU reference, same schedule ----
     ids_sample = torch.from_numpy(env_ids[sample].astype(np.int64)).to(dev)
     if collect and world > 1:
         q_sample, info_sample, ids_sample = (gather_rows(x, world) for x in (q_sample, info_sample, ids_sample))
     if rank == 0:
         q_gpu, counts_gpu, ids = q_sample.cpu().numpy(), info_sample.cpu().numpy(), ids_sample.cpu().numpy()
-        from cassie_amd._lib import lib
-        threads = lib().cassie_host_cpu_count()
+        threads = rt.host_threads()
         tg_replay = pd_targets(ids, (replay_steps + HOLD - 1) // HOLD + 1)      # seeds depend on the global env id only
         orc = replay_on_oracle(model, ids, lambda p: tg_replay[p], replay_steps, hfield, threads,
-                               envs=HostChainEnvs if drive else OracleEnvs)
+                               envs=rt.replay_envs(drive))
         q_ref = orc.qpos()
         err_abs = np.abs(q_gpu - q_ref)
         err_rel = err_abs / np.maximum(1.0, np.abs(q_ref))
@@ -633,7 +705,29 @@ def true_reference(model_name, q0, targets, nsteps):
         return "unavailable"
 
 
-def main():
+def free_port():
+    """A TCP port that is free on 127.0.0.1 right now (the rendezvous of the ranks bench.py starts itself)."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(ngpus, argv):
+    """`python bench.py --gpus N` without a launcher around it (WORLD_SIZE unset): start the N ranks ourselves -- this very
+    file under torch.distributed.run, one rank per GPU (rank r binds GPU r through LOCAL_RANK), rendezvous on 127.0.0.1 at a
+    port picked free -- pass their output through (rank 0 prints the ONE JSON line) and return the launcher's exit code."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ngpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC (RCCL between the ranks' processes)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // ngpus)))
+    return subprocess.call(cmd, env=env)
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
@@ -660,7 +754,14 @@ def main():
                     help="validation aid: initialise the process group and run the observation all-gather / barriers even with one rank")
     ap.add_argument("--mode", default="drive-pd", choices=["drive-pd", "exact-pd"],
                     help="what the device-resident kernel computes per substep (see device_rollout)")
-    args = ap.parse_args()
+    ap.add_argument("--dry-run-cpu", action="store_true",
+                    help="TEST INFRASTRUCTURE (tests/test_multirank.py): run main()'s launch / sharding / gather / reduction path on CPU "
+                         "ranks (gloo) with a stand-in for the GPU batch (tests/bench_standin.py); no physics, nothing is measured")
+    args = ap.parse_args(argv)
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # started the way the driver starts N = 1: no launcher around us -- start the ranks ourselves
+        return launch_ranks(args.gpus, argv)
 
     import torch
     import torch.distributed as dist
@@ -669,16 +770,26 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the physics library has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+        raise SystemExit("--gpus %d, but the launcher started %d rank(s) (WORLD_SIZE)" % (args.gpus, world))
+    if args.dry_run_cpu:
+        import bench_standin
+        rt = bench_standin.CpuRuntime(local_rank)
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU: the physics library has no CPU fallback")
+        if local_rank >= torch.cuda.device_count():
+            raise SystemExit("rank %d wants GPU %d, but this node shows %d" % (rank, local_rank, torch.cuda.device_count()))
+        torch.cuda.set_device(local_rank)
+        rt = GpuRuntime(local_rank)
     collect = world > 1 or args.force_collectives
     if collect:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if "MASTER_PORT" not in os.environ:
+            os.environ["MASTER_PORT"] = str(free_port())   # (a single rank: nobody else has to find it)
+        if args.dry_run_cpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from cassie_amd import Model
 
@@ -692,7 +803,7 @@ def main():
         hfield[95:105, 95:105] = 0
     nstreams = max(1, args.streams)
     r = device_rollout(model, args.mode, n, args.steps, args.warmup, rank, world, local_rank, args.substeps_per_launch, args.parity_envs, hfield,
-                       collect=collect, repeats=repeats, nstreams=nstreams)
+                       collect=collect, repeats=repeats, nstreams=nstreams, rt=rt)
 
     if rank == 0:
         elapsed, kern_ms, timed_launches = r["elapsed"], r["kernel_ms"], r["launches"]
@@ -707,7 +818,7 @@ def main():
         achieved = algo_bytes * world * n * args.steps / elapsed / 1e9 / world
         rate = lambda sec: world * n * args.steps / sec
         value = rate(elapsed)
-        traffic, traffic_src = pmc_traffic(n * steps_per_launch, args.model)
+        traffic, traffic_src = pmc_traffic(n * steps_per_launch, args.model, envs_per_launch=n, pod=pod)
         api = {"drive-pd": "phys_batch_step in CM_DRIVE_PD mode (device-resident, include/cassie_phys.h): pd_input's motor PD on the encoder "
                            "measurements + motor model with torque delay + physics in one kernel -- cassie_sim_step_pd's drive-level semantics "
                            "without the Agility safety layer / estimator",
@@ -718,13 +829,17 @@ def main():
             "value_min": rate(max(r["region_s"])), "value_max": rate(min(r["region_s"])),
             "max_qpos_err": r["parity"]["max_qpos_err"], "max_qpos_rel_err": r["parity"]["max_qpos_rel_err"],
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%d envs/GPU x %d GPU = %d envs (%s), %s.xml, %d-step episodes from the cassie_sim_init pose restarted at "
-                                   "staggered phases (untimed pre-roll of %d steps), random joint-PD targets re-drawn every %d steps; `value` is "
-                                   "the device-resident API, the MEDIAN of %d fenced timed regions of %d steps each (value_min / value_max: the "
-                                   "slowest / fastest region); `value_step_pd` is cassie_sim_step_pd itself, batched (Agility blocks on host "
-                                   "threads); `value_all_outputs_every_substep` is the every-P-row-every-substep figure"
-                                   % (n, world, world * n, shape, args.model, EPISODE, PREROLL, HOLD, repeats, args.steps),
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic" if not args.dry_run_cpu else rt.name,
+            "config": {"workload": "READ FIRST -- `value` is the device-resident API (phys_batch_step_range in CM_DRIVE_PD mode), the batch stepped as %d "
+                                   "env ranges on %d streams that nothing joins between policy steps; beside it in this line: `value_step_pd` = "
+                                   "cassie_sim_step_pd itself, batched (the API BASELINE configs[1] names; Agility blocks on host threads, PCIe every "
+                                   "step), `value_one_stream` = the whole batch as ONE launch per policy step, `value_all_outputs_every_substep` = "
+                                   "every output of every P-row formed by every substep.  Workload: %d envs/GPU x %d GPU = %d envs (%s), %s.xml, "
+                                   "%d-step episodes from the cassie_sim_init pose restarted at staggered phases (untimed pre-roll of %d steps), "
+                                   "random joint-PD targets re-drawn every %d steps; `value` is the MEDIAN of %d fenced timed regions of %d steps "
+                                   "each (value_min / value_max: the slowest / fastest region)"
+                                   % (r["streams"], r["streams"], n, world, world * n, shape, args.model, EPISODE, PREROLL, HOLD, repeats, args.steps),
                        "api_of_value": api, "mode": args.mode,
                        "envs_per_gpu": n, "envs_total": world * n, "baseline_config": shape, "parallelism": "env-sharded x%d" % world,
                        "obs_allgather_every_steps": HOLD if collect else None,
@@ -764,7 +879,7 @@ def main():
             "frac_envs_handed_over_to_the_full_kernel_in_the_last_launch": r["frac_envs_handed_over_last_launch"],
             "mean_constraint_rows": r["mean_constraint_rows"], "mean_pgs_iterations": r["mean_pgs_iterations"], "mean_pgs_guarded_sweeps": r["mean_pgs_guarded_sweeps"],
         }
-        if world == 1 and args.model == "cassie" and args.total_envs is None:
+        if world == 1 and args.model == "cassie" and args.total_envs is None and not args.dry_run_cpu:
             # the GPU legs first, back to back with the timed region; the CPU legs (tens of seconds with an idle GPU) last
             if not args.no_other_mode:
                 other = "exact-pd" if args.mode == "drive-pd" else "drive-pd"
@@ -803,7 +918,8 @@ def main():
         print(json.dumps(out), flush=True)
     if collect:
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -247,6 +247,11 @@ class Batch:
         """Row-capped fast kernel ahead of the full one (default on; results are bit for bit the same either way)."""
         lib().phys_batch_set_fast_rows(self._h, 1 if on else 0)
 
+    def set_waves_per_env(self, waves=2):
+        """Two-wave form of the fast kernels (default 2; results are bit for bit the same either way)."""
+        if lib().phys_batch_set_waves_per_env(self._h, int(waves)) != 0:
+            raise ValueError("waves per env: 1 or 2")
+
     def fast_rows_progress(self):
         """Substeps of the last stepping launch the fast kernel completed per env (< the launch's count: handed over there)."""
         out = np.zeros(self.nenv, dtype=np.int32)

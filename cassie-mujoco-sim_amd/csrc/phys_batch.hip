@@ -60,6 +60,7 @@ struct phys_batch {
     size_t ev_used = 0;
     int *d_progress = nullptr;      /* [nenv] substeps completed by the row-capped fast instantiation (PhysIO::progress) */
     bool fast_rows = true;          /* use the row-capped fast instantiation where one exists (phys_batch_set_fast_rows) */
+    int waves_per_env = 2;          /* two-wave form of the fast instantiations (phys_batch_set_waves_per_env) */
     double *d_scratch_out = nullptr; /* [nenv][nv + nsensordata + nu]: where phys_batch_forward_kinematics sends qacc / sensordata / actuator_velocity */
 };
 
@@ -171,8 +172,8 @@ static int launch(phys_batch *b, int nsub, int integrate, hipStream_t s, bool sc
          * behind it finishes the envs that met a substep with more rows (and is the only one for forward / read-out passes) */
         const bool fast = b->fast_rows && integrate && !wp && !io.ext && b->d_progress;
         io.progress = fast ? b->d_progress : nullptr;
-        if (!hf && !wp) { launched = ck::launch_step_cassie(grid, s, io, fast, ev_after); ev_after = nullptr; }
-        else if (hf && !wp) { launched = ck::launch_step_cassie_hfield(grid, s, io, fast, ev_after); ev_after = nullptr; }
+        if (!hf && !wp) { launched = ck::launch_step_cassie(grid, s, io, fast, ev_after, b->waves_per_env); ev_after = nullptr; }
+        else if (hf && !wp) { launched = ck::launch_step_cassie_hfield(grid, s, io, fast, ev_after, b->waves_per_env); ev_after = nullptr; }
         else launched = ck::launch_step_cassie_all(grid, s, io);
     } else if (matches(ck::TopoCassieTray38::table, ck::TopoCassieTray38::nv, ck::TopoCassieTray38::body_levels)) launched = ck::launch_step_tray(grid, s, io, hf);
     else launched = ck::launch_step_generic(grid, s, io, hm.nv > 32);
@@ -683,6 +684,12 @@ int phys_batch_kernel_timing(phys_batch_t *b, int *launches, double *total_ms) {
 int phys_batch_set_fast_rows(phys_batch_t *b, int on) {
     if (!b) return -1;
     b->fast_rows = on != 0;
+    return 0;
+}
+
+int phys_batch_set_waves_per_env(phys_batch_t *b, int waves) {
+    if (!b || (waves != 1 && waves != 2)) return -1;
+    b->waves_per_env = waves;
     return 0;
 }
 

@@ -59,7 +59,8 @@ constexpr int NB = CM_MAXBODY;
 constexpr int NG = CM_MAXGEOM;
 constexpr int NROW = 64;       /* rows 0..62 constraints, column 63 = qfrc_smooth */
 constexpr int FAST_ROWS = 31;  /* rows of the row-capped fast instantiation (+ the qfrc_smooth column: half of the full tile) */
-constexpr int NSTAMP = 48;   /* 0..15 stage boundaries, 16..47 sub-stage stamps (tools/stage_profile.py names them) */
+constexpr int NSTAMP = 48;   /* 0..15 stage boundaries, 16..32 sub-stage stamps, 33..39 the two-wave form's barrier arrivals / departures,
+                                40..41 where the hardware placed the env's wave(s) (tools/stage_profile.py names them) */
 #define CK_TRI(k, i) ((k) * ((k) + 1) / 2 + (i))
 #define CK_STAMP(i) do { if (io.prof && lane == 0) io.prof[(size_t)env * NSTAMP + (i)] = wv::clock(); CK_FRESH(); } while (0)
 /* stage boundary: re-derive the lane index and its aliases (see wv::fresh_lane) */
@@ -168,6 +169,8 @@ struct EnvShared {
     int c_root[CM_MAXCON][2];               /* tree roots of the two bodies, their dof chains, summed inverse weights */
     unsigned long long c_dofmask[CM_MAXCON][2];
     double c_tran[CM_MAXCON];
+    /* two-wave form (NW = 2): what wave 0 tells wave 1 at the workgroup barriers -- 0 = carry on, 1 = this env's launch ends here */
+    int cmd[2];
 };
 
 /* ------------------------------------------------------------ small math --- */
@@ -1187,9 +1190,19 @@ WV_DRIVE_FN void drive_level_io(const PhysIO &io, SH &S, ModelPtr m, int env, in
  * pairs handled by the whole wave.  The launcher picks the instantiation from the model (phys_batch.hip). */
 enum { FEAT_HFIELD = 1, FEAT_WAVEPAIRS = 2, FEAT_ALL = 3 };
 
-template <int NVP, class TOPO, int FEAT, int MAXR>
+template <int NVP, class TOPO, int FEAT, int MAXR, int NW>
 WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count, MAXR> &S, int env, int sub_start) {
     typedef LPack<TOPO, NVP> LP;
+    static_assert(NW == 1 || NW == 2, "one or two wavefronts per env");
+    static_assert(NW == 1 || TOPO::is_static, "the two-wave form exists for the compile-time topologies");
+    /* NW = 2: the env is stepped by TWO wavefronts that share the env's LDS block.  Wave 0 runs the substep as written below
+     * except for the mass-matrix group (centres of mass, cinert, cdof, composite inertias, M's columns, the two
+     * factorisations), which wave 1 runs beside wave 0's collision, velocity / bias-force and constraint-row stages; the two
+     * meet at three workgroup barriers per substep (F: poses are in LDS; X: cdof / com / cinert are, and the contact list;
+     * J: the factors are).  Every value is computed by the same instructions from the same operands as in the one-wave
+     * form, so the results are bit for bit the same. */
+    const int wid = NW == 2 ? wv::wave_id() : 0;
+
     static_assert(LP::covers() && LP::distinct(), "packed factor rows must hold every ancestor pair, each in its own slot");
     const ModelPtr m_launch = (ModelPtr)(io.models + (size_t)env * io.model_stride);
     ModelPtr m = m_launch;
@@ -1199,6 +1212,8 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
     int warn = 0;
 
     /* ---------------- load state (coalesced, env-major) ---------------- */
+    if (NW == 1 || wid == 0) {
+    if (lane == 0) S.cmd[0] = 0;
     if (lane < nq) S.qpos[lane] = io.qpos[(size_t)env * io.sq + lane];
     if (lane < nv) {
         S.qvel[lane] = io.qvel[(size_t)env * io.sqv + lane];
@@ -1215,6 +1230,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
         if (lane < nu) S.actvel[lane] = io.actuator_velocity[(size_t)env * io.su + lane];
         drive_state_load(io, S, env, lane);
         drive_consts_load(io, S, m, env, lane);
+    }
     }
     double time = io.time[env];
 
@@ -1250,7 +1266,223 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
     for (int u = 0; u < nu; ++u) if (isdof && m->act_dofid[u] == k_) kact = u;
     wv::sync();
 
+    /* ---------------- the mass-matrix stage group: com of every kinematic tree, cinert, cdof, composite inertias, M's columns.
+     * One wave form: called in line by the substep loop, between the geoms and the factorisations.  Two-wave form: wave 1's
+     * program (below) calls it between the barriers F and X.  Reads the pose tiles (xmat, xipos, xanchor, xaxis), writes
+     * com, cinert, cdof, crb and the buf tile; leaves the lane's columns of M and M + hB in col / colh. ---------------- */
+    auto mass_matrix_columns = [&](const double pf_mass, const double (&pf_iner)[3], const double (&ximat)[9], double (&col)[NVP], double (&colh)[NVP]) {
+        /* where crb[body] . cdof goes between the composite inertias and M's columns: the buf tile -- except in the two-wave
+         * height-field form, where wave 0's height-field result table lies over that tile at this time: there the joint
+         * anchors / axes, which nothing reads once cdof is formed, give their place */
+        constexpr bool cbuf_over_anchors = NW == 2 && (FEAT & FEAT_HFIELD) != 0;
+        static_assert(!cbuf_over_anchors || NVP <= CM_MAXJNT, "crb . cdof (NVP x 6) must fit the xanchor + xaxis tiles");
+        static_assert(offsetof(decltype(S.x.s), xaxis) - offsetof(decltype(S.x.s), xanchor) == sizeof(double) * CM_MAXJNT * 3, "xanchor and xaxis are contiguous");
+        double (*const cbuf)[6] = cbuf_over_anchors ? reinterpret_cast<double (*)[6]>(&S.x.s.xanchor[0][0]) : S.x.s.buf;
+        /* ================= com of every kinematic tree (wave reduction per root) ================= */
+        const double bmass = (isbody && b > 0) ? pf_mass : 0.0;
+        {
+            /* one masked DPP tree reduction per kinematic tree (wave_sum returns the total in every lane) */
+            const double px = isbody ? S.x.s.xipos[b < NB ? b : 0][0] : 0.0, py = isbody ? S.x.s.xipos[b < NB ? b : 0][1] : 0.0,
+                         pz = isbody ? S.x.s.xipos[b < NB ? b : 0][2] : 0.0;
+            for (int ri = 0; ri < m->nroot; ++ri) {
+                const int r = m->root_body[ri], e = m->body_subtreeend[r];
+                const double w = (isbody && b >= r && b < e) ? bmass : 0.0;
+                const double sm = wv::wave_sum(w), sx = wv::wave_sum(w * px), sy = wv::wave_sum(w * py), sz = wv::wave_sum(w * pz);
+                if (lane == 0) {
+                    if (sm < CM_MINVAL) { S.com[r][0] = S.x.s.xipos[r][0]; S.com[r][1] = S.x.s.xipos[r][1]; S.com[r][2] = S.x.s.xipos[r][2]; }
+                    else { const double inv = 1.0 / sm; S.com[r][0] = sx * inv; S.com[r][1] = sy * inv; S.com[r][2] = sz * inv; }
+                }
+            }
+        }
+        wv::sync();
+        CK_STAMP(18);
+        /* ================= cinert (lane = body), cdof (lane = dof) ================= */
+        if (lane < NB) {
+            double ci[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            if (isbody && b > 0) {
+                const double I0 = pf_iner[0], I1 = pf_iner[1], I2 = pf_iner[2];
+                const double *c = S.com[broot];
+                double dif[3] = {S.x.s.xipos[b][0] - c[0], S.x.s.xipos[b][1] - c[1], S.x.s.xipos[b][2] - c[2]};
+                double d2 = dot3(dif, dif);
+                const double *R = ximat;
+                double W00 = R[0] * I0 * R[0] + R[1] * I1 * R[1] + R[2] * I2 * R[2];
+                double W11 = R[3] * I0 * R[3] + R[4] * I1 * R[4] + R[5] * I2 * R[5];
+                double W22 = R[6] * I0 * R[6] + R[7] * I1 * R[7] + R[8] * I2 * R[8];
+                double W01 = R[0] * I0 * R[3] + R[1] * I1 * R[4] + R[2] * I2 * R[5];
+                double W02 = R[0] * I0 * R[6] + R[1] * I1 * R[7] + R[2] * I2 * R[8];
+                double W12 = R[3] * I0 * R[6] + R[4] * I1 * R[7] + R[5] * I2 * R[8];
+                ci[0] = W00 + bmass * (d2 - dif[0] * dif[0]);
+                ci[1] = W11 + bmass * (d2 - dif[1] * dif[1]);
+                ci[2] = W22 + bmass * (d2 - dif[2] * dif[2]);
+                ci[3] = W01 - bmass * dif[0] * dif[1];
+                ci[4] = W02 - bmass * dif[0] * dif[2];
+                ci[5] = W12 - bmass * dif[1] * dif[2];
+                ci[6] = bmass * dif[0]; ci[7] = bmass * dif[1]; ci[8] = bmass * dif[2]; ci[9] = bmass;
+            }
+            for (int i = 0; i < 10; ++i) S.x.s.cinert[lane][i] = ci[i];
+        }
+        {
+        double cd[6] = {0, 0, 0, 0, 0, 0};
+        if (isdof) {
+            const double *c = S.com[kroot];
+            double off[3] = {c[0] - S.x.s.xanchor[kjnt][0], c[1] - S.x.s.xanchor[kjnt][1], c[2] - S.x.s.xanchor[kjnt][2]};
+            const int sub_k = k_ - kda;
+            if (kjt == CM_JNT_SLIDE) {
+                for (int i = 0; i < 3; ++i) cd[3 + i] = S.x.s.xaxis[kjnt][i];
+            } else if (kjt == CM_JNT_HINGE) {
+                for (int i = 0; i < 3; ++i) cd[i] = S.x.s.xaxis[kjnt][i];
+                cross3(cd + 3, cd, off);
+            } else if (kjt == CM_JNT_FREE && sub_k < 3) {
+                cd[3 + sub_k] = 1.0;
+            } else {
+                const int a = (kjt == CM_JNT_FREE) ? sub_k - 3 : sub_k;
+                cd[0] = S.x.s.xmat[kbody][a]; cd[1] = S.x.s.xmat[kbody][3 + a]; cd[2] = S.x.s.xmat[kbody][6 + a];
+                cross3(cd + 3, cd, off);
+            }
+        }
+        if (lane < NVP) for (int i = 0; i < 6; ++i) S.cdof[lane][i] = cd[i]; /* zero rows past nv */
+        }
+        wv::sync();
+        CK_STAMP(2);
+
+        /* ================= P2 CRBA: composite inertias, then one COLUMN of M per lane ================= */
+        /* composite inertias: crb_b = sum of cinert_c over the contiguous subtree range [b, bend): dense loop over all
+         * bodies with a per-lane range predicate, operands staged four bodies at a time */
+        /* A 0/1-weighted sum over bodies is a matrix product, W (body x body: c in b's subtree) times cinert (body x 10), and its
+         * result layout on the matrix core -- lane l holds rows (l >> 4) + 4 v, column l & 15 -- is a layout the LDS tile can be
+         * written in directly: 16 v_mfma_f64_16x16x4_f64 (two blocks of 16 bodies x eight blocks of four summands, even and odd
+         * blocks in separate accumulators), the weights built from the subtree masks in registers, the summands single LDS reads.
+         * (fma(1, x, acc) is acc + x, fma(0, x, acc) is acc: the sums are plain sums, in body order.) */
+        {
+            const int mi = lane & 15, mk = lane >> 4;
+            const unsigned mine = (isbody && b > 0) ? (unsigned)(((1ull << bend) - 1ull) ^ ((1ull << b) - 1ull)) : 0u; /* bodies [b, bend) */
+            const unsigned w0 = (unsigned)wv::shfl_i((int)mine, mi) >> mk, w1 = (unsigned)wv::shfl_i((int)mine, 16 + mi) >> mk;
+            double bv[NB / 4];
+#pragma unroll
+            for (int kb = 0; kb < NB / 4; ++kb) { const double v = S.x.s.cinert[4 * kb + mk][mi < 10 ? mi : 0]; bv[kb] = mi < 10 ? v : 0.0; }
+            wv::mfma_acc d0a = {{0, 0, 0, 0}}, d0b = {{0, 0, 0, 0}}, d1a = {{0, 0, 0, 0}}, d1b = {{0, 0, 0, 0}};
+#pragma unroll
+            for (int kb = 0; kb < NB / 4; kb += 2)
+                wv::mfma_f64_16x16x4_x4((double)((w0 >> (4 * kb)) & 1u), bv[kb], d0a, (double)((w1 >> (4 * kb)) & 1u), bv[kb], d1a,
+                                        (double)((w0 >> (4 * kb + 4)) & 1u), bv[kb + 1], d0b, (double)((w1 >> (4 * kb + 4)) & 1u), bv[kb + 1], d1b);
+            wv::mfma_f64_drain4(d0a, d0b, d1a, d1b);
+            if (mi < 10) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    S.x.s.crb[mk + 4 * v][mi] = d0a.c[v] + d0b.c[v];
+                    S.x.s.crb[16 + mk + 4 * v][mi] = d1a.c[v] + d1b.c[v];
+                }
+            }
+        }
+        wv::sync();
+        CK_STAMP(19);
+        if (lane < NVP) {
+            double bf[6] = {0, 0, 0, 0, 0, 0}, cd[6];
+            for (int i = 0; i < 6; ++i) cd[i] = S.cdof[lane][i];
+            if (isdof) mul_inert_vec(bf, S.x.s.crb[kbody], cd);
+            for (int i = 0; i < 6; ++i) cbuf[lane][i] = bf[i];
+        }
+        wv::sync();
+        CK_STAMP(20);
+        double cdm[6]; /* this lane's motion axis, fetched where it is used rather than carried in registers */
+        /* armature and h * damping sit on the diagonal only: they are added where the pivots are read (wave-uniform
+         * scalars there) instead of being selected into one lane-dependent entry of each column here */
+        /* M[i][lane] = cdof_lane . (crb[body_i] cdof_i): the buf rows are broadcast reads, staged eight rows at a time so
+         * the LDS latency is paid once per group instead of once per row */
+        if constexpr (NVP == 32) {
+            /* 32 columns on 64 lanes: lanes l and l + 32 both work for column l, on rows [0, 16) and [16, 32); the lower lane
+             * takes the upper one's sixteen entries through the lane swap */
+            const int hk = lane & 31, roff = lane < 32 ? 0 : 16;
+            const unsigned hdesc = (unsigned)wv::shfl_i((int)(unsigned)kdesc, hk) >> roff; /* (kdesc: no bit at or past nv <= 32) */
+            for (int i = 0; i < 6; ++i) cdm[i] = S.cdof[hk][i];
+            const double (*bufr)[6] = &cbuf[roff];
+            double part[16];
+#pragma unroll
+            for (int i0 = 0; i0 < 16; i0 += 8) {
+                double bb[8][6];
+#pragma unroll
+                for (int ii = 0; ii < 8; ++ii)
+#pragma unroll
+                    for (int t = 0; t < 6; ++t) bb[ii][t] = bufr[i0 + ii][t];
+                wv::sched_fence();
+#pragma unroll
+                for (int ii = 0; ii < 8; ++ii) {
+                    const double v = (cdm[0] * bb[ii][0] + cdm[1] * bb[ii][1]) + (cdm[2] * bb[ii][2] + cdm[3] * bb[ii][3]) + (cdm[4] * bb[ii][4] + cdm[5] * bb[ii][5]);
+                    part[i0 + ii] = ((hdesc >> (i0 + ii)) & 1u) ? v : 0.0;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const double up = wv::from_upper_half(part[i]);
+                col[i] = part[i]; colh[i] = part[i];
+                col[16 + i] = up; colh[16 + i] = up;
+            }
+        } else {
+        for (int i = 0; i < 6; ++i) cdm[i] = S.cdof[lane < NVP ? lane : 0][i];
+#pragma unroll
+        for (int i0 = 0; i0 < NVP; i0 += 8) {
+            double bb[8][6];
+#pragma unroll
+            for (int ii = 0; ii < 8; ++ii)
+#pragma unroll
+                for (int t = 0; t < 6; ++t) bb[ii][t] = cbuf[i0 + ii][t];
+            wv::sched_fence();
+#pragma unroll
+            for (int ii = 0; ii < 8; ++ii) {
+                const int i = i0 + ii;
+                double v = (cdm[0] * bb[ii][0] + cdm[1] * bb[ii][1]) + (cdm[2] * bb[ii][2] + cdm[3] * bb[ii][3]) + (cdm[4] * bb[ii][4] + cdm[5] * bb[ii][5]);
+                /* kdesc holds no bit at or past nv; with a compile-time topology the bound is a constant, not a branch */
+                if (TOPO::is_static ? (i >= TOPO::nv || !((kdesc >> i) & 1ull)) : !(i < nv && ((kdesc >> i) & 1ull))) v = 0;
+                col[i] = v;
+                colh[i] = v;
+            }
+        }
+        }
+        if (io.ext && isdof) {
+            cm_ext_t *ex = io.ext + env;
+#pragma unroll
+            for (int i = 0; i < NVP; ++i) if (i < nv && i >= k_) { const double v = (i == k_) ? col[i] + m->dof_armature[k_] : col[i]; ex->qM[i][k_] = v; ex->qM[k_][i] = v; }
+        }
+        CK_STAMP(3);
+    };
+
+    /* ---------------- two-wave form: wave 1's program ---------------- */
+    if constexpr (NW == 2) {
+        if (wid == 1) {
+            for (int sub1 = sub_start;;) {
+                /* this substep's constants are requested ahead of the barrier, where their trip through memory costs nothing */
+                const int pb = isbody ? b : 0;
+                const double mass = m->body_mass[pb];
+                double iner[3], imat[9];
+                for (int i = 0; i < 3; ++i) iner[i] = m->body_inertia[pb][i];
+                for (int i = 0; i < 9; ++i) imat[i] = m->body_imat[pb][i];
+                CK_STAMP(35);
+                wv::block_barrier(); /* F: wave 0 has the poses, the inertial origins and the joint anchors / axes in LDS */
+                if (wv::opaque(S.cmd[0])) return;
+                CK_STAMP(36);
+                double ximat[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+                if (isbody && b > 0) {
+                    double xm[9];
+                    for (int i = 0; i < 9; ++i) xm[i] = S.x.s.xmat[b][i];
+                    for (int i = 0; i < 3; ++i)
+                        for (int c = 0; c < 3; ++c) ximat[3 * i + c] = xm[3 * i] * imat[c] + xm[3 * i + 1] * imat[3 + c] + xm[3 * i + 2] * imat[6 + c];
+                }
+                double col[NVP], colh[NVP];
+                mass_matrix_columns(mass, iner, ximat, col, colh);
+                wv::block_barrier(); /* X: com, cinert and cdof are in LDS (wave 0's velocity and row stages read them) */
+                if (wv::opaque(S.cmd[0])) return; /* (the row-capped instantiation hands this substep over) */
+                CK_STAMP(38);
+                factor_pair_by_height<NVP, TOPO>(m, h, S, col, colh, lane);
+                CK_STAMP(4);
+                wv::block_barrier(); /* J: the factors of M and M + hB are in LDS */
+                CK_STAMP(39);
+                if (!io.integrate || ++sub1 >= io.nsub) return;
+            }
+        }
+    }
+
     bool bailed = false;
+    bool release_wave1 = false; /* two-wave form: this wave left the loop behind J while wave 1 waits at the next F */
     int sub = sub_start;
     for (; sub < io.nsub; ++sub) {
         /* Outputs that every substep recomputes (sensordata, qacc, actuator_velocity, xpos / xquat, the solver statistics)
@@ -1267,7 +1499,11 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
             bool badv = false;
             if (lane < nq) { double v = S.qpos[lane]; badv |= !(v == v) || fabs(v) > 1e10; }
             if (lane < nv) { double v = S.qvel[lane]; badv |= !(v == v) || fabs(v) > 1e10; }
-            if (wv::ballot(badv) != 0ull) { warn |= WARN_DIVERGED; break; }
+            if (wv::ballot(badv) != 0ull) {
+                warn |= WARN_DIVERGED;
+                if constexpr (NW == 2) { if (lane == 0) S.cmd[0] = 1; wv::block_barrier(); } /* (F) */
+                break;
+            }
         }
         if (io.drive_mode) {
             /* (the row-capped instantiation runs this pass after it knows that the substep fits its rows, see below: a
@@ -1512,6 +1748,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
             mulmatvec3(xw, S.x.s.xmat[pb], xl);
             for (int i = 0; i < 3; ++i) { S.x.s.xanchor[lane][i] = aw[i] + S.x.s.xpos[pb][i]; S.x.s.xaxis[lane][i] = xw[i]; }
         }
+        if constexpr (NW == 2) wv::block_barrier(); /* F */
         CK_STAMP(1);
 
         /* geoms (lane = collision geom) */
@@ -1525,179 +1762,20 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
             for (int i = 0; i < 3; ++i)
                 for (int c = 0; c < 3; ++c) S.x.s.geom_xmat[g][3 * i + c] = R[3 * i] * gm[c] + R[3 * i + 1] * gm[3 + c] + R[3 * i + 2] * gm[6 + c];
         }
+        if constexpr (NW == 2) wv::sync(); /* (the collision stage is next in this wave: its lanes read other lanes' geoms) */
 
         CK_STAMP(17);
-        /* ================= com of every kinematic tree (wave reduction per root) ================= */
-        const double bmass = (isbody && b > 0) ? pf_mass : 0.0;
-        {
-            /* one masked DPP tree reduction per kinematic tree (wave_sum returns the total in every lane) */
-            const double px = isbody ? S.x.s.xipos[b < NB ? b : 0][0] : 0.0, py = isbody ? S.x.s.xipos[b < NB ? b : 0][1] : 0.0,
-                         pz = isbody ? S.x.s.xipos[b < NB ? b : 0][2] : 0.0;
-            for (int ri = 0; ri < m->nroot; ++ri) {
-                const int r = m->root_body[ri], e = m->body_subtreeend[r];
-                const double w = (isbody && b >= r && b < e) ? bmass : 0.0;
-                const double sm = wv::wave_sum(w), sx = wv::wave_sum(w * px), sy = wv::wave_sum(w * py), sz = wv::wave_sum(w * pz);
-                if (lane == 0) {
-                    if (sm < CM_MINVAL) { S.com[r][0] = S.x.s.xipos[r][0]; S.com[r][1] = S.x.s.xipos[r][1]; S.com[r][2] = S.x.s.xipos[r][2]; }
-                    else { const double inv = 1.0 / sm; S.com[r][0] = sx * inv; S.com[r][1] = sy * inv; S.com[r][2] = sz * inv; }
-                }
-            }
-        }
-        wv::sync();
-        CK_STAMP(18);
-        /* ================= cinert (lane = body), cdof (lane = dof) ================= */
-        if (lane < NB) {
-            double ci[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-            if (isbody && b > 0) {
-                const double I0 = pf_iner[0], I1 = pf_iner[1], I2 = pf_iner[2];
-                const double *c = S.com[broot];
-                double dif[3] = {S.x.s.xipos[b][0] - c[0], S.x.s.xipos[b][1] - c[1], S.x.s.xipos[b][2] - c[2]};
-                double d2 = dot3(dif, dif);
-                const double *R = ximat;
-                double W00 = R[0] * I0 * R[0] + R[1] * I1 * R[1] + R[2] * I2 * R[2];
-                double W11 = R[3] * I0 * R[3] + R[4] * I1 * R[4] + R[5] * I2 * R[5];
-                double W22 = R[6] * I0 * R[6] + R[7] * I1 * R[7] + R[8] * I2 * R[8];
-                double W01 = R[0] * I0 * R[3] + R[1] * I1 * R[4] + R[2] * I2 * R[5];
-                double W02 = R[0] * I0 * R[6] + R[1] * I1 * R[7] + R[2] * I2 * R[8];
-                double W12 = R[3] * I0 * R[6] + R[4] * I1 * R[7] + R[5] * I2 * R[8];
-                ci[0] = W00 + bmass * (d2 - dif[0] * dif[0]);
-                ci[1] = W11 + bmass * (d2 - dif[1] * dif[1]);
-                ci[2] = W22 + bmass * (d2 - dif[2] * dif[2]);
-                ci[3] = W01 - bmass * dif[0] * dif[1];
-                ci[4] = W02 - bmass * dif[0] * dif[2];
-                ci[5] = W12 - bmass * dif[1] * dif[2];
-                ci[6] = bmass * dif[0]; ci[7] = bmass * dif[1]; ci[8] = bmass * dif[2]; ci[9] = bmass;
-            }
-            for (int i = 0; i < 10; ++i) S.x.s.cinert[lane][i] = ci[i];
-        }
-        {
-        double cd[6] = {0, 0, 0, 0, 0, 0};
-        if (isdof) {
-            const double *c = S.com[kroot];
-            double off[3] = {c[0] - S.x.s.xanchor[kjnt][0], c[1] - S.x.s.xanchor[kjnt][1], c[2] - S.x.s.xanchor[kjnt][2]};
-            const int sub_k = k_ - kda;
-            if (kjt == CM_JNT_SLIDE) {
-                for (int i = 0; i < 3; ++i) cd[3 + i] = S.x.s.xaxis[kjnt][i];
-            } else if (kjt == CM_JNT_HINGE) {
-                for (int i = 0; i < 3; ++i) cd[i] = S.x.s.xaxis[kjnt][i];
-                cross3(cd + 3, cd, off);
-            } else if (kjt == CM_JNT_FREE && sub_k < 3) {
-                cd[3 + sub_k] = 1.0;
-            } else {
-                const int a = (kjt == CM_JNT_FREE) ? sub_k - 3 : sub_k;
-                cd[0] = S.x.s.xmat[kbody][a]; cd[1] = S.x.s.xmat[kbody][3 + a]; cd[2] = S.x.s.xmat[kbody][6 + a];
-                cross3(cd + 3, cd, off);
-            }
-        }
-        if (lane < NVP) for (int i = 0; i < 6; ++i) S.cdof[lane][i] = cd[i]; /* zero rows past nv */
-        }
-        wv::sync();
-        CK_STAMP(2);
-
-        /* ================= P2 CRBA: composite inertias, then one COLUMN of M per lane ================= */
-        /* composite inertias: crb_b = sum of cinert_c over the contiguous subtree range [b, bend): dense loop over all
-         * bodies with a per-lane range predicate, operands staged four bodies at a time */
-        /* A 0/1-weighted sum over bodies is a matrix product, W (body x body: c in b's subtree) times cinert (body x 10), and its
-         * result layout on the matrix core -- lane l holds rows (l >> 4) + 4 v, column l & 15 -- is a layout the LDS tile can be
-         * written in directly: 16 v_mfma_f64_16x16x4_f64 (two blocks of 16 bodies x eight blocks of four summands, even and odd
-         * blocks in separate accumulators), the weights built from the subtree masks in registers, the summands single LDS reads.
-         * (fma(1, x, acc) is acc + x, fma(0, x, acc) is acc: the sums are plain sums, in body order.) */
-        {
-            const int mi = lane & 15, mk = lane >> 4;
-            const unsigned mine = (isbody && b > 0) ? (unsigned)(((1ull << bend) - 1ull) ^ ((1ull << b) - 1ull)) : 0u; /* bodies [b, bend) */
-            const unsigned w0 = (unsigned)wv::shfl_i((int)mine, mi) >> mk, w1 = (unsigned)wv::shfl_i((int)mine, 16 + mi) >> mk;
-            double bv[NB / 4];
-#pragma unroll
-            for (int kb = 0; kb < NB / 4; ++kb) { const double v = S.x.s.cinert[4 * kb + mk][mi < 10 ? mi : 0]; bv[kb] = mi < 10 ? v : 0.0; }
-            wv::mfma_acc d0a = {{0, 0, 0, 0}}, d0b = {{0, 0, 0, 0}}, d1a = {{0, 0, 0, 0}}, d1b = {{0, 0, 0, 0}};
-#pragma unroll
-            for (int kb = 0; kb < NB / 4; kb += 2)
-                wv::mfma_f64_16x16x4_x4((double)((w0 >> (4 * kb)) & 1u), bv[kb], d0a, (double)((w1 >> (4 * kb)) & 1u), bv[kb], d1a,
-                                        (double)((w0 >> (4 * kb + 4)) & 1u), bv[kb + 1], d0b, (double)((w1 >> (4 * kb + 4)) & 1u), bv[kb + 1], d1b);
-            wv::mfma_f64_drain4(d0a, d0b, d1a, d1b);
-            if (mi < 10) {
-#pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    S.x.s.crb[mk + 4 * v][mi] = d0a.c[v] + d0b.c[v];
-                    S.x.s.crb[16 + mk + 4 * v][mi] = d1a.c[v] + d1b.c[v];
-                }
-            }
-        }
-        wv::sync();
-        CK_STAMP(19);
-        if (lane < NVP) {
-            double bf[6] = {0, 0, 0, 0, 0, 0}, cd[6];
-            for (int i = 0; i < 6; ++i) cd[i] = S.cdof[lane][i];
-            if (isdof) mul_inert_vec(bf, S.x.s.crb[kbody], cd);
-            for (int i = 0; i < 6; ++i) S.x.s.buf[lane][i] = bf[i];
-        }
-        wv::sync();
-        CK_STAMP(20);
+        /* (com of every kinematic tree, cinert, cdof, composite inertias, M's columns: mass_matrix_columns, defined ahead of
+         * the loop -- in the two-wave form wave 1 runs them, and the factorisations, beside this wave's collision, velocity
+         * and constraint-row stages) */
         double col[NVP], colh[NVP]; /* col[i] = M[i][lane] (i >= lane); colh: same for M + h*diag(damping) */
-        double cdm[6]; /* this lane's motion axis, fetched where it is used rather than carried in registers */
-        /* armature and h * damping sit on the diagonal only: they are added where the pivots are read (wave-uniform
-         * scalars there) instead of being selected into one lane-dependent entry of each column here */
-        /* M[i][lane] = cdof_lane . (crb[body_i] cdof_i): the buf rows are broadcast reads, staged eight rows at a time so
-         * the LDS latency is paid once per group instead of once per row */
-        if constexpr (NVP == 32) {
-            /* 32 columns on 64 lanes: lanes l and l + 32 both work for column l, on rows [0, 16) and [16, 32); the lower lane
-             * takes the upper one's sixteen entries through the lane swap */
-            const int hk = lane & 31, roff = lane < 32 ? 0 : 16;
-            const unsigned hdesc = (unsigned)wv::shfl_i((int)(unsigned)kdesc, hk) >> roff; /* (kdesc: no bit at or past nv <= 32) */
-            for (int i = 0; i < 6; ++i) cdm[i] = S.cdof[hk][i];
-            const double (*bufr)[6] = &S.x.s.buf[roff];
-            double part[16];
-#pragma unroll
-            for (int i0 = 0; i0 < 16; i0 += 8) {
-                double bb[8][6];
-#pragma unroll
-                for (int ii = 0; ii < 8; ++ii)
-#pragma unroll
-                    for (int t = 0; t < 6; ++t) bb[ii][t] = bufr[i0 + ii][t];
-                wv::sched_fence();
-#pragma unroll
-                for (int ii = 0; ii < 8; ++ii) {
-                    const double v = (cdm[0] * bb[ii][0] + cdm[1] * bb[ii][1]) + (cdm[2] * bb[ii][2] + cdm[3] * bb[ii][3]) + (cdm[4] * bb[ii][4] + cdm[5] * bb[ii][5]);
-                    part[i0 + ii] = ((hdesc >> (i0 + ii)) & 1u) ? v : 0.0;
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const double up = wv::from_upper_half(part[i]);
-                col[i] = part[i]; colh[i] = part[i];
-                col[16 + i] = up; colh[16 + i] = up;
-            }
-        } else {
-        for (int i = 0; i < 6; ++i) cdm[i] = S.cdof[lane < NVP ? lane : 0][i];
-#pragma unroll
-        for (int i0 = 0; i0 < NVP; i0 += 8) {
-            double bb[8][6];
-#pragma unroll
-            for (int ii = 0; ii < 8; ++ii)
-#pragma unroll
-                for (int t = 0; t < 6; ++t) bb[ii][t] = S.x.s.buf[i0 + ii][t];
-            wv::sched_fence();
-#pragma unroll
-            for (int ii = 0; ii < 8; ++ii) {
-                const int i = i0 + ii;
-                double v = (cdm[0] * bb[ii][0] + cdm[1] * bb[ii][1]) + (cdm[2] * bb[ii][2] + cdm[3] * bb[ii][3]) + (cdm[4] * bb[ii][4] + cdm[5] * bb[ii][5]);
-                /* kdesc holds no bit at or past nv; with a compile-time topology the bound is a constant, not a branch */
-                if (TOPO::is_static ? (i >= TOPO::nv || !((kdesc >> i) & 1ull)) : !(i < nv && ((kdesc >> i) & 1ull))) v = 0;
-                col[i] = v;
-                colh[i] = v;
-            }
-        }
-        }
-        if (io.ext && isdof) {
-            cm_ext_t *ex = io.ext + env;
-#pragma unroll
-            for (int i = 0; i < NVP; ++i) if (i < nv && i >= k_) { const double v = (i == k_) ? col[i] + m->dof_armature[k_] : col[i]; ex->qM[i][k_] = v; ex->qM[k_][i] = v; }
-        }
-        CK_STAMP(3);
+        if constexpr (NW == 1) mass_matrix_columns(pf_mass, pf_iner, ximat, col, colh);
 
         /* ================= P3 factor M and M + hB in registers; park the factors in LDS ================= */
         constexpr bool by_height = TOPO::is_static;
-        if constexpr (by_height) {
+        if constexpr (NW == 2) {
+            /* (wave 1) */
+        } else if constexpr (by_height) {
             factor_pair_by_height<NVP, TOPO>(m, h, S, col, colh, lane);
         } else {
             factor_pair_in_registers<NVP, TOPO>(m, h, col, colh, lane, nv, S.dinv, S.rsd, S.dinvH);
@@ -1709,7 +1787,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
                 }
             }
         }
-        CK_STAMP(4);
+        if constexpr (NW == 1) CK_STAMP(4);
 
         /* ================= P4 collision ================= */
         /* Requested here, read behind the collision passes (joint limits; the dof-chain indices of the velocity stage): the
@@ -2042,12 +2120,17 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
             const int neq = m->neq;
             const bool eact = lane < neq && m->eq_active[lane < neq ? lane : 0] != 0;
             const int need = 3 * wv::popc64(wv::ballot(eact)) + wv::popc64(lob) + wv::popc64(hib) + 4 * ncon;
-            if (need > MAXR) { bailed = true; break; }
+            if (need > MAXR) {
+                bailed = true;
+                if constexpr (NW == 2) { if (lane == 0) S.cmd[0] = 1; wv::block_barrier(); } /* (X) */
+                break;
+            }
             if (io.drive_mode) {
                 if (io.integrate) drive_level_io(io, S, m, env, lane, lastsub);
                 wv::sync();
             }
         }
+        if constexpr (NW == 2) { CK_STAMP(33); wv::block_barrier(); } /* X */
         CK_STAMP(5);
 
         /* ================= P6 velocities and bias forces ================= */
@@ -2505,6 +2588,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
             }
         }
         wv::sync(); /* every reader of the body-stage tiles is done: region x becomes the Y staging tile */
+        if constexpr (NW == 2) { CK_STAMP(34); wv::block_barrier(); } /* J */
         CK_STAMP(8);
 
         /* ================= half solve in registers: Y = D^-1/2 L^-T [J^T | qfrc_smooth], lane = column ================= */
@@ -2835,7 +2919,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
         }
         {
             const bool badv = isdof && (!(qacc == qacc) || fabs(qacc) > 1e10);
-            if (wv::ballot(badv) != 0ull) { warn |= WARN_DIVERGED; break; }
+            if (wv::ballot(badv) != 0ull) { warn |= WARN_DIVERGED; release_wave1 = NW == 2 && io.integrate && sub + 1 < io.nsub; break; }
         }
         if (isdof) S.qacc[k_] = qacc;
         wv::sync();
@@ -2943,6 +3027,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
         CK_STAMP(14);
     }
 
+    if constexpr (NW == 2) if (release_wave1) { if (lane == 0) S.cmd[0] = 1; wv::block_barrier(); } /* (F) */
     /* ---------------- store state ---------------- */
     if (io.progress && !io.resume && lane == 0) io.progress[env] = bailed ? sub : io.nsub; /* (the resume pass leaves the record) */
     if (io.integrate && io.drive_mode) {
@@ -2982,8 +3067,8 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
  * scratch per lane -- and shortens every unrolled row loop.  An env whose substep needs more rows is handed over to the full
  * instantiation through PhysIO::progress (see there); results are bit for bit those of the full instantiation alone, because
  * the arithmetic of a substep that fits is the same in both. */
-template <int NVP, class TOPO, int FEAT = FEAT_ALL, int MAXR = CM_MAXEFC>
-WV_GLOBAL void __launch_bounds__(WV_WAVE) WV_OCC cassie_step_kernel(PhysIO io) {
+template <int NVP, class TOPO, int FEAT = FEAT_ALL, int MAXR = CM_MAXEFC, int NW = 1>
+WV_GLOBAL void __launch_bounds__(WV_WAVE * NW) WV_OCC WV_WAVES_PER_SIMD(NW) cassie_step_kernel(PhysIO io) {
     WV_SHARED EnvShared<NVP, LPack<TOPO, NVP>::count, MAXR> S;
     const int slot = wv::env_id();
     if (slot >= io.nenv) return;
@@ -2992,8 +3077,9 @@ WV_GLOBAL void __launch_bounds__(WV_WAVE) WV_OCC cassie_step_kernel(PhysIO io) {
     const int sub_start = io.resume ? io.progress[env] : 0;
     if (sub_start >= io.nsub) return; /* resume pass: the fast instantiation finished this env */
     const long long t0 = io.cost ? wv::clock() : 0;
-    env_step<NVP, TOPO, FEAT, MAXR>(io, S, env, sub_start);
-    if (io.cost && wv::lane() == 0) { /* 64-clock units: 32 bits hold minutes */
+    env_step<NVP, TOPO, FEAT, MAXR, NW>(io, S, env, sub_start);
+    if (io.prof && wv::lane() == 0) io.prof[(size_t)env * NSTAMP + 40 + (NW == 2 ? wv::wave_id() : 0)] = wv::hw_id(); /* (profiling aid: the CU / SIMD of the wave) */
+    if (io.cost && wv::lane() == 0 && (NW == 1 || wv::wave_id() == 0)) { /* 64-clock units: 32 bits hold minutes */
         const unsigned c = (unsigned)((wv::clock() - t0) >> 6);
         io.cost[env] = io.resume ? io.cost[env] + c : c;
     }

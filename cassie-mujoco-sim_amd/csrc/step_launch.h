@@ -14,17 +14,22 @@
 namespace ck {
 /* io.progress must be set when fast is; io.resume is managed here */
 /* after_first (may be null): recorded behind the first kernel of the launch -- the one that does the work -- for per-kernel timing */
-bool launch_step_cassie(dim3 grid, hipStream_t s, PhysIO io, bool fast, hipEvent_t after_first);            /* <32, TopoCassie32, 0>: plain cassie.xml */
-bool launch_step_cassie_hfield(dim3 grid, hipStream_t s, PhysIO io, bool fast, hipEvent_t after_first);     /* <32, TopoCassie32, FEAT_HFIELD> */
+/* waves: 2 = the row-capped fast instantiation in its two-wave form (two wavefronts per env, see env_step), 1 = one wave per env */
+bool launch_step_cassie(dim3 grid, hipStream_t s, PhysIO io, bool fast, hipEvent_t after_first, int waves);            /* <32, TopoCassie32, 0>: plain cassie.xml */
+bool launch_step_cassie_hfield(dim3 grid, hipStream_t s, PhysIO io, bool fast, hipEvent_t after_first, int waves);     /* <32, TopoCassie32, FEAT_HFIELD> */
+/* the two-wave forms of the fast instantiations, in translation units of their own (kernels_*_2w.hip) */
+bool launch_fast_cassie_2w(dim3 grid, hipStream_t s, PhysIO io);
+bool launch_fast_cassie_hfield_2w(dim3 grid, hipStream_t s, PhysIO io);
 bool launch_step_cassie_all(dim3 grid, hipStream_t s, PhysIO io);                   /* <32, TopoCassie32, FEAT_ALL> */
 bool launch_step_tray(dim3 grid, hipStream_t s, PhysIO io, bool hfield);            /* <40, TopoCassieTray38, FEAT_WAVEPAIRS | FEAT_ALL> */
 bool launch_step_generic(dim3 grid, hipStream_t s, PhysIO io, bool wide);           /* <32 | 40, TopoRuntime, FEAT_ALL> */
 
 template <int NVP, class TOPO, int FEAT>
-inline bool launch_fast_then_full(dim3 grid, hipStream_t s, PhysIO io, bool fast, hipEvent_t after_first) {
+inline bool launch_fast_then_full(dim3 grid, hipStream_t s, PhysIO io, bool fast, hipEvent_t after_first, bool (*fast_2w)(dim3, hipStream_t, PhysIO)) {
     if (fast) {
         io.resume = 0;
-        hipLaunchKernelGGL((cassie_step_kernel<NVP, TOPO, FEAT, FAST_ROWS>), grid, dim3(WV_WAVE), 0, s, io);
+        if (fast_2w) { if (!fast_2w(grid, s, io)) return false; }
+        else hipLaunchKernelGGL((cassie_step_kernel<NVP, TOPO, FEAT, FAST_ROWS>), grid, dim3(WV_WAVE), 0, s, io);
         if (hipGetLastError() != hipSuccess) return false;
         if (after_first) { (void)hipEventRecord(after_first, s); after_first = nullptr; }
         io.resume = 1;

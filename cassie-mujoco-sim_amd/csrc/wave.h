@@ -15,6 +15,8 @@
 #define WV_GLOBAL __global__
 #define WV_SHARED __shared__
 #define WV_WAVE 64
+/* at least n of a kernel's waves resident per SIMD (512 / n registers per lane); n = 1 leaves the compiler's default */
+#define WV_WAVES_PER_SIMD(n) __attribute__((amdgpu_waves_per_eu(n)))
 /* address-space qualifier of the model pointer: nothing in the kernel writes the model, and the constant address
  * space lets the wave-uniform reads (sizes, options, solver parameters, pair-loop bounds) issue as scalar loads
  * even after the kernel has stored to global memory -- with a generic pointer every one of them is a 64-lane
@@ -23,7 +25,17 @@
 
 namespace wv {
 
-WV_DEVICE int lane() { return (int)threadIdx.x; }
+WV_DEVICE int lane() { return (int)(threadIdx.x & 63u); }
+/* Two-wave workgroups (the step kernel's NW = 2 form: one env = two wavefronts that work on different stage groups of the
+ * same substep): which wave this is (wave-uniform, in a scalar register), and the barrier between the workgroup's waves.
+ * The barrier drains this wave's LDS traffic (so the other wave sees what was written) but NOT its vector-memory loads:
+ * model constants requested a stage ahead stay in flight across it. */
+WV_DEVICE int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+WV_DEVICE void block_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
 /* the lane index recomputed from nothing (two VALU ops) through an asm the optimiser cannot merge or hoist: values
  * derived from it (LDS addresses, lane predicates) then live only inside the stage that asked, instead of being
  * computed once at the top of the kernel and carried -- i.e. spilled -- across everything in between */
@@ -177,6 +189,14 @@ WV_DEVICE constexpr bool test_skip_com_init() { return false; }
 template <class S> WV_DEVICE void test_launch_hook(S *, unsigned long) {}
 
 WV_DEVICE long long clock() { return (long long)__builtin_readcyclecounter(); }
+/* where the hardware placed this wave (profiling aid): HW_ID (wave slot [3:0], SIMD [5:4], CU [11:8], SH [12], SE [15:13], workgroup slot
+ * [19:16]) in the low word, XCC_ID in the high word */
+WV_DEVICE long long hw_id() {
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    return (long long)(((unsigned long long)xcc << 32) | hw);
+}
 
 WV_DEVICE int popc64(unsigned long long x) { return __popcll(x); }
 /* max of two doubles that are known not to be signalling NaNs, as the single instruction */

@@ -212,6 +212,10 @@ int phys_batch_set_balance(phys_batch_t *b, int on);
 int phys_batch_enable_kernel_timing(phys_batch_t *b, int on);
 int phys_batch_kernel_timing(phys_batch_t *b, int *launches, double *total_ms);
 int phys_batch_set_fast_rows(phys_batch_t *b, int on);
+/* 2 (default): the row-capped fast kernels run in their two-wave form -- two wavefronts per env, the mass-matrix stage group
+ * (centres of mass, composite inertias, M, its two factorisations) on the second wave beside the first wave's collision,
+ * velocity and constraint-row stages; 1: one wavefront per env.  Same results, bit for bit (a measurement aid). */
+int phys_batch_set_waves_per_env(phys_batch_t *b, int waves);
 /* diagnostics: how many substeps of the last stepping launch the fast kernel completed for every env ([nenv] ints; less than
  * the launch's substep count = the env was handed over to the full kernel there) */
 int phys_batch_download_progress(phys_batch_t *b, int *host);

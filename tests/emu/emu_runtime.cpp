@@ -4,6 +4,13 @@
  * scheduling with a rendezvous at every cross-lane primitive.  Because the
  * kernel keeps all collectives in wave-uniform control flow, "resume every lane
  * until its next rendezvous" reproduces the SIMT semantics exactly.
+ *
+ * Workgroups of two waves (the step kernel's NW = 2 form): 128 coroutines; the
+ * cross-lane primitives are rendezvous of ONE wave's 64 lanes, wv::block_barrier
+ * is a rendezvous of the workgroup.  A wave that has ended does not take part in
+ * later barriers (as on the hardware).  How the two waves interleave between
+ * barriers is a test parameter (emu_wave_schedule): a program free of LDS races
+ * gives the same bits under every schedule.
  */
 #include <cstdio>
 #include <cstdlib>
@@ -12,17 +19,20 @@
 #include "small_kernels.h"
 
 namespace {
-constexpr int NL = 64;
+constexpr int NL = 64, NWMAX = 2, NLMAX = NL * NWMAX;
 constexpr size_t STACK_BYTES = 1 << 20;
 
 struct LaneCtx { void *sp; char *stack; bool done; };
-LaneCtx g_lane[NL];
+LaneCtx g_lane[NLMAX];
 void *g_sched_sp;
 int g_cur = 0, g_env = 0;
-double g_xd[NL];
-int g_xi[NL];
+double g_xd[NLMAX];
+int g_xi[NLMAX];
+int g_kind[NLMAX];      /* what the lane yielded at: 0 = a rendezvous of its wave, 1 = the workgroup barrier */
+int g_wave_schedule = 0; /* 0: the waves take turns, one rendezvous each; 1: wave 0 runs whenever it can; 2: wave 1 does */
 void (*g_body)() = nullptr;
 bool g_mismatch = false;
+inline int wave_base() { return g_cur & ~(NL - 1); }
 
 extern "C" void emu_switch(void **save_sp, void *load_sp);
 asm(R"(
@@ -47,7 +57,8 @@ emu_switch:
     ret
 )");
 
-void rendezvous() { emu_switch(&g_lane[g_cur].sp, g_sched_sp); }
+void rendezvous() { g_kind[g_cur] = 0; emu_switch(&g_lane[g_cur].sp, g_sched_sp); }
+void barrier_rendezvous() { g_kind[g_cur] = 1; emu_switch(&g_lane[g_cur].sp, g_sched_sp); }
 
 void lane_entry() {
     g_body();
@@ -56,9 +67,10 @@ void lane_entry() {
     abort(); /* a finished lane is never resumed */
 }
 
-void run_block(void (*body)()) {
+void run_block(void (*body)(), int nwaves = 1) {
     g_body = body;
-    for (int l = 0; l < NL; ++l) {
+    const int nl = NL * nwaves;
+    for (int l = 0; l < nl; ++l) {
         if (!g_lane[l].stack) g_lane[l].stack = (char *)aligned_alloc(64, STACK_BYTES);
         uintptr_t top = ((uintptr_t)g_lane[l].stack + STACK_BYTES) & ~(uintptr_t)15;
         void **slot = (void **)(top - 16); /* 16-byte aligned return-address slot */
@@ -68,28 +80,44 @@ void run_block(void (*body)()) {
         g_lane[l].sp = sp;
         g_lane[l].done = false;
     }
+    bool wave_done[NWMAX] = {false, false}, at_barrier[NWMAX] = {false, false};
     for (;;) {
-        int ndone = 0;
-        for (int l = 0; l < NL; ++l) {
-            if (g_lane[l].done) { ++ndone; continue; }
-            g_cur = l;
-            emu_switch(&g_sched_sp, g_lane[l].sp);
-            if (g_lane[l].done) ++ndone;
+        /* one turn: every wave that can run resumes its 64 lanes once, i.e. up to its next rendezvous */
+        for (int t = 0; t < nwaves; ++t) {
+            const int w = g_wave_schedule == 2 ? nwaves - 1 - t : t;
+            if (wave_done[w] || at_barrier[w]) continue;
+            int ndone = 0, nbar = 0;
+            for (int l = w * NL; l < (w + 1) * NL; ++l) {
+                if (g_lane[l].done) { ++ndone; continue; }
+                g_cur = l;
+                emu_switch(&g_sched_sp, g_lane[l].sp);
+                if (g_lane[l].done) ++ndone;
+                else if (g_kind[l] == 1) ++nbar;
+            }
+            if (ndone == NL) wave_done[w] = true;
+            else if (ndone != 0) { g_mismatch = true; fprintf(stderr, "emu: lanes of wave %d left the kernel at different rendezvous counts (%d done)\n", w, ndone); abort(); }
+            else if (nbar == NL) at_barrier[w] = true;
+            else if (nbar != 0) { g_mismatch = true; fprintf(stderr, "emu: %d lanes of wave %d are at the workgroup barrier, the others at a wave rendezvous\n", nbar, w); abort(); }
+            if (g_wave_schedule != 0) break; /* the preferred wave runs on until it is blocked or done */
         }
-        if (ndone == NL) break;
-        if (ndone != 0) { g_mismatch = true; fprintf(stderr, "emu: lanes left the kernel at different rendezvous counts (%d done)\n", ndone); abort(); }
+        bool all_done = true, all_blocked = true;
+        for (int w = 0; w < nwaves; ++w) { all_done = all_done && wave_done[w]; all_blocked = all_blocked && (wave_done[w] || at_barrier[w]); }
+        if (all_done) break;
+        if (all_blocked) for (int w = 0; w < nwaves; ++w) at_barrier[w] = false; /* the barrier opens: every wave still alive has arrived */
     }
 }
 }  // namespace
 
 namespace wv {
-int lane() { return g_cur; }
+int lane() { return g_cur & (NL - 1); }
+int wave_id() { return g_cur / NL; }
 int env_id() { return g_env; }
 void sync() { rendezvous(); }
+void block_barrier() { barrier_rendezvous(); }
 double shfl(double v, int src) {
     g_xd[g_cur] = v;
     rendezvous();
-    double r = g_xd[src & 63];
+    double r = g_xd[wave_base() + (src & 63)];
     rendezvous();
     return r;
 }
@@ -97,21 +125,21 @@ double shfl_xor(double v, int mask) { return shfl(v, g_cur ^ mask); }
 int shfl_i(int v, int src) {
     g_xi[g_cur] = v;
     rendezvous();
-    int r = g_xi[src & 63];
+    int r = g_xi[wave_base() + (src & 63)];
     rendezvous();
     return r;
 }
 double readlane(double v, int src) { return shfl(v, src); }
 /* the matrix-core instruction as the device performs it: per element the FMA chain over k = 0 .. 3 on top of C */
-static double g_xa[64], g_xb[64];
+static double g_xa[NLMAX], g_xb[NLMAX];
 void mfma_f64_16x16x4(double a, double b, double (&c)[4]) {
     g_xa[g_cur] = a; g_xb[g_cur] = b;
     rendezvous();
-    const int l = g_cur, j = l & 15;
+    const int l = g_cur & 63, j = l & 15, wb = wave_base();
     for (int v = 0; v < 4; ++v) {
         const int i = (l >> 4) + 4 * v;
         double acc = c[v];
-        for (int k = 0; k < 4; ++k) acc = std::fma(g_xa[i + 16 * k], g_xb[j + 16 * k], acc);
+        for (int k = 0; k < 4; ++k) acc = std::fma(g_xa[wb + i + 16 * k], g_xb[wb + j + 16 * k], acc);
         c[v] = acc;
     }
     rendezvous();
@@ -120,7 +148,7 @@ unsigned long long ballot(bool p) {
     g_xi[g_cur] = p ? 1 : 0;
     rendezvous();
     unsigned long long m = 0;
-    for (int l = 0; l < NL; ++l) if (g_xi[l]) m |= 1ull << l;
+    for (int l = 0; l < NL; ++l) if (g_xi[wave_base() + l]) m |= 1ull << l;
     rendezvous();
     return m;
 }
@@ -167,6 +195,13 @@ extern "C" unsigned long emu_offsetof32(int which) {
 static int g_force_runtime_topology = 0;
 static void body32s() { ck::cassie_step_kernel<32, ck::TopoCassie32>(g_io); }
 static void body32s_fast() { ck::cassie_step_kernel<32, ck::TopoCassie32, ck::FEAT_ALL, ck::FAST_ROWS>(g_io); }
+/* the two-wave forms (wave 1 runs the mass-matrix stage group beside wave 0's collision / velocity / row stages) */
+static void body32s_2w() { ck::cassie_step_kernel<32, ck::TopoCassie32, ck::FEAT_ALL, CM_MAXEFC, 2>(g_io); }
+static void body32s_fast_2w() { ck::cassie_step_kernel<32, ck::TopoCassie32, ck::FEAT_ALL, ck::FAST_ROWS, 2>(g_io); }
+static void body40s_2w() { ck::cassie_step_kernel<40, ck::TopoCassieTray38, ck::FEAT_WAVEPAIRS, CM_MAXEFC, 2>(g_io); } /* (no height-field pairs) */
+static int g_two_waves = 0;
+extern "C" void emu_two_waves(int on) { g_two_waves = on; }
+extern "C" void emu_wave_schedule(int mode) { g_wave_schedule = mode; }
 /* the row-capped fast instantiation ahead of the full one, as phys_batch.hip launches them (PhysIO::progress / resume);
  * g_fast_bails counts the envs the fast instantiation handed over */
 static int g_fast_rows = 0, g_fast_bails = 0;
@@ -214,14 +249,16 @@ extern "C" int emu_phys_run(const cm_model_t *model, int nenv, int nsub, int int
             static int progress[1 << 16];
             if (g_fast_rows && integrate && e < (1 << 16)) {
                 g_io.progress = progress; g_io.resume = 0;
-                run_block(body32s_fast);
+                if (g_two_waves) run_block(body32s_fast_2w, 2); else run_block(body32s_fast);
                 if (progress[e] < nsub) ++g_fast_bails;
                 g_io.resume = 1;
             }
-            run_block(body32s);
+            if (g_two_waves) run_block(body32s_2w, 2); else run_block(body32s);
             g_io.progress = nullptr; g_io.resume = 0;
         }
-        else if (!g_force_runtime_topology && topo_matches(model, ck::TopoCassieTray38::table, ck::TopoCassieTray38::nv, ck::TopoCassieTray38::body_levels)) run_block(body40s);
+        else if (!g_force_runtime_topology && topo_matches(model, ck::TopoCassieTray38::table, ck::TopoCassieTray38::nv, ck::TopoCassieTray38::body_levels)) {
+            if (g_two_waves && model->nhfpair == 0 && model->hfield_geom < 0) run_block(body40s_2w, 2); else run_block(body40s);
+        }
         else run_block(model->nv <= 32 ? body32 : body40);
     }
     return 0;

@@ -22,11 +22,14 @@
 #define WV_WAVE 64
 #define WV_CONST_AS
 #define __launch_bounds__(x)
+#define WV_WAVES_PER_SIMD(n)
 
 namespace wv {
 int lane();
+int wave_id();
 int env_id();
 void sync();
+void block_barrier();
 double shfl(double v, int src_lane);
 double shfl_xor(double v, int mask);
 int shfl_i(int v, int src_lane);
@@ -49,6 +52,7 @@ unsigned long long ballot(bool p);
 double wave_sum(double v);
 float wave_sum_f32(float v);
 inline long long clock() { return 0; }
+inline long long hw_id() { return 0; }
 inline double max_raw(double a, double b) { return a > b ? a : b; }
 inline int opaque(int x) { return x; }
 inline void sched_fence() {}
@@ -63,11 +67,11 @@ inline bool test_skip_com_init() { return g_skip_com_init != 0; }
 /* LDS is not initialised on the device: fill the env's block with NaN patterns so that a read-before-write shows */
 inline void test_launch_hook(void *shared, unsigned long size) {
     if (g_poison_lds) {
-        if (lane() == 0) {
+        if (lane() == 0 && wave_id() == 0) {
             const unsigned long lo = g_poison_lo < size ? g_poison_lo : size, hi = g_poison_hi < size ? g_poison_hi : size;
             if (hi > lo) memset((char *)shared + lo, 0xff, hi - lo);
         }
-        sync();
+        block_barrier();
     }
 }
 inline int fresh_lane() { return lane(); }

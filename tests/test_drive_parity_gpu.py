@@ -259,6 +259,51 @@ def test_row_capped_fast_kernel_equals_the_full_kernel_bit_for_bit(built, name, 
         assert a.tobytes() == c.tobytes()
 
 
+@pytest.mark.parametrize("name", ["cassie", "cassie_hfield"])
+def test_two_wave_form_of_the_fast_kernel_equals_the_one_wave_form_bit_for_bit(built, name):
+    """phys_batch_set_waves_per_env: the row-capped fast kernels run as two wavefronts per env (wave 1: the mass-matrix stage
+    group beside wave 0's collision / velocity / row stages, three workgroup barriers per substep).  Every value is computed by
+    the same instructions from the same operands, so state, outputs, solver statistics, measurement block and drive state
+    must be BIT FOR BIT those of the one-wave form -- under the stress targets, i.e. with envs handed over to the (one-wave)
+    full kernel in the middle of fused launches, and with substeps of every length of launch (1 .. HOLD)."""
+    model = Model(name)
+    n, npol = 1024, 24
+    hf = G.terrain(name)
+    tg = _stress_targets(np.arange(n), npol)
+    q0 = np.tile(model.qpos_init(), (n, 1))
+    if name == "cassie_hfield":
+        for e in range(n):
+            q0[e, 0], q0[e, 1] = G.start_xy(name, e)
+    out = []
+    for waves in (1, 2):
+        b = Batch(model, n)
+        try:
+            b.set_waves_per_env(waves)
+            if hf is not None:
+                b.set_hfield(hf)
+            b.set(P.F_QPOS, q0)
+            b.set(P.F_PD_KP, np.tile(bench.PD_KP, (n, 1)))
+            b.set(P.F_PD_KD, np.tile(bench.PD_KD, (n, 1)))
+            b.forward()
+            b.set_drive_mode(P.DRIVE_PD)
+            handed = 0
+            for p in range(npol):
+                b.set(P.F_PD_PTARGET, tg[p])
+                b.step(bench.HOLD if p % 3 else (1, 2, 7, 20)[(p // 3) % 4])
+                handed += int(np.count_nonzero(b.fast_rows_progress() < (bench.HOLD if p % 3 else (1, 2, 7, 20)[(p // 3) % 4])))
+            w, info = b.warnings()
+            rec = [b.get(P.F_QPOS), b.get(P.F_QVEL), b.get(P.F_QACC_WARMSTART), b.get(P.F_QACC), b.get(P.F_SENSORDATA), b.get(P.F_TIME), w, info[:, :3].copy(),
+                   b.get(P.F_MEAS), b.get(P.F_CTRL), b.get(P.F_XPOS), b.get(P.F_XQUAT), b.get(P.F_ACTUATOR_VELOCITY)]
+            rec += [np.frombuffer(b"".join(device_state_bytes(s)), dtype=np.uint8) for s in b.get_drive_state(0, 64)]
+            out.append((rec, handed))
+        finally:
+            b.close()
+    print("%s: %d / %d env-launches handed over (one wave / two waves)" % (name, out[0][1], out[1][1]))
+    assert out[0][1] == out[1][1] and out[0][1] > 20
+    for a, c in zip(out[0][0], out[1][0]):
+        assert a.tobytes() == c.tobytes()
+
+
 def test_device_reset_equals_a_fresh_batch(cassie):
     """phys_batch_reset_envs: envs restarted on the device continue bit for bit like envs of a fresh batch (the benchmark's
     episode restarts; reference src/cassiemujoco.c:1023-1029 / :2008-2034 role), in the drive mode whose state the reset also

@@ -349,3 +349,77 @@ def test_row_capped_fast_kernel_hands_over_mid_launch_and_changes_nothing(cassie
             assert a == b
         else:
             assert a.tobytes() == b.tobytes()
+
+
+# ---- the two-wave form (NW = 2): wave 1 runs the mass-matrix stage group beside wave 0's collision / velocity / row stages ----
+def _two_wave_workload(model, drive, fast, two_waves, schedule, poison=False, nlaunch=5, nsub=12, stress=True):
+    """A few fused launches of the benchmark's PD workload (optionally with the +-10 rad stress targets, which force hand-overs
+    between the row-capped and the full instantiation); returns everything a launch leaves behind, as bytes."""
+    import bench
+    import emu_py
+    from cassie_amd import phys as P
+    from hostchain_py import device_state_bytes
+    lib = emu_py.lib()
+    pod, n = model.pod, 2
+    lib.emu_fast_rows(1 if fast else 0); lib.emu_two_waves(1 if two_waves else 0); lib.emu_wave_schedule(schedule); lib.emu_poison_lds(1 if poison else 0)
+    try:
+        emu = EmuBatch(pod, n)
+        emu.qpos[:] = model.qpos_init()
+        emu.qpos[:, 2] -= 0.15
+        if pod.nhfpair > 0:
+            import test_hfield
+            emu.hfield = test_hfield.terrain()
+        emu.pd_kp, emu.pd_kd = np.tile(bench.PD_KP, (n, 1)), np.tile(bench.PD_KD, (n, 1))
+        if drive:
+            emu.forward()
+            emu.drive_mode = P.DRIVE_PD
+        rows = []
+        for p in range(nlaunch):
+            tg = np.empty((n, 10))
+            for e in range(n):
+                tg[e] = bench.PD_OFFSET + np.random.default_rng(977 + 31 * p + e).uniform(-10 if stress else -0.3, 10 if stress else 0.3, 10)
+            emu.pd_ptarget = tg
+            emu.step(nsub)
+            rows.append(emu.info.copy())
+        emu.forward()                                    # a forward-only pass goes through the same kernel (integrate = 0)
+        return [emu.qpos.tobytes(), emu.qvel.tobytes(), emu.qacc_warmstart.tobytes(), emu.qacc.tobytes(), emu.sensordata.tobytes(),
+                emu.actuator_velocity.tobytes(), emu.meas.tobytes(), emu.warn.tobytes(), emu.time.tobytes(), emu.xpos.tobytes(), emu.xquat.tobytes(),
+                np.array(rows).tobytes(), [device_state_bytes(emu.drive_state[e]) for e in range(n)]], np.array(rows), lib.emu_fast_bails()
+    finally:
+        lib.emu_fast_rows(0); lib.emu_two_waves(0); lib.emu_wave_schedule(0); lib.emu_poison_lds(0)
+
+
+@pytest.mark.parametrize("drive", [False, True])
+def test_two_wave_form_is_bit_for_bit_the_one_wave_form_under_every_wave_schedule(cassie, drive):
+    """NW = 2 computes every value by the same instructions from the same operands: state, outputs, solver statistics and the
+    drive-level state must equal the one-wave form's bit for bit -- with the waves taking turns, with wave 0 running ahead
+    to every barrier and with wave 1 doing so (an LDS race between the waves would show as a difference between schedules),
+    on a workload that hands envs over from the row-capped to the full instantiation in the middle of fused launches."""
+    ref, rows, _ = _two_wave_workload(cassie, drive, fast=True, two_waves=False, schedule=0)
+    assert rows[:, :, 1].max() > 31 and rows[:, :, 1].min() <= 31
+    for schedule in (0, 1, 2):
+        got, _, bails = _two_wave_workload(cassie, drive, fast=True, two_waves=True, schedule=schedule)
+        assert bails > 0
+        assert got == ref, schedule
+    # the full instantiation alone, two waves
+    got, _, _ = _two_wave_workload(cassie, drive, fast=False, two_waves=True, schedule=2)
+    assert got == ref
+
+
+def test_two_wave_form_never_reads_lds_it_has_not_written(cassie):
+    """LDS filled with NaN patterns at the start of every launch: same bits (wave 1 reads only what wave 0 -- or itself -- has
+    written in this launch)."""
+    ref, _, _ = _two_wave_workload(cassie, True, fast=True, two_waves=False, schedule=0, nlaunch=3, stress=False)
+    for schedule in (1, 2):
+        got, _, _ = _two_wave_workload(cassie, True, fast=True, two_waves=True, schedule=schedule, poison=True, nlaunch=3, stress=False)
+        assert got == ref
+
+
+@pytest.mark.parametrize("name", ["cassie_hfield", "cassie_tray_box"])
+def test_two_wave_form_on_the_other_models(name, built):
+    from cassie_amd import Model
+    model = Model(name)
+    ref, _, _ = _two_wave_workload(model, True, fast=True, two_waves=False, schedule=0, nlaunch=2, nsub=8, stress=False)
+    for schedule in (1, 2):
+        got, _, _ = _two_wave_workload(model, True, fast=True, two_waves=True, schedule=schedule, poison=True, nlaunch=2, nsub=8, stress=False)
+        assert got == ref

@@ -14,6 +14,8 @@ for n in (int(a) for a in (sys.argv[1:] or ["512", "4096"])):
     b = Batch(m, n)
     if os.environ.get("FULL_KERNEL"):
         b.set_fast_rows(False)      # the stamps of the full instantiation alone (default: the row-capped fast one, where an env fits it)
+    WAVES = int(os.environ.get("WAVES", "2"))
+    b.set_waves_per_env(WAVES)
     b.set(P.F_QPOS, np.tile(m.qpos_init(), (n, 1)))
     rng = np.random.default_rng(0)
     b.set(P.F_PD_PTARGET, np.array([0.0045, 0, 0.4973, -1.1997, -1.5968] * 2) + rng.uniform(-0.3, 0.3, (n, 10)))
@@ -24,6 +26,29 @@ for n in (int(a) for a in (sys.argv[1:] or ["512", "4096"])):
     ms = b.time_steps(NSUB, 50 if NSUB == 1 else 4) / NSUB
     st = b.profile_step(NSUB)
     w, info = b.warnings()
+    if WAVES == 2 and not os.environ.get("FULL_KERNEL"):
+        # two-wave form: wave 0 and wave 1 have timelines of their own, meeting at the barriers F, X and J
+        dur = lambda a, c: (st[:, c] - st[:, a]).astype(float).mean()
+        tot0 = dur(0, 14)
+        print("nenv %d, %d substeps per launch, TWO WAVES PER ENV: %.3f ms/step; wave 0's last substep %.0f cycles; nefc mean %.1f iters mean %.1f"
+              % (n, NSUB, ms, tot0, info[:, 1].mean(), info[:, 2].mean()))
+        for nm, a, c in [("w0 drive io + kinematics (incl. F)", 0, 1), ("w0 geoms", 1, 17), ("w0 collision (+ drive io)", 17, 33), ("w0 WAIT at X", 33, 5),
+                         ("w0 velocity+rne", 5, 6), ("w0 qfrc_smooth", 6, 7), ("w0 rows+J+sensors1", 7, 34), ("w0 WAIT at J", 34, 8), ("w0 halfsolve", 8, 9),
+                         ("w0 A", 9, 10), ("w0 pgs", 10, 11), ("w0 qacc", 11, 12), ("w0 sensors2", 12, 13), ("w0 euler", 13, 14),
+                         ("w1 WAIT at F", 35, 36), ("w1 com+cinert+cdof", 36, 2), ("w1 crba + M columns", 2, 3), ("w1 WAIT at X", 3, 38),
+                         ("w1 factor", 38, 4), ("w1 WAIT at J", 4, 39), ("w1 busy (F..factor done)", 36, 4), ("w0 F -> J (its parallel part)", 1, 8)]:
+            print("  %-36s %9.0f cycles  %5.1f%%" % (nm, dur(a, c), 100 * dur(a, c) / tot0))
+        hw0, hw1 = st[:, 40], st[:, 41]
+        simd = lambda h: (h >> 4) & 3
+        cu = lambda h: ((h >> 32) << 12) | (((h >> 13) & 7) << 5) | (((h >> 12) & 1) << 4) | ((h >> 8) & 15)
+        pairs = {}
+        for a, c in zip(simd(hw0), simd(hw1)):
+            pairs[(int(a), int(c))] = pairs.get((int(a), int(c)), 0) + 1
+        print("  placement: (SIMD of wave 0, SIMD of wave 1) -> envs:", dict(sorted(pairs.items())))
+        print("  same CU for both waves: %d of %d; heavy waves (wave 0) per SIMD id:" % (int(np.sum(cu(hw0) == cu(hw1))), n), np.bincount(simd(hw0), minlength=4).tolist(),
+              "; distinct CUs seen: %d; workgroup-slot ids:" % len(set(cu(hw0).tolist())), np.bincount((hw0 >> 16) & 15, minlength=16).tolist())
+        b.close()
+        continue
     d = np.diff(st[:, :15], axis=1).astype(float)
     tot = (st[:, 14] - st[:, 0]).astype(float)
     print("nenv %d, %d substeps per launch: %.3f ms/step; per-env kernel cycles mean %.0f (min %.0f max %.0f); nefc mean %.1f iters mean %.1f (guarded %.2f)"
