@@ -814,7 +814,7 @@ def main(argv=None):
         # whole GPU: algorithmic bytes of every env-step of a timed region / the region's time (= value x bytes per env-step);
         # one launch of the dominant kernel: its env-steps x bytes / its own mean duration
         launch_env_steps = n * steps_per_launch / r["streams"]
-        achieved_one = algo_bytes * launch_env_steps / (kern_ms * 1e-3) / 1e9
+        achieved_one = algo_bytes * launch_env_steps / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else None   # (None: the CPU stand-in times no kernel)
         achieved = algo_bytes * world * n * args.steps / elapsed / 1e9 / world
         rate = lambda sec: world * n * args.steps / sec
         value = rate(elapsed)
@@ -863,7 +863,7 @@ def main(argv=None):
                                            "overlap; ONE launch of the dominant kernel (%d env-steps, `kernel_ms` = its mean duration from a HIP "
                                            "event pair around every launch on its stream -- what rocprofv3 averages) moves %.2f GB/s, and a range "
                                            "needs `stream_ms_per_policy_step` per policy step (that kernel + the resume pass waiting for wave "
-                                           "slots + order / restart kernels)" % (r["streams"], launch_env_steps, achieved_one)) if r["streams"] > 1 else
+                                           "slots + order / restart kernels)" % (r["streams"], launch_env_steps, achieved_one or 0.0)) if r["streams"] > 1 else
                                           "algorithmic bytes of one launch / the dominant kernel's mean duration (a HIP event pair around every launch on the launch stream)",
                          "achieved_one_launch": achieved_one, "stream_ms_per_policy_step": r["stream_ms"], "kernel_launches_timed": r["kernel_launches"],
                          "kernel": {"cassie": "ck::cassie_step_kernel<32, ck::TopoCassie32, 0, 31> (row-capped fast instantiation; <..., 63> finishes handed-over envs)",

@@ -96,6 +96,7 @@ def _declare(L):
     L.phys_batch_set_balance.argtypes = [vp, c.c_int]
     L.phys_batch_set_fast_rows.argtypes = [vp, c.c_int]
     L.phys_batch_set_waves_per_env.argtypes = [vp, c.c_int]
+    L.phys_batch_download_cost.argtypes = [vp, vp]
     if hasattr(L, "phys_batch_kernel_timing"):
         L.phys_batch_enable_kernel_timing.argtypes = [vp, c.c_int]
         L.phys_batch_kernel_timing.argtypes = [vp, c.POINTER(c.c_int), c.POINTER(c.c_double)]

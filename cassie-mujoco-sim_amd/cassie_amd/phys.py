@@ -52,6 +52,7 @@ class Model:
     def __init__(self, path_or_name="cassie"):
         L = lib()
         err = ctypes.create_string_buffer(1024)
+        self.name = os.path.splitext(os.path.basename(str(path_or_name)))[0]   # "cassie", "cassie_hfield", ...
         self._h = L.phys_model_load(model_path(path_or_name).encode(), err, len(err))
         if not self._h:
             raise RuntimeError("model load failed: " + err.value.decode())
@@ -251,6 +252,13 @@ class Batch:
         """Two-wave form of the fast kernels (default 2; results are bit for bit the same either way)."""
         if lib().phys_batch_set_waves_per_env(self._h, int(waves)) != 0:
             raise ValueError("waves per env: 1 or 2")
+
+    def launch_cost(self):
+        """Shader clocks every env's last stepping launch took, first to last instruction (diagnostics; batches >= 2048 envs)."""
+        out = np.zeros(self.nenv, dtype=np.uint32)
+        if lib().phys_batch_download_cost(self._h, out.ctypes.data) != 0:
+            raise RuntimeError("cost download failed (balancing is off or the batch is small)")
+        return out.astype(np.float64) * 64.0
 
     def fast_rows_progress(self):
         """Substeps of the last stepping launch the fast kernel completed per env (< the launch's count: handed over there)."""

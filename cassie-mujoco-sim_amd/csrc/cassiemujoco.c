@@ -148,19 +148,27 @@ static void sim_recompile(cassie_sim_t *c)
 {
     const unsigned long long print = phys_model_fingerprint(c->m);
     if (print == c->model_print) return;
-    c->model_print = print;
+    /* (the fingerprint is recorded only once the edit has reached the device: a failed compile or upload is retried -- and
+     * reported -- by every later step instead of leaving the stale device model in use silently) */
     cm_model_t pod;
     char err[256];
     if (phys_model_compile(c->m, &pod, err, sizeof err) != 0) {
-        fprintf(stderr, "cassiemujoco: model compile failed: %s\n", err);
+        fprintf(stderr, "cassiemujoco: model compile failed (the device keeps the last good model; retried at the next step): %s\n", err);
         return;
     }
     if (memcmp(&pod, &c->pod, sizeof pod) != 0) {
+        if (phys_batch_set_model(c->b, &pod, -1) != 0) {
+            fprintf(stderr, "cassiemujoco: model upload failed (retried at the next step): %s\n", phys_last_error());
+            return;
+        }
         c->pod = pod;
-        phys_batch_set_model(c->b, &c->pod, -1);
         const float *hf = phys_model_hfield_data(c->m);
-        if (hf) phys_batch_set_hfield(c->b, hf, phys_model_size(c->m, PHYS_NHFIELDDATA));
+        if (hf && phys_batch_set_hfield(c->b, hf, phys_model_size(c->m, PHYS_NHFIELDDATA)) != 0) {
+            fprintf(stderr, "cassiemujoco: terrain upload failed (retried at the next step): %s\n", phys_last_error());
+            return;
+        }
     }
+    c->model_print = print;
 }
 
 static void sim_push_hfield(cassie_sim_t *c)

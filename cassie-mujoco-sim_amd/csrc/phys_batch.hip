@@ -52,7 +52,13 @@ struct phys_batch {
     bool balance = true;
     unsigned *d_cost = nullptr;
     int *d_order = nullptr;
-    int launches_since_order = 0;
+    /* d_order holds a permutation of the env ids of every range it was last sorted for (the order kernel sorts one launch's
+     * range [env0, env0 + n) at a time) and the identity everywhere else.  A launch may use the array only for a range that is
+     * exactly one of these segments, or that lies wholly in identity territory: any other range would step envs outside itself
+     * and skip envs inside it.  launch() keeps the list and puts overlapping segments back to the identity first. */
+    struct OrderSeg { int env0, n, launches_since_sort; };
+    std::vector<OrderSeg> order_segs;
+    std::vector<int> order_ident;   /* 0 .. nenv - 1, the source of those resets */
     cm_ext_t *d_ext = nullptr;
     /* per-kernel timing (phys_batch_kernel_timing): event pairs around the kernel of every stepping launch that does the work */
     bool timing = false;
@@ -128,10 +134,32 @@ static void note_stream(phys_batch *b, hipStream_t s) {
     b->recent_next = (b->recent_next + 1) % 4;
 }
 
+/* The launch-order array for the range [env0, env0 + n): returns the range's segment record (created if the range lies in
+ * identity territory), after resetting every segment that overlaps the range without coinciding with it (stream-ordered
+ * copies on the launch's stream; ranges in flight on other streams must not overlap this one anyway -- their state would race). */
+static phys_batch::OrderSeg *order_segment_for(phys_batch *b, int env0, int n, hipStream_t s) {
+    for (auto &g : b->order_segs) if (g.env0 == env0 && g.n == n) return &g;
+    for (size_t i = 0; i < b->order_segs.size();) {
+        const auto g = b->order_segs[i];
+        if (g.env0 < env0 + n && env0 < g.env0 + g.n) {
+            if (!hip_ok(hipMemcpyAsync(b->d_order + g.env0, b->order_ident.data() + g.env0, sizeof(int) * (size_t)g.n, hipMemcpyHostToDevice, s), "hipMemcpy(order reset)")) return nullptr;
+            b->order_segs.erase(b->order_segs.begin() + (long)i);
+        } else ++i;
+    }
+    b->order_segs.push_back({env0, n, 0});
+    return &b->order_segs.back();
+}
+
 static int launch(phys_batch *b, int nsub, int integrate, hipStream_t s, bool scratch_outputs = false, int env0 = 0, int n = -1) {
     ck::PhysIO io = make_io(b, nsub, integrate);
     if (n < 0) n = b->nenv;
     io.env0 = env0; io.nenv = n;
+    phys_batch::OrderSeg *seg = nullptr;
+    if (io.order && !integrate) { io.order = nullptr; io.cost = nullptr; } /* forward / read-out passes: one substep, nothing to balance (identity order) */
+    if (io.order) {
+        seg = order_segment_for(b, env0, n, s);
+        if (!seg) { io.order = nullptr; io.cost = nullptr; }
+    }
     if (scratch_outputs) {
         /* a read-out pass: the step outputs the caller's fields hold (sensordata and actuator_velocity of the last STEP feed
          * the encoder / motor models of the next one; qacc) stay as they are */
@@ -181,8 +209,8 @@ static int launch(phys_batch *b, int nsub, int integrate, hipStream_t s, bool sc
     if (!launched) { (void)hip_ok(hipErrorLaunchFailure, "cassie_step_kernel launch"); return -1; }
     if (!hip_ok(hipGetLastError(), "cassie_step_kernel launch")) return -1;
     /* the next launch's order from this one's per-env cost: after every long launch, now and then after short ones */
-    if (io.order && integrate && (nsub >= 8 || ++b->launches_since_order >= 16)) {
-        b->launches_since_order = 0;
+    if (io.order && integrate && (nsub >= 8 || ++seg->launches_since_sort >= 16)) {
+        seg->launches_since_sort = 0;
         hipLaunchKernelGGL(ck::cassie_order_kernel, dim3(1), dim3(ck::ORDER_THREADS), 0, s, b->d_cost, b->d_order, n, env0);
         if (!hip_ok(hipGetLastError(), "cassie_order_kernel launch")) return -1;
     }
@@ -245,10 +273,10 @@ phys_batch_t *phys_batch_create(const cm_model_t *model, int nenv, int device) {
     ok = ok && hip_ok(hipMalloc((void **)&b->d_info, sizeof(int) * 4 * nenv), "hipMalloc(info)");
     ok = ok && hip_ok(hipMemset(b->d_info, 0, sizeof(int) * 4 * nenv), "hipMemset(info)");
     if (nenv >= 2048) { /* fewer envs than a couple per wave slot leave nothing to balance */
-        std::vector<int> ident((size_t)nenv);
-        for (int e = 0; e < nenv; ++e) ident[(size_t)e] = e;
+        b->order_ident.resize((size_t)nenv);
+        for (int e = 0; e < nenv; ++e) b->order_ident[(size_t)e] = e;
         ok = ok && hip_ok(hipMalloc((void **)&b->d_order, sizeof(int) * (size_t)nenv), "hipMalloc(order)");
-        ok = ok && hip_ok(hipMemcpy(b->d_order, ident.data(), sizeof(int) * (size_t)nenv, hipMemcpyHostToDevice), "hipMemcpy(order)");
+        ok = ok && hip_ok(hipMemcpy(b->d_order, b->order_ident.data(), sizeof(int) * (size_t)nenv, hipMemcpyHostToDevice), "hipMemcpy(order)");
         ok = ok && hip_ok(hipMalloc((void **)&b->d_cost, sizeof(unsigned) * (size_t)nenv), "hipMalloc(cost)");
         ok = ok && hip_ok(hipMemset(b->d_cost, 0, sizeof(unsigned) * (size_t)nenv), "hipMemset(cost)");
     }
@@ -382,7 +410,8 @@ int phys_batch_upload(phys_batch_t *b, int field, const double *host, int env0, 
 int phys_batch_download(phys_batch_t *b, int field, double *host, int env0, int n) {
     if (!b || !host || field < 0 || field >= PHYS_F_COUNT || env0 < 0 || n < 0 || env0 + n > b->nenv) return -1;
     (void)hipSetDevice(b->device);
-    return copy_rows(b, field, host, env0, n, false, "download") && hip_ok(hipStreamSynchronize(b->stream), "download sync") ? 0 : -1;
+    /* (launches on callers' streams -- step_range, reset_envs -- may still be writing the field) */
+    return quiesce(b) && copy_rows(b, field, host, env0, n, false, "download") && hip_ok(hipStreamSynchronize(b->stream), "download sync") ? 0 : -1;
 }
 
 int phys_batch_upload_async(phys_batch_t *b, int field, const double *host, int env0, int n) {
@@ -409,7 +438,7 @@ void phys_host_free(void *p) { if (p) (void)hipHostFree(p); }
 int phys_batch_download_warn(phys_batch_t *b, int *host_warn, int *host_info) {
     if (!b) return -1;
     (void)hipSetDevice(b->device);
-    bool ok = hip_ok(hipStreamSynchronize(b->stream), "sync");
+    bool ok = quiesce(b);
     if (host_warn) ok = ok && hip_ok(hipMemcpy(host_warn, b->d_warn, sizeof(int) * b->nenv, hipMemcpyDeviceToHost), "warn");
     if (host_info) ok = ok && hip_ok(hipMemcpy(host_info, b->d_info, sizeof(int) * 4 * b->nenv, hipMemcpyDeviceToHost), "info");
     return ok ? 0 : -1;
@@ -584,7 +613,7 @@ int phys_batch_reset_envs(phys_batch_t *b, int first, int stride, int count, con
 int phys_batch_sync(phys_batch_t *b) {
     if (!b) return -1;
     (void)hipSetDevice(b->device);
-    return hip_ok(hipStreamSynchronize(b->stream), "hipStreamSynchronize") ? 0 : -1;
+    return quiesce(b) ? 0 : -1; /* the batch's stream and the callers' streams of the recent launches (step_range / reset_envs) */
 }
 
 int phys_batch_enable_ext(phys_batch_t *b, int on) {
@@ -691,6 +720,12 @@ int phys_batch_set_waves_per_env(phys_batch_t *b, int waves) {
     if (!b || (waves != 1 && waves != 2)) return -1;
     b->waves_per_env = waves;
     return 0;
+}
+
+int phys_batch_download_cost(phys_batch_t *b, unsigned *host) {
+    if (!b || !host || !b->d_cost) return -1;
+    (void)hipSetDevice(b->device);
+    return quiesce(b) && hip_ok(hipMemcpy(host, b->d_cost, sizeof(unsigned) * (size_t)b->nenv, hipMemcpyDeviceToHost), "cost download") ? 0 : -1;
 }
 
 int phys_batch_set_balance(phys_batch_t *b, int on) {

@@ -9,6 +9,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "physics_kernel.h"
 
 namespace ck {
@@ -20,12 +22,18 @@ bool launch_step_cassie_hfield(dim3 grid, hipStream_t s, PhysIO io, bool fast, h
 /* the two-wave forms of the fast instantiations, in translation units of their own (kernels_*_2w.hip) */
 bool launch_fast_cassie_2w(dim3 grid, hipStream_t s, PhysIO io);
 bool launch_fast_cassie_hfield_2w(dim3 grid, hipStream_t s, PhysIO io);
+/* ... and of the full instantiations in their role as the pass behind the fast kernel (io.resume = 1): there a workgroup must be
+ * placeable wherever a fast kernel's is -- two waves of 256 registers -- or it waits for a SIMD to empty while the other
+ * env range's kernel keeps every SIMD half full (the one-wave full kernel holds 421 registers) */
+bool launch_full_cassie_2w(dim3 grid, hipStream_t s, PhysIO io);
+bool launch_full_cassie_hfield_2w(dim3 grid, hipStream_t s, PhysIO io);
 bool launch_step_cassie_all(dim3 grid, hipStream_t s, PhysIO io);                   /* <32, TopoCassie32, FEAT_ALL> */
 bool launch_step_tray(dim3 grid, hipStream_t s, PhysIO io, bool hfield);            /* <40, TopoCassieTray38, FEAT_WAVEPAIRS | FEAT_ALL> */
 bool launch_step_generic(dim3 grid, hipStream_t s, PhysIO io, bool wide);           /* <32 | 40, TopoRuntime, FEAT_ALL> */
 
 template <int NVP, class TOPO, int FEAT>
-inline bool launch_fast_then_full(dim3 grid, hipStream_t s, PhysIO io, bool fast, hipEvent_t after_first, bool (*fast_2w)(dim3, hipStream_t, PhysIO)) {
+inline bool launch_fast_then_full(dim3 grid, hipStream_t s, PhysIO io, bool fast, hipEvent_t after_first, bool (*fast_2w)(dim3, hipStream_t, PhysIO),
+                                  bool (*full_2w)(dim3, hipStream_t, PhysIO)) {
     if (fast) {
         io.resume = 0;
         if (fast_2w) { if (!fast_2w(grid, s, io)) return false; }
@@ -36,7 +44,13 @@ inline bool launch_fast_then_full(dim3 grid, hipStream_t s, PhysIO io, bool fast
     } else {
         io.progress = nullptr; io.resume = 0;
     }
-    hipLaunchKernelGGL((cassie_step_kernel<NVP, TOPO, FEAT>), grid, dim3(WV_WAVE), 0, s, io);
+    /* (measurement aid, CASSIE_DEBUG_SKIP_RESUME_PASS: what the pass behind the fast kernel costs -- handed-over envs are then
+     * left unfinished, so only for workloads that hand nothing over) */
+    static const bool skip_resume = getenv("CASSIE_DEBUG_SKIP_RESUME_PASS") != nullptr;
+    static const bool resume_one_wave = getenv("CASSIE_DEBUG_RESUME_ONE_WAVE") != nullptr; /* (measurement aid: the pass behind a two-wave fast kernel as one-wave workgroups) */
+    if (fast && skip_resume) {}
+    else if (fast && full_2w && !resume_one_wave) { if (!full_2w(grid, s, io)) return false; }
+    else hipLaunchKernelGGL((cassie_step_kernel<NVP, TOPO, FEAT>), grid, dim3(WV_WAVE), 0, s, io);
     if (after_first) (void)hipEventRecord(after_first, s);
     return hipGetLastError() == hipSuccess;
 }

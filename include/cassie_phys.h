@@ -202,6 +202,9 @@ int phys_batch_set_all_outputs_every_substep(phys_batch_t *b, int on);
  * and the next launch starts the expensive envs first, so the wave slots finish together instead of the launch waiting
  * for whichever slot drew the slow envs last.  Results do not depend on it (envs are independent). */
 int phys_batch_set_balance(phys_batch_t *b, int on);
+/* diagnostics (batches of 2048 envs and more, balancing on): what the last stepping launch cost every env, in units of 64
+ * shader clocks from the env's first to its last instruction ([nenv] unsigned) -- the figure the launch order is sorted by */
+int phys_batch_download_cost(phys_batch_t *b, unsigned *host);
 /* on (default): stepping launches of the Cassie instantiations run the row-capped fast kernel first and the full kernel
  * only finishes envs that needed more than 31 constraint rows in some substep; off: the full kernel alone (same results,
  * bit for bit -- a validation / measurement aid) */

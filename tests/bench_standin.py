@@ -2,7 +2,9 @@
 ranks, env sharding, the per-range launch / restart / gather schedule, fences, max-over-ranks reduction, the parity rows of
 every rank reaching rank 0 under their global env ids, ONE JSON line from rank 0) can be driven end to end on a box without
 GPUs (`bench.py --dry-run-cpu`, tests/test_multirank.py).  No physics is computed and nothing is measured: a "step" adds
-nsub * 1e-3 * (the bound PD targets) to the first ten qpos columns, and the "CPU reference" replays that arithmetic.
+nsub * (the bound PD targets rounded to 1/1024: every sum is exact in fp64, whatever the launch boundaries) to the first ten
+qpos columns, and the "CPU reference" replays that arithmetic -- so the stand-in's qpos error is exactly zero unless a shard
+is mislabelled, a restart hits the wrong rows or a gather is out of global env order.
 Never imported by the product or by a GPU run of bench.py."""
 import contextlib
 import ctypes
@@ -65,7 +67,7 @@ class StandInBatch:
 
     def step_range(self, first, cnt, nsub, stream=None):
         tg = _view(self.ptr[self.P.F_PD_PTARGET], self.nenv, 10)
-        self._qpos()[first:first + cnt, :10] += (1e-3 * nsub) * tg[first:first + cnt]
+        self._qpos()[first:first + cnt, :10] += nsub * (np.round(tg[first:first + cnt] * 1024.0) / 1024.0)
         self.launches += 1
 
     def step(self, nsub, stream=None):
@@ -76,6 +78,7 @@ class StandInBatch:
         init = _view(init_ptr, 1, nobs)[0]
         rows = _view(self.ptr[self.P.F_QPOS], self.nenv, nobs, nobs)
         rows[r0:r0 + stride * k:stride] = init
+        rows[r0:r0 + stride * k:stride, :10] = 0.0        # (a dyadic base: the sums of the stand-in's "steps" stay exact)
 
     def kernel_timing(self):
         n, self.launches = self.launches, 0
@@ -98,9 +101,10 @@ class StandInEnvs:
 
     def restart(self, group):
         self.q[self.ids % self.bench.NGROUP == group] = self.q0
+        self.q[self.ids % self.bench.NGROUP == group, :10] = 0.0
 
     def step(self, nsub, targets, threads=1):
-        self.q[:, :10] += (1e-3 * nsub) * np.asarray(targets)
+        self.q[:, :10] += nsub * (np.round(np.asarray(targets) * 1024.0) / 1024.0)
 
     def qpos(self):
         return self.q.copy()

@@ -113,3 +113,34 @@ def test_emulated_drive_pd_path_against_the_host_chain_replay(cassie, monkeypatc
     orc = bench.replay_on_oracle(cassie, ids, lambda p: tg[p], total, envs=bench.HostChainEnvs)
     assert np.max(np.abs(emu.qpos - orc.qpos())) < 1e-11
     assert np.array_equal(emu.info[:, :3], orc.counts())
+
+
+def test_hand_over_figure_counts_against_the_last_launch_not_against_hold():
+    """the driver's `--steps 20` regions end with a 20-substep launch; the fast kernel records 20 completed
+    substeps for an env it did NOT hand over, which must not read as "handed over" because 20 < HOLD."""
+    import bench
+    progress = np.array([20, 20, 20, 7, 20, 0])
+    assert bench.handed_over_in_last_launch(progress, 20) == 2.0          # the envs short of THIS launch's 20 substeps
+    assert bench.handed_over_in_last_launch(np.full(4096, 20), 20) == 0.0
+    assert bench.handed_over_in_last_launch(np.full(4096, 50), 50) == 0.0
+    assert bench.has_fast_kernel("cassie") and bench.has_fast_kernel("cassie_hfield") and not bench.has_fast_kernel("cassie_tray_box")
+    # the schedule of `--steps 20 --warmup 5` after the pre-roll: the last launch of a region has at most 20 substeps
+    seen = []
+    sch = bench.Schedule(step=seen.append, bind_targets=lambda p: None, restart=lambda g: None)
+    sch.run(bench.PREROLL + 5, 20)
+    assert sum(seen) == 20 and seen[-1] <= 20
+
+
+def test_pmc_traffic_scales_only_the_per_substep_part(cassie):
+    """roofline.traffic for a launch of another length than the profiled 50 substeps: the per-env launch I/O (state in, state
+    and last-substep outputs out) stays, only the per-env-step remainder scales."""
+    import bench
+    pod = cassie.pod
+    fixed = bench.launch_io_bytes_per_env(pod)
+    assert 5000 < fixed < 12000
+    t50, src = bench.pmc_traffic(4096 * 50, "cassie", envs_per_launch=4096, pod=pod)
+    t20, _ = bench.pmc_traffic(4096 * 20, "cassie", envs_per_launch=4096, pod=pod)
+    if t50 is None:
+        pytest.skip("no committed PMC summary")
+    assert t20 > 0.4 * t50 + 0.5 * fixed * 4096 * 0.6          # far above the linear 0.4 x: the fixed part does not shrink
+    assert t20 >= fixed * 4096 and t20 < t50

@@ -387,3 +387,40 @@ def test_stepping_in_ranges_on_two_streams_equals_stepping_the_whole_batch(cassi
     assert not out[0][6].any() and out[0][7][:, 0].max() >= 2
     for a, c in zip(out[0], out[1]):
         assert a.tobytes() == c.tobytes()
+
+
+def test_launch_order_survives_a_change_of_the_range_partition(cassie):
+    """the longest-job-first order array is a permutation PER RANGE it was sorted for.  A whole-batch launch
+    sorts [0, n); a later step_range over half the batch -- or over ranges that straddle the old ones -- must still step
+    exactly its own envs, each once: the library puts segments that overlap a new range back to the identity first.  Envs are
+    independent, so however the batch is cut into launches the state must equal that of whole-batch stepping, bit for bit."""
+    import torch
+    n = 4096                                               # (balancing is on for batches of 2048 envs and more)
+    tg = bench.pd_targets(np.arange(n), 3)
+    q0 = np.tile(cassie.qpos_init(), (n, 1))
+    q0[:, 2] -= 0.01 * (np.arange(n) % 7)                  # different contact situations -> different costs -> a real permutation
+
+    def run(cut):
+        b = Batch(cassie, n)
+        try:
+            b.set(P.F_QPOS, q0)
+            b.set(P.F_PD_KP, np.tile(bench.PD_KP, (n, 1))); b.set(P.F_PD_KD, np.tile(bench.PD_KD, (n, 1)))
+            b.set_pd_mode(True)
+            s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+            for p in range(3):
+                b.set(P.F_PD_PTARGET, tg[p])
+                for k, (first, cnt) in enumerate(cut(p)):
+                    if (first, cnt) == (0, n):
+                        b.step(20)
+                    else:
+                        b.step_range(first, cnt, 20, (s1, s2)[k % 2].cuda_stream)
+                b.sync()                                   # (waits for the callers' streams too)
+            return b.get(P.F_QPOS), b.get(P.F_QVEL), b.warnings()[1][:, :3].copy()
+        finally:
+            b.close()
+    whole = run(lambda p: [(0, n)])
+    halves_after_whole = run(lambda p: [(0, n)] if p == 0 else [(0, n // 2), (n // 2, n // 2)])
+    straddling = run(lambda p: [(0, n // 2), (n // 2, n // 2)] if p == 0 else ([(0, 1500), (1500, n - 1500)] if p == 1 else [(0, 1000), (1000, 2000), (3000, n - 3000)]))
+    for other in (halves_after_whole, straddling):
+        for a, c in zip(whole, other):
+            assert a.tobytes() == c.tobytes()

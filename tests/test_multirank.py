@@ -207,3 +207,38 @@ def test_env_ranges_and_restart_rows_per_stream():
                 assert c == 0 or (rows[0] >= first and rows[-1] < first + cnt)
                 got.append(rows)
             assert np.array_equal(np.concatenate(got), want), (rank, n, k, g)
+
+
+def test_bench_main_starts_its_own_ranks_and_prints_one_line_for_all_of_them():
+    """`python3 bench.py --gpus 2` the way the driver starts N = 1 -- no launcher, WORLD_SIZE unset: main() must start the two
+    ranks itself (torch.distributed.run on 127.0.0.1, a port picked free), shard the envs, run the per-range launch /
+    restart / gather schedule and the fenced regions on every rank, and rank 0 must print ONE JSON line with n_gpus = 2, the
+    gathered observation block verified and the parity rows of BOTH ranks labelled with their rank.  Runs on CPU ranks
+    (gloo) with the stand-in for the GPU batch (tests/bench_standin.py, `--dry-run-cpu`): no physics, the control flow is
+    what is under test -- a mislabelled shard or a gather out of global env order shows as a non-zero stand-in error."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "60", "--warmup", "20", "--repeats", "2",
+           "--envs-per-gpu", "48", "--parity-envs", "12", "--dry-run-cpu"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 60 and d["warmup"] == 20 and d["scaling"] == "weak"
+    assert d["config"]["envs_total"] == 96 and d["config"]["parallelism"] == "env-sharded x2"
+    assert d["obs_allgather_ok"] is True
+    assert d["config"]["obs_allgather_every_steps"] == 50
+    per_rank = d["parity"]["max_qpos_err_per_rank"]
+    assert sorted(per_rank) == ["0", "1"] and d["parity"]["ranks_compared"] == 2
+    assert d["max_qpos_err"] == 0.0 and all(v == 0.0 for v in per_rank.values())
+    assert d["value"] > 0 and d["value_min"] <= d["value"] <= d["value_max"]
+    assert "stand-in" in d["data"]                     # nobody can mistake this line for a measurement
+
+
+def test_bench_refuses_a_rank_count_that_is_not_the_launchers():
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--dry-run-cpu"], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode != 0 and "WORLD_SIZE" in (out.stderr + out.stdout)

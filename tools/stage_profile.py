@@ -24,7 +24,22 @@ for n in (int(a) for a in (sys.argv[1:] or ["512", "4096"])):
     b.set_pd_mode(True)
     b.step(300); b.sync()
     ms = b.time_steps(NSUB, 50 if NSUB == 1 else 4) / NSUB
+    if os.environ.get("TWO_STREAM_LOAD"):
+        # the stamps of a launch that shares the GPU with another batch's launches (the bench's two-range stepping): a second batch is
+        # given two launches of its own, asynchronously, right before the profiled launch
+        b2 = Batch(m, n)
+        b2.set_waves_per_env(WAVES)
+        b2.set(P.F_QPOS, b.get(P.F_QPOS)); b2.set(P.F_QVEL, b.get(P.F_QVEL))
+        b2.set(P.F_PD_PTARGET, b.get(P.F_PD_PTARGET)); b2.set(P.F_PD_KP, b.get(P.F_PD_KP)); b2.set(P.F_PD_KD, b.get(P.F_PD_KD))
+        b2.set_pd_mode(True)
+        b2.step(NSUB); b2.sync()
+        b2.step(NSUB); b2.step(NSUB); b2.step(NSUB)
     st = b.profile_step(NSUB)
+    if os.environ.get("TWO_STREAM_LOAD"):
+        b2.sync(); b2.close()
+    if n >= 2048:
+        c = b.launch_cost()
+        print("  whole launch per env: %.0f shader clocks = %.0f per substep (mean; min %.0f max %.0f per substep)" % (c.mean(), c.mean() / NSUB, c.min() / NSUB, c.max() / NSUB))
     w, info = b.warnings()
     if WAVES == 2 and not os.environ.get("FULL_KERNEL"):
         # two-wave form: wave 0 and wave 1 have timelines of their own, meeting at the barriers F, X and J
