@@ -2,7 +2,8 @@
 #include "step_launch.h"
 namespace ck {
 bool launch_full_cassie_hfield_2w(dim3 grid, hipStream_t s, PhysIO io) {
-    hipLaunchKernelGGL((cassie_step_kernel<32, TopoCassie32, FEAT_HFIELD, CM_MAXEFC, 2>), grid, dim3(2 * WV_WAVE), 0, s, io);
+    if (io.handover_list) hipLaunchKernelGGL((cassie_step_kernel<32, TopoCassie32, FEAT_HFIELD, CM_MAXEFC, 2, true>), grid, dim3(2 * WV_WAVE), 0, s, io);
+    else hipLaunchKernelGGL((cassie_step_kernel<32, TopoCassie32, FEAT_HFIELD, CM_MAXEFC, 2>), grid, dim3(2 * WV_WAVE), 0, s, io);
     return hipGetLastError() == hipSuccess;
 }
 }  // namespace ck

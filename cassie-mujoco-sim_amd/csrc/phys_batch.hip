@@ -65,6 +65,10 @@ struct phys_batch {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
     size_t ev_used = 0;
     int *d_progress = nullptr;      /* [nenv] substeps completed by the row-capped fast instantiation (PhysIO::progress) */
+    /* the hand-over list (PhysIO::handover_list): env ids per range, [count, ticket] pairs indexed by a range's first env, and
+     * -- in pinned host memory the device writes -- the number of envs the last launch of a range handed over */
+    int *d_handover_list = nullptr, *d_handover_count = nullptr;
+    int *h_handover_seen = nullptr, *d_handover_seen = nullptr;
     bool fast_rows = true;          /* use the row-capped fast instantiation where one exists (phys_batch_set_fast_rows) */
     int waves_per_env = 2;          /* two-wave form of the fast instantiations (phys_batch_set_waves_per_env) */
     double *d_scratch_out = nullptr; /* [nenv][nv + nsensordata + nu]: where phys_batch_forward_kinematics sends qacc / sensordata / actuator_velocity */
@@ -200,8 +204,18 @@ static int launch(phys_batch *b, int nsub, int integrate, hipStream_t s, bool sc
          * behind it finishes the envs that met a substep with more rows (and is the only one for forward / read-out passes) */
         const bool fast = b->fast_rows && integrate && !wp && !io.ext && b->d_progress;
         io.progress = fast ? b->d_progress : nullptr;
-        if (!hf && !wp) { launched = ck::launch_step_cassie(grid, s, io, fast, ev_after, b->waves_per_env); ev_after = nullptr; }
-        else if (hf && !wp) { launched = ck::launch_step_cassie_hfield(grid, s, io, fast, ev_after, b->waves_per_env); ev_after = nullptr; }
+        dim3 pass_grid = grid;
+        if (fast && b->d_handover_list) {
+            /* the pass behind the fast kernel walks the hand-over list with a small grid: twice what the range's last launch
+             * handed over (the launcher learns that a launch late, through host memory) plus 16, at most one workgroup per env */
+            io.handover_list = b->d_handover_list; io.handover_count = b->d_handover_count + 2 * (size_t)env0;
+            io.handover_seen = b->d_handover_seen + env0;
+            const int seen = b->h_handover_seen[env0];
+            const long want = 2L * (seen > 0 ? seen : 0) + 16;
+            pass_grid = dim3((unsigned)(want < n ? want : n));
+        }
+        if (!hf && !wp) { launched = ck::launch_step_cassie(grid, pass_grid, s, io, fast, ev_after, b->waves_per_env); ev_after = nullptr; }
+        else if (hf && !wp) { launched = ck::launch_step_cassie_hfield(grid, pass_grid, s, io, fast, ev_after, b->waves_per_env); ev_after = nullptr; }
         else launched = ck::launch_step_cassie_all(grid, s, io);
     } else if (matches(ck::TopoCassieTray38::table, ck::TopoCassieTray38::nv, ck::TopoCassieTray38::body_levels)) launched = ck::launch_step_tray(grid, s, io, hf);
     else launched = ck::launch_step_generic(grid, s, io, hm.nv > 32);
@@ -282,6 +296,12 @@ phys_batch_t *phys_batch_create(const cm_model_t *model, int nenv, int device) {
     }
     ok = ok && hip_ok(hipMalloc((void **)&b->d_progress, sizeof(int) * (size_t)nenv), "hipMalloc(progress)");
     ok = ok && hip_ok(hipMemset(b->d_progress, 0, sizeof(int) * (size_t)nenv), "hipMemset(progress)");
+    ok = ok && hip_ok(hipMalloc((void **)&b->d_handover_list, sizeof(int) * (size_t)nenv), "hipMalloc(hand-over list)");
+    ok = ok && hip_ok(hipMalloc((void **)&b->d_handover_count, sizeof(int) * 2 * (size_t)nenv), "hipMalloc(hand-over counts)");
+    ok = ok && hip_ok(hipMemset(b->d_handover_count, 0, sizeof(int) * 2 * (size_t)nenv), "hipMemset(hand-over counts)");
+    ok = ok && hip_ok(hipHostMalloc((void **)&b->h_handover_seen, sizeof(int) * (size_t)nenv, hipHostMallocMapped), "hipHostMalloc(hand-over seen)");
+    if (ok) memset(b->h_handover_seen, 0, sizeof(int) * (size_t)nenv);
+    ok = ok && hip_ok(hipHostGetDevicePointer((void **)&b->d_handover_seen, b->h_handover_seen, 0), "hipHostGetDevicePointer");
     ok = ok && hip_ok(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking), "hipStreamCreate");
     ok = ok && hip_ok(hipEventCreate(&b->ev0), "hipEventCreate") && hip_ok(hipEventCreate(&b->ev1), "hipEventCreate");
     ok = ok && hip_ok(hipEventCreateWithFlags(&b->ev_mark, hipEventDisableTiming), "hipEventCreate");
@@ -308,6 +328,9 @@ void phys_batch_free(phys_batch_t *b) {
     if (b->d_ext) (void)hipFree(b->d_ext);
     if (b->d_scratch_out) (void)hipFree(b->d_scratch_out);
     if (b->d_progress) (void)hipFree(b->d_progress);
+    if (b->d_handover_list) (void)hipFree(b->d_handover_list);
+    if (b->d_handover_count) (void)hipFree(b->d_handover_count);
+    if (b->h_handover_seen) (void)hipHostFree(b->h_handover_seen);
     for (auto &e : b->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (b->d_drive) (void)hipFree(b->d_drive);
     if (b->d_order) (void)hipFree(b->d_order);

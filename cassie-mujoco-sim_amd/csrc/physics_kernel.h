@@ -125,6 +125,14 @@ struct PhysIO {
      * there (and returns at once for the others).  progress may be null (then resume must be 0). */
     int *progress;
     int resume;
+    /* The hand-over list (may be null: then the pass behind the fast kernel is one workgroup per env of the launch, each looking
+     * up its env's record).  The fast instantiation appends every env it hands over to handover_list[env0 ...] (one atomic add on
+     * *handover_count per env); the pass behind it is then a SMALL fixed grid whose workgroups walk the list -- entry blockIdx,
+     * blockIdx + gridDim, ... -- so that a launch that handed nothing over costs a few workgroup placements, not one per env.
+     * The last workgroup of the pass to finish (a ticket on handover_count[1]) zeroes the count for the next launch and reports
+     * it to *handover_seen (host memory: the launcher sizes the next pass's grid by it). */
+    int *handover_list, *handover_count;
+    volatile int *handover_seen;
 };
 
 /* MAXR: constraint rows this instantiation can hold (CM_MAXEFC, or fewer in the row-capped fast instantiation, see
@@ -169,7 +177,8 @@ struct EnvShared {
     int c_root[CM_MAXCON][2];               /* tree roots of the two bodies, their dof chains, summed inverse weights */
     unsigned long long c_dofmask[CM_MAXCON][2];
     double c_tran[CM_MAXCON];
-    /* two-wave form (NW = 2): what wave 0 tells wave 1 at the workgroup barriers -- 0 = carry on, 1 = this env's launch ends here */
+    /* two-wave form (NW = 2): cmd[0] = what wave 0 tells wave 1 at the workgroup barriers -- 0 = carry on, 1 = this env's launch
+     * ends here; cmd[1] = the substep (+ 1) whose body forces wave 0's velocity stage has put in LDS (wave 1 waits for it) */
     int cmd[2];
 };
 
@@ -1184,11 +1193,294 @@ WV_DRIVE_FN void drive_level_io(const PhysIO &io, SH &S, ModelPtr m, int env, in
     }
 }
 
+/* FEAT selects the collision code a model needs (see env_step) */
+enum { FEAT_HFIELD = 1, FEAT_WAVEPAIRS = 2, FEAT_ALL = 3 };
+
+/* what a lane is, as a body and as a dof: model indices read once per launch and handed to the stage functions that both waves of
+ * the two-wave form call */
+struct LaneIds { int nbody, nv, broot, bend, kjnt, kbody, kjt, kda, kroot, kbend; unsigned long long kdesc; };
+
+/* ---------------- the mass-matrix stage group: com of every kinematic tree, cinert, cdof, composite inertias, M's columns.
+ * One-wave form: called in line by the substep loop, between the geoms and the factorisations.  Two-wave form: wave 1's
+ * program calls it between the barriers F and X.  Reads the pose tiles (xmat, xipos, xanchor, xaxis), writes com, cinert, cdof,
+ * crb and the buf tile; leaves the lane's columns of M and M + hB in col / colh.  (A function, not a lambda of env_step: a
+ * closure over the lane variables that the stage boundaries re-derive would pin them in memory.) ---------------- */
+template <int NVP, class TOPO, int FEAT, int NW, class SH>
+WV_DEVICE void mass_matrix_columns(const PhysIO &io, SH &S, ModelPtr m, int env, const LaneIds &ids, const double pf_mass, const double (&pf_iner)[3],
+                                   const double (&ximat)[9], double (&col)[NVP], double (&colh)[NVP]) {
+    const int nbody = ids.nbody, nv = ids.nv, broot = ids.broot, bend = ids.bend, kjnt = ids.kjnt, kbody = ids.kbody, kjt = ids.kjt, kda = ids.kda, kroot = ids.kroot;
+    const unsigned long long kdesc = ids.kdesc;
+    int lane = wv::fresh_lane(), b = lane, k_ = lane;
+    bool isbody = b < nbody, isdof = k_ < nv;
+    /* where crb[body] . cdof goes between the composite inertias and M's columns: the buf tile -- except in the two-wave
+     * height-field form, where wave 0's height-field result table lies over that tile at this time: there the joint
+     * anchors / axes, which nothing reads once cdof is formed, give their place */
+    constexpr bool cbuf_over_anchors = NW == 2 && (FEAT & FEAT_HFIELD) != 0;
+    static_assert(!cbuf_over_anchors || NVP <= CM_MAXJNT, "crb . cdof (NVP x 6) must fit the xanchor + xaxis tiles");
+    static_assert(offsetof(decltype(S.x.s), xaxis) - offsetof(decltype(S.x.s), xanchor) == sizeof(double) * CM_MAXJNT * 3, "xanchor and xaxis are contiguous");
+    double (*const cbuf)[6] = cbuf_over_anchors ? reinterpret_cast<double (*)[6]>(&S.x.s.xanchor[0][0]) : S.x.s.buf;
+    /* ================= com of every kinematic tree (wave reduction per root) ================= */
+    const double bmass = (isbody && b > 0) ? pf_mass : 0.0;
+    {
+        /* one masked DPP tree reduction per kinematic tree (wave_sum returns the total in every lane) */
+        const double px = isbody ? S.x.s.xipos[b < NB ? b : 0][0] : 0.0, py = isbody ? S.x.s.xipos[b < NB ? b : 0][1] : 0.0,
+                     pz = isbody ? S.x.s.xipos[b < NB ? b : 0][2] : 0.0;
+        for (int ri = 0; ri < m->nroot; ++ri) {
+            const int r = m->root_body[ri], e = m->body_subtreeend[r];
+            const double w = (isbody && b >= r && b < e) ? bmass : 0.0;
+            const double sm = wv::wave_sum(w), sx = wv::wave_sum(w * px), sy = wv::wave_sum(w * py), sz = wv::wave_sum(w * pz);
+            if (lane == 0) {
+                if (sm < CM_MINVAL) { S.com[r][0] = S.x.s.xipos[r][0]; S.com[r][1] = S.x.s.xipos[r][1]; S.com[r][2] = S.x.s.xipos[r][2]; }
+                else { const double inv = 1.0 / sm; S.com[r][0] = sx * inv; S.com[r][1] = sy * inv; S.com[r][2] = sz * inv; }
+            }
+        }
+    }
+    wv::sync();
+    CK_STAMP(18);
+    /* ================= cinert (lane = body), cdof (lane = dof) ================= */
+    if (lane < NB) {
+        double ci[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (isbody && b > 0) {
+            const double I0 = pf_iner[0], I1 = pf_iner[1], I2 = pf_iner[2];
+            const double *c = S.com[broot];
+            double dif[3] = {S.x.s.xipos[b][0] - c[0], S.x.s.xipos[b][1] - c[1], S.x.s.xipos[b][2] - c[2]};
+            double d2 = dot3(dif, dif);
+            const double *R = ximat;
+            double W00 = R[0] * I0 * R[0] + R[1] * I1 * R[1] + R[2] * I2 * R[2];
+            double W11 = R[3] * I0 * R[3] + R[4] * I1 * R[4] + R[5] * I2 * R[5];
+            double W22 = R[6] * I0 * R[6] + R[7] * I1 * R[7] + R[8] * I2 * R[8];
+            double W01 = R[0] * I0 * R[3] + R[1] * I1 * R[4] + R[2] * I2 * R[5];
+            double W02 = R[0] * I0 * R[6] + R[1] * I1 * R[7] + R[2] * I2 * R[8];
+            double W12 = R[3] * I0 * R[6] + R[4] * I1 * R[7] + R[5] * I2 * R[8];
+            ci[0] = W00 + bmass * (d2 - dif[0] * dif[0]);
+            ci[1] = W11 + bmass * (d2 - dif[1] * dif[1]);
+            ci[2] = W22 + bmass * (d2 - dif[2] * dif[2]);
+            ci[3] = W01 - bmass * dif[0] * dif[1];
+            ci[4] = W02 - bmass * dif[0] * dif[2];
+            ci[5] = W12 - bmass * dif[1] * dif[2];
+            ci[6] = bmass * dif[0]; ci[7] = bmass * dif[1]; ci[8] = bmass * dif[2]; ci[9] = bmass;
+        }
+        for (int i = 0; i < 10; ++i) S.x.s.cinert[lane][i] = ci[i];
+    }
+    {
+    double cd[6] = {0, 0, 0, 0, 0, 0};
+    if (isdof) {
+        const double *c = S.com[kroot];
+        double off[3] = {c[0] - S.x.s.xanchor[kjnt][0], c[1] - S.x.s.xanchor[kjnt][1], c[2] - S.x.s.xanchor[kjnt][2]};
+        const int sub_k = k_ - kda;
+        if (kjt == CM_JNT_SLIDE) {
+            for (int i = 0; i < 3; ++i) cd[3 + i] = S.x.s.xaxis[kjnt][i];
+        } else if (kjt == CM_JNT_HINGE) {
+            for (int i = 0; i < 3; ++i) cd[i] = S.x.s.xaxis[kjnt][i];
+            cross3(cd + 3, cd, off);
+        } else if (kjt == CM_JNT_FREE && sub_k < 3) {
+            cd[3 + sub_k] = 1.0;
+        } else {
+            const int a = (kjt == CM_JNT_FREE) ? sub_k - 3 : sub_k;
+            cd[0] = S.x.s.xmat[kbody][a]; cd[1] = S.x.s.xmat[kbody][3 + a]; cd[2] = S.x.s.xmat[kbody][6 + a];
+            cross3(cd + 3, cd, off);
+        }
+    }
+    if (lane < NVP) for (int i = 0; i < 6; ++i) S.cdof[lane][i] = cd[i]; /* zero rows past nv */
+    }
+    wv::sync();
+    CK_STAMP(2);
+
+    /* ================= P2 CRBA: composite inertias, then one COLUMN of M per lane ================= */
+    /* composite inertias: crb_b = sum of cinert_c over the contiguous subtree range [b, bend): dense loop over all
+     * bodies with a per-lane range predicate, operands staged four bodies at a time */
+    /* A 0/1-weighted sum over bodies is a matrix product, W (body x body: c in b's subtree) times cinert (body x 10), and its
+     * result layout on the matrix core -- lane l holds rows (l >> 4) + 4 v, column l & 15 -- is a layout the LDS tile can be
+     * written in directly: 16 v_mfma_f64_16x16x4_f64 (two blocks of 16 bodies x eight blocks of four summands, even and odd
+     * blocks in separate accumulators), the weights built from the subtree masks in registers, the summands single LDS reads.
+     * (fma(1, x, acc) is acc + x, fma(0, x, acc) is acc: the sums are plain sums, in body order.) */
+    {
+        const int mi = lane & 15, mk = lane >> 4;
+        const unsigned mine = (isbody && b > 0) ? (unsigned)(((1ull << bend) - 1ull) ^ ((1ull << b) - 1ull)) : 0u; /* bodies [b, bend) */
+        const unsigned w0 = (unsigned)wv::shfl_i((int)mine, mi) >> mk, w1 = (unsigned)wv::shfl_i((int)mine, 16 + mi) >> mk;
+        double bv[NB / 4];
+#pragma unroll
+        for (int kb = 0; kb < NB / 4; ++kb) { const double v = S.x.s.cinert[4 * kb + mk][mi < 10 ? mi : 0]; bv[kb] = mi < 10 ? v : 0.0; }
+        wv::mfma_acc d0a = {{0, 0, 0, 0}}, d0b = {{0, 0, 0, 0}}, d1a = {{0, 0, 0, 0}}, d1b = {{0, 0, 0, 0}};
+#pragma unroll
+        for (int kb = 0; kb < NB / 4; kb += 2)
+            wv::mfma_f64_16x16x4_x4((double)((w0 >> (4 * kb)) & 1u), bv[kb], d0a, (double)((w1 >> (4 * kb)) & 1u), bv[kb], d1a,
+                                    (double)((w0 >> (4 * kb + 4)) & 1u), bv[kb + 1], d0b, (double)((w1 >> (4 * kb + 4)) & 1u), bv[kb + 1], d1b);
+        wv::mfma_f64_drain4(d0a, d0b, d1a, d1b);
+        if (mi < 10) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                S.x.s.crb[mk + 4 * v][mi] = d0a.c[v] + d0b.c[v];
+                S.x.s.crb[16 + mk + 4 * v][mi] = d1a.c[v] + d1b.c[v];
+            }
+        }
+    }
+    wv::sync();
+    CK_STAMP(19);
+    if (lane < NVP) {
+        double bf[6] = {0, 0, 0, 0, 0, 0}, cd[6];
+        for (int i = 0; i < 6; ++i) cd[i] = S.cdof[lane][i];
+        if (isdof) mul_inert_vec(bf, S.x.s.crb[kbody], cd);
+        for (int i = 0; i < 6; ++i) cbuf[lane][i] = bf[i];
+    }
+    wv::sync();
+    CK_STAMP(20);
+    double cdm[6]; /* this lane's motion axis, fetched where it is used rather than carried in registers */
+    /* armature and h * damping sit on the diagonal only: they are added where the pivots are read (wave-uniform
+     * scalars there) instead of being selected into one lane-dependent entry of each column here */
+    /* M[i][lane] = cdof_lane . (crb[body_i] cdof_i): the buf rows are broadcast reads, staged eight rows at a time so
+     * the LDS latency is paid once per group instead of once per row */
+    if constexpr (NVP == 32) {
+        /* 32 columns on 64 lanes: lanes l and l + 32 both work for column l, on rows [0, 16) and [16, 32); the lower lane
+         * takes the upper one's sixteen entries through the lane swap */
+        const int hk = lane & 31, roff = lane < 32 ? 0 : 16;
+        const unsigned hdesc = (unsigned)wv::shfl_i((int)(unsigned)kdesc, hk) >> roff; /* (kdesc: no bit at or past nv <= 32) */
+        for (int i = 0; i < 6; ++i) cdm[i] = S.cdof[hk][i];
+        const double (*bufr)[6] = &cbuf[roff];
+        double part[16];
+#pragma unroll
+        for (int i0 = 0; i0 < 16; i0 += 8) {
+            double bb[8][6];
+#pragma unroll
+            for (int ii = 0; ii < 8; ++ii)
+#pragma unroll
+                for (int t = 0; t < 6; ++t) bb[ii][t] = bufr[i0 + ii][t];
+            wv::sched_fence();
+#pragma unroll
+            for (int ii = 0; ii < 8; ++ii) {
+                const double v = (cdm[0] * bb[ii][0] + cdm[1] * bb[ii][1]) + (cdm[2] * bb[ii][2] + cdm[3] * bb[ii][3]) + (cdm[4] * bb[ii][4] + cdm[5] * bb[ii][5]);
+                part[i0 + ii] = ((hdesc >> (i0 + ii)) & 1u) ? v : 0.0;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const double up = wv::from_upper_half(part[i]);
+            col[i] = part[i]; colh[i] = part[i];
+            col[16 + i] = up; colh[16 + i] = up;
+        }
+    } else {
+    for (int i = 0; i < 6; ++i) cdm[i] = S.cdof[lane < NVP ? lane : 0][i];
+#pragma unroll
+    for (int i0 = 0; i0 < NVP; i0 += 8) {
+        double bb[8][6];
+#pragma unroll
+        for (int ii = 0; ii < 8; ++ii)
+#pragma unroll
+            for (int t = 0; t < 6; ++t) bb[ii][t] = cbuf[i0 + ii][t];
+        wv::sched_fence();
+#pragma unroll
+        for (int ii = 0; ii < 8; ++ii) {
+            const int i = i0 + ii;
+            double v = (cdm[0] * bb[ii][0] + cdm[1] * bb[ii][1]) + (cdm[2] * bb[ii][2] + cdm[3] * bb[ii][3]) + (cdm[4] * bb[ii][4] + cdm[5] * bb[ii][5]);
+            /* kdesc holds no bit at or past nv; with a compile-time topology the bound is a constant, not a branch */
+            if (TOPO::is_static ? (i >= TOPO::nv || !((kdesc >> i) & 1ull)) : !(i < nv && ((kdesc >> i) & 1ull))) v = 0;
+            col[i] = v;
+            colh[i] = v;
+        }
+    }
+    }
+    if (io.ext && isdof) {
+        cm_ext_t *ex = io.ext + env;
+#pragma unroll
+        for (int i = 0; i < NVP; ++i) if (i < nv && i >= k_) { const double v = (i == k_) ? col[i] + m->dof_armature[k_] : col[i]; ex->qM[i][k_] = v; ex->qM[k_][i] = v; }
+    }
+    CK_STAMP(3);
+}
+
+/* ---------------- bias forces projected on the motion axes, passive forces, actuation -> qfrc_smooth (lane = dof).  Reads the
+ * cfrc tile the velocity stage left, cdof, qpos / qvel / ctrl; writes S.qfrc_smooth.  One-wave form: in line behind the
+ * velocity stage.  Two-wave form: wave 1, behind its factorisations, once wave 0 has published the cfrc tile. ---------------- */
+template <int NVP, class SH>
+WV_DEVICE void bias_forces_and_qfrc_smooth(const PhysIO &io, SH &S, ModelPtr m, int env, const LaneIds &ids, const double kdamp, const double kstiff,
+                                           const double kref, const double kgear, const double klo, const double khi, const int kq, const int ka) {
+    const int nbody = ids.nbody, nv = ids.nv, kbody = ids.kbody, kbend = ids.kbend;
+    int lane = wv::fresh_lane(), b = lane, k_ = lane;
+    bool isbody = b < nbody, isdof = k_ < nv;
+    /* lane = dof: project the subtree's force on the motion axis; subtree = contiguous body range [kbody, kbend) */
+    double qfrc_bias = 0;
+    if constexpr (NVP == 32) {
+        /* (32 dofs on 64 lanes: the two halves of the wave split the bodies of the loop, as in the composite-inertia sums) */
+        double acc[6] = {0, 0, 0, 0, 0, 0};
+        const int hk = lane & 31, hkbody = wv::shfl_i(kbody, hk), hkbend = wv::shfl_i(kbend, hk), coff = lane < 32 ? 0 : NB / 2;
+        const unsigned ksub = hk < nv ? (unsigned)(((1ull << hkbend) - 1ull) ^ ((1ull << hkbody) - 1ull)) >> coff : 0u; /* bodies [kbody, kbend) */
+        const double (*cfr)[6] = &S.x.s.cfrc[coff];
+#pragma unroll
+        for (int c0 = 0; c0 < NB / 2; c0 += 4) {
+            double ff[4][6];
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+                for (int t = 0; t < 6; ++t) ff[cc][t] = cfr[c0 + cc][t];
+            wv::sched_fence();
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                const double w = bitf(ksub, c0 + cc);
+#pragma unroll
+                for (int t = 0; t < 6; ++t) acc[t] = fma(w, ff[cc][t], acc[t]);
+            }
+        }
+        for (int i = 0; i < 6; ++i) { acc[i] += wv::from_upper_half(acc[i]); qfrc_bias += S.cdof[lane < NVP ? lane : 0][i] * acc[i]; }
+    } else {
+        double acc[6] = {0, 0, 0, 0, 0, 0};
+        const unsigned ksub = isdof ? (unsigned)(((1ull << kbend) - 1ull) ^ ((1ull << kbody) - 1ull)) : 0u; /* bodies [kbody, kbend) */
+#pragma unroll
+        for (int c0 = 0; c0 < NB; c0 += 4) {
+            double ff[4][6];
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+                for (int t = 0; t < 6; ++t) ff[cc][t] = S.x.s.cfrc[c0 + cc][t];
+            wv::sched_fence();
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                const double w = bitf(ksub, c0 + cc);
+#pragma unroll
+                for (int t = 0; t < 6; ++t) acc[t] = fma(w, ff[cc][t], acc[t]);
+            }
+        }
+        for (int i = 0; i < 6; ++i) qfrc_bias += S.cdof[lane < NVP ? lane : 0][i] * acc[i];
+    }
+    CK_STAMP(6);
+
+    /* ================= P6/P7/P8 passive + actuation -> qfrc_smooth (lane = dof) ================= */
+    {
+        if (isdof) {
+            double f = -kdamp * S.qvel[k_];
+            f -= kstiff * (S.qpos[kq] - kref);
+            f -= qfrc_bias;
+            if (io.qfrc_applied) f += io.qfrc_applied[(size_t)env * io.sv + k_];
+            f += kgear * clampd(S.ctrl[ka], klo, khi);
+            S.qfrc_smooth[k_] = f;
+        }
+    }
+    if (io.xfrc_applied) {
+        /* Cartesian perturbations: [force, torque] at the body's inertial origin, read straight from HBM (wave-uniform
+         * addresses; the perturbation API is not a hot path and its 1.5 KB tile is better spent elsewhere) */
+        if (isdof) {
+            const double *xfa = io.xfrc_applied + ((size_t)env * io.sb) * 6;
+            double f = 0;
+            for (int bb = 1; bb < nbody; ++bb) {
+                if (!((m->body_dofmask[bb] >> k_) & 1ull)) continue;
+                const double xf[6] = {xfa[bb * 6], xfa[bb * 6 + 1], xfa[bb * 6 + 2], xfa[bb * 6 + 3], xfa[bb * 6 + 4], xfa[bb * 6 + 5]};
+                if (xf[0] == 0 && xf[1] == 0 && xf[2] == 0 && xf[3] == 0 && xf[4] == 0 && xf[5] == 0) continue;
+                const double *c = S.com[m->body_rootid[bb]];
+                double off[3] = {S.x.s.xipos[bb][0] - c[0], S.x.s.xipos[bb][1] - c[1], S.x.s.xipos[bb][2] - c[2]};
+                double t[3], cdk[6];
+                for (int i = 0; i < 6; ++i) cdk[i] = S.cdof[k_][i];
+                cross3(t, cdk, off);
+                for (int i = 0; i < 3; ++i) f += (cdk[3 + i] + t[i]) * xf[i] + cdk[i] * xf[3 + i];
+            }
+            S.qfrc_smooth[k_] += f;
+        }
+    }
+    wv::sync();
+    CK_STAMP(7);
+}
+
 /* ======================================================== the env step ==== */
 /* FEAT selects the collision code a model needs, so that the instantiation for plain cassie.xml does not carry the
  * register pressure of paths it never takes: FEAT_HFIELD = height-field pairs, FEAT_WAVEPAIRS = plane-box / box-box
  * pairs handled by the whole wave.  The launcher picks the instantiation from the model (phys_batch.hip). */
-enum { FEAT_HFIELD = 1, FEAT_WAVEPAIRS = 2, FEAT_ALL = 3 };
 
 template <int NVP, class TOPO, int FEAT, int MAXR, int NW>
 WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count, MAXR> &S, int env, int sub_start) {
@@ -1213,7 +1505,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
 
     /* ---------------- load state (coalesced, env-major) ---------------- */
     if (NW == 1 || wid == 0) {
-    if (lane == 0) S.cmd[0] = 0;
+    if (lane == 0) { S.cmd[0] = 0; S.cmd[1] = 0; }
     if (lane < nq) S.qpos[lane] = io.qpos[(size_t)env * io.sq + lane];
     if (lane < nv) {
         S.qvel[lane] = io.qvel[(size_t)env * io.sqv + lane];
@@ -1264,187 +1556,8 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
     /* actuator acting on this dof (at most one per dof in the supported subset) */
     int kact = -1;
     for (int u = 0; u < nu; ++u) if (isdof && m->act_dofid[u] == k_) kact = u;
+    const LaneIds ids = {nbody, nv, broot, bend, kjnt, kbody, kjt, kda, kroot, kbend, kdesc};
     wv::sync();
-
-    /* ---------------- the mass-matrix stage group: com of every kinematic tree, cinert, cdof, composite inertias, M's columns.
-     * One wave form: called in line by the substep loop, between the geoms and the factorisations.  Two-wave form: wave 1's
-     * program (below) calls it between the barriers F and X.  Reads the pose tiles (xmat, xipos, xanchor, xaxis), writes
-     * com, cinert, cdof, crb and the buf tile; leaves the lane's columns of M and M + hB in col / colh. ---------------- */
-    auto mass_matrix_columns = [&](const double pf_mass, const double (&pf_iner)[3], const double (&ximat)[9], double (&col)[NVP], double (&colh)[NVP]) {
-        /* where crb[body] . cdof goes between the composite inertias and M's columns: the buf tile -- except in the two-wave
-         * height-field form, where wave 0's height-field result table lies over that tile at this time: there the joint
-         * anchors / axes, which nothing reads once cdof is formed, give their place */
-        constexpr bool cbuf_over_anchors = NW == 2 && (FEAT & FEAT_HFIELD) != 0;
-        static_assert(!cbuf_over_anchors || NVP <= CM_MAXJNT, "crb . cdof (NVP x 6) must fit the xanchor + xaxis tiles");
-        static_assert(offsetof(decltype(S.x.s), xaxis) - offsetof(decltype(S.x.s), xanchor) == sizeof(double) * CM_MAXJNT * 3, "xanchor and xaxis are contiguous");
-        double (*const cbuf)[6] = cbuf_over_anchors ? reinterpret_cast<double (*)[6]>(&S.x.s.xanchor[0][0]) : S.x.s.buf;
-        /* ================= com of every kinematic tree (wave reduction per root) ================= */
-        const double bmass = (isbody && b > 0) ? pf_mass : 0.0;
-        {
-            /* one masked DPP tree reduction per kinematic tree (wave_sum returns the total in every lane) */
-            const double px = isbody ? S.x.s.xipos[b < NB ? b : 0][0] : 0.0, py = isbody ? S.x.s.xipos[b < NB ? b : 0][1] : 0.0,
-                         pz = isbody ? S.x.s.xipos[b < NB ? b : 0][2] : 0.0;
-            for (int ri = 0; ri < m->nroot; ++ri) {
-                const int r = m->root_body[ri], e = m->body_subtreeend[r];
-                const double w = (isbody && b >= r && b < e) ? bmass : 0.0;
-                const double sm = wv::wave_sum(w), sx = wv::wave_sum(w * px), sy = wv::wave_sum(w * py), sz = wv::wave_sum(w * pz);
-                if (lane == 0) {
-                    if (sm < CM_MINVAL) { S.com[r][0] = S.x.s.xipos[r][0]; S.com[r][1] = S.x.s.xipos[r][1]; S.com[r][2] = S.x.s.xipos[r][2]; }
-                    else { const double inv = 1.0 / sm; S.com[r][0] = sx * inv; S.com[r][1] = sy * inv; S.com[r][2] = sz * inv; }
-                }
-            }
-        }
-        wv::sync();
-        CK_STAMP(18);
-        /* ================= cinert (lane = body), cdof (lane = dof) ================= */
-        if (lane < NB) {
-            double ci[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-            if (isbody && b > 0) {
-                const double I0 = pf_iner[0], I1 = pf_iner[1], I2 = pf_iner[2];
-                const double *c = S.com[broot];
-                double dif[3] = {S.x.s.xipos[b][0] - c[0], S.x.s.xipos[b][1] - c[1], S.x.s.xipos[b][2] - c[2]};
-                double d2 = dot3(dif, dif);
-                const double *R = ximat;
-                double W00 = R[0] * I0 * R[0] + R[1] * I1 * R[1] + R[2] * I2 * R[2];
-                double W11 = R[3] * I0 * R[3] + R[4] * I1 * R[4] + R[5] * I2 * R[5];
-                double W22 = R[6] * I0 * R[6] + R[7] * I1 * R[7] + R[8] * I2 * R[8];
-                double W01 = R[0] * I0 * R[3] + R[1] * I1 * R[4] + R[2] * I2 * R[5];
-                double W02 = R[0] * I0 * R[6] + R[1] * I1 * R[7] + R[2] * I2 * R[8];
-                double W12 = R[3] * I0 * R[6] + R[4] * I1 * R[7] + R[5] * I2 * R[8];
-                ci[0] = W00 + bmass * (d2 - dif[0] * dif[0]);
-                ci[1] = W11 + bmass * (d2 - dif[1] * dif[1]);
-                ci[2] = W22 + bmass * (d2 - dif[2] * dif[2]);
-                ci[3] = W01 - bmass * dif[0] * dif[1];
-                ci[4] = W02 - bmass * dif[0] * dif[2];
-                ci[5] = W12 - bmass * dif[1] * dif[2];
-                ci[6] = bmass * dif[0]; ci[7] = bmass * dif[1]; ci[8] = bmass * dif[2]; ci[9] = bmass;
-            }
-            for (int i = 0; i < 10; ++i) S.x.s.cinert[lane][i] = ci[i];
-        }
-        {
-        double cd[6] = {0, 0, 0, 0, 0, 0};
-        if (isdof) {
-            const double *c = S.com[kroot];
-            double off[3] = {c[0] - S.x.s.xanchor[kjnt][0], c[1] - S.x.s.xanchor[kjnt][1], c[2] - S.x.s.xanchor[kjnt][2]};
-            const int sub_k = k_ - kda;
-            if (kjt == CM_JNT_SLIDE) {
-                for (int i = 0; i < 3; ++i) cd[3 + i] = S.x.s.xaxis[kjnt][i];
-            } else if (kjt == CM_JNT_HINGE) {
-                for (int i = 0; i < 3; ++i) cd[i] = S.x.s.xaxis[kjnt][i];
-                cross3(cd + 3, cd, off);
-            } else if (kjt == CM_JNT_FREE && sub_k < 3) {
-                cd[3 + sub_k] = 1.0;
-            } else {
-                const int a = (kjt == CM_JNT_FREE) ? sub_k - 3 : sub_k;
-                cd[0] = S.x.s.xmat[kbody][a]; cd[1] = S.x.s.xmat[kbody][3 + a]; cd[2] = S.x.s.xmat[kbody][6 + a];
-                cross3(cd + 3, cd, off);
-            }
-        }
-        if (lane < NVP) for (int i = 0; i < 6; ++i) S.cdof[lane][i] = cd[i]; /* zero rows past nv */
-        }
-        wv::sync();
-        CK_STAMP(2);
-
-        /* ================= P2 CRBA: composite inertias, then one COLUMN of M per lane ================= */
-        /* composite inertias: crb_b = sum of cinert_c over the contiguous subtree range [b, bend): dense loop over all
-         * bodies with a per-lane range predicate, operands staged four bodies at a time */
-        /* A 0/1-weighted sum over bodies is a matrix product, W (body x body: c in b's subtree) times cinert (body x 10), and its
-         * result layout on the matrix core -- lane l holds rows (l >> 4) + 4 v, column l & 15 -- is a layout the LDS tile can be
-         * written in directly: 16 v_mfma_f64_16x16x4_f64 (two blocks of 16 bodies x eight blocks of four summands, even and odd
-         * blocks in separate accumulators), the weights built from the subtree masks in registers, the summands single LDS reads.
-         * (fma(1, x, acc) is acc + x, fma(0, x, acc) is acc: the sums are plain sums, in body order.) */
-        {
-            const int mi = lane & 15, mk = lane >> 4;
-            const unsigned mine = (isbody && b > 0) ? (unsigned)(((1ull << bend) - 1ull) ^ ((1ull << b) - 1ull)) : 0u; /* bodies [b, bend) */
-            const unsigned w0 = (unsigned)wv::shfl_i((int)mine, mi) >> mk, w1 = (unsigned)wv::shfl_i((int)mine, 16 + mi) >> mk;
-            double bv[NB / 4];
-#pragma unroll
-            for (int kb = 0; kb < NB / 4; ++kb) { const double v = S.x.s.cinert[4 * kb + mk][mi < 10 ? mi : 0]; bv[kb] = mi < 10 ? v : 0.0; }
-            wv::mfma_acc d0a = {{0, 0, 0, 0}}, d0b = {{0, 0, 0, 0}}, d1a = {{0, 0, 0, 0}}, d1b = {{0, 0, 0, 0}};
-#pragma unroll
-            for (int kb = 0; kb < NB / 4; kb += 2)
-                wv::mfma_f64_16x16x4_x4((double)((w0 >> (4 * kb)) & 1u), bv[kb], d0a, (double)((w1 >> (4 * kb)) & 1u), bv[kb], d1a,
-                                        (double)((w0 >> (4 * kb + 4)) & 1u), bv[kb + 1], d0b, (double)((w1 >> (4 * kb + 4)) & 1u), bv[kb + 1], d1b);
-            wv::mfma_f64_drain4(d0a, d0b, d1a, d1b);
-            if (mi < 10) {
-#pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    S.x.s.crb[mk + 4 * v][mi] = d0a.c[v] + d0b.c[v];
-                    S.x.s.crb[16 + mk + 4 * v][mi] = d1a.c[v] + d1b.c[v];
-                }
-            }
-        }
-        wv::sync();
-        CK_STAMP(19);
-        if (lane < NVP) {
-            double bf[6] = {0, 0, 0, 0, 0, 0}, cd[6];
-            for (int i = 0; i < 6; ++i) cd[i] = S.cdof[lane][i];
-            if (isdof) mul_inert_vec(bf, S.x.s.crb[kbody], cd);
-            for (int i = 0; i < 6; ++i) cbuf[lane][i] = bf[i];
-        }
-        wv::sync();
-        CK_STAMP(20);
-        double cdm[6]; /* this lane's motion axis, fetched where it is used rather than carried in registers */
-        /* armature and h * damping sit on the diagonal only: they are added where the pivots are read (wave-uniform
-         * scalars there) instead of being selected into one lane-dependent entry of each column here */
-        /* M[i][lane] = cdof_lane . (crb[body_i] cdof_i): the buf rows are broadcast reads, staged eight rows at a time so
-         * the LDS latency is paid once per group instead of once per row */
-        if constexpr (NVP == 32) {
-            /* 32 columns on 64 lanes: lanes l and l + 32 both work for column l, on rows [0, 16) and [16, 32); the lower lane
-             * takes the upper one's sixteen entries through the lane swap */
-            const int hk = lane & 31, roff = lane < 32 ? 0 : 16;
-            const unsigned hdesc = (unsigned)wv::shfl_i((int)(unsigned)kdesc, hk) >> roff; /* (kdesc: no bit at or past nv <= 32) */
-            for (int i = 0; i < 6; ++i) cdm[i] = S.cdof[hk][i];
-            const double (*bufr)[6] = &cbuf[roff];
-            double part[16];
-#pragma unroll
-            for (int i0 = 0; i0 < 16; i0 += 8) {
-                double bb[8][6];
-#pragma unroll
-                for (int ii = 0; ii < 8; ++ii)
-#pragma unroll
-                    for (int t = 0; t < 6; ++t) bb[ii][t] = bufr[i0 + ii][t];
-                wv::sched_fence();
-#pragma unroll
-                for (int ii = 0; ii < 8; ++ii) {
-                    const double v = (cdm[0] * bb[ii][0] + cdm[1] * bb[ii][1]) + (cdm[2] * bb[ii][2] + cdm[3] * bb[ii][3]) + (cdm[4] * bb[ii][4] + cdm[5] * bb[ii][5]);
-                    part[i0 + ii] = ((hdesc >> (i0 + ii)) & 1u) ? v : 0.0;
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const double up = wv::from_upper_half(part[i]);
-                col[i] = part[i]; colh[i] = part[i];
-                col[16 + i] = up; colh[16 + i] = up;
-            }
-        } else {
-        for (int i = 0; i < 6; ++i) cdm[i] = S.cdof[lane < NVP ? lane : 0][i];
-#pragma unroll
-        for (int i0 = 0; i0 < NVP; i0 += 8) {
-            double bb[8][6];
-#pragma unroll
-            for (int ii = 0; ii < 8; ++ii)
-#pragma unroll
-                for (int t = 0; t < 6; ++t) bb[ii][t] = cbuf[i0 + ii][t];
-            wv::sched_fence();
-#pragma unroll
-            for (int ii = 0; ii < 8; ++ii) {
-                const int i = i0 + ii;
-                double v = (cdm[0] * bb[ii][0] + cdm[1] * bb[ii][1]) + (cdm[2] * bb[ii][2] + cdm[3] * bb[ii][3]) + (cdm[4] * bb[ii][4] + cdm[5] * bb[ii][5]);
-                /* kdesc holds no bit at or past nv; with a compile-time topology the bound is a constant, not a branch */
-                if (TOPO::is_static ? (i >= TOPO::nv || !((kdesc >> i) & 1ull)) : !(i < nv && ((kdesc >> i) & 1ull))) v = 0;
-                col[i] = v;
-                colh[i] = v;
-            }
-        }
-        }
-        if (io.ext && isdof) {
-            cm_ext_t *ex = io.ext + env;
-#pragma unroll
-            for (int i = 0; i < NVP; ++i) if (i < nv && i >= k_) { const double v = (i == k_) ? col[i] + m->dof_armature[k_] : col[i]; ex->qM[i][k_] = v; ex->qM[k_][i] = v; }
-        }
-        CK_STAMP(3);
-    };
 
     /* ---------------- two-wave form: wave 1's program ---------------- */
     if constexpr (NW == 2) {
@@ -1468,12 +1581,25 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
                         for (int c = 0; c < 3; ++c) ximat[3 * i + c] = xm[3 * i] * imat[c] + xm[3 * i + 1] * imat[3 + c] + xm[3 * i + 2] * imat[6 + c];
                 }
                 double col[NVP], colh[NVP];
-                mass_matrix_columns(mass, iner, ximat, col, colh);
+                mass_matrix_columns<NVP, TOPO, FEAT, NW>(io, S, m, env, ids, mass, iner, ximat, col, colh);
                 wv::block_barrier(); /* X: com, cinert and cdof are in LDS (wave 0's velocity and row stages read them) */
                 if (wv::opaque(S.cmd[0])) return; /* (the row-capped instantiation hands this substep over) */
                 CK_STAMP(38);
+                if (io.drive_mode) {
+                    /* the drive-level pass of this substep (ctrl for the passive stage below; the encoder / filter state) */
+                    if (io.integrate) drive_level_io(io, S, m, env, lane, sub1 == io.nsub - 1);
+                    wv::sync();
+                }
                 factor_pair_by_height<NVP, TOPO>(m, h, S, col, colh, lane);
                 CK_STAMP(4);
+                {
+                    const int kd = isdof ? k_ : 0;
+                    const double kdamp = m->dof_damping[kd], kstiff = m->dof_stiffness[kd], kref = m->dof_springref[kd];
+                    const double kgear = m->dof_gear[kd], klo = m->dof_ctrl_lo[kd], khi = m->dof_ctrl_hi[kd];
+                    const int kq = m->dof_qadr[kd], ka = m->dof_act[kd];
+                    wv::wait_for(&S.cmd[1], sub1 + 1); /* wave 0's velocity stage has the body forces (cfrc) in LDS */
+                    bias_forces_and_qfrc_smooth<NVP>(io, S, m, env, ids, kdamp, kstiff, kref, kgear, klo, khi, kq, ka);
+                }
                 wv::block_barrier(); /* J: the factors of M and M + hB are in LDS */
                 CK_STAMP(39);
                 if (!io.integrate || ++sub1 >= io.nsub) return;
@@ -1508,7 +1634,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
         if (io.drive_mode) {
             /* (the row-capped instantiation runs this pass after it knows that the substep fits its rows, see below: a
              * substep it hands over must not have advanced the filter histories and delay lines) */
-            if constexpr (MAXR == CM_MAXEFC) {
+            if constexpr (MAXR == CM_MAXEFC && NW == 1) { /* (two-wave form: wave 1, behind the barrier X) */
                 if (io.integrate) drive_level_io(io, S, m, env, lane, lastsub); /* mj_forward leaves the drive-level state alone */
                 wv::sync();
             }
@@ -1769,7 +1895,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
          * the loop -- in the two-wave form wave 1 runs them, and the factorisations, beside this wave's collision, velocity
          * and constraint-row stages) */
         double col[NVP], colh[NVP]; /* col[i] = M[i][lane] (i >= lane); colh: same for M + h*diag(damping) */
-        if constexpr (NW == 1) mass_matrix_columns(pf_mass, pf_iner, ximat, col, colh);
+        if constexpr (NW == 1) mass_matrix_columns<NVP, TOPO, FEAT, NW>(io, S, m, env, ids, pf_mass, pf_iner, ximat, col, colh);
 
         /* ================= P3 factor M and M + hB in registers; park the factors in LDS ================= */
         constexpr bool by_height = TOPO::is_static;
@@ -2125,7 +2251,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
                 if constexpr (NW == 2) { if (lane == 0) S.cmd[0] = 1; wv::block_barrier(); } /* (X) */
                 break;
             }
-            if (io.drive_mode) {
+            if constexpr (NW == 1) if (io.drive_mode) {
                 if (io.integrate) drive_level_io(io, S, m, env, lane, lastsub);
                 wv::sync();
             }
@@ -2215,91 +2341,17 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
         }
         wv::sync();
         CK_STAMP(24);
-        /* lane = dof: project the subtree's force on the motion axis; subtree = contiguous body range [kbody, kbend) */
-        double qfrc_bias = 0;
-        if constexpr (NVP == 32) {
-            /* (32 dofs on 64 lanes: the two halves of the wave split the bodies of the loop, as in the composite-inertia sums) */
-            double acc[6] = {0, 0, 0, 0, 0, 0};
-            const int hk = lane & 31, hkbody = wv::shfl_i(kbody, hk), hkbend = wv::shfl_i(kbend, hk), coff = lane < 32 ? 0 : NB / 2;
-            const unsigned ksub = hk < nv ? (unsigned)(((1ull << hkbend) - 1ull) ^ ((1ull << hkbody) - 1ull)) >> coff : 0u; /* bodies [kbody, kbend) */
-            const double (*cfr)[6] = &S.x.s.cfrc[coff];
-#pragma unroll
-            for (int c0 = 0; c0 < NB / 2; c0 += 4) {
-                double ff[4][6];
-#pragma unroll
-                for (int cc = 0; cc < 4; ++cc)
-#pragma unroll
-                    for (int t = 0; t < 6; ++t) ff[cc][t] = cfr[c0 + cc][t];
-                wv::sched_fence();
-#pragma unroll
-                for (int cc = 0; cc < 4; ++cc) {
-                    const double w = bitf(ksub, c0 + cc);
-#pragma unroll
-                    for (int t = 0; t < 6; ++t) acc[t] = fma(w, ff[cc][t], acc[t]);
-                }
-            }
-            for (int i = 0; i < 6; ++i) { acc[i] += wv::from_upper_half(acc[i]); qfrc_bias += S.cdof[lane < NVP ? lane : 0][i] * acc[i]; }
-        } else {
-            double acc[6] = {0, 0, 0, 0, 0, 0};
-            const unsigned ksub = isdof ? (unsigned)(((1ull << kbend) - 1ull) ^ ((1ull << kbody) - 1ull)) : 0u; /* bodies [kbody, kbend) */
-#pragma unroll
-            for (int c0 = 0; c0 < NB; c0 += 4) {
-                double ff[4][6];
-#pragma unroll
-                for (int cc = 0; cc < 4; ++cc)
-#pragma unroll
-                    for (int t = 0; t < 6; ++t) ff[cc][t] = S.x.s.cfrc[c0 + cc][t];
-                wv::sched_fence();
-#pragma unroll
-                for (int cc = 0; cc < 4; ++cc) {
-                    const double w = bitf(ksub, c0 + cc);
-#pragma unroll
-                    for (int t = 0; t < 6; ++t) acc[t] = fma(w, ff[cc][t], acc[t]);
-                }
-            }
-            for (int i = 0; i < 6; ++i) qfrc_bias += S.cdof[lane < NVP ? lane : 0][i] * acc[i];
-        }
-        CK_STAMP(6);
-
-        /* ================= P6/P7/P8 passive + actuation -> qfrc_smooth (lane = dof) ================= */
         /* The equality rows' constants are requested here, two stages ahead of the rows' geometry: with every equality active (the
          * usual case, closed form in the row assignment below) row r belongs to equality r / 3 */
+        if constexpr (NW == 2) {
+            /* the body forces are in LDS: wave 1 projects them on the motion axes and forms qfrc_smooth behind its
+             * factorisations (bias_forces_and_qfrc_smooth), while this wave goes on to the constraint rows */
+            wv::publish(&S.cmd[1], sub + 1);
+        } else bias_forces_and_qfrc_smooth<NVP>(io, S, m, env, ids, kdamp, kstiff, kref, kgear, klo, khi, kq, ka);
         const int pf_eq = lane < 3 * m->neq ? lane / 3 : 0;
         /* (only what the rows' LDS reads hang on: the bodies and their roots; the anchors, masks and solver parameters are read in place,
          * where their trip to memory runs under those LDS reads -- carrying them too pushes launch-long values into scratch) */
         int pf_eb1 = m->eq_body1[pf_eq], pf_eb2 = m->eq_body2[pf_eq], pf_er1 = m->eq_root[pf_eq][0], pf_er2 = m->eq_root[pf_eq][1];
-        {
-            if (isdof) {
-                double f = -kdamp * S.qvel[k_];
-                f -= kstiff * (S.qpos[kq] - kref);
-                f -= qfrc_bias;
-                if (io.qfrc_applied) f += io.qfrc_applied[(size_t)env * io.sv + k_];
-                f += kgear * clampd(S.ctrl[ka], klo, khi);
-                S.qfrc_smooth[k_] = f;
-            }
-        }
-        if (io.xfrc_applied) {
-            /* Cartesian perturbations: [force, torque] at the body's inertial origin, read straight from HBM (wave-uniform
-             * addresses; the perturbation API is not a hot path and its 1.5 KB tile is better spent elsewhere) */
-            if (isdof) {
-                const double *xfa = io.xfrc_applied + ((size_t)env * io.sb) * 6;
-                double f = 0;
-                for (int bb = 1; bb < nbody; ++bb) {
-                    if (!((m->body_dofmask[bb] >> k_) & 1ull)) continue;
-                    const double xf[6] = {xfa[bb * 6], xfa[bb * 6 + 1], xfa[bb * 6 + 2], xfa[bb * 6 + 3], xfa[bb * 6 + 4], xfa[bb * 6 + 5]};
-                    if (xf[0] == 0 && xf[1] == 0 && xf[2] == 0 && xf[3] == 0 && xf[4] == 0 && xf[5] == 0) continue;
-                    const double *c = S.com[m->body_rootid[bb]];
-                    double off[3] = {S.x.s.xipos[bb][0] - c[0], S.x.s.xipos[bb][1] - c[1], S.x.s.xipos[bb][2] - c[2]};
-                    double t[3], cdk[6];
-                    for (int i = 0; i < 6; ++i) cdk[i] = S.cdof[k_][i];
-                    cross3(t, cdk, off);
-                    for (int i = 0; i < 3; ++i) f += (cdk[3 + i] + t[i]) * xf[i] + cdk[i] * xf[3 + i];
-                }
-                S.qfrc_smooth[k_] += f;
-            }
-        }
-        wv::sync();
-        CK_STAMP(7);
 
         /* ================= P5 constraint rows: lane = row ================= */
         /* row descriptor assignment is wave-uniform bookkeeping; every lane keeps its own row */
@@ -2464,7 +2516,8 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
             for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
                 for (int t = 0; t < 6; ++t) cc[kk][t] = S.cdof[k0 + kk][t];
-                qv[kk] = S.qvel[k0 + kk]; qw[kk] = S.qacc_ws[k0 + kk]; qs[kk] = S.qfrc_smooth[k0 + kk];
+                qv[kk] = S.qvel[k0 + kk]; qw[kk] = S.qacc_ws[k0 + kk];
+                if constexpr (NW == 1) qs[kk] = S.qfrc_smooth[k0 + kk]; else qs[kk] = 0.0; /* (two-wave form: behind the barrier J) */
             }
             wv::sched_fence();
 #pragma unroll
@@ -2489,6 +2542,16 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
             }
         }
         CK_STAMP(28);
+        if constexpr (NW == 2) {
+            /* J: wave 1 is done with this substep -- the factors of M and M + hB and qfrc_smooth are in LDS, and its drive-level pass
+             * has read the previous substep's sensor words, which the sensor stage below replaces */
+            CK_STAMP(34); wv::block_barrier();
+            /* lane 63's column of the staged matrix is qfrc_smooth */
+            if (lastcol) {
+#pragma unroll
+                for (int k = 0; k < NVP; ++k) ycol[k] = (TOPO::is_static ? k < TOPO::nv : k < nv) ? S.qfrc_smooth[k] : 0.0;
+            }
+        }
         const double raref = rtype >= 0 ? -rB * jvel - rK * rimp * (rpos - rmargin) : 0.0;
 
         /* ---- sensors, part 1 (lane = sensor): everything that does not need qacc is final here; the
@@ -2588,7 +2651,6 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
             }
         }
         wv::sync(); /* every reader of the body-stage tiles is done: region x becomes the Y staging tile */
-        if constexpr (NW == 2) { CK_STAMP(34); wv::block_barrier(); } /* J */
         CK_STAMP(8);
 
         /* ================= half solve in registers: Y = D^-1/2 L^-T [J^T | qfrc_smooth], lane = column ================= */
@@ -3029,7 +3091,10 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
 
     if constexpr (NW == 2) if (release_wave1) { if (lane == 0) S.cmd[0] = 1; wv::block_barrier(); } /* (F) */
     /* ---------------- store state ---------------- */
-    if (io.progress && !io.resume && lane == 0) io.progress[env] = bailed ? sub : io.nsub; /* (the resume pass leaves the record) */
+    if (io.progress && !io.resume && lane == 0) {
+        io.progress[env] = bailed ? sub : io.nsub; /* (the resume pass leaves the record) */
+        if (bailed && io.handover_list) io.handover_list[io.env0 + wv::atomic_add(io.handover_count, 1)] = env;
+    }
     if (io.integrate && io.drive_mode) {
         drive_state_store(io, S, env, lane);
         if (lane < nu) io.ctrl[(size_t)env * io.su + lane] = S.ctrl[lane]; /* the applied torque: d->ctrl of the reference */
@@ -3067,10 +3132,31 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
  * scratch per lane -- and shortens every unrolled row loop.  An env whose substep needs more rows is handed over to the full
  * instantiation through PhysIO::progress (see there); results are bit for bit those of the full instantiation alone, because
  * the arithmetic of a substep that fits is the same in both. */
-template <int NVP, class TOPO, int FEAT = FEAT_ALL, int MAXR = CM_MAXEFC, int NW = 1>
+/* WALK: the instantiation is the pass behind the fast kernel in its list-walking form (PhysIO::handover_list): a small grid whose
+ * workgroups each finish the handed-over envs blockIdx, blockIdx + gridDim, ... of the list.  (A template parameter and not a
+ * run-time branch: env_step is inlined, and two call sites would be two copies of it in one kernel.) */
+template <int NVP, class TOPO, int FEAT = FEAT_ALL, int MAXR = CM_MAXEFC, int NW = 1, bool WALK = false>
 WV_GLOBAL void __launch_bounds__(WV_WAVE * NW) WV_OCC WV_WAVES_PER_SIMD(NW) cassie_step_kernel(PhysIO io) {
     WV_SHARED EnvShared<NVP, LPack<TOPO, NVP>::count, MAXR> S;
     const int slot = wv::env_id();
+    if constexpr (WALK) {
+        /* the pass behind the fast kernel, as a small grid walking the hand-over list (PhysIO::handover_list) */
+        wv::test_launch_hook(&S, sizeof S);
+        const int count = wv::opaque(wv::shfl_i(wv::lane() == 0 ? wv::atomic_add(io.handover_count, 0) : 0, 0));
+        for (int idx = slot; idx < count; idx += wv::grid_size()) {
+            const int env = io.handover_list[io.env0 + idx];
+            const long long t0 = io.cost ? wv::clock() : 0;
+            env_step<NVP, TOPO, FEAT, MAXR, NW>(io, S, env, io.progress[env]);
+            if (io.cost && wv::lane() == 0 && (NW == 1 || wv::wave_id() == 0)) io.cost[env] += (unsigned)((wv::clock() - t0) >> 6);
+            if constexpr (NW == 2) wv::block_barrier(); /* both waves are done with this env before either starts the next */
+            else wv::sync();
+        }
+        /* every workgroup has read the count before it draws its ticket: the last one to draw may clear it */
+        if (wv::lane() == 0 && (NW == 1 || wv::wave_id() == 0) && wv::atomic_add(io.handover_count + 1, 1) == wv::grid_size() - 1) {
+            io.handover_count[0] = 0; io.handover_count[1] = 0;
+            if (io.handover_seen) *io.handover_seen = count;
+        }
+    } else {
     if (slot >= io.nenv) return;
     wv::test_launch_hook(&S, sizeof S); /* CPU emulator only (poisons LDS so that a read-before-write shows); empty on the device */
     const int env = io.order ? io.order[io.env0 + slot] : io.env0 + slot; /* order holds absolute env ids, sorted range by range */
@@ -3082,6 +3168,7 @@ WV_GLOBAL void __launch_bounds__(WV_WAVE * NW) WV_OCC WV_WAVES_PER_SIMD(NW) cass
     if (io.cost && wv::lane() == 0 && (NW == 1 || wv::wave_id() == 0)) { /* 64-clock units: 32 bits hold minutes */
         const unsigned c = (unsigned)((wv::clock() - t0) >> 6);
         io.cost[env] = io.resume ? io.cost[env] + c : c;
+    }
     }
 }
 

@@ -17,8 +17,9 @@ namespace ck {
 /* io.progress must be set when fast is; io.resume is managed here */
 /* after_first (may be null): recorded behind the first kernel of the launch -- the one that does the work -- for per-kernel timing */
 /* waves: 2 = the row-capped fast instantiation in its two-wave form (two wavefronts per env, see env_step), 1 = one wave per env */
-bool launch_step_cassie(dim3 grid, hipStream_t s, PhysIO io, bool fast, hipEvent_t after_first, int waves);            /* <32, TopoCassie32, 0>: plain cassie.xml */
-bool launch_step_cassie_hfield(dim3 grid, hipStream_t s, PhysIO io, bool fast, hipEvent_t after_first, int waves);     /* <32, TopoCassie32, FEAT_HFIELD> */
+/* pass_grid: the grid of the pass behind the fast kernel (= grid, or fewer workgroups when it walks the hand-over list) */
+bool launch_step_cassie(dim3 grid, dim3 pass_grid, hipStream_t s, PhysIO io, bool fast, hipEvent_t after_first, int waves);            /* <32, TopoCassie32, 0>: plain cassie.xml */
+bool launch_step_cassie_hfield(dim3 grid, dim3 pass_grid, hipStream_t s, PhysIO io, bool fast, hipEvent_t after_first, int waves);     /* <32, TopoCassie32, FEAT_HFIELD> */
 /* the two-wave forms of the fast instantiations, in translation units of their own (kernels_*_2w.hip) */
 bool launch_fast_cassie_2w(dim3 grid, hipStream_t s, PhysIO io);
 bool launch_fast_cassie_hfield_2w(dim3 grid, hipStream_t s, PhysIO io);
@@ -32,7 +33,7 @@ bool launch_step_tray(dim3 grid, hipStream_t s, PhysIO io, bool hfield);        
 bool launch_step_generic(dim3 grid, hipStream_t s, PhysIO io, bool wide);           /* <32 | 40, TopoRuntime, FEAT_ALL> */
 
 template <int NVP, class TOPO, int FEAT>
-inline bool launch_fast_then_full(dim3 grid, hipStream_t s, PhysIO io, bool fast, hipEvent_t after_first, bool (*fast_2w)(dim3, hipStream_t, PhysIO),
+inline bool launch_fast_then_full(dim3 grid, dim3 pass_grid, hipStream_t s, PhysIO io, bool fast, hipEvent_t after_first, bool (*fast_2w)(dim3, hipStream_t, PhysIO),
                                   bool (*full_2w)(dim3, hipStream_t, PhysIO)) {
     if (fast) {
         io.resume = 0;
@@ -42,15 +43,19 @@ inline bool launch_fast_then_full(dim3 grid, hipStream_t s, PhysIO io, bool fast
         if (after_first) { (void)hipEventRecord(after_first, s); after_first = nullptr; }
         io.resume = 1;
     } else {
-        io.progress = nullptr; io.resume = 0;
+        io.progress = nullptr; io.resume = 0; io.handover_list = nullptr;
+        pass_grid = grid;
     }
     /* (measurement aid, CASSIE_DEBUG_SKIP_RESUME_PASS: what the pass behind the fast kernel costs -- handed-over envs are then
      * left unfinished, so only for workloads that hand nothing over) */
     static const bool skip_resume = getenv("CASSIE_DEBUG_SKIP_RESUME_PASS") != nullptr;
     static const bool resume_one_wave = getenv("CASSIE_DEBUG_RESUME_ONE_WAVE") != nullptr; /* (measurement aid: the pass behind a two-wave fast kernel as one-wave workgroups) */
     if (fast && skip_resume) {}
-    else if (fast && full_2w && !resume_one_wave) { if (!full_2w(grid, s, io)) return false; }
-    else hipLaunchKernelGGL((cassie_step_kernel<NVP, TOPO, FEAT>), grid, dim3(WV_WAVE), 0, s, io);
+    else if (fast && full_2w && !resume_one_wave) { if (!full_2w(pass_grid, s, io)) return false; }
+    else { /* the one-wave full kernel: one workgroup per env of the launch (no list walk) */
+        io.handover_list = nullptr;
+        hipLaunchKernelGGL((cassie_step_kernel<NVP, TOPO, FEAT>), grid, dim3(WV_WAVE), 0, s, io);
+    }
     if (after_first) (void)hipEventRecord(after_first, s);
     return hipGetLastError() == hipSuccess;
 }

@@ -31,6 +31,17 @@ WV_DEVICE int lane() { return (int)(threadIdx.x & 63u); }
  * The barrier drains this wave's LDS traffic (so the other wave sees what was written) but NOT its vector-memory loads:
  * model constants requested a stage ahead stay in flight across it. */
 WV_DEVICE int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+/* One-directional hand-over between the two waves of a workgroup through a word in LDS, where a barrier would make the producer
+ * wait for the consumer: publish() after the data (this wave's LDS writes are complete before the word changes), wait_for() before
+ * reading it (polls, sleeping a few clocks between reads; both waves are resident, so the producer always gets to run). */
+WV_DEVICE void publish(int *flag, int value) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    if (threadIdx.x % 64u == 0) *(volatile int *)flag = value;
+}
+WV_DEVICE void wait_for(const int *flag, int value) {
+    while (__builtin_amdgcn_readfirstlane(*(const volatile int *)flag) != value) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
 WV_DEVICE void block_barrier() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     __builtin_amdgcn_s_barrier();
@@ -45,6 +56,9 @@ WV_DEVICE int fresh_lane() {
     return x;
 }
 WV_DEVICE int env_id() { return (int)blockIdx.x; }
+WV_DEVICE int grid_size() { return (int)gridDim.x; }
+/* device-scope atomic add on an int in global memory, returns the old value */
+WV_DEVICE int atomic_add(int *p, int v) { return atomicAdd(p, v); }
 
 /* Orders LDS traffic between the lanes of the wave.  The workgroup IS one wave, whose LDS instructions are issued and
  * executed in program order, so a later read already sees an earlier write of any lane: all that is needed is that

@@ -25,7 +25,7 @@ constexpr size_t STACK_BYTES = 1 << 20;
 struct LaneCtx { void *sp; char *stack; bool done; };
 LaneCtx g_lane[NLMAX];
 void *g_sched_sp;
-int g_cur = 0, g_env = 0;
+int g_cur = 0, g_env = 0, g_grid = 1;
 double g_xd[NLMAX];
 int g_xi[NLMAX];
 int g_kind[NLMAX];      /* what the lane yielded at: 0 = a rendezvous of its wave, 1 = the workgroup barrier */
@@ -59,6 +59,7 @@ emu_switch:
 
 void rendezvous() { g_kind[g_cur] = 0; emu_switch(&g_lane[g_cur].sp, g_sched_sp); }
 void barrier_rendezvous() { g_kind[g_cur] = 1; emu_switch(&g_lane[g_cur].sp, g_sched_sp); }
+void spin_rendezvous() { g_kind[g_cur] = 2; emu_switch(&g_lane[g_cur].sp, g_sched_sp); }
 
 void lane_entry() {
     g_body();
@@ -86,19 +87,21 @@ void run_block(void (*body)(), int nwaves = 1) {
         for (int t = 0; t < nwaves; ++t) {
             const int w = g_wave_schedule == 2 ? nwaves - 1 - t : t;
             if (wave_done[w] || at_barrier[w]) continue;
-            int ndone = 0, nbar = 0;
+            int ndone = 0, nbar = 0, nspin = 0;
             for (int l = w * NL; l < (w + 1) * NL; ++l) {
                 if (g_lane[l].done) { ++ndone; continue; }
                 g_cur = l;
                 emu_switch(&g_sched_sp, g_lane[l].sp);
                 if (g_lane[l].done) ++ndone;
                 else if (g_kind[l] == 1) ++nbar;
+                else if (g_kind[l] == 2) ++nspin;
             }
             if (ndone == NL) wave_done[w] = true;
             else if (ndone != 0) { g_mismatch = true; fprintf(stderr, "emu: lanes of wave %d left the kernel at different rendezvous counts (%d done)\n", w, ndone); abort(); }
             else if (nbar == NL) at_barrier[w] = true;
             else if (nbar != 0) { g_mismatch = true; fprintf(stderr, "emu: %d lanes of wave %d are at the workgroup barrier, the others at a wave rendezvous\n", nbar, w); abort(); }
-            if (g_wave_schedule != 0) break; /* the preferred wave runs on until it is blocked or done */
+            if (nspin != 0 && nspin != NL) { g_mismatch = true; fprintf(stderr, "emu: %d lanes of wave %d poll a flag, the others do not\n", nspin, w); abort(); }
+            if (g_wave_schedule != 0 && nspin == 0) break; /* the preferred wave runs on until it is blocked, polling or done */
         }
         bool all_done = true, all_blocked = true;
         for (int w = 0; w < nwaves; ++w) { all_done = all_done && wave_done[w]; all_blocked = all_blocked && (wave_done[w] || at_barrier[w]); }
@@ -112,8 +115,10 @@ namespace wv {
 int lane() { return g_cur & (NL - 1); }
 int wave_id() { return g_cur / NL; }
 int env_id() { return g_env; }
+int grid_size() { return g_grid; }
 void sync() { rendezvous(); }
 void block_barrier() { barrier_rendezvous(); }
+void spin_yield() { spin_rendezvous(); }
 double shfl(double v, int src) {
     g_xd[g_cur] = v;
     rendezvous();
@@ -197,9 +202,13 @@ static void body32s() { ck::cassie_step_kernel<32, ck::TopoCassie32>(g_io); }
 static void body32s_fast() { ck::cassie_step_kernel<32, ck::TopoCassie32, ck::FEAT_ALL, ck::FAST_ROWS>(g_io); }
 /* the two-wave forms (wave 1 runs the mass-matrix stage group beside wave 0's collision / velocity / row stages) */
 static void body32s_2w() { ck::cassie_step_kernel<32, ck::TopoCassie32, ck::FEAT_ALL, CM_MAXEFC, 2>(g_io); }
+/* the full instantiation as the list-walking pass behind the fast kernel */
+static void body32s_walk() { ck::cassie_step_kernel<32, ck::TopoCassie32, ck::FEAT_ALL, CM_MAXEFC, 1, true>(g_io); }
+static void body32s_2w_walk() { ck::cassie_step_kernel<32, ck::TopoCassie32, ck::FEAT_ALL, CM_MAXEFC, 2, true>(g_io); }
 static void body32s_fast_2w() { ck::cassie_step_kernel<32, ck::TopoCassie32, ck::FEAT_ALL, ck::FAST_ROWS, 2>(g_io); }
 static void body40s_2w() { ck::cassie_step_kernel<40, ck::TopoCassieTray38, ck::FEAT_WAVEPAIRS, CM_MAXEFC, 2>(g_io); } /* (no height-field pairs) */
-static int g_two_waves = 0;
+static int g_two_waves = 0, g_resume_grid = 2;
+extern "C" void emu_resume_grid(int n) { g_resume_grid = n > 0 ? n : 1; }
 extern "C" void emu_two_waves(int on) { g_two_waves = on; }
 extern "C" void emu_wave_schedule(int mode) { g_wave_schedule = mode; }
 /* the row-capped fast instantiation ahead of the full one, as phys_batch.hip launches them (PhysIO::progress / resume);
@@ -243,18 +252,36 @@ extern "C" int emu_phys_run(const cm_model_t *model, int nenv, int nsub, int int
     g_io.pd_ptarget = pd_ptarget; g_io.pd_kp = pd_kp; g_io.pd_kd = pd_kd;
     g_io.drive_mode = g_drive_mode; g_io.drive_state = g_drive_state; g_io.drive_cmd = g_drive_cmd; g_io.meas = g_meas;
     g_io.pd_dtarget = g_pd_dtarget; g_io.pd_torque = g_pd_torque;
+    const bool cassie32 = !g_force_runtime_topology && topo_matches(model, ck::TopoCassie32::table, ck::TopoCassie32::nv, ck::TopoCassie32::body_levels);
+    if (cassie32 && g_fast_rows && integrate && nenv <= (1 << 16)) {
+        /* as phys_batch.hip launches them: the row-capped fast instantiation for every env (it appends the envs it hands over to
+         * the hand-over list), then the full instantiation as ONE small grid walking that list (here: g_resume_grid workgroups) */
+        static int progress[1 << 16], list[1 << 16], count[2];
+        static volatile int seen;
+        count[0] = count[1] = 0; seen = -1;
+        g_io.progress = progress; g_io.resume = 0; g_io.handover_list = list; g_io.handover_count = count; g_io.handover_seen = &seen;
+        g_grid = nenv;
+        for (int e = 0; e < nenv; ++e) {
+            g_env = e;
+            if (g_two_waves) run_block(body32s_fast_2w, 2); else run_block(body32s_fast);
+            if (progress[e] < nsub) ++g_fast_bails;
+        }
+        const int handed = count[0];
+        g_io.resume = 1;
+        g_grid = g_resume_grid;
+        for (int wg = 0; wg < g_resume_grid; ++wg) {
+            g_env = wg;
+            if (g_two_waves) run_block(body32s_2w_walk, 2); else run_block(body32s_walk);
+        }
+        g_grid = 1;
+        g_io.progress = nullptr; g_io.resume = 0; g_io.handover_list = nullptr; g_io.handover_count = nullptr; g_io.handover_seen = nullptr;
+        if (count[0] != 0 || count[1] != 0 || seen != handed) { fprintf(stderr, "emu: the pass behind the fast kernel left count %d ticket %d seen %d (handed %d)\n", count[0], count[1], (int)seen, handed); abort(); }
+        return 0;
+    }
     for (int e = 0; e < nenv; ++e) {
         g_env = e;
-        if (!g_force_runtime_topology && topo_matches(model, ck::TopoCassie32::table, ck::TopoCassie32::nv, ck::TopoCassie32::body_levels)) {
-            static int progress[1 << 16];
-            if (g_fast_rows && integrate && e < (1 << 16)) {
-                g_io.progress = progress; g_io.resume = 0;
-                if (g_two_waves) run_block(body32s_fast_2w, 2); else run_block(body32s_fast);
-                if (progress[e] < nsub) ++g_fast_bails;
-                g_io.resume = 1;
-            }
+        if (cassie32) {
             if (g_two_waves) run_block(body32s_2w, 2); else run_block(body32s);
-            g_io.progress = nullptr; g_io.resume = 0;
         }
         else if (!g_force_runtime_topology && topo_matches(model, ck::TopoCassieTray38::table, ck::TopoCassieTray38::nv, ck::TopoCassieTray38::body_levels)) {
             if (g_two_waves && model->nhfpair == 0 && model->hfield_geom < 0) run_block(body40s_2w, 2); else run_block(body40s);

@@ -28,8 +28,14 @@ namespace wv {
 int lane();
 int wave_id();
 int env_id();
+int grid_size();
+inline int atomic_add(int *p, int v) { const int old = *p; *p = old + v; return old; } /* (lanes run one at a time) */
 void sync();
 void block_barrier();
+void spin_yield();
+inline void publish(int *flag, int value) { sync(); if (lane() == 0) *flag = value; sync(); }
+int shfl_i(int v, int src_lane);
+inline void wait_for(const int *flag, int value) { while (shfl_i(*flag, 0) != value) spin_yield(); } /* (lane 0's reading decides for the wave) */
 double shfl(double v, int src_lane);
 double shfl_xor(double v, int mask);
 int shfl_i(int v, int src_lane);

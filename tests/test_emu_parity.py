@@ -397,8 +397,13 @@ def test_two_wave_form_is_bit_for_bit_the_one_wave_form_under_every_wave_schedul
     on a workload that hands envs over from the row-capped to the full instantiation in the middle of fused launches."""
     ref, rows, _ = _two_wave_workload(cassie, drive, fast=True, two_waves=False, schedule=0)
     assert rows[:, :, 1].max() > 31 and rows[:, :, 1].min() <= 31
+    import emu_py
     for schedule in (0, 1, 2):
-        got, _, bails = _two_wave_workload(cassie, drive, fast=True, two_waves=True, schedule=schedule)
+        emu_py.lib().emu_resume_grid((2, 1, 3)[schedule])      # workgroups of the pass that walks the hand-over list
+        try:
+            got, _, bails = _two_wave_workload(cassie, drive, fast=True, two_waves=True, schedule=schedule)
+        finally:
+            emu_py.lib().emu_resume_grid(2)
         assert bails > 0
         assert got == ref, schedule
     # the full instantiation alone, two waves
