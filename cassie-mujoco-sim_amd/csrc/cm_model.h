@@ -41,9 +41,15 @@ extern "C" {
 #define CM_HF_SLOTS  6       /* sample spheres per height-field pair: two ends + at most four interior ones */
 #define CM_HF_MAXC    4      /* contacts per capsule / height-field pair with CM_FLAG_HFMULTI */
 #define CM_HF_SLOTS_DENSE 10 /* the same with CM_FLAG_HFDENSE: two ends + at most eight interior ones (six pairs per wave pass) */
+/* (CM_MAXCON / CM_MAXEFC can be raised from the command line for ORACLE-ONLY studies of what the caps and the collision
+ * definitions cost in fidelity -- tools/collision_fidelity.py; the kernel's row stages are built around 63 = one row per lane) */
+#ifndef CM_MAXCON
 #define CM_MAXCON    16      /* contacts kept per env-step */
+#endif
 #define CM_MAXSLIDE  3       /* slide joints ahead of a body's rotational joint (kin_simple) */
+#ifndef CM_MAXEFC
 #define CM_MAXEFC    63      /* constraint rows per env-step (lane 63 is the qfrc_smooth column) */
+#endif
 
 /* joint types (same numbering as MuJoCo's mjtJoint) */
 enum { CM_JNT_FREE = 0, CM_JNT_BALL = 1, CM_JNT_SLIDE = 2, CM_JNT_HINGE = 3 };

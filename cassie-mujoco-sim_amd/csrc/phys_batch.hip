@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <utility>
@@ -71,6 +72,7 @@ struct phys_batch {
     int *h_handover_seen = nullptr, *d_handover_seen = nullptr;
     bool fast_rows = true;          /* use the row-capped fast instantiation where one exists (phys_batch_set_fast_rows) */
     int waves_per_env = 2;          /* two-wave form of the fast instantiations (phys_batch_set_waves_per_env) */
+    int waves_per_env_tray = 1;     /* ... of the 40-dof instantiation (its two-wave form spills: measured, profiles/round4) */
     double *d_scratch_out = nullptr; /* [nenv][nv + nsensordata + nu]: where phys_batch_forward_kinematics sends qacc / sensordata / actuator_velocity */
 };
 
@@ -217,7 +219,7 @@ static int launch(phys_batch *b, int nsub, int integrate, hipStream_t s, bool sc
         if (!hf && !wp) { launched = ck::launch_step_cassie(grid, pass_grid, s, io, fast, ev_after, b->waves_per_env); ev_after = nullptr; }
         else if (hf && !wp) { launched = ck::launch_step_cassie_hfield(grid, pass_grid, s, io, fast, ev_after, b->waves_per_env); ev_after = nullptr; }
         else launched = ck::launch_step_cassie_all(grid, s, io);
-    } else if (matches(ck::TopoCassieTray38::table, ck::TopoCassieTray38::nv, ck::TopoCassieTray38::body_levels)) launched = ck::launch_step_tray(grid, s, io, hf);
+    } else if (matches(ck::TopoCassieTray38::table, ck::TopoCassieTray38::nv, ck::TopoCassieTray38::body_levels)) launched = ck::launch_step_tray(grid, s, io, hf, integrate && !io.ext ? b->waves_per_env_tray : 1);
     else launched = ck::launch_step_generic(grid, s, io, hm.nv > 32);
     if (ev_after) (void)hipEventRecord(ev_after, s);
     if (!launched) { (void)hip_ok(hipErrorLaunchFailure, "cassie_step_kernel launch"); return -1; }
@@ -742,6 +744,7 @@ int phys_batch_set_fast_rows(phys_batch_t *b, int on) {
 int phys_batch_set_waves_per_env(phys_batch_t *b, int waves) {
     if (!b || (waves != 1 && waves != 2)) return -1;
     b->waves_per_env = waves;
+    b->waves_per_env_tray = waves == 2 && getenv("CASSIE_TRAY_TWO_WAVES") ? 2 : 1; /* (measurement aid) */
     return 0;
 }
 

@@ -29,7 +29,8 @@ bool launch_fast_cassie_hfield_2w(dim3 grid, hipStream_t s, PhysIO io);
 bool launch_full_cassie_2w(dim3 grid, hipStream_t s, PhysIO io);
 bool launch_full_cassie_hfield_2w(dim3 grid, hipStream_t s, PhysIO io);
 bool launch_step_cassie_all(dim3 grid, hipStream_t s, PhysIO io);                   /* <32, TopoCassie32, FEAT_ALL> */
-bool launch_step_tray(dim3 grid, hipStream_t s, PhysIO io, bool hfield);            /* <40, TopoCassieTray38, FEAT_WAVEPAIRS | FEAT_ALL> */
+bool launch_step_tray(dim3 grid, hipStream_t s, PhysIO io, bool hfield, int waves); /* <40, TopoCassieTray38, FEAT_WAVEPAIRS | FEAT_ALL> */
+bool launch_step_tray_2w(dim3 grid, hipStream_t s, PhysIO io);                      /* <40, TopoCassieTray38, FEAT_WAVEPAIRS, 63, 2>: two waves per env (kernels_tray_2w.hip) */
 bool launch_step_generic(dim3 grid, hipStream_t s, PhysIO io, bool wide);           /* <32 | 40, TopoRuntime, FEAT_ALL> */
 
 template <int NVP, class TOPO, int FEAT>

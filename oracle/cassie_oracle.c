@@ -16,6 +16,22 @@
 
 static const float *g_hfield = 0;
 void co_set_hfield(const float *data) { g_hfield = data; }
+/* contacts one geom pair can report: two (four with CM_FLAG_HFMULTI; box-box four), or -- study builds only -- one per grid
+ * triangle under a capsule */
+#ifdef CO_STUDY
+#define CO_RC_MAX 96
+/* ORACLE-ONLY STUDY MODES (tools/collision_fidelity.py; built with -DCO_STUDY and raised CM_MAXCON / CM_MAXEFC; never part of
+ * the parity oracle): what the collision definitions of DESIGN.md 4.2 cost in fidelity against MuJoCo-shaped contact sets.
+ *   hfield mode 1: one contact per PENETRATED GRID TRIANGLE under a sphere / capsule -- MuJoCo builds one prism per grid
+ *                  triangle and reports one contact per penetrated prism (why reference model/cassie_hfield.xml:4 asks for
+ *                  nconmax = 300); here: per triangle the deepest of the capsule's sample spheres (samples 2.5 mm apart)
+ *   box mode 8   : box-box keeps up to eight clipped-face candidates (MuJoCo's mjc_BoxBox returns up to eight) instead of four */
+static int g_study_hfield_mode = 0, g_study_box_keep = 4;
+void co_study_set_hfield_mode(int mode) { g_study_hfield_mode = mode; }
+void co_study_set_box_contacts(int n) { g_study_box_keep = n < 1 ? 1 : (n > 8 ? 8 : n); }
+#else
+#define CO_RC_MAX 8
+#endif
 unsigned long co_sizeof_data(void) { return sizeof(co_data_t); }
 
 /* ------------------------------------------------------------ small math --- */
@@ -605,7 +621,12 @@ static int box_box(raw_contact_t *c, const double *p1, const double *m1, const d
         }
     int nvalid = 0;
     for (int q = 0; q < 24; ++q) { if (cand[q].valid && cand[q].w > margin) cand[q].valid = 0; nvalid += cand[q].valid; }
-    if (nvalid > 4)                                                   /* keep the 4 deepest; within 1e-9 the earlier candidate wins */
+#ifdef CO_STUDY
+    const int bb_keep = g_study_box_keep;
+#else
+    const int bb_keep = 4;
+#endif
+    if (nvalid > bb_keep)                                             /* keep the 4 deepest; within 1e-9 the earlier candidate wins */
         for (int q = 0; q < 24; ++q) {
             if (!cand[q].valid) continue;
             int rank = 0;
@@ -613,10 +634,10 @@ static int box_box(raw_contact_t *c, const double *p1, const double *m1, const d
                 if (r == q || !cand[r].valid) continue;
                 if (cand[r].w < cand[q].w - 1e-9 || (fabs(cand[r].w - cand[q].w) <= 1e-9 && r < q)) ++rank;
             }
-            if (rank >= 4) cand[q].valid = 2;                         /* dropped (marked, so ranks of the others stay put) */
+            if (rank >= bb_keep) cand[q].valid = 2;                   /* dropped (marked, so ranks of the others stay put) */
         }
     int nc = 0;
-    for (int q = 0; q < 24 && nc < 4; ++q) {
+    for (int q = 0; q < 24 && nc < bb_keep; ++q) {
         if (cand[q].valid != 1) continue;
         c[nc].dist = cand[q].w;
         for (int x = 0; x < 3; ++x) {
@@ -724,6 +745,66 @@ static int hfield_sphere(raw_contact_t *c, const cm_model_t *m, const float *dat
     for (int k = 0; k < 3; ++k) { c->normal[k] = nw[k]; c->pos[k] = ps[k] - nw[k] * (r + 0.5 * dist); c->tangent[k] = 0; }
     return 1;
 }
+#ifdef CO_STUDY
+/* study mode 1: one contact per penetrated grid triangle under a capsule (a sphere is a capsule of half length 0): the capsule's
+ * axis is sampled every 2.5 mm, every triangle under the footprint keeps its deepest sample sphere, and every triangle whose
+ * deepest sample is within the margin gives one contact (position on the sample sphere's surface, normal = that sample's
+ * closest-feature direction, as in the default definition).  At most CO_RC_MAX contacts, deepest first. */
+static int hfield_capsule_per_triangle(raw_contact_t *c, const cm_model_t *m, const float *data, const double *ph, const double *mh, const double *pc,
+                                       const double *axw, double r, double h, double margin) {
+    if (!data || m->hfield_nrow < 2 || m->hfield_ncol < 2) return 0;
+    const double sx = m->hfield_size[0], sy = m->hfield_size[1], sz = m->hfield_size[2];
+    double d[3] = {pc[0] - ph[0], pc[1] - ph[1], pc[2] - ph[2]}, p0[3], ax[3];
+    mulmatTvec3(p0, mh, d);
+    mulmatTvec3(ax, mh, axw);
+    const int nc = m->hfield_ncol, nr = m->hfield_nrow;
+    const double dx = 2 * sx / (nc - 1), dy = 2 * sy / (nr - 1), reach = r + (margin > 0 ? margin : 0);
+    const double xa = p0[0] - h * fabs(ax[0]) - reach, xb = p0[0] + h * fabs(ax[0]) + reach, ya = p0[1] - h * fabs(ax[1]) - reach, yb = p0[1] + h * fabs(ax[1]) + reach;
+    int j0 = (int)floor((xa + sx) / dx), j1 = (int)floor((xb + sx) / dx), i0 = (int)floor((ya + sy) / dy), i1 = (int)floor((yb + sy) / dy);
+    if (j0 < 0) j0 = 0;
+    if (i0 < 0) i0 = 0;
+    if (j1 > nc - 2) j1 = nc - 2;
+    if (i1 > nr - 2) i1 = nr - 2;
+    const int ns = h > 0 ? 1 + 2 * (int)ceil(h / 0.0025) : 1;
+    raw_contact_t all[512];
+    int nall = 0;
+    for (int i = i0; i <= i1; ++i)
+        for (int j = j0; j <= j1; ++j)
+            for (int tri = 0; tri < 2; ++tri) {
+                const double x0 = -sx + j * dx, y0 = -sy + i * dy;
+                const double v00[3] = {x0, y0, sz * data[i * nc + j]}, v10[3] = {x0 + dx, y0, sz * data[i * nc + j + 1]};
+                const double v01[3] = {x0, y0 + dy, sz * data[(i + 1) * nc + j]}, v11[3] = {x0 + dx, y0 + dy, sz * data[(i + 1) * nc + j + 1]};
+                double best = 1e300, bn[3] = {0, 0, 1}, bp[3] = {0, 0, 0};
+                for (int k = 0; k < ns; ++k) {
+                    const double t = ns > 1 ? -h + 2 * h * k / (ns - 1) : 0.0;
+                    const double p[3] = {p0[0] + t * ax[0], p0[1] + t * ax[1], p0[2] + t * ax[2]};
+                    double cur = 1e300, cn[3] = {0, 0, 1};
+                    if (tri == 0) hfield_triangle(p, v00, v10, v01, &cur, cn); else hfield_triangle(p, v11, v01, v10, &cur, cn);
+                    if (cur < best) { best = cur; for (int q = 0; q < 3; ++q) { bn[q] = cn[q]; bp[q] = p[q]; } }
+                }
+                if (best > 1e299 || best - r > margin) continue;
+                raw_contact_t rc;
+                double nw[3], pw[3];
+                mulmatvec3(nw, mh, bn);
+                mulmatvec3(pw, mh, bp);
+                rc.dist = best - r;
+                for (int q = 0; q < 3; ++q) { rc.normal[q] = nw[q]; rc.pos[q] = pw[q] + ph[q] - nw[q] * (r + 0.5 * rc.dist); rc.tangent[q] = h > 0 ? axw[q] : 0.0; }
+                if (nall < 512) all[nall++] = rc;
+            }
+    /* deepest first (ties: grid order), at most CO_RC_MAX */
+    int n = 0;
+    char used[512];
+    memset(used, 0, sizeof used);
+    while (n < CO_RC_MAX) {
+        int best_i = -1;
+        for (int k = 0; k < nall; ++k) if (!used[k] && (best_i < 0 || all[k].dist < all[best_i].dist)) best_i = k;
+        if (best_i < 0) break;
+        used[best_i] = 1;
+        c[n++] = all[best_i];
+    }
+    return n;
+}
+#endif
 /* test hook: one sphere (world centre ps, radius r) against the height field geom of the model; out = dist, pos, normal */
 int co_test_hfield_sphere(const cm_model_t *m, const double *ps, double r, double margin, double *out) {
     if (m->hfield_geom < 0) return 0;
@@ -841,7 +922,7 @@ void co_collision(const cm_model_t *m, co_data_t *d) {
             double dif[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
             if (dot3(dif, n) > margin + m->geom_rbound[g2]) continue;
         }
-        raw_contact_t rc[8];
+        raw_contact_t rc[CO_RC_MAX];
         (void)mulmat3;
         int n = 0;
         if (t1 == CM_GEOM_PLANE && t2 == CM_GEOM_SPHERE) n = plane_sphere(rc, p1, m1, p2, m->geom_size[g2][0], margin);
@@ -849,6 +930,12 @@ void co_collision(const cm_model_t *m, co_data_t *d) {
         else if (t1 == CM_GEOM_SPHERE && t2 == CM_GEOM_SPHERE) n = sphere_sphere(rc, p1, m->geom_size[g1][0], p2, m->geom_size[g2][0], margin);
         else if (t1 == CM_GEOM_SPHERE && t2 == CM_GEOM_CAPSULE) n = sphere_capsule(rc, p1, m->geom_size[g1][0], p2, m2, m->geom_size[g2], margin);
         else if (t1 == CM_GEOM_CAPSULE && t2 == CM_GEOM_CAPSULE) n = capsule_capsule(rc, p1, m1, m->geom_size[g1], p2, m2, m->geom_size[g2], margin);
+#ifdef CO_STUDY
+        else if (t1 == CM_GEOM_HFIELD && (t2 == CM_GEOM_SPHERE || t2 == CM_GEOM_CAPSULE) && g_study_hfield_mode == 1) {
+            const double axw[3] = {m2[2], m2[5], m2[8]};
+            n = hfield_capsule_per_triangle(rc, m, g_hfield, p1, m1, p2, axw, m->geom_size[g2][0], t2 == CM_GEOM_CAPSULE ? m->geom_size[g2][1] : 0.0, margin);
+        }
+#endif
         else if (t1 == CM_GEOM_HFIELD && t2 == CM_GEOM_SPHERE) n = hfield_sphere(rc, m, g_hfield, p1, m1, p2, m->geom_size[g2][0], margin);
         else if (t1 == CM_GEOM_HFIELD && t2 == CM_GEOM_CAPSULE) n = hfield_capsule(rc, m, g_hfield, p1, m1, p2, m2, m->geom_size[g2], margin);
         else if (t1 == CM_GEOM_SPHERE && t2 == CM_GEOM_BOX) n = sphere_box(rc, p1, m->geom_size[g1][0], p2, m2, m->geom_size[g2], margin);
