@@ -2,11 +2,26 @@
  * plane-box / box-box pairs handled by the whole wave; with or without height-field pairs */
 #include "step_launch.h"
 namespace ck {
-bool launch_step_tray(dim3 grid, hipStream_t s, PhysIO io, bool hfield, int waves) {
+bool launch_step_tray(dim3 grid, dim3 pass_grid, hipStream_t s, PhysIO io, bool hfield, bool fast, hipEvent_t after_first, int waves) {
+    if (waves == 2 && !hfield) {
+        /* two waves per env: the fast instantiation first (when asked for), the full one behind it or alone */
+        if (fast) {
+            io.resume = 0;
+            if (!launch_fast_tray_2w(grid, s, io)) return false;
+            if (after_first) { (void)hipEventRecord(after_first, s); after_first = nullptr; }
+            io.resume = 1;
+            if (!launch_full_tray_2w(pass_grid, s, io)) return false;
+        } else {
+            io.progress = nullptr; io.resume = 0; io.handover_list = nullptr;
+            if (!launch_full_tray_2w(grid, s, io)) return false;
+        }
+        if (after_first) (void)hipEventRecord(after_first, s);
+        return true;
+    }
     io.progress = nullptr; io.resume = 0; io.handover_list = nullptr;
-    if (waves == 2 && !hfield) return launch_step_tray_2w(grid, s, io);
     if (!hfield) hipLaunchKernelGGL((cassie_step_kernel<40, TopoCassieTray38, FEAT_WAVEPAIRS>), grid, dim3(WV_WAVE), 0, s, io);
     else hipLaunchKernelGGL((cassie_step_kernel<40, TopoCassieTray38, FEAT_ALL>), grid, dim3(WV_WAVE), 0, s, io);
+    if (after_first) (void)hipEventRecord(after_first, s);
     return hipGetLastError() == hipSuccess;
 }
 }  // namespace ck

@@ -24,6 +24,8 @@
 
 void phys_set_last_error(const char *s);
 
+constexpr int DEFAULT_TRAY_WAVES = 1; /* the 40-dof model's default form (decided by measurement, profiles/round4/tray_two_waves_ab.txt) */
+
 struct phys_batch {
     int nenv = 0, device = 0;
     cm_model_t host_model;          /* copy of the shared model (sizes) */
@@ -72,7 +74,7 @@ struct phys_batch {
     int *h_handover_seen = nullptr, *d_handover_seen = nullptr;
     bool fast_rows = true;          /* use the row-capped fast instantiation where one exists (phys_batch_set_fast_rows) */
     int waves_per_env = 2;          /* two-wave form of the fast instantiations (phys_batch_set_waves_per_env) */
-    int waves_per_env_tray = 1;     /* ... of the 40-dof instantiation (its two-wave form spills: measured, profiles/round4) */
+    int waves_per_env_tray = DEFAULT_TRAY_WAVES; /* ... of the 40-dof instantiations (CASSIE_TRAY_TWO_WAVES=0/1 overrides the default: A/B aid) */
     double *d_scratch_out = nullptr; /* [nenv][nv + nsensordata + nu]: where phys_batch_forward_kinematics sends qacc / sensordata / actuator_velocity */
 };
 
@@ -201,10 +203,9 @@ static int launch(phys_batch *b, int nsub, int integrate, hipStream_t s, bool sc
             ++b->ev_used;
         }
     }
-    if (matches(ck::TopoCassie32::table, ck::TopoCassie32::nv, ck::TopoCassie32::body_levels)) {
-        /* stepping launches of the two Cassie instantiations go through the row-capped fast instantiation first; the full one
-         * behind it finishes the envs that met a substep with more rows (and is the only one for forward / read-out passes) */
-        const bool fast = b->fast_rows && integrate && !wp && !io.ext && b->d_progress;
+    /* a row-capped fast instantiation with the full one behind it: the fast kernel's record of completed substeps, and the
+     * hand-over list the pass behind it walks -> the grid of that pass */
+    auto fast_then_full = [&](bool fast) {
         io.progress = fast ? b->d_progress : nullptr;
         dim3 pass_grid = grid;
         if (fast && b->d_handover_list) {
@@ -216,10 +217,24 @@ static int launch(phys_batch *b, int nsub, int integrate, hipStream_t s, bool sc
             const long want = 2L * (seen > 0 ? seen : 0) + 16;
             pass_grid = dim3((unsigned)(want < n ? want : n));
         }
+        return pass_grid;
+    };
+    if (matches(ck::TopoCassie32::table, ck::TopoCassie32::nv, ck::TopoCassie32::body_levels)) {
+        /* stepping launches of the two Cassie instantiations go through the row-capped fast instantiation first; the full one
+         * behind it finishes the envs that met a substep with more rows (and is the only one for forward / read-out passes) */
+        const bool fast = b->fast_rows && integrate && !wp && !io.ext && b->d_progress;
+        const dim3 pass_grid = fast_then_full(fast);
         if (!hf && !wp) { launched = ck::launch_step_cassie(grid, pass_grid, s, io, fast, ev_after, b->waves_per_env); ev_after = nullptr; }
         else if (hf && !wp) { launched = ck::launch_step_cassie_hfield(grid, pass_grid, s, io, fast, ev_after, b->waves_per_env); ev_after = nullptr; }
         else launched = ck::launch_step_cassie_all(grid, s, io);
-    } else if (matches(ck::TopoCassieTray38::table, ck::TopoCassieTray38::nv, ck::TopoCassieTray38::body_levels)) launched = ck::launch_step_tray(grid, s, io, hf, integrate && !io.ext ? b->waves_per_env_tray : 1);
+    } else if (matches(ck::TopoCassieTray38::table, ck::TopoCassieTray38::nv, ck::TopoCassieTray38::body_levels)) {
+        /* the 40-dof model: in its two-wave form a fast instantiation of 47 rows (the boxes resting on the tray take it to 32 .. 40
+         * routinely) with the full one behind it; one wave per env: the full instantiation alone */
+        const bool two = integrate && !io.ext && !hf && b->waves_per_env_tray == 2;
+        const bool fast = two && b->fast_rows && b->d_progress;
+        const dim3 pass_grid = fast_then_full(fast);
+        launched = ck::launch_step_tray(grid, pass_grid, s, io, hf, fast, ev_after, two ? 2 : 1); ev_after = nullptr;
+    }
     else launched = ck::launch_step_generic(grid, s, io, hm.nv > 32);
     if (ev_after) (void)hipEventRecord(ev_after, s);
     if (!launched) { (void)hip_ok(hipErrorLaunchFailure, "cassie_step_kernel launch"); return -1; }
@@ -269,6 +284,7 @@ phys_batch_t *phys_batch_create(const cm_model_t *model, int nenv, int device) {
     if (!hip_ok(hipSetDevice(device), "hipSetDevice")) return nullptr;
     phys_batch *b = new phys_batch;
     b->nenv = nenv; b->device = device;
+    if (const char *tw = getenv("CASSIE_TRAY_TWO_WAVES")) b->waves_per_env_tray = atoi(tw) ? 2 : 1;
     b->host_model = *model;
     const int d[PHYS_F_COUNT] = {model->nq, model->nv, model->nv, 1, model->nu, model->nv, model->nbody * 6,
                                  model->nv, model->nsensordata, model->nu, model->nbody * 3, model->nbody * 4,
@@ -744,7 +760,7 @@ int phys_batch_set_fast_rows(phys_batch_t *b, int on) {
 int phys_batch_set_waves_per_env(phys_batch_t *b, int waves) {
     if (!b || (waves != 1 && waves != 2)) return -1;
     b->waves_per_env = waves;
-    b->waves_per_env_tray = waves == 2 && getenv("CASSIE_TRAY_TWO_WAVES") ? 2 : 1; /* (measurement aid) */
+    b->waves_per_env_tray = waves;
     return 0;
 }
 

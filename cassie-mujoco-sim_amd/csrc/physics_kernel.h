@@ -177,9 +177,11 @@ struct EnvShared {
     int c_root[CM_MAXCON][2];               /* tree roots of the two bodies, their dof chains, summed inverse weights */
     unsigned long long c_dofmask[CM_MAXCON][2];
     double c_tran[CM_MAXCON];
-    /* two-wave form (NW = 2): cmd[0] = what wave 0 tells wave 1 at the workgroup barriers -- 0 = carry on, 1 = this env's launch
-     * ends here; cmd[1] = the substep (+ 1) whose body forces wave 0's velocity stage has put in LDS (wave 1 waits for it) */
-    int cmd[2];
+    /* two-wave form (NW = 2): cmd[0] = what the waves tell each other at the workgroup barriers -- 0 = carry on, 1 = this env's
+     * launch ends here (wave 0: diverged state, or the row-capped instantiation hands the substep over), 2 = wave 1 found a
+     * diverged qacc; cmd[1] = the substep (+ 1) whose body forces wave 0's velocity stage has put in LDS, cmd[2] = the substep
+     * (+ 1) whose staged matrix Y wave 0 has put in LDS (wave 1 waits for either) */
+    int cmd[4];
 };
 
 /* ------------------------------------------------------------ small math --- */
@@ -1477,6 +1479,130 @@ WV_DEVICE void bias_forces_and_qfrc_smooth(const PhysIO &io, SH &S, ModelPtr m, 
     CK_STAMP(7);
 }
 
+/* ---------------- the stages behind the constraint solve, as functions both forms share: in the one-wave form the substep loop calls
+ * them in line, in the two-wave form wave 1 runs them (with the factor rows staged while wave 0 is still in its PGS sweeps). ---------------- */
+/* this lane's row of the unit-triangular factor of M (zeros outside its ancestors): the forward substitution's operand */
+template <int NVP, class TOPO, class SH>
+WV_DEVICE void stage_factor_row(const SH &S, int k_, bool isdof, double (&lrow)[NVP]) {
+    typedef LPack<TOPO, NVP> LP;
+    const typename LP::Row myrow = LP::row_of(k_);
+#pragma unroll
+    for (int i = 0; i < NVP; ++i) {
+        if constexpr (LP::packed) {
+            const bool has = isdof && i < k_ && LP::row_has(myrow, i);
+            const double v = S.Lp[has ? LP::row_idx(myrow, i) : 0];
+            lrow[i] = has ? v : 0.0;
+        } else lrow[i] = (isdof && i < k_) ? S.Lp[CK_TRI(k_, i)] : 0.0;
+    }
+}
+/* this lane's column and row of the factor of M + hB (the Euler step's two substitutions) */
+template <int NVP, class TOPO, class SH>
+WV_DEVICE void stage_factor_h(const SH &S, int k_, bool isdof, int nv, double (&lcol)[NVP], double (&lrowh)[NVP]) {
+    typedef LPack<TOPO, NVP> LP;
+    const typename LP::Row myrow = LP::row_of(k_);
+#pragma unroll
+    for (int k = 0; k < NVP; ++k) {
+        const bool inrange = TOPO::is_static ? k < TOPO::nv : k < nv;
+        if constexpr (LP::packed) {
+            const bool hasc = inrange && isdof && k > k_ && LP::col_has(k, k_), hasr = isdof && k < k_ && LP::row_has(myrow, k);
+            const double vc = S.LHp[hasc ? LP::col_idx(k, k_) : 0], vr = S.LHp[hasr ? LP::row_idx(myrow, k) : 0];
+            lcol[k] = hasc ? vc : 0.0;
+            lrowh[k] = hasr ? vr : 0.0;
+        } else {
+            lcol[k] = (inrange && isdof && k > k_) ? S.LHp[CK_TRI(k, k_)] : 0.0;
+            lrowh[k] = (isdof && k < k_) ? S.LHp[CK_TRI(k_, k)] : 0.0;
+        }
+    }
+}
+/* what a substep still owes once qacc is in LDS: the accelerometers (they need qacc), the actuator velocities, and -- in the last
+ * substep of a launch -- the outputs in HBM.  aslot / sb: which accelerometer this lane is (-1: none) and its body. */
+template <class SH>
+WV_DEVICE void outputs_after_qacc(const PhysIO &io, SH &S, ModelPtr m, int env, int lane, bool isdof, int k_, int nu, double qacc, int aslot, int sb, bool need_imu,
+                                  bool lastsub, double pf_agear, int pf_adof, int ncon, int nefc, int iters, int nguarded) {
+    if (aslot >= 0 && need_imu) {
+        const double *pa = S.accel[aslot];
+        double acc_ang[3] = {pa[0], pa[1], pa[2]}, acc_lin[3] = {pa[3], pa[4], pa[5]}, acc_dif[3] = {pa[6], pa[7], pa[8]};
+        for (unsigned long long mk = m->body_dofmask[sb]; mk; mk &= mk - 1) {
+            const int k = wv::popc64((mk & (0ull - mk)) - 1);
+            const double qa = S.qacc[k];
+            for (int i = 0; i < 3; ++i) { acc_ang[i] += S.cdof[k][i] * qa; acc_lin[i] += S.cdof[k][3 + i] * qa; }
+        }
+        double t[3], lin[3], vlin[3], corr[3], outv[3];
+        cross3(t, acc_dif, acc_ang);
+        for (int i = 0; i < 3; ++i) lin[i] = acc_lin[i] - t[i];
+        cross3(t, acc_dif, pa + 18);
+        for (int i = 0; i < 3; ++i) vlin[i] = pa[21 + i] - t[i];
+        cross3(corr, pa + 18, vlin);
+        for (int i = 0; i < 3; ++i) lin[i] += corr[i];
+        mulmatTvec3(outv, pa + 9, lin);
+        const double cut = m->sensor_cutoff[lane];
+        const int adr = m->sensor_adr[lane];
+        for (int i = 0; i < 3; ++i) {
+            const double v = cut > 0 ? clampd(outv[i], -cut, cut) : outv[i];
+            if (lastsub) io.sensordata[(size_t)env * io.ssd + adr + i] = v;
+            if (io.drive_mode) S.sens[adr + i] = v;
+        }
+    }
+    if (lane < nu) {
+        const double av = pf_agear * S.qvel[pf_adof];
+        if (lastsub) io.actuator_velocity[(size_t)env * io.su + lane] = av;
+        if (io.drive_mode) S.actvel[lane] = av;
+    }
+    if (io.info && lane == 0 && lastsub) {
+        io.info[(size_t)env * 4 + 0] = ncon; io.info[(size_t)env * 4 + 1] = nefc;
+        io.info[(size_t)env * 4 + 2] = iters; io.info[(size_t)env * 4 + 3] = nguarded;
+    }
+    if (isdof && lastsub) io.qacc[(size_t)env * io.sv + k_] = qacc;
+}
+/* P12: semi-implicit Euler with implicit joint damping, then the positions (lane = dof, then lane = joint) */
+template <int NVP, class TOPO, class SH>
+WV_DEVICE void euler_step(SH &S, ModelPtr m, int lane, bool isdof, int k_, int nv, int njnt, double h, double qacc, const double (&lcol)[NVP],
+                          const double (&lrowh)[NVP], double dih, double pf_kdamp, int pf_ejt, int pf_eqa, int pf_eda) {
+    double qacc_int = qacc;
+    if (m->flags & CM_FLAG_EULERDAMP) {
+        /* (M + hB) x = M qacc  <=>  x = qacc - (M + hB)^-1 (hB qacc) */
+        double w = isdof ? h * pf_kdamp * qacc : 0.0;
+        w = solve_backward<NVP, TOPO>(w, lcol, lane, nv); /* L^-T */
+        w *= dih;
+        w = solve_forward<NVP, TOPO>(w, lrowh, lane, nv);  /* L^-1 */
+        qacc_int = qacc - w;
+    }
+    if (isdof) {
+        S.qvel[k_] += h * qacc_int;
+        S.qacc_ws[k_] = qacc;
+    }
+    wv::sync();
+    {
+        /* lane = joint.  Hinges and slides are one FMA; a ball (or the rotation of a free joint) turns its quaternion by
+         * h * |w| about w -- through the stage's own bounded-range sincos and reciprocal-square-root normalisations (the
+         * library's sin + cos, a square root and two divisions, run for three lanes, were a tenth of this stage).  The
+         * sincos sits outside the lane branches: its range check is a wave vote. */
+        const int jt = lane < njnt ? pf_ejt : -1;
+        int qa = pf_eqa, da = pf_eda;
+        if (jt == CM_JNT_HINGE || jt == CM_JNT_SLIDE) S.qpos[qa] += h * S.qvel[da];
+        if (jt == CM_JNT_FREE) {
+            for (int i = 0; i < 3; ++i) S.qpos[qa + i] += h * S.qvel[da + i];
+            qa += 3; da += 3;
+        }
+        const bool turns = jt == CM_JNT_FREE || jt == CM_JNT_BALL;
+        double ax[3] = {1, 0, 0}, ang = 0;
+        if (turns) {
+            for (int i = 0; i < 3; ++i) ax[i] = S.qvel[da + i];
+            ang = h * normalize3_fast(ax);
+        }
+        double sn, cs;
+        sincos_bounded(0.5 * ang, sn, cs);
+        if (turns) {
+            double qr[4] = {cs, ax[0] * sn, ax[1] * sn, ax[2] * sn};
+            double q[4] = {S.qpos[qa], S.qpos[qa + 1], S.qpos[qa + 2], S.qpos[qa + 3]};
+            normalize4_fast(q);
+            mulquat(q, q, qr);
+            for (int i = 0; i < 4; ++i) S.qpos[qa + i] = q[i];
+        }
+    }
+    wv::sync();
+}
+
 /* ======================================================== the env step ==== */
 /* FEAT selects the collision code a model needs, so that the instantiation for plain cassie.xml does not carry the
  * register pressure of paths it never takes: FEAT_HFIELD = height-field pairs, FEAT_WAVEPAIRS = plane-box / box-box
@@ -1505,7 +1631,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
 
     /* ---------------- load state (coalesced, env-major) ---------------- */
     if (NW == 1 || wid == 0) {
-    if (lane == 0) { S.cmd[0] = 0; S.cmd[1] = 0; }
+    if (lane == 0) { S.cmd[0] = 0; S.cmd[1] = 0; S.cmd[2] = 0; }
     if (lane < nq) S.qpos[lane] = io.qpos[(size_t)env * io.sq + lane];
     if (lane < nv) {
         S.qvel[lane] = io.qvel[(size_t)env * io.sqv + lane];
@@ -1600,15 +1726,97 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
                     wv::wait_for(&S.cmd[1], sub1 + 1); /* wave 0's velocity stage has the body forces (cfrc) in LDS */
                     bias_forces_and_qfrc_smooth<NVP>(io, S, m, env, ids, kdamp, kstiff, kref, kgear, klo, khi, kq, ka);
                 }
-                wv::block_barrier(); /* J: the factors of M and M + hB are in LDS */
+                wv::block_barrier(); /* J: the factors of M and M + hB and qfrc_smooth are in LDS */
                 CK_STAMP(39);
+                /* ---- the stages behind wave 0's constraint solve: operands staged now, while wave 0 assembles and solves ---- */
+                {
+                    const bool lastsub = sub1 == io.nsub - 1 || !io.integrate;
+                    const bool need_imu = lastsub || io.all_outputs_every_substep || (io.drive_mode && sub1 + 2 == io.nsub);
+                    const bool need_pos = lastsub || io.drive_mode || io.all_outputs_every_substep;
+                    const bool issens = lane < m->nsensor && need_pos;
+                    const int ls = issens ? lane : 0;
+                    const int stype = issens ? m->sensor_type[ls] : -1, sb = m->sensor_body[ls];
+                    const int aslot = stype == CM_SENS_ACCELEROMETER ? m->sensor_slot[ls] : -1; /* which accelerometer this lane is */
+                    const int pf_u = lane < nu ? lane : 0, pf_ej = lane < njnt ? lane : 0;
+                    const double pf_agear = m->act_gear[pf_u], pf_kdamp = m->dof_damping[isdof ? k_ : 0];
+                    const int pf_adof = m->act_dofid[pf_u], pf_ejt = m->jnt_type[pf_ej], pf_eqa = m->jnt_qposadr[pf_ej], pf_eda = m->jnt_dofadr[pf_ej];
+                    const double *const fbuf = &S.c_solimp[0][0];
+                    double lrow[NVP];
+                    stage_factor_row<NVP, TOPO>(S, k_, isdof, lrow);
+                    const double rsdk = isdof ? S.rsd[k_] : 0.0;
+                    const int kk = isdof ? k_ : 0;
+                    /* this lane's column of the staged matrix (row MAXR = the qfrc_smooth column), once wave 0 has put it in LDS: the
+                     * row-capped instantiation keeps it in registers across wave 0's solve, the full one reads it at its use */
+                    constexpr bool stage_y = MAXR <= 31;
+                    double ycolk[stage_y ? MAXR + 1 : 1];
+                    if constexpr (stage_y) {
+                        wv::wait_for(&S.cmd[2], sub1 + 1);
+#pragma unroll
+                        for (int r = 0; r <= MAXR; ++r) ycolk[r] = S.x.Yr[r][kk];
+                    }
+                    wv::block_barrier(); /* P: wave 0's row forces and solver statistics are in LDS */
+                    const double f = fbuf[lane];
+                    const int ncon = (int)fbuf[64], nefc = (int)fbuf[65], iters = (int)fbuf[66], nguarded = (int)fbuf[67];
+                    /* ================= qacc = L^-1 D^-1/2 (y63 + Y f)  (lane = dof) ================= */
+                    double z, z1 = 0, z2 = 0, z3 = 0;
+                    if constexpr (stage_y) {
+                        /* (the summation order of the one-wave form's loop: rows four to a group into four partial sums, the rows of
+                         * the last, partial group into the first) */
+                        z = isdof ? ycolk[MAXR] : 0.0;
+#pragma unroll
+                        for (int r = 0; r < MAXR; r += 4) {
+                            if (r + 4 <= nefc) {
+                                z += ycolk[r] * wv::readlane(f, r); z1 += ycolk[r + 1 < MAXR ? r + 1 : r] * wv::readlane(f, r + 1);
+                                z2 += ycolk[r + 2 < MAXR ? r + 2 : r] * wv::readlane(f, r + 2); z3 += ycolk[r + 3 < MAXR ? r + 3 : r] * wv::readlane(f, r + 3);
+                            } else {
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) if (r + j < nefc && r + j < MAXR) z += ycolk[r + j < MAXR ? r + j : r] * wv::readlane(f, r + j);
+                            }
+                        }
+                    } else {
+                        z = isdof ? S.x.Yr[MAXR][k_] : 0.0;
+                        int r = 0;
+                        for (; r + 4 <= nefc; r += 4) {
+                            const double y0 = S.x.Yr[r][kk], y1 = S.x.Yr[r + 1][kk], y2 = S.x.Yr[r + 2][kk], y3 = S.x.Yr[r + 3][kk];
+                            z += y0 * wv::readlane(f, r); z1 += y1 * wv::readlane(f, r + 1);
+                            z2 += y2 * wv::readlane(f, r + 2); z3 += y3 * wv::readlane(f, r + 3);
+                        }
+                        for (; r < nefc; ++r) z += S.x.Yr[r][kk] * wv::readlane(f, r);
+                    }
+                    z = (z + z1) + (z2 + z3);
+                    if (!isdof) z = 0.0;
+                    if (isdof) z *= rsdk;
+                    /* (the Euler step's operands are requested here: their LDS latency runs under the substitution below) */
+                    double lcol[NVP], lrowh[NVP];
+                    stage_factor_h<NVP, TOPO>(S, k_, isdof, nv, lcol, lrowh);
+                    const double dih = isdof ? S.dinvH[k_] : 0.0;
+                    wv::sched_fence();
+                    const double qacc = solve_forward<NVP, TOPO>(z, lrow, lane, nv);
+                    {
+                        const bool badv = isdof && (!(qacc == qacc) || fabs(qacc) > 1e10);
+                        if (wv::ballot(badv) != 0ull) { /* diverged: the state stays as it is, wave 0 raises the flag */
+                            if (lane == 0) S.cmd[0] = 2;
+                            wv::block_barrier(); /* E */
+                            return;
+                        }
+                    }
+                    if (isdof) S.qacc[k_] = qacc;
+                    wv::sync();
+                    CK_STAMP(12);
+                    outputs_after_qacc(io, S, m, env, lane, isdof, k_, nu, qacc, aslot, sb, need_imu, lastsub, pf_agear, pf_adof, ncon, nefc, iters, nguarded);
+                    CK_STAMP(13);
+                    if (io.integrate) {
+                        euler_step<NVP, TOPO>(S, m, lane, isdof, k_, nv, njnt, h, qacc, lcol, lrowh, dih, pf_kdamp, pf_ejt, pf_eqa, pf_eda);
+                    }
+                    CK_STAMP(14);
+                    wv::block_barrier(); /* E: the substep is complete (qpos / qvel / warm start of the next one are in LDS) */
+                }
                 if (!io.integrate || ++sub1 >= io.nsub) return;
             }
         }
     }
 
     bool bailed = false;
-    bool release_wave1 = false; /* two-wave form: this wave left the loop behind J while wave 1 waits at the next F */
     int sub = sub_start;
     for (; sub < io.nsub; ++sub) {
         /* Outputs that every substep recomputes (sensordata, qacc, actuator_velocity, xpos / xquat, the solver statistics)
@@ -2696,6 +2904,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
             for (int k = 0; k < NVP; ++k) S.x.Yr[yrow][k] = ycol[k];
         }
         wv::sync();
+        if constexpr (NW == 2) wv::publish(&S.cmd[2], sub + 1); /* wave 1 stages its column of Y for the qacc stage while this wave solves */
         CK_STAMP(9);
 
         /* ================= P9: this lane's row of A = Y^T Y + diag(R), b = Y^T y63 - aref ================= */
@@ -2742,6 +2951,34 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
 #pragma unroll
             for (int k = 0; k < NVP; ++k) wv::touch(ycol[k]);
             diag_yy = Am[myrow][myrow];
+        } else if constexpr (NW == 2 && NVP > 32) {
+            /* the 40-dof instantiation at the 256 registers of the two-wave form: one staged row at a time, half a row in flight
+             * (the row-pair loop below keeps two staged rows beside this lane's column and its row of A: 330 registers); the same
+             * four partial sums per product, in the same order */
+#pragma unroll
+            for (int r = 0; r < MAXR; ++r) {
+                double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+                if (r < nefc) {
+#pragma unroll
+                    for (int k0 = 0; k0 < NVP; k0 += NVP / 2) {
+                        double ya[NVP / 2];
+#pragma unroll
+                        for (int k = 0; k < NVP / 2; ++k) ya[k] = S.x.Yr[r][k0 + k];
+#pragma unroll
+                        for (int k = 0; k < NVP / 2; k += 4) {
+                            a0 += ya[k] * ycol[k0 + k]; a1 += ya[k + 1] * ycol[k0 + k + 1];
+                            a2 += ya[k + 2] * ycol[k0 + k + 2]; a3 += ya[k + 3] * ycol[k0 + k + 3];
+                        }
+                    }
+                }
+                arow[r] = (a0 + a1) + (a2 + a3);
+            }
+            {
+                double acc = 0;
+#pragma unroll
+                for (int k = 0; k < NVP; ++k) acc = fma(S.x.Yr[MAXR][k], ycol[k], acc);
+                rb = acc - raref;
+            }
         } else {
 #pragma unroll
         for (int r = 0; r < MAXR; r += 2) {
@@ -2943,6 +3180,23 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
             }
         }
 
+        if constexpr (NW == 2) {
+            /* Two-wave form: the stages behind the solve -- qacc, the accelerometers, the substep's outputs, the Euler step -- are
+             * wave 1's, which has staged their operands (its row of L, its column of Y, its row and column of the factor of
+             * M + hB) while this wave was in its PGS sweeps.  The row forces and the solver statistics go through LDS -- the contacts'
+             * solimp slots, which nothing reads behind the rows' impedances -- at barrier P; barrier E ends the substep. */
+            static_assert(sizeof(S.c_solimp) >= 68 * sizeof(double), "the row forces are handed over through the contacts' solimp slots");
+            double *const fbuf = &S.c_solimp[0][0];
+            fbuf[lane] = f;
+            if (lane == 0) { fbuf[64] = (double)ncon; fbuf[65] = (double)nefc; fbuf[66] = (double)iters; fbuf[67] = (double)nguarded; }
+            wv::block_barrier(); /* P */
+            wv::block_barrier(); /* E */
+            CK_STAMP(37);
+            if (wv::opaque(S.cmd[0])) { warn |= WARN_DIVERGED; break; }
+            if (!io.integrate) break;
+            time += h;
+            continue;
+        }
         /* ================= qacc = L^-1 D^-1/2 (y63 + Y f)  (lane = dof) ================= */
         /* (constants of the stages behind the solves, requested ahead of them: actuator velocities, the Euler step) */
         const int pf_u = lane < nu ? lane : 0, pf_ej = lane < njnt ? lane : 0;
@@ -2968,128 +3222,33 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
             if (isdof) z *= S.rsd[k_];
             /* forward substitution with this lane's row of L staged first (all LDS reads in flight together) */
             double lrow[NVP];
-            const typename LP::Row myrow = LP::row_of(k_);
-#pragma unroll
-            for (int i = 0; i < NVP; ++i) {
-                if constexpr (LP::packed) {
-                    const bool has = isdof && i < k_ && LP::row_has(myrow, i);
-                    const double v = S.Lp[has ? LP::row_idx(myrow, i) : 0];
-                    lrow[i] = has ? v : 0.0;
-                } else lrow[i] = (isdof && i < k_) ? S.Lp[CK_TRI(k_, i)] : 0.0;
-            }
+            stage_factor_row<NVP, TOPO>(S, k_, isdof, lrow);
             qacc = solve_forward<NVP, TOPO>(z, lrow, lane, nv);
         }
         {
             const bool badv = isdof && (!(qacc == qacc) || fabs(qacc) > 1e10);
-            if (wv::ballot(badv) != 0ull) { warn |= WARN_DIVERGED; release_wave1 = NW == 2 && io.integrate && sub + 1 < io.nsub; break; }
+            if (wv::ballot(badv) != 0ull) { warn |= WARN_DIVERGED; break; }
         }
         if (isdof) S.qacc[k_] = qacc;
         wv::sync();
         CK_STAMP(12);
 
-        /* ---- sensors, part 2: the accelerometer needs qacc ---- */
-        if (aslot >= 0 && need_imu) {
-            const double *pa = S.accel[aslot];
-            double acc_ang[3] = {pa[0], pa[1], pa[2]}, acc_lin[3] = {pa[3], pa[4], pa[5]}, acc_dif[3] = {pa[6], pa[7], pa[8]};
-            for (unsigned long long mk = m->body_dofmask[sb]; mk; mk &= mk - 1) {
-                const int k = wv::popc64((mk & (0ull - mk)) - 1);
-                const double qa = S.qacc[k];
-                for (int i = 0; i < 3; ++i) { acc_ang[i] += S.cdof[k][i] * qa; acc_lin[i] += S.cdof[k][3 + i] * qa; }
-            }
-            double t[3], lin[3], vlin[3], corr[3], outv[3];
-            cross3(t, acc_dif, acc_ang);
-            for (int i = 0; i < 3; ++i) lin[i] = acc_lin[i] - t[i];
-            cross3(t, acc_dif, pa + 18);
-            for (int i = 0; i < 3; ++i) vlin[i] = pa[21 + i] - t[i];
-            cross3(corr, pa + 18, vlin);
-            for (int i = 0; i < 3; ++i) lin[i] += corr[i];
-            mulmatTvec3(outv, pa + 9, lin);
-            const double cut = m->sensor_cutoff[lane];
-            const int adr = m->sensor_adr[lane];
-            for (int i = 0; i < 3; ++i) {
-                const double v = cut > 0 ? clampd(outv[i], -cut, cut) : outv[i];
-                if (lastsub) io.sensordata[(size_t)env * io.ssd + adr + i] = v;
-                if (io.drive_mode) S.sens[adr + i] = v;
-            }
-        }
-        if (lane < nu) {
-            const double av = pf_agear * S.qvel[pf_adof];
-            if (lastsub) io.actuator_velocity[(size_t)env * io.su + lane] = av;
-            if (io.drive_mode) S.actvel[lane] = av;
-        }
-        if (io.info && lane == 0 && lastsub) {
-            io.info[(size_t)env * 4 + 0] = ncon; io.info[(size_t)env * 4 + 1] = nefc;
-            io.info[(size_t)env * 4 + 2] = iters; io.info[(size_t)env * 4 + 3] = nguarded;
-        }
-        if (isdof && lastsub) io.qacc[(size_t)env * io.sv + k_] = qacc;
+        /* ---- sensors, part 2 (the accelerometer needs qacc), actuator velocities, the last substep's outputs ---- */
+        outputs_after_qacc(io, S, m, env, lane, isdof, k_, nu, qacc, aslot, sb, need_imu, lastsub, pf_agear, pf_adof, ncon, nefc, iters, nguarded);
         if (!io.integrate) break;
         CK_STAMP(13);
 
         /* ================= P12 semi-implicit Euler with implicit joint damping ================= */
-        double qacc_int = qacc;
-        if (m->flags & CM_FLAG_EULERDAMP) {
-            /* (M + hB) x = M qacc  <=>  x = qacc - (M + hB)^-1 (hB qacc) */
-            double w = isdof ? h * pf_kdamp * qacc : 0.0;
-            double lcol[NVP], lrowh[NVP]; /* this lane's column and row of the factor of M + hB, staged before the chains */
-            const typename LP::Row myrow = LP::row_of(k_);
-#pragma unroll
-            for (int k = 0; k < NVP; ++k) {
-                const bool inrange = TOPO::is_static ? k < TOPO::nv : k < nv;
-                if constexpr (LP::packed) {
-                    const bool hasc = inrange && isdof && k > k_ && LP::col_has(k, k_), hasr = isdof && k < k_ && LP::row_has(myrow, k);
-                    const double vc = S.LHp[hasc ? LP::col_idx(k, k_) : 0], vr = S.LHp[hasr ? LP::row_idx(myrow, k) : 0];
-                    lcol[k] = hasc ? vc : 0.0;
-                    lrowh[k] = hasr ? vr : 0.0;
-                } else {
-                    lcol[k] = (inrange && isdof && k > k_) ? S.LHp[CK_TRI(k, k_)] : 0.0;
-                    lrowh[k] = (isdof && k < k_) ? S.LHp[CK_TRI(k_, k)] : 0.0;
-                }
-            }
-            const double dih = isdof ? S.dinvH[k_] : 0.0;
-            w = solve_backward<NVP, TOPO>(w, lcol, lane, nv); /* L^-T */
-            w *= dih;
-            w = solve_forward<NVP, TOPO>(w, lrowh, lane, nv);  /* L^-1 */
-            qacc_int = qacc - w;
-        }
-        if (isdof) {
-            S.qvel[k_] += h * qacc_int;
-            S.qacc_ws[k_] = qacc;
-        }
-        wv::sync();
         {
-            /* lane = joint.  Hinges and slides are one FMA; a ball (or the rotation of a free joint) turns its quaternion by
-             * h * |w| about w -- through the stage's own bounded-range sincos and reciprocal-square-root normalisations (the
-             * library's sin + cos, a square root and two divisions, run for three lanes, were a tenth of this stage).  The
-             * sincos sits outside the lane branches: its range check is a wave vote. */
-            const int jt = lane < njnt ? pf_ejt : -1;
-            int qa = pf_eqa, da = pf_eda;
-            if (jt == CM_JNT_HINGE || jt == CM_JNT_SLIDE) S.qpos[qa] += h * S.qvel[da];
-            if (jt == CM_JNT_FREE) {
-                for (int i = 0; i < 3; ++i) S.qpos[qa + i] += h * S.qvel[da + i];
-                qa += 3; da += 3;
-            }
-            const bool turns = jt == CM_JNT_FREE || jt == CM_JNT_BALL;
-            double ax[3] = {1, 0, 0}, ang = 0;
-            if (turns) {
-                for (int i = 0; i < 3; ++i) ax[i] = S.qvel[da + i];
-                ang = h * normalize3_fast(ax);
-            }
-            double sn, cs;
-            sincos_bounded(0.5 * ang, sn, cs);
-            if (turns) {
-                double qr[4] = {cs, ax[0] * sn, ax[1] * sn, ax[2] * sn};
-                double q[4] = {S.qpos[qa], S.qpos[qa + 1], S.qpos[qa + 2], S.qpos[qa + 3]};
-                normalize4_fast(q);
-                mulquat(q, q, qr);
-                for (int i = 0; i < 4; ++i) S.qpos[qa + i] = q[i];
-            }
+            double lcol[NVP], lrowh[NVP]; /* this lane's column and row of the factor of M + hB, staged before the chains */
+            stage_factor_h<NVP, TOPO>(S, k_, isdof, nv, lcol, lrowh);
+            const double dih = isdof ? S.dinvH[k_] : 0.0;
+            euler_step<NVP, TOPO>(S, m, lane, isdof, k_, nv, njnt, h, qacc, lcol, lrowh, dih, pf_kdamp, pf_ejt, pf_eqa, pf_eda);
         }
         time += h;
-        wv::sync();
         CK_STAMP(14);
     }
 
-    if constexpr (NW == 2) if (release_wave1) { if (lane == 0) S.cmd[0] = 1; wv::block_barrier(); } /* (F) */
     /* ---------------- store state ---------------- */
     if (io.progress && !io.resume && lane == 0) {
         io.progress[env] = bailed ? sub : io.nsub; /* (the resume pass leaves the record) */

@@ -29,9 +29,13 @@ bool launch_fast_cassie_hfield_2w(dim3 grid, hipStream_t s, PhysIO io);
 bool launch_full_cassie_2w(dim3 grid, hipStream_t s, PhysIO io);
 bool launch_full_cassie_hfield_2w(dim3 grid, hipStream_t s, PhysIO io);
 bool launch_step_cassie_all(dim3 grid, hipStream_t s, PhysIO io);                   /* <32, TopoCassie32, FEAT_ALL> */
-bool launch_step_tray(dim3 grid, hipStream_t s, PhysIO io, bool hfield, int waves); /* <40, TopoCassieTray38, FEAT_WAVEPAIRS | FEAT_ALL> */
-bool launch_step_tray_2w(dim3 grid, hipStream_t s, PhysIO io);                      /* <40, TopoCassieTray38, FEAT_WAVEPAIRS, 63, 2>: two waves per env (kernels_tray_2w.hip) */
+bool launch_step_tray(dim3 grid, dim3 pass_grid, hipStream_t s, PhysIO io, bool hfield, bool fast, hipEvent_t after_first, int waves); /* <40, TopoCassieTray38, FEAT_WAVEPAIRS | FEAT_ALL> */
+/* the 40-dof model's two-wave forms: the fast instantiation (FAST_ROWS_TRAY rows) and the full one (alone, or as the list-walking pass) */
+bool launch_fast_tray_2w(dim3 grid, hipStream_t s, PhysIO io);
+bool launch_full_tray_2w(dim3 grid, hipStream_t s, PhysIO io);
 bool launch_step_generic(dim3 grid, hipStream_t s, PhysIO io, bool wide);           /* <32 | 40, TopoRuntime, FEAT_ALL> */
+
+constexpr int FAST_ROWS_TRAY = 47; /* the 40-dof model's fast instantiation: Cassie + tray + cube at rest use 32 .. 40 rows */
 
 template <int NVP, class TOPO, int FEAT>
 inline bool launch_fast_then_full(dim3 grid, dim3 pass_grid, hipStream_t s, PhysIO io, bool fast, hipEvent_t after_first, bool (*fast_2w)(dim3, hipStream_t, PhysIO),

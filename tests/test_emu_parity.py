@@ -95,14 +95,33 @@ def test_applied_forces(cassie):
     assert np.max(np.abs(emu.qvel[0] - o.qvel)) < 1e-10
 
 
-def test_divergence_flag_is_sticky_and_state_untouched(cassie):
-    emu = EmuBatch(cassie.pod, 1)
-    emu.qpos[:] = cassie.qpos_init()
-    emu.qvel[0, 3] = np.nan
-    q = emu.qpos.copy()
-    emu.step(3)
-    assert emu.warn[0] & 8
-    assert np.array_equal(q, emu.qpos)
+@pytest.mark.parametrize("two_waves", [0, 1])
+def test_divergence_flag_is_sticky_and_state_untouched(cassie, two_waves):
+    """A NaN in the state (caught at the top of the substep) and a diverged qacc (caught behind the solve -- in the two-wave form
+    by wave 1, which tells wave 0 at the substep's last barrier): sticky flag, state left as it is."""
+    import emu_py
+    emu_py.lib().emu_two_waves(two_waves); emu_py.lib().emu_fast_rows(two_waves)
+    try:
+        emu = EmuBatch(cassie.pod, 1)
+        emu.qpos[:] = cassie.qpos_init()
+        emu.qvel[0, 3] = np.nan
+        q = emu.qpos.copy()
+        emu.step(3)
+        assert emu.warn[0] & 8
+        assert np.array_equal(q, emu.qpos)
+        # a finite state whose acceleration is not: a torque of 1e300 passes the state check and overflows qacc
+        emu = EmuBatch(cassie.pod, 1)
+        emu.qpos[:] = cassie.qpos_init()
+        emu.qfrc_applied = np.zeros((1, cassie.pod.nv)); emu.xfrc_applied = np.zeros((1, cassie.pod.nbody, 6))
+        emu.qfrc_applied[0, 8] = 1e306
+        q, v = emu.qpos.copy(), emu.qvel.copy()
+        emu.step(3)
+        assert emu.warn[0] & 8
+        assert np.array_equal(q, emu.qpos) and np.array_equal(v, emu.qvel)
+        emu.forward()                                     # (a forward pass over the same state: same verdict, no hang)
+        assert emu.warn[0] & 8
+    finally:
+        emu_py.lib().emu_two_waves(0); emu_py.lib().emu_fast_rows(0)
 
 
 def test_on_device_pd_mode(cassie):
