@@ -232,7 +232,7 @@ def launch_io_bytes_per_env(pod, drive=True):
 
 
 def pmc_traffic(env_steps_per_launch, model_name="cassie", envs_per_launch=None, pod=None):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (tools/gpu_pmc.sh: FETCH_SIZE and WRITE_SIZE in
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (tools/gpu_pmc_all.sh: FETCH_SIZE and WRITE_SIZE in
     separate --pmc runs, corrected as MI355X_MICROARCH.md prescribes), brought to this run's launch shape: the passes
     profile 50-substep launches, and a launch's traffic is a per-env part that does not depend on the substep count (state
     in, state and last-substep outputs out: launch_io_bytes_per_env) plus a per-env-step part (model constants, terrain,
@@ -844,6 +844,7 @@ def main(argv=None):
                        "envs_per_gpu": n, "envs_total": world * n, "baseline_config": shape, "parallelism": "env-sharded x%d" % world,
                        "obs_allgather_every_steps": HOLD if collect else None,
                        "streams": r["streams"],
+                       "wavefronts_per_env": (1 if args.model == "cassie_tray_box" or os.environ.get("CASSIE_WAVES_PER_ENV") == "1" else 2),
                        "streams_note": ("the %d envs of a GPU are stepped as %d contiguous ranges, each on its own stream at its own pace "
                                         "(phys_batch_step_range): per policy step every range gets its restarts, its PD targets and one "
                                         "launch, and nothing on the device joins the ranges between policy steps, so one range's workgroups "
@@ -866,9 +867,12 @@ def main(argv=None):
                                            "slots + order / restart kernels)" % (r["streams"], launch_env_steps, achieved_one or 0.0)) if r["streams"] > 1 else
                                           "algorithmic bytes of one launch / the dominant kernel's mean duration (a HIP event pair around every launch on the launch stream)",
                          "achieved_one_launch": achieved_one, "stream_ms_per_policy_step": r["stream_ms"], "kernel_launches_timed": r["kernel_launches"],
-                         "kernel": {"cassie": "ck::cassie_step_kernel<32, ck::TopoCassie32, 0, 31> (row-capped fast instantiation; <..., 63> finishes handed-over envs)",
-                                    "cassie_hfield": "ck::cassie_step_kernel<32, ck::TopoCassie32, 1, 31> (row-capped fast instantiation; <..., 63> finishes handed-over envs)",
-                                    "cassie_tray_box": "ck::cassie_step_kernel<40, ck::TopoCassieTray38, 2, 63>"}[args.model], "kernel_ms": kern_ms, "algorithmic_bytes_per_env_step": algo_bytes, "env_steps_per_launch": launch_env_steps,
+                         "kernel": {"cassie": "ck::cassie_step_kernel<32, ck::TopoCassie32, 0, 31, 2, false> (row-capped fast instantiation, TWO wavefronts per env; "
+                                              "<..., 63, 2, true> walks the list of handed-over envs behind it)",
+                                    "cassie_hfield": "ck::cassie_step_kernel<32, ck::TopoCassie32, 1, 31, 2, false> (row-capped fast instantiation, two wavefronts per env; "
+                                                     "<..., 63, 2, true> walks the list of handed-over envs behind it)",
+                                    "cassie_tray_box": "ck::cassie_step_kernel<40, ck::TopoCassieTray38, 2, 63, 1, false> (one wavefront per env: the two-wave form of the 40-dof "
+                                                       "instantiation spills and is slower, profiles/round4)"}[args.model], "kernel_ms": kern_ms, "algorithmic_bytes_per_env_step": algo_bytes, "env_steps_per_launch": launch_env_steps,
                          "note": "latency-bound by design: ~2 KB of state vs ~0.22 MFLOP of serially dependent fp64 per env-step"},
             # the more telling bound: ~0.22 MFLOP of algorithmic fp64 work per env-step against the fp64 vector peak
             "roofline_fp64": {"bound": "fp64-valu", "achieved": value * 0.22e6 / 1e12, "peak": 78.6 * world, "unit": "TFLOP/s",

@@ -37,6 +37,7 @@ n_env_steps = 4096 * 50
 g = lambda k: per.get(k, float("nan"))
 derived = {
     "env_steps_per_launch": n_env_steps,
+    "envs_per_launch": 4096,
     "valu_insts_per_env_step": g("SQ_INSTS_VALU") / n_env_steps,
     "salu_insts_per_env_step": g("SQ_INSTS_SALU") / n_env_steps,
     "lds_insts_per_env_step": g("SQ_INSTS_LDS") / n_env_steps,
