@@ -310,14 +310,14 @@ def replay_on_oracle(model, env_ids, targets_of, total_steps, hfield=None, threa
     return o
 
 
-def cpu_baseline(model, budget_s=12.0):
+def cpu_baseline(model, budget_s=12.0, hfield=None):
     """Times the CPU oracle on a bounded sample of the same workload (staggered 1000-step episodes under the PD
     workload), all usable host cores (OpenMP over envs)."""
     from cassie_amd._lib import lib
     cores = lib().cassie_host_cpu_count()      # affinity- and cgroup-quota-aware
     nenv = 16 * cores
     ids = np.arange(nenv)
-    o = OracleEnvs(model, ids)
+    o = OracleEnvs(model, ids, hfield)
     npol = 400
     tg = pd_targets(ids, npol)
     done, t_used, pol = 0, 0.0, 0
@@ -919,6 +919,8 @@ def main(argv=None):
                 out["cpu_baseline"] = cpu_baseline(model)
             tsample = np.arange(8)
             out["true_reference"] = true_reference(args.model, model.qpos_init(), pd_targets(tsample, EPISODE // HOLD + 1), EPISODE)
+        elif world == 1 and args.total_envs is None and not args.dry_run_cpu and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(model, hfield=hfield)      # configs 4 / 5: the oracle on this box's cores, same workload
         print(json.dumps(out), flush=True)
     if collect:
         dist.destroy_process_group()
