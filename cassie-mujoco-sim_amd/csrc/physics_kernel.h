@@ -1,7 +1,8 @@
 /*
  * physics_kernel.h -- the batched Cassie physics step for gfx950 (MI355X):
- * ONE WAVEFRONT (64 lanes) PER ENVIRONMENT, one single-wave workgroup per env,
- * four envs resident per CU (one per SIMD, <= 40 KB of LDS each).
+ * ONE WORKGROUP PER ENVIRONMENT, four envs resident per CU (<= 40 KB of LDS each), stepped by one wavefront (64 lanes; every
+ * stage below is written for one wave) or -- the Cassie instantiations since round 4 -- by TWO, which split the substep's
+ * stage graph between them (env_step, NW = 2: two waves per SIMD at 256 registers each).
  *
  * This is the hot path of the reference -- the mj_step1_fp + mj_step2_fp pair at
  * reference src/cassiemujoco.c:1130-1134 (arithmetic inside MuJoCo 2.1.0; stage
@@ -40,6 +41,10 @@
  * pre-pass; box-box by separating axes with the clipped-face candidates one to a lane; FEAT_* template flags that keep
  * collision code a model does not need out of its instantiation; outputs stored by the last substep only; a derive kernel
  * for the batched getters; a longest-job-first launch order.
+ *
+ * Round 4: the two-wave form (wave 1: mass-matrix group, drive-level pass, factorisations, bias / passive stage, the stages
+ * behind the solve; five workgroup barriers and two LDS flags per substep; bit for bit the one-wave form); the hand-over list
+ * and the list-walking pass behind the row-capped fast instantiation.
  *
  * Numerically this follows the same algorithm as oracle/cassie_oracle.c but with
  * its own operation order (half solves, reciprocal multiplies, wave reductions,
@@ -1614,11 +1619,13 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
     static_assert(NW == 1 || NW == 2, "one or two wavefronts per env");
     static_assert(NW == 1 || TOPO::is_static, "the two-wave form exists for the compile-time topologies");
     /* NW = 2: the env is stepped by TWO wavefronts that share the env's LDS block.  Wave 0 runs the substep as written below
-     * except for the mass-matrix group (centres of mass, cinert, cdof, composite inertias, M's columns, the two
-     * factorisations), which wave 1 runs beside wave 0's collision, velocity / bias-force and constraint-row stages; the two
-     * meet at three workgroup barriers per substep (F: poses are in LDS; X: cdof / com / cinert are, and the contact list;
-     * J: the factors are).  Every value is computed by the same instructions from the same operands as in the one-wave
-     * form, so the results are bit for bit the same. */
+     * except for the stages wave 1 runs beside it (wave 1's program, ahead of the substep loop): the mass-matrix group (centres
+     * of mass, cinert, cdof, composite inertias, M's columns), the drive-level pass, the two factorisations and the bias /
+     * passive stage beside wave 0's collision, velocity and constraint-row stages; then qacc, the accelerometers, the substep's
+     * outputs and the Euler step behind wave 0's solve, with their operands staged while wave 0 solves.  Five workgroup
+     * barriers per substep (F: poses in LDS; X: com / cinert / cdof and the contact list; J: the factors and qfrc_smooth; P: the
+     * row forces; E: the substep is complete) and two one-directional flags (cmd[1], cmd[2]).  Every value is computed by the
+     * same instructions from the same operands as in the one-wave form, so the results are bit for bit the same. */
     const int wid = NW == 2 ? wv::wave_id() : 0;
 
     static_assert(LP::covers() && LP::distinct(), "packed factor rows must hold every ancestor pair, each in its own slot");
@@ -3284,7 +3291,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
     }
 }
 
-/* one single-wave workgroup per environment.
+/* one workgroup (NW wavefronts) per environment.
  *
  * MAXR < CM_MAXEFC is the row-capped FAST instantiation: the constraint stages hold MAXR rows (31: a Cassie on its feet uses
  * 20 .. 28), which halves the register arrays of the solve (A's rows, the PGS row chain) -- 112 instead of 316 bytes of

@@ -35,6 +35,7 @@ bool launch_fast_tray_2w(dim3 grid, hipStream_t s, PhysIO io);
 bool launch_full_tray_2w(dim3 grid, hipStream_t s, PhysIO io);
 bool launch_step_generic(dim3 grid, hipStream_t s, PhysIO io, bool wide);           /* <32 | 40, TopoRuntime, FEAT_ALL> */
 
+constexpr unsigned SMALL_BATCH = 512; /* envs up to which the full kernel alone runs in its two-wave form (half the chip's workgroup slots) */
 constexpr int FAST_ROWS_TRAY = 47; /* the 40-dof model's fast instantiation: Cassie + tray + cube at rest use 32 .. 40 rows */
 
 template <int NVP, class TOPO, int FEAT>
@@ -57,6 +58,12 @@ inline bool launch_fast_then_full(dim3 grid, dim3 pass_grid, hipStream_t s, Phys
     static const bool resume_one_wave = getenv("CASSIE_DEBUG_RESUME_ONE_WAVE") != nullptr; /* (measurement aid: the pass behind a two-wave fast kernel as one-wave workgroups) */
     if (fast && skip_resume) {}
     else if (fast && full_2w && !resume_one_wave) { if (!full_2w(pass_grid, s, io)) return false; }
+    else if (!fast && full_2w && grid.x <= SMALL_BATCH) {
+        /* the full kernel alone (forward / read-out passes, batches with the read-out enabled such as a cassie_sim_t) on a
+         * batch too small to fill the chip: latency is what counts, and two wavefronts per env cut it by a fifth */
+        io.handover_list = nullptr;
+        if (!full_2w(grid, s, io)) return false;
+    }
     else { /* the one-wave full kernel: one workgroup per env of the launch (no list walk) */
         io.handover_list = nullptr;
         hipLaunchKernelGGL((cassie_step_kernel<NVP, TOPO, FEAT>), grid, dim3(WV_WAVE), 0, s, io);

@@ -309,7 +309,7 @@ extern "C" int emu_derive(const cm_model_t *model, int nenv, double *qpos, doubl
     for (int i = 0; i < 6; ++i) g_dio.ids[i] = ids[i];
     for (int e = 0; e < nenv; ++e) {
         g_env = e;
-        if (topo_matches(model, ck::TopoCassie32::table, ck::TopoCassie32::nv, ck::TopoCassie32::body_levels)) run_block(body32s);
+        if (topo_matches(model, ck::TopoCassie32::table, ck::TopoCassie32::nv, ck::TopoCassie32::body_levels)) { if (g_two_waves) run_block(body32s_2w, 2); else run_block(body32s); }
         else if (topo_matches(model, ck::TopoCassieTray38::table, ck::TopoCassieTray38::nv, ck::TopoCassieTray38::body_levels)) run_block(body40s);
         else run_block(model->nv <= 32 ? body32 : body40);
         run_block(body_derive);

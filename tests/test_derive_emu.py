@@ -13,7 +13,22 @@ from oracle_py import Oracle, arr, lib as olib
 from derive_check import check_derived_block, foot_ids as _ids
 
 
-def test_derived_block_against_first_principles(cassie):
+import pytest
+
+
+@pytest.mark.parametrize("two_waves", [0, 1])
+def test_derived_block_against_first_principles(cassie, two_waves):
+    """(two_waves: the forward pass with the read-out enabled through the full instantiation's two-wave form -- what a
+    cassie_sim_t, a batch of one env with the read-out on, runs since round 4)"""
+    import emu_py
+    emu_py.lib().emu_two_waves(two_waves)
+    try:
+        _derived_block(cassie)
+    finally:
+        emu_py.lib().emu_two_waves(0)
+
+
+def _derived_block(cassie):
     pod = cassie.pod
     rng = np.random.default_rng(5)
     n = 3
