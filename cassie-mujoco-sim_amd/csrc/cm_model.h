@@ -42,7 +42,7 @@ extern "C" {
 #define CM_HF_MAXC    4      /* contacts per capsule / height-field pair with CM_FLAG_HFMULTI */
 #define CM_HF_SLOTS_DENSE 10 /* the same with CM_FLAG_HFDENSE: two ends + at most eight interior ones (six pairs per wave pass) */
 /* (CM_MAXCON / CM_MAXEFC can be raised from the command line for ORACLE-ONLY studies of what the caps and the collision
- * definitions cost in fidelity -- tools/collision_fidelity.py; the kernel's row stages are built around 63 = one row per lane) */
+ * definitions cost in fidelity -- tests/collision_fidelity_study.py; the kernel's row stages are built around 63 = one row per lane) */
 #ifndef CM_MAXCON
 #define CM_MAXCON    16      /* contacts kept per env-step */
 #endif

@@ -20,7 +20,7 @@ void co_set_hfield(const float *data) { g_hfield = data; }
  * triangle under a capsule */
 #ifdef CO_STUDY
 #define CO_RC_MAX 96
-/* ORACLE-ONLY STUDY MODES (tools/collision_fidelity.py; built with -DCO_STUDY and raised CM_MAXCON / CM_MAXEFC; never part of
+/* ORACLE-ONLY STUDY MODES (tests/collision_fidelity_study.py; built with -DCO_STUDY and raised CM_MAXCON / CM_MAXEFC; never part of
  * the parity oracle): what the collision definitions of DESIGN.md 4.2 cost in fidelity against MuJoCo-shaped contact sets.
  *   hfield mode 1: one contact per PENETRATED GRID TRIANGLE under a sphere / capsule -- MuJoCo builds one prism per grid
  *                  triangle and reports one contact per penetrated prism (why reference model/cassie_hfield.xml:4 asks for

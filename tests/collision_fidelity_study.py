@@ -18,7 +18,7 @@ import time
 
 import numpy as np
 
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # (lives under tests/: it builds and runs the oracle, which only test infrastructure may)
 sys.path.insert(0, os.path.join(REPO, "cassie-mujoco-sim_amd")); sys.path.insert(0, os.path.join(REPO, "tests")); sys.path.insert(0, REPO)
 import bench                                             # noqa: E402
 import golden_physics as G                               # noqa: E402
