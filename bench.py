@@ -818,7 +818,8 @@ def main(argv=None):
         achieved = algo_bytes * world * n * args.steps / elapsed / 1e9 / world
         rate = lambda sec: world * n * args.steps / sec
         value = rate(elapsed)
-        traffic, traffic_src = pmc_traffic(n * steps_per_launch, args.model, envs_per_launch=n, pod=pod)
+        # (per launch of the dominant kernel, like `achieved_one_launch`: one env range's launch)
+        traffic, traffic_src = pmc_traffic(n * steps_per_launch / r["streams"], args.model, envs_per_launch=n / r["streams"], pod=pod)
         api = {"drive-pd": "phys_batch_step in CM_DRIVE_PD mode (device-resident, include/cassie_phys.h): pd_input's motor PD on the encoder "
                            "measurements + motor model with torque delay + physics in one kernel -- cassie_sim_step_pd's drive-level semantics "
                            "without the Agility safety layer / estimator",
@@ -863,8 +864,8 @@ def main(argv=None):
                          "achieved_note": ("per GPU: algorithmic bytes of all env-steps of a timed region / the region's time.  The %d env ranges' launches "
                                            "overlap; ONE launch of the dominant kernel (%d env-steps, `kernel_ms` = its mean duration from a HIP "
                                            "event pair around every launch on its stream -- what rocprofv3 averages) moves %.2f GB/s, and a range "
-                                           "needs `stream_ms_per_policy_step` per policy step (that kernel + the resume pass waiting for wave "
-                                           "slots + order / restart kernels)" % (r["streams"], launch_env_steps, achieved_one or 0.0)) if r["streams"] > 1 else
+                                           "needs `stream_ms_per_policy_step` per policy step (that kernel + the list-walking pass behind it + "
+                                           "order / restart kernels)" % (r["streams"], launch_env_steps, achieved_one or 0.0)) if r["streams"] > 1 else
                                           "algorithmic bytes of one launch / the dominant kernel's mean duration (a HIP event pair around every launch on the launch stream)",
                          "achieved_one_launch": achieved_one, "stream_ms_per_policy_step": r["stream_ms"], "kernel_launches_timed": r["kernel_launches"],
                          "kernel": {"cassie": "ck::cassie_step_kernel<32, ck::TopoCassie32, 0, 31, 2, false> (row-capped fast instantiation, TWO wavefronts per env; "
