@@ -260,6 +260,13 @@ class Batch:
             raise RuntimeError("cost download failed (balancing is off or the batch is small)")
         return out.astype(np.float64) * 64.0
 
+    def handover_pending(self):
+        """Validation aid: entries left in the hand-over lists once the batch's streams are idle (0 in every mode)."""
+        r = lib().phys_batch_debug_handover_pending(self._h)
+        if r < 0:
+            raise RuntimeError("hand-over count download failed")
+        return r
+
     def fast_rows_progress(self):
         """Substeps of the last stepping launch the fast kernel completed per env (< the launch's count: handed over there)."""
         out = np.zeros(self.nenv, dtype=np.int32)

@@ -770,6 +770,17 @@ int phys_batch_download_cost(phys_batch_t *b, unsigned *host) {
     return quiesce(b) && hip_ok(hipMemcpy(host, b->d_cost, sizeof(unsigned) * (size_t)b->nenv, hipMemcpyDeviceToHost), "cost download") ? 0 : -1;
 }
 
+int phys_batch_debug_handover_pending(phys_batch_t *b) {
+    if (!b) return -1;
+    if (!b->d_handover_count) return 0;
+    (void)hipSetDevice(b->device);
+    std::vector<int> h(2 * (size_t)b->nenv);
+    if (!quiesce(b) || !hip_ok(hipMemcpy(h.data(), b->d_handover_count, sizeof(int) * h.size(), hipMemcpyDeviceToHost), "hand-over count download")) return -1;
+    long total = 0;
+    for (int v : h) total += v < 0 ? -(long)v : v;
+    return total > 0x7fffffff ? 0x7fffffff : (int)total;
+}
+
 int phys_batch_set_balance(phys_batch_t *b, int on) {
     if (!b) return -1;
     b->balance = on != 0;

@@ -41,6 +41,15 @@ constexpr int FAST_ROWS_TRAY = 47; /* the 40-dof model's fast instantiation: Cas
 template <int NVP, class TOPO, int FEAT>
 inline bool launch_fast_then_full(dim3 grid, dim3 pass_grid, hipStream_t s, PhysIO io, bool fast, hipEvent_t after_first, bool (*fast_2w)(dim3, hipStream_t, PhysIO),
                                   bool (*full_2w)(dim3, hipStream_t, PhysIO)) {
+    /* (measurement aids: CASSIE_DEBUG_SKIP_RESUME_PASS -- what the pass behind the fast kernel costs; handed-over envs are then
+     * left unfinished, so only for workloads that hand nothing over; CASSIE_DEBUG_RESUME_ONE_WAVE -- the pass behind a two-wave
+     * fast kernel as one-wave workgroups) */
+    static const bool skip_resume = getenv("CASSIE_DEBUG_SKIP_RESUME_PASS") != nullptr;
+    static const bool resume_one_wave = getenv("CASSIE_DEBUG_RESUME_ONE_WAVE") != nullptr;
+    /* the hand-over list is kept only when the pass behind the fast kernel walks it (and clears its count): a fast kernel that
+     * appended to a list nobody clears would run past the list's end after a few launches */
+    const bool walk = fast && full_2w && !resume_one_wave && !skip_resume;
+    if (!walk) { io.handover_list = nullptr; pass_grid = grid; }
     if (fast) {
         io.resume = 0;
         if (fast_2w) { if (!fast_2w(grid, s, io)) return false; }
@@ -52,12 +61,8 @@ inline bool launch_fast_then_full(dim3 grid, dim3 pass_grid, hipStream_t s, Phys
         io.progress = nullptr; io.resume = 0; io.handover_list = nullptr;
         pass_grid = grid;
     }
-    /* (measurement aid, CASSIE_DEBUG_SKIP_RESUME_PASS: what the pass behind the fast kernel costs -- handed-over envs are then
-     * left unfinished, so only for workloads that hand nothing over) */
-    static const bool skip_resume = getenv("CASSIE_DEBUG_SKIP_RESUME_PASS") != nullptr;
-    static const bool resume_one_wave = getenv("CASSIE_DEBUG_RESUME_ONE_WAVE") != nullptr; /* (measurement aid: the pass behind a two-wave fast kernel as one-wave workgroups) */
     if (fast && skip_resume) {}
-    else if (fast && full_2w && !resume_one_wave) { if (!full_2w(pass_grid, s, io)) return false; }
+    else if (walk) { if (!full_2w(pass_grid, s, io)) return false; }
     else if (!fast && full_2w && grid.x <= SMALL_BATCH) {
         /* the full kernel alone (forward / read-out passes, batches with the read-out enabled such as a cassie_sim_t) on a
          * batch too small to fill the chip: latency is what counts, and two wavefronts per env cut it by a fifth */

@@ -205,6 +205,10 @@ int phys_batch_set_balance(phys_batch_t *b, int on);
 /* diagnostics (batches of 2048 envs and more, balancing on): what the last stepping launch cost every env, in units of 64
  * shader clocks from the env's first to its last instruction ([nenv] unsigned) -- the figure the launch order is sorted by */
 int phys_batch_download_cost(phys_batch_t *b, unsigned *host);
+/* validation aid: entries (and walker tickets) left in the hand-over lists of the batch's env ranges once its streams are idle
+ * -- 0 whatever the mode: the pass behind the fast kernel clears what it walked, and a fast kernel whose pass does not walk the
+ * list is not given one; -1 on error */
+int phys_batch_debug_handover_pending(phys_batch_t *b);
 /* on (default): stepping launches of the Cassie instantiations run the row-capped fast kernel first and the full kernel
  * only finishes envs that needed more than 31 constraint rows in some substep; off: the full kernel alone (same results,
  * bit for bit -- a validation / measurement aid) */

@@ -291,6 +291,9 @@ def test_two_wave_form_of_the_fast_kernel_equals_the_one_wave_form_bit_for_bit(b
                 b.set(P.F_PD_PTARGET, tg[p])
                 b.step(bench.HOLD if p % 3 else (1, 2, 7, 20)[(p // 3) % 4])
                 handed += int(np.count_nonzero(b.fast_rows_progress() < (bench.HOLD if p % 3 else (1, 2, 7, 20)[(p // 3) % 4])))
+                # the hand-over lists are empty between launches: the two-wave pass clears what it walked, and the one-wave
+                # pass (one workgroup per env, no walk) must not leave the fast kernel a list that nobody clears
+                assert b.handover_pending() == 0
             w, info = b.warnings()
             rec = [b.get(P.F_QPOS), b.get(P.F_QVEL), b.get(P.F_QACC_WARMSTART), b.get(P.F_QACC), b.get(P.F_SENSORDATA), b.get(P.F_TIME), w, info[:, :3].copy(),
                    b.get(P.F_MEAS), b.get(P.F_CTRL), b.get(P.F_XPOS), b.get(P.F_XQUAT), b.get(P.F_ACTUATOR_VELOCITY)]
