@@ -211,7 +211,7 @@ def max_over_ranks(seconds, world, device=None):
 
 def has_fast_kernel(model_name):
     """Models whose stepping launches start the row-capped fast instantiation (phys_batch.hip, launch)."""
-    return model_name in ("cassie", "cassie_hfield")
+    return model_name in ("cassie", "cassie_hfield", "cassie_tray_box")
 
 
 def handed_over_in_last_launch(progress, nsub_of_last_launch):
@@ -661,6 +661,12 @@ def device_rollout(model, mode, n, steps, warmup, rank, world, local_rank, subst
     res["envs_with_warnings"] = int(stats[0])
     res["mean_constraint_rows"], res["mean_pgs_iterations"], res["mean_pgs_guarded_sweeps"] = (float(stats[k] / (world * n)) for k in (1, 2, 3))
     res["frac_envs_handed_over_last_launch"] = None if np.isnan(stats[4]) else float(stats[4] / (world * n))
+    # what the last launch cost an env, first to last instruction, in shader clocks per substep (phys_batch_download_cost: batches
+    # that keep a launch order) -> how full the GPU's workgroup slots were over the timed regions, see main()
+    try:
+        res["env_clocks_per_substep"] = float(np.mean(b.launch_cost())) / max(1, last_launch["nsub"])
+    except (RuntimeError, AttributeError):
+        res["env_clocks_per_substep"] = None
     # ---- the metric's second half: sampled envs of EVERY rank against the CPU reference, same schedule ----
     ids_sample = torch.from_numpy(env_ids[sample].astype(np.int64)).to(dev)
     if collect and world > 1:
@@ -687,6 +693,24 @@ def device_rollout(model, mode, n, steps, warmup, rank, world, local_rank, subst
                                      "kp * 2 pi / 2^bits / gear for one step: agreement is to rounding only as long as no count flips")
     b.close()
     return res
+
+
+SLOTS_PER_GPU = 256 * 4        # one env per workgroup, 40 KB of LDS each: four workgroups per CU
+SHADER_CLOCK_HZ = 2.4e9        # MI355X peak engine clock; measured under this kernel: 2.38 - 2.39 GHz (profiles/round4/clock_and_slots.txt)
+
+
+def slot_occupancy(env_clocks_per_substep, n, substeps, elapsed_s):
+    """Where a timed region's time goes, one level above the kernel: every env-step occupies one of the GPU's 1024 workgroup
+    slots for `env_clocks_per_substep`; busy_frac = slot time used / slot time available over the region.  The rest is slots
+    waiting for work: the drain at the end of each range's launch (no env of a launch may start the next one before all have
+    finished this one) and the gaps between a range's launches."""
+    if not env_clocks_per_substep or not elapsed_s:
+        return None
+    busy = n * substeps * env_clocks_per_substep / SHADER_CLOCK_HZ / (SLOTS_PER_GPU * elapsed_s)
+    return {"env_clocks_per_substep": env_clocks_per_substep, "slots": SLOTS_PER_GPU, "clock_hz_assumed": SHADER_CLOCK_HZ,
+            "busy_frac": busy,
+            "rate_with_every_slot_busy": SLOTS_PER_GPU * SHADER_CLOCK_HZ / env_clocks_per_substep,
+            "note": "per GPU, from the LAST launch's per-env clocks (first to last instruction of the fast kernel + the pass behind it)"}
 
 
 def true_reference(model_name, q0, targets, nsteps):
@@ -872,13 +896,15 @@ def main(argv=None):
                                               "<..., 63, 2, true> walks the list of handed-over envs behind it)",
                                     "cassie_hfield": "ck::cassie_step_kernel<32, ck::TopoCassie32, 1, 31, 2, false> (row-capped fast instantiation, two wavefronts per env; "
                                                      "<..., 63, 2, true> walks the list of handed-over envs behind it)",
-                                    "cassie_tray_box": "ck::cassie_step_kernel<40, ck::TopoCassieTray38, 2, 63, 1, false> (one wavefront per env: the two-wave form of the 40-dof "
-                                                       "instantiation spills and is slower, profiles/round4)"}[args.model], "kernel_ms": kern_ms, "algorithmic_bytes_per_env_step": algo_bytes, "env_steps_per_launch": launch_env_steps,
+                                    "cassie_tray_box": "ck::cassie_step_kernel<40, ck::TopoCassieTray38, 2, 47, 1, false> (row-capped instantiation of 47 rows, ONE wavefront "
+                                                       "per env and 512 registers, Gram matrix on the matrix core; <..., 63, 2, true> walks the list of handed-over envs "
+                                                       "behind it; the two-wave form of the 40-dof instantiation spills and is slower, profiles/round4)"}[args.model], "kernel_ms": kern_ms, "algorithmic_bytes_per_env_step": algo_bytes, "env_steps_per_launch": launch_env_steps,
                          "note": "latency-bound by design: ~2 KB of state vs ~0.22 MFLOP of serially dependent fp64 per env-step"},
             # the more telling bound: ~0.22 MFLOP of algorithmic fp64 work per env-step against the fp64 vector peak
             "roofline_fp64": {"bound": "fp64-valu", "achieved": value * 0.22e6 / 1e12, "peak": 78.6 * world, "unit": "TFLOP/s",
                               "frac": value * 0.22e6 / 1e12 / (78.6 * world),
                               "note": "algorithmic flops (SURVEY.md 8a estimate), not counting lanes that idle or recompute"},
+            "workgroup_slots": slot_occupancy(r["env_clocks_per_substep"], n, r["steps"], r["elapsed"]),
             "envs_with_warnings": r["envs_with_warnings"],
             **({"obs_allgather_ok": r.get("gather_ok")} if collect else {}),   # rank 0's rows of the last gathered block = its snapshot
             "frac_envs_handed_over_to_the_full_kernel_in_the_last_launch": r["frac_envs_handed_over_last_launch"],

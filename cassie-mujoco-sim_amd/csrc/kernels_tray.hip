@@ -3,11 +3,12 @@
 #include "step_launch.h"
 namespace ck {
 bool launch_step_tray(dim3 grid, dim3 pass_grid, hipStream_t s, PhysIO io, bool hfield, bool fast, hipEvent_t after_first, int waves) {
-    if (waves == 2 && !hfield) {
-        /* two waves per env: the fast instantiation first (when asked for), the full one behind it or alone */
+    if ((waves == 2 || fast) && !hfield) {
+        /* the fast instantiation first (when asked for: one wave per env with its Gram matrix on the matrix core, or two waves per
+         * env), the full one in its two-wave form behind it, walking the hand-over list -- or alone (two waves per env) */
         if (fast) {
             io.resume = 0;
-            if (!launch_fast_tray_2w(grid, s, io)) return false;
+            if (!(waves == 2 ? launch_fast_tray_2w(grid, s, io) : launch_fast_tray(grid, s, io))) return false;
             if (after_first) { (void)hipEventRecord(after_first, s); after_first = nullptr; }
             io.resume = 1;
             if (!launch_full_tray_2w(pass_grid, s, io)) return false;

@@ -1,0 +1,10 @@
+/* cassie_tray_box.xml (BASELINE config 5), the row-capped instantiation (47 rows) with ONE wavefront per env and 512 registers:
+ * the Gram matrix of the staged rows on the matrix core, through the staged tile's own LDS (physics_kernel.h, gram_in_place);
+ * a substep with more rows hands the env over to the full instantiation behind it (launch_full_tray_2w walks the list) */
+#include "step_launch.h"
+namespace ck {
+bool launch_fast_tray(dim3 grid, hipStream_t s, PhysIO io) {
+    hipLaunchKernelGGL((cassie_step_kernel<40, TopoCassieTray38, FEAT_WAVEPAIRS, FAST_ROWS_TRAY>), grid, dim3(WV_WAVE), 0, s, io);
+    return hipGetLastError() == hipSuccess;
+}
+}  // namespace ck

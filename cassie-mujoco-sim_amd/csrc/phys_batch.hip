@@ -228,10 +228,11 @@ static int launch(phys_batch *b, int nsub, int integrate, hipStream_t s, bool sc
         else if (hf && !wp) { launched = ck::launch_step_cassie_hfield(grid, pass_grid, s, io, fast, ev_after, b->waves_per_env); ev_after = nullptr; }
         else launched = ck::launch_step_cassie_all(grid, s, io);
     } else if (matches(ck::TopoCassieTray38::table, ck::TopoCassieTray38::nv, ck::TopoCassieTray38::body_levels)) {
-        /* the 40-dof model: in its two-wave form a fast instantiation of 47 rows (the boxes resting on the tray take it to 32 .. 40
-         * routinely) with the full one behind it; one wave per env: the full instantiation alone */
-        const bool two = integrate && !io.ext && !hf && b->waves_per_env_tray == 2;
-        const bool fast = two && b->fast_rows && b->d_progress;
+        /* the 40-dof model: a fast instantiation of 47 rows (the boxes resting on the tray take it to 32 .. 40 routinely) -- one wave
+         * per env and the Gram matrix on the matrix core by default, or the two-wave form -- with the full one behind it */
+        const bool plain = integrate && !io.ext && !hf;
+        const bool two = plain && b->waves_per_env_tray == 2;
+        const bool fast = plain && b->fast_rows && b->d_progress;
         const dim3 pass_grid = fast_then_full(fast);
         launched = ck::launch_step_tray(grid, pass_grid, s, io, hf, fast, ev_after, two ? 2 : 1); ev_after = nullptr;
     }

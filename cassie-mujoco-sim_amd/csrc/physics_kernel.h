@@ -64,6 +64,7 @@ constexpr int NB = CM_MAXBODY;
 constexpr int NG = CM_MAXGEOM;
 constexpr int NROW = 64;       /* rows 0..62 constraints, column 63 = qfrc_smooth */
 constexpr int FAST_ROWS = 31;  /* rows of the row-capped fast instantiation (+ the qfrc_smooth column: half of the full tile) */
+constexpr int FAST_ROWS_TRAY = 47; /* the 40-dof model's fast instantiation: Cassie + tray + cube at rest use 32 .. 40 rows (+ the qfrc_smooth row: three blocks of 16) */
 constexpr int NSTAMP = 48;   /* 0..15 stage boundaries, 16..32 sub-stage stamps, 33..39 the two-wave form's barrier arrivals / departures,
                                 40..41 where the hardware placed the env's wave(s) (tools/stage_profile.py names them) */
 #define CK_TRI(k, i) ((k) * ((k) + 1) / 2 + (i))
@@ -2927,6 +2928,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
          *     body-stage region behind the staged tile) so that every lane ends up with its own row in registers;
          *   - the full instantiation forms the same chains on the vector unit, two rows at a time. */
         constexpr bool gram_on_matrix_core = MAXR == 31 && NVP % 4 == 0;
+        constexpr bool gram_in_place = MAXR == 47 && NVP == 40 && NW == 1; /* (the same on the matrix core, through the staged tile's own LDS: see there) */
         if constexpr (gram_on_matrix_core) {
             constexpr int YP = EnvShared<NVP, LPack<TOPO, NVP>::count, MAXR>::YP;
             static_assert(2 * (MAXR + 1) * YP * sizeof(double) <= sizeof(S.x), "the Gram matrix is parked behind the staged tile");
@@ -2958,13 +2960,61 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
 #pragma unroll
             for (int k = 0; k < NVP; ++k) wv::touch(ycol[k]);
             diag_yy = Am[myrow][myrow];
-        } else if constexpr (NW == 2 && NVP > 32) {
+        } else if constexpr (gram_in_place) {
+            /* The 40-dof model's row-capped instantiation, one wave per env (512 registers): the 48 x 48 Gram matrix of the staged
+             * tile (47 rows + the qfrc_smooth row) on the matrix core -- six 16 x 16 tiles x NVP / 4 blocks of dofs, the three
+             * tiles of rows 32 .. 47 only when the substep has that many rows.  There is no LDS behind the staged tile to turn the
+             * tiles into one row per lane, so it happens IN the region of the staged tile: every staged value is an operand of the
+             * products and sits in a register by then (row 16 I + (lane & 15), dofs 4 kb + (lane >> 4)), the tiles overwrite the
+             * staged tile, every lane takes its row of A, and the lanes store their rows of the tile once more (they still
+             * hold them). */
+            constexpr int AP = 49, AR = MAXR + 1; /* A at a leading dimension that keeps rows and columns off each other's banks */
+            static_assert(AR == 48, "three blocks of sixteen staged rows");
+            static_assert(AR * AP * sizeof(double) <= sizeof(S.x), "the matrix fits the region of the staged tile");
+            double (*Am)[AP] = (double (*)[AP])&S.x.Yr[0][0];
+            const int mi = lane & 15, mk = lane >> 4;
+            double y0[NVP / 4], y1[NVP / 4], y2[NVP / 4];
+#pragma unroll
+            for (int kb = 0; kb < NVP / 4; ++kb) { y0[kb] = S.x.Yr[mi][4 * kb + mk]; y1[kb] = S.x.Yr[16 + mi][4 * kb + mk]; y2[kb] = S.x.Yr[32 + mi][4 * kb + mk]; }
+            wv::mfma_acc t00 = {{0, 0, 0, 0}}, t01 = {{0, 0, 0, 0}}, t11 = {{0, 0, 0, 0}}, t02 = {{0, 0, 0, 0}}, t12 = {{0, 0, 0, 0}}, t22 = {{0, 0, 0, 0}};
+#pragma unroll
+            for (int kb = 0; kb < NVP / 4; ++kb) wv::mfma_f64_16x16x4_x3(y0[kb], y2[kb], t02, y1[kb], y2[kb], t12, y2[kb], y2[kb], t22); /* (row 47: always) */
+#pragma unroll
+            for (int kb = 0; kb < NVP / 4; ++kb) wv::mfma_f64_16x16x4_x3(y0[kb], y0[kb], t00, y0[kb], y1[kb], t01, y1[kb], y1[kb], t11);
+            wv::mfma_f64_drain(t00, t01, t11);
+            wv::mfma_f64_drain(t02, t12, t22);
+            wv::sync(); /* every operand is in registers: the tile's rows may go */
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int row = mk + 4 * v; /* (a lane's four values of a tile: rows mk + 4 v of column mi, as wave.h lays the result out) */
+                Am[row][mi] = t00.c[v];
+                Am[row][16 + mi] = t01.c[v]; Am[16 + mi][row] = t01.c[v];
+                Am[16 + row][16 + mi] = t11.c[v];
+                Am[row][32 + mi] = t02.c[v]; Am[32 + mi][row] = t02.c[v];
+                Am[16 + row][32 + mi] = t12.c[v]; Am[32 + mi][16 + row] = t12.c[v];
+                Am[32 + row][32 + mi] = t22.c[v];
+            }
+            wv::sync();
+            const int myrow = lane < AR ? lane : AR - 1; /* (lanes past the staged rows hold no row: they take one and never use it) */
+#pragma unroll
+            for (int t = 0; t < MAXR; ++t) arow[t] = Am[myrow][t];
+            rb = Am[myrow][MAXR] - raref;
+            wv::sync();
+            /* the staged tile as it was: the staging store over again */
+            if (r_ < MAXR || lastcol) {
+                const int yrow = lastcol ? MAXR : r_;
+#pragma unroll
+                for (int k = 0; k < NVP; ++k) S.x.Yr[yrow][k] = ycol[k];
+            }
+            wv::sync();
+        }
+        else if constexpr (NW == 2 && NVP > 32) {
             /* the 40-dof instantiation at the 256 registers of the two-wave form: one staged row at a time, half a row in flight
              * (the row-pair loop below keeps two staged rows beside this lane's column and its row of A: 330 registers); the same
-             * four partial sums per product, in the same order */
+             * chain per product */
 #pragma unroll
             for (int r = 0; r < MAXR; ++r) {
-                double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+                double acc = 0;
                 if (r < nefc) {
 #pragma unroll
                     for (int k0 = 0; k0 < NVP; k0 += NVP / 2) {
@@ -2972,13 +3022,10 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
 #pragma unroll
                         for (int k = 0; k < NVP / 2; ++k) ya[k] = S.x.Yr[r][k0 + k];
 #pragma unroll
-                        for (int k = 0; k < NVP / 2; k += 4) {
-                            a0 += ya[k] * ycol[k0 + k]; a1 += ya[k + 1] * ycol[k0 + k + 1];
-                            a2 += ya[k + 2] * ycol[k0 + k + 2]; a3 += ya[k + 3] * ycol[k0 + k + 3];
-                        }
+                        for (int k = 0; k < NVP / 2; ++k) acc = fma(ya[k], ycol[k0 + k], acc);
                     }
                 }
-                arow[r] = (a0 + a1) + (a2 + a3);
+                arow[r] = acc;
             }
             {
                 double acc = 0;
@@ -3006,6 +3053,16 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
                     /* (the instantiation with a row-capped twin: the chain of the matrix core, see above) */
 #pragma unroll
                     for (int k = 0; k < NVP; ++k) { acc0 = fma(ya[k], ycol[k], acc0); if (r + 1 < MAXR) acc1 = fma(yb[k], ycol[k], acc1); }
+                } else if constexpr (NVP == 40) {
+                    /* (likewise: its substeps of at most 47 rows go through the matrix core, the in-place form above; the second
+                     * row's late half arrives while the chains run over the early halves) */
+#pragma unroll
+                    for (int k = 0; k < YB1; ++k) { acc0 = fma(ya[k], ycol[k], acc0); if (r + 1 < MAXR) acc1 = fma(yb[k], ycol[k], acc1); }
+                    wv::sched_fence();
+#pragma unroll
+                    for (int k = YB1; k < NVP; ++k) yb[k] = S.x.Yr[r + 1 < MAXR ? r + 1 : r][k];
+#pragma unroll
+                    for (int k = YB1; k < NVP; ++k) { acc0 = fma(ya[k], ycol[k], acc0); if (r + 1 < MAXR) acc1 = fma(yb[k], ycol[k], acc1); }
                 } else {
                 double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
 #pragma unroll
@@ -3052,7 +3109,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
         double Aii = 1.0;
         if constexpr (gram_on_matrix_core) { if (isrow) Aii = diag_yy + rR; }
         else if (isrow) {
-            if constexpr (NVP == 32) { /* (the instantiation with a row-capped twin: the chain of the matrix core) */
+            if constexpr (NVP == 32 || NVP == 40) { /* (the instantiations with a matrix-core form: its chain) */
                 double d = 0;
 #pragma unroll
                 for (int k = 0; k < NVP; ++k) d = fma(ycol[k], ycol[k], d);
@@ -3331,6 +3388,9 @@ WV_GLOBAL void __launch_bounds__(WV_WAVE * NW) WV_OCC WV_WAVES_PER_SIMD(NW) cass
     const long long t0 = io.cost ? wv::clock() : 0;
     env_step<NVP, TOPO, FEAT, MAXR, NW>(io, S, env, sub_start);
     if (io.prof && wv::lane() == 0) io.prof[(size_t)env * NSTAMP + 40 + (NW == 2 ? wv::wave_id() : 0)] = wv::hw_id(); /* (profiling aid: the CU / SIMD of the wave) */
+    if (io.prof && wv::lane() == 0 && (NW == 1 || wv::wave_id() == 0)) { /* (profiling aid: the shader clock against the 100 MHz wall clock at the env's end) */
+        io.prof[(size_t)env * NSTAMP + 42] = wv::clock(); io.prof[(size_t)env * NSTAMP + 43] = wv::wall_clock();
+    }
     if (io.cost && wv::lane() == 0 && (NW == 1 || wv::wave_id() == 0)) { /* 64-clock units: 32 bits hold minutes */
         const unsigned c = (unsigned)((wv::clock() - t0) >> 6);
         io.cost[env] = io.resume ? io.cost[env] + c : c;

@@ -32,11 +32,11 @@ bool launch_step_cassie_all(dim3 grid, hipStream_t s, PhysIO io);               
 bool launch_step_tray(dim3 grid, dim3 pass_grid, hipStream_t s, PhysIO io, bool hfield, bool fast, hipEvent_t after_first, int waves); /* <40, TopoCassieTray38, FEAT_WAVEPAIRS | FEAT_ALL> */
 /* the 40-dof model's two-wave forms: the fast instantiation (FAST_ROWS_TRAY rows) and the full one (alone, or as the list-walking pass) */
 bool launch_fast_tray_2w(dim3 grid, hipStream_t s, PhysIO io);
+bool launch_fast_tray(dim3 grid, hipStream_t s, PhysIO io);   /* one wave per env, 47 rows, Gram matrix on the matrix core (kernels_tray_fast.hip) */
 bool launch_full_tray_2w(dim3 grid, hipStream_t s, PhysIO io);
 bool launch_step_generic(dim3 grid, hipStream_t s, PhysIO io, bool wide);           /* <32 | 40, TopoRuntime, FEAT_ALL> */
 
 constexpr unsigned SMALL_BATCH = 512; /* envs up to which the full kernel alone runs in its two-wave form (half the chip's workgroup slots) */
-constexpr int FAST_ROWS_TRAY = 47; /* the 40-dof model's fast instantiation: Cassie + tray + cube at rest use 32 .. 40 rows */
 
 template <int NVP, class TOPO, int FEAT>
 inline bool launch_fast_then_full(dim3 grid, dim3 pass_grid, hipStream_t s, PhysIO io, bool fast, hipEvent_t after_first, bool (*fast_2w)(dim3, hipStream_t, PhysIO),

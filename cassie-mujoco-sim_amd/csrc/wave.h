@@ -203,6 +203,7 @@ WV_DEVICE constexpr bool test_skip_com_init() { return false; }
 template <class S> WV_DEVICE void test_launch_hook(S *, unsigned long) {}
 
 WV_DEVICE long long clock() { return (long long)__builtin_readcyclecounter(); }
+WV_DEVICE long long wall_clock() { return (long long)__builtin_readsteadycounter(); } /* constant 100 MHz (s_memrealtime) */
 /* where the hardware placed this wave (profiling aid): HW_ID (wave slot [3:0], SIMD [5:4], CU [11:8], SH [12], SE [15:13], workgroup slot
  * [19:16]) in the low word, XCC_ID in the high word */
 WV_DEVICE long long hw_id() {

@@ -217,6 +217,11 @@ static int g_fast_rows = 0, g_fast_bails = 0;
 extern "C" void emu_fast_rows(int on) { g_fast_rows = on; }
 extern "C" int emu_fast_bails(void) { return g_fast_bails; }
 static void body40s() { ck::cassie_step_kernel<40, ck::TopoCassieTray38>(g_io); }
+/* the 40-dof model's row-capped instantiation (47 rows, one wave per env: the Gram matrix through the staged tile's own LDS) and
+ * the full one as the list-walking pass behind it (no height-field pairs) */
+static void body40s_fast() { ck::cassie_step_kernel<40, ck::TopoCassieTray38, ck::FEAT_WAVEPAIRS, ck::FAST_ROWS_TRAY>(g_io); }
+static void body40s_walk() { ck::cassie_step_kernel<40, ck::TopoCassieTray38, ck::FEAT_WAVEPAIRS, CM_MAXEFC, 1, true>(g_io); }
+static void body40s_2w_walk() { ck::cassie_step_kernel<40, ck::TopoCassieTray38, ck::FEAT_WAVEPAIRS, CM_MAXEFC, 2, true>(g_io); }
 static void body32() { ck::cassie_step_kernel<32, ck::TopoRuntime>(g_io); }
 static void body40() { ck::cassie_step_kernel<40, ck::TopoRuntime>(g_io); }
 extern "C" void emu_force_runtime_topology(int on) { g_force_runtime_topology = on; }
@@ -253,7 +258,9 @@ extern "C" int emu_phys_run(const cm_model_t *model, int nenv, int nsub, int int
     g_io.drive_mode = g_drive_mode; g_io.drive_state = g_drive_state; g_io.drive_cmd = g_drive_cmd; g_io.meas = g_meas;
     g_io.pd_dtarget = g_pd_dtarget; g_io.pd_torque = g_pd_torque;
     const bool cassie32 = !g_force_runtime_topology && topo_matches(model, ck::TopoCassie32::table, ck::TopoCassie32::nv, ck::TopoCassie32::body_levels);
-    if (cassie32 && g_fast_rows && integrate && nenv <= (1 << 16)) {
+    const bool tray38 = !cassie32 && !g_force_runtime_topology && model->nhfpair == 0 && model->hfield_geom < 0 &&
+                        topo_matches(model, ck::TopoCassieTray38::table, ck::TopoCassieTray38::nv, ck::TopoCassieTray38::body_levels);
+    if ((cassie32 || tray38) && g_fast_rows && integrate && nenv <= (1 << 16)) {
         /* as phys_batch.hip launches them: the row-capped fast instantiation for every env (it appends the envs it hands over to
          * the hand-over list), then the full instantiation as ONE small grid walking that list (here: g_resume_grid workgroups) */
         static int progress[1 << 16], list[1 << 16], count[2];
@@ -263,7 +270,8 @@ extern "C" int emu_phys_run(const cm_model_t *model, int nenv, int nsub, int int
         g_grid = nenv;
         for (int e = 0; e < nenv; ++e) {
             g_env = e;
-            if (g_two_waves) run_block(body32s_fast_2w, 2); else run_block(body32s_fast);
+            if (tray38) run_block(body40s_fast);
+            else if (g_two_waves) run_block(body32s_fast_2w, 2); else run_block(body32s_fast);
             if (progress[e] < nsub) ++g_fast_bails;
         }
         const int handed = count[0];
@@ -271,7 +279,8 @@ extern "C" int emu_phys_run(const cm_model_t *model, int nenv, int nsub, int int
         g_grid = g_resume_grid;
         for (int wg = 0; wg < g_resume_grid; ++wg) {
             g_env = wg;
-            if (g_two_waves) run_block(body32s_2w_walk, 2); else run_block(body32s_walk);
+            if (tray38) { if (g_two_waves) run_block(body40s_2w_walk, 2); else run_block(body40s_walk); }
+            else if (g_two_waves) run_block(body32s_2w_walk, 2); else run_block(body32s_walk);
         }
         g_grid = 1;
         g_io.progress = nullptr; g_io.resume = 0; g_io.handover_list = nullptr; g_io.handover_count = nullptr; g_io.handover_seen = nullptr;

@@ -58,6 +58,7 @@ unsigned long long ballot(bool p);
 double wave_sum(double v);
 float wave_sum_f32(float v);
 inline long long clock() { return 0; }
+inline long long wall_clock() { return 0; }
 inline long long hw_id() { return 0; }
 inline double max_raw(double a, double b) { return a > b ? a : b; }
 inline int opaque(int x) { return x; }

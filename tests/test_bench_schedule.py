@@ -123,7 +123,7 @@ def test_hand_over_figure_counts_against_the_last_launch_not_against_hold():
     assert bench.handed_over_in_last_launch(progress, 20) == 2.0          # the envs short of THIS launch's 20 substeps
     assert bench.handed_over_in_last_launch(np.full(4096, 20), 20) == 0.0
     assert bench.handed_over_in_last_launch(np.full(4096, 50), 50) == 0.0
-    assert bench.has_fast_kernel("cassie") and bench.has_fast_kernel("cassie_hfield") and not bench.has_fast_kernel("cassie_tray_box")
+    assert all(bench.has_fast_kernel(m) for m in ("cassie", "cassie_hfield", "cassie_tray_box"))   # (the tray model's: 47 rows, round 4)
     # the schedule of `--steps 20 --warmup 5` after the pre-roll: the last launch of a region has at most 20 substeps
     seen = []
     sch = bench.Schedule(step=seen.append, bind_targets=lambda p: None, restart=lambda g: None)
@@ -144,3 +144,15 @@ def test_pmc_traffic_scales_only_the_per_substep_part(cassie):
         pytest.skip("no committed PMC summary")
     assert t20 > 0.4 * t50 + 0.5 * fixed * 4096 * 0.6          # far above the linear 0.4 x: the fixed part does not shrink
     assert t20 >= fixed * 4096 and t20 < t50
+
+
+def test_slot_occupancy_figure():
+    """bench.slot_occupancy: 1024 slots, every env-step holding one for its clocks -- a region that keeps every slot busy reads 1.0."""
+    import bench
+    n, substeps, clocks = 4096, 1000 * bench.HOLD, 80000.0
+    full = n * substeps * clocks / bench.SHADER_CLOCK_HZ / bench.SLOTS_PER_GPU      # the region's time with no slot ever idle
+    o = bench.slot_occupancy(clocks, n, substeps, full)
+    assert abs(o["busy_frac"] - 1.0) < 1e-12
+    assert abs(o["rate_with_every_slot_busy"] - n * substeps / full) < 1e-3
+    assert abs(bench.slot_occupancy(clocks, n, substeps, 1.25 * full)["busy_frac"] - 0.8) < 1e-12
+    assert bench.slot_occupancy(None, n, substeps, full) is None      # a batch that keeps no per-env clocks

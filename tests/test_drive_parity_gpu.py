@@ -209,7 +209,7 @@ def test_stress_variant_pm10_rad_targets(built, name):
         oracle_py.set_hfield(None)
 
 
-@pytest.mark.parametrize("name,mode", [("cassie", "exact"), ("cassie", "drive"), ("cassie_hfield", "drive")])
+@pytest.mark.parametrize("name,mode", [("cassie", "exact"), ("cassie", "drive"), ("cassie_hfield", "drive"), ("cassie_tray_box", "drive")])
 def test_row_capped_fast_kernel_equals_the_full_kernel_bit_for_bit(built, name, mode):
     """Stepping launches of the Cassie instantiations run the row-capped fast kernel (31 rows) first; the full kernel behind it
     finishes the envs that met a substep with more rows (PhysIO::progress).  Under the +-10 rad stress targets thousands of
@@ -254,7 +254,10 @@ def test_row_capped_fast_kernel_equals_the_full_kernel_bit_for_bit(built, name, 
             b.close()
     rows = out[0][7]
     print("%s %s: %d of %d env-launches were handed over to the full kernel; rows of a launch's last substep up to %d" % (name, mode, handed, n * npol, rows.max()))
-    assert 50 < handed < n * npol // 2                 # the hand-over happened often, and most launches stayed in the fast kernel
+    if name == "cassie_tray_box":   # (47 rows, one wave per env, Gram matrix on the matrix core; the full kernel forms it on the vector unit)
+        assert handed < n * npol // 2
+    else:
+        assert 50 < handed < n * npol // 2             # the hand-over happened often, and most launches stayed in the fast kernel
     for a, c in zip(out[0], out[1]):
         assert a.tobytes() == c.tobytes()
 

@@ -393,10 +393,11 @@ def _two_wave_workload(model, drive, fast, two_waves, schedule, poison=False, nl
             emu.forward()
             emu.drive_mode = P.DRIVE_PD
         rows = []
+        amp = (10.0 if stress else 0.3) if isinstance(stress, bool) else float(stress)   # (a number: the targets' amplitude in rad)
         for p in range(nlaunch):
             tg = np.empty((n, 10))
             for e in range(n):
-                tg[e] = bench.PD_OFFSET + np.random.default_rng(977 + 31 * p + e).uniform(-10 if stress else -0.3, 10 if stress else 0.3, 10)
+                tg[e] = bench.PD_OFFSET + np.random.default_rng(977 + 31 * p + e).uniform(-amp, amp, 10)
             emu.pd_ptarget = tg
             emu.step(nsub)
             rows.append(emu.info.copy())
@@ -447,3 +448,34 @@ def test_two_wave_form_on_the_other_models(name, built):
     for schedule in (1, 2):
         got, _, _ = _two_wave_workload(model, True, fast=True, two_waves=True, schedule=schedule, poison=True, nlaunch=2, nsub=8, stress=False)
         assert got == ref
+
+
+def test_tray_fast_instantiation_is_bit_for_bit_the_full_one(built):
+    """cassie_tray_box.xml: the 47-row instantiation forms its Gram matrix on the matrix core through the staged tile's own LDS
+    (physics_kernel.h, gram_in_place) and hands substeps with more rows over to the full instantiation, which forms the same
+    chains on the vector unit: state, outputs and solver statistics must be those of the full instantiation alone, bit for
+    bit -- at rest on the tray (32 .. 40 rows) and under the stress targets (rows past 47: hand-overs), LDS poisoned."""
+    from cassie_amd import Model
+    import emu_py
+    model = Model("cassie_tray_box")
+    margins = [model.pod.jnt_margin[j] for j in range(model.pod.njnt)]
+    for stress in (False, True):
+        # (the second round: every limited joint inside its limit's margin all the time -- 16 more rows while the robot still stands)
+        for j in range(model.pod.njnt):
+            model.pod.jnt_margin[j] = 10.0 if stress and model.pod.jnt_limited[j] else margins[j]
+        ref, rows, before = _two_wave_workload(model, True, fast=False, two_waves=False, schedule=0, nlaunch=3, nsub=10, stress=stress)
+        got, _, bails = _two_wave_workload(model, True, fast=True, two_waves=False, schedule=0, poison=True, nlaunch=3, nsub=10, stress=stress)
+        bails -= before       # (the emulator's count of handed-over envs runs on from test to test)
+        assert got == ref, stress
+        if stress:
+            assert rows[:, :, 1].max() > 47 and bails > 0, (rows[:, :, 1].max(), bails)
+        else:
+            assert 16 < rows[:, :, 1].max() <= 47 and bails == 0, (rows[:, :, 1].max(), bails)
+    # the walking pass in its two-wave form (what phys_batch.hip launches behind the fast kernel)
+    emu_py.lib().emu_resume_grid(1)
+    before = emu_py.lib().emu_fast_bails()
+    try:
+        got, _, bails = _two_wave_workload(model, True, fast=True, two_waves=True, schedule=1, nlaunch=3, nsub=10, stress=True)
+    finally:
+        emu_py.lib().emu_resume_grid(2)
+    assert got == ref and bails > before

@@ -34,3 +34,22 @@ def test_fast_cassie_kernel_keeps_its_registers_and_its_lds(tmp_path):
     assert sum(l.startswith("s_barrier") for l in body) <= 16, "workgroup barriers: F, X, J, P, E per substep in each wave's program + the exits"
     # A = Y Y^T: 3 tiles x 8 dof blocks; composite inertias: 2 body blocks x 8 summand blocks
     assert sum(l.startswith("v_mfma_f64_16x16x4_f64") for l in body) == 24 + 16
+
+
+@pytest.mark.skipif(not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")), reason="needs hipcc")
+def test_tray_fast_kernel_keeps_its_gram_matrix_on_the_matrix_core(tmp_path):
+    """The 40-dof model's row-capped instantiation (47 rows, one wave per env, 512 registers): the 48 x 48 Gram matrix of the staged
+    tile as six tiles x ten dof blocks on the matrix core (+ the 16 instructions of the composite-inertia sums), next to no scratch
+    traffic (a run-time choice between this form and the vector loop in ONE kernel sent 4 000 values to scratch: it is an
+    instantiation of its own for that reason), four workgroups per CU."""
+    isa = tmp_path / "tray_fast.s"
+    env = dict(os.environ, MAXRS="47", NW="1", NVP="40", TOPO="TopoCassieTray38", FEAT="2", KEEP=str(isa))
+    out = subprocess.run(["bash", os.path.join(REPO, "tools", "kernel_resources.sh")], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout + out.stderr
+    text = out.stdout
+    val = lambda key: int(re.search(key + r"[^:]*: *(\d+)", text).group(1))
+    assert val("ScratchSize") <= 256, text
+    assert val("LDS Size") <= 40960, text
+    body = [l.split(";")[0].strip() for l in isa.read_text().split("\n")]
+    assert sum(l.startswith(("scratch_load", "scratch_store")) for l in body) <= 12, "scratch traffic in the tray model's fast kernel"
+    assert sum(l.startswith("v_mfma_f64_16x16x4_f64") for l in body) == 60 + 16

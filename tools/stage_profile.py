@@ -8,7 +8,7 @@ from cassie_amd import Batch, Model
 from cassie_amd import phys as P
 names = ["kinematics", "geoms+com+cinert+cdof", "crba", "factor", "collision", "velocity+rne", "qfrc_smooth",
          "rows+J", "halfsolve", "A", "pgs", "qacc", "sensors", "euler"]
-m = Model("cassie")
+m = Model(os.environ.get("MODEL", "cassie"))   # MODEL=cassie_tray_box: the 40-dof instantiation (one wave per env by default)
 NSUB = int(os.environ.get("NSUB", "1"))   # substeps fused per launch (the bench uses 50)
 for n in (int(a) for a in (sys.argv[1:] or ["512", "4096"])):
     b = Batch(m, n)
@@ -41,6 +41,39 @@ for n in (int(a) for a in (sys.argv[1:] or ["512", "4096"])):
         c = b.launch_cost()
         print("  whole launch per env: %.0f shader clocks = %.0f per substep (mean; min %.0f max %.0f per substep)" % (c.mean(), c.mean() / NSUB, c.min() / NSUB, c.max() / NSUB))
     w, info = b.warnings()
+    # the shader clock against the constant 100 MHz wall clock, both read at each env's end: the clock the chip really ran at
+    # under this load (a straight-line fit over every env's end of launch), and the launch's span on the wall clock
+    ce, we = st[:, 42].astype(float), st[:, 43].astype(float)
+    if os.environ.get("DUMP"):
+        np.savez_compressed(os.environ["DUMP"] + "_%d_w%d.npz" % (n, WAVES), st=st, cost=b.launch_cost() if n >= 2048 else np.zeros(0), info=info)
+    if np.ptp(we) > 0:
+        # (the shader clock has a base of its own in every XCD: one fit per XCD, all with the same slope)
+        xcc = (st[:, 40] >> 32).astype(int)
+        slopes = []
+        for x in np.unique(xcc):
+            k = xcc == x
+            if np.ptp(we[k]) > 0:
+                fit = np.polyfit(we[k] - we[k].min(), ce[k] - ce[k].min(), 1)
+                slopes.append(fit[0])
+                ce[k] = (ce[k] - ce[k].min() - fit[1]) + (we[k].min() - we.min()) * fit[0]   # onto one time base: that of the wall clock
+        slope = float(np.mean(slopes))
+        print("  shader clock / wall clock over the envs' ends, per XCD: %s ticks per 10 ns -> %.3f GHz; ends span %.3f ms on the wall clock (launch of %d substeps: %.3f ms)"
+              % (np.round(slopes, 2).tolist(), slope * 0.1, np.ptp(we) * 1e-5, NSUB, ms * NSUB))
+    if n >= 2048 and np.ptp(we) > 0:
+        # workgroup-slot occupancy over the launch: every env's start = its end - its cost (shader clocks; the fast kernel's envs)
+        cost = b.launch_cost()
+        start, end = ce - cost, ce
+        t0, t1 = start.min(), end.max()
+        slots = 256 * 4
+        print("  workgroup slots: sum of env durations / (%d slots x launch span) = %.3f; span %.0f clocks = %.3f ms at the fitted clock"
+              % (slots, cost.sum() / (slots * (t1 - t0)), t1 - t0, (t1 - t0) / (slope * 1e5)))
+        grid = np.linspace(t0, t1, 21)
+        act = [(int(np.sum((start <= t) & (end > t)))) for t in grid]
+        print("  envs in flight at 0, 5, .. 100 %% of the span:", act)
+        cuid = ((st[:, 40] >> 32) << 12) | (((st[:, 40] >> 13) & 7) << 5) | (((st[:, 40] >> 12) & 1) << 4) | ((st[:, 40] >> 8) & 15)
+        per_cu = np.array([cost[cuid == c].sum() for c in np.unique(cuid)])
+        print("  per CU: envs (first 8 CUs) %s, summed env clocks / 4 slots: mean %.0f min %.0f max %.0f (span %.0f)"
+              % (np.bincount(np.unique(cuid, return_inverse=True)[1]).tolist()[:8], per_cu.mean() / 4, per_cu.min() / 4, per_cu.max() / 4, t1 - t0))
     if WAVES == 2 and not os.environ.get("FULL_KERNEL"):
         # two-wave form: wave 0 and wave 1 have timelines of their own, meeting at the barriers F, X and J
         dur = lambda a, c: (st[:, c] - st[:, a]).astype(float).mean()
