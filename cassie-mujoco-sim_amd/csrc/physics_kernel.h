@@ -66,7 +66,8 @@ constexpr int NROW = 64;       /* rows 0..62 constraints, column 63 = qfrc_smoot
 constexpr int FAST_ROWS = 31;  /* rows of the row-capped fast instantiation (+ the qfrc_smooth column: half of the full tile) */
 constexpr int FAST_ROWS_TRAY = 47; /* the 40-dof model's fast instantiation: Cassie + tray + cube at rest use 32 .. 40 rows (+ the qfrc_smooth row: three blocks of 16) */
 constexpr int NSTAMP = 48;   /* 0..15 stage boundaries, 16..32 sub-stage stamps, 33..39 the two-wave form's barrier arrivals / departures,
-                                40..41 where the hardware placed the env's wave(s) (tools/stage_profile.py names them) */
+                                40..41 where the hardware placed the env's wave(s), 42..43 shader clock and 100 MHz clock at the env's end,
+                                44..46 the height-field pre-pass (tools/stage_profile.py names them) */
 #define CK_TRI(k, i) ((k) * ((k) + 1) / 2 + (i))
 #define CK_STAMP(i) do { if (io.prof && lane == 0) io.prof[(size_t)env * NSTAMP + (i)] = wv::clock(); CK_FRESH(); } while (0)
 /* stage boundary: re-derive the lane index and its aliases (see wv::fresh_lane) */
@@ -698,6 +699,130 @@ WV_DEVICE int hfield_sphere(RawContact &c, ModelPtr m, const float *data, const 
     if (best > 1e299) return 0;
     const double dist = best - r;
     if (dist > margin) return 0;
+    double nw[3];
+    mulmatvec3(nw, mh, bn);
+    c.dist = dist;
+    for (int k = 0; k < 3; ++k) { c.normal[k] = nw[k]; c.pos[k] = ps[k] - nw[k] * (r + 0.5 * dist); c.tangent[k] = 0; }
+    return 1;
+}
+
+/* The same for up to 64 sample spheres at once, one per lane (`mine`: this lane has one), with the WHOLE WAVE sharing the grid
+ * cells under all of them: a sphere of a foot capsule covers 15 .. 25 cells and the pelvis sphere none, and with one lane
+ * walking each sphere's cells the wave took as long as its slowest lane (26 k clocks, a quarter of the height-field model's
+ * substep).  Here the cells of all spheres form one task list (sphere by sphere, a sphere's cells in its scan order), lane t
+ * of round q takes task 64 q + t -- looks its sphere up in a table the spheres wrote their lane numbers into, fetches the
+ * sphere from that lane, tests the cell's two triangles -- and a segmented minimum scan over the lanes of one sphere hands the round's
+ * closest feature to the sphere's record in LDS.  Ties go to the earlier task, and a sphere's earlier rounds win over later
+ * ones, which is the strict `<` of the sequential scan: results are those of hfield_sphere bit for bit.
+ * work: HF_WINDOW bytes (the sphere of every task of a window) + 4 doubles per lane (closest distance, normal). */
+#ifdef CK_EMULATED
+constexpr int HF_WINDOW = 128;  /* (the CPU emulator's tests go through several windows per pass; results do not depend on the size) */
+#else
+constexpr int HF_WINDOW = 1024;
+#endif
+WV_DEVICE int hfield_spheres_wave(RawContact &c, ModelPtr m, const float *data, const double *ph, const double *mh, bool mine, const double *ps,
+                                  double r, double margin, int lane, double *work) {
+    const bool grid_ok = data && m->hfield_nrow >= 2 && m->hfield_ncol >= 2;
+    const double sx = m->hfield_size[0], sy = m->hfield_size[1], sz = m->hfield_size[2];
+    const int nc = m->hfield_ncol, nr = m->hfield_nrow;
+    const double dx = 2 * sx / (nc > 1 ? nc - 1 : 1), dy = 2 * sy / (nr > 1 ? nr - 1 : 1);
+    double pl[3] = {0, 0, 0};
+    const double reach = r + (margin > 0 ? margin : 0);
+    int i0 = 0, j0 = 0, wj = 1, ncell = 0;
+    if (mine && grid_ok) {
+        double d[3] = {ps[0] - ph[0], ps[1] - ph[1], ps[2] - ph[2]};
+        mulmatTvec3(pl, mh, d);
+        if (!(fabs(pl[0]) > sx + reach || fabs(pl[1]) > sy + reach || pl[2] - r > sz + margin)) {
+            int j1 = (int)floor((pl[0] + reach + sx) / dx), i1 = (int)floor((pl[1] + reach + sy) / dy);
+            j0 = (int)floor((pl[0] - reach + sx) / dx); i0 = (int)floor((pl[1] - reach + sy) / dy);
+            if (j0 < 0) j0 = 0;
+            if (i0 < 0) i0 = 0;
+            if (j1 > nc - 2) j1 = nc - 2;
+            if (i1 > nr - 2) i1 = nr - 2;
+            if (j1 >= j0 && i1 >= i0) { wj = j1 - j0 + 1; ncell = wj * (i1 - i0 + 1); }
+        }
+    }
+    /* running cell counts (inclusive), lane by lane */
+    int endx = ncell;
+#pragma unroll
+    for (int dlt = 1; dlt < WV_WAVE; dlt *= 2) { const int t = wv::shfl_i(endx, (lane - dlt) & 63); if (lane >= dlt) endx += t; }
+    const int total = wv::shfl_i(endx, WV_WAVE - 1);
+    int maxcell = ncell;
+#pragma unroll
+    for (int msk = WV_WAVE / 2; msk >= 1; msk /= 2) { const int o = wv::shfl_i(maxcell, lane ^ msk); maxcell = o > maxcell ? o : maxcell; }
+    unsigned char *const owner = (unsigned char *)work;      /* the sphere (lane) of every task of a window of HF_WINDOW tasks */
+    double *const rec = work + HF_WINDOW / 8 + 4 * lane;
+    rec[0] = 1e300; rec[1] = 0; rec[2] = 0; rec[3] = 1;
+    const int start = endx - ncell;
+    for (int win = 0; win < total; win += HF_WINDOW) {
+        /* every sphere writes its lane over its tasks of this window */
+        for (int cc = 0; cc < maxcell; ++cc) {
+            const int at = start + cc - win;
+            if (cc < ncell && at >= 0 && at < HF_WINDOW) owner[at] = (unsigned char)lane;
+        }
+        wv::sync();
+        const int wend = total - win < HF_WINDOW ? total - win : HF_WINDOW;
+        /* a round's tasks: sphere, cell, the cell's four heights -- requested one round ahead of their use, so that the trip to
+         * memory runs under the previous round's triangles */
+        struct Task { bool act; int own; double q0, q1, q2, qreach, x0, y0; float h00, h10, h01, h11; bool cull; };
+        auto request = [&](int base, Task &t) {
+            const int task = base + lane;
+            t.act = task < wend;
+            t.own = t.act ? (int)owner[task] : lane;
+            t.q0 = wv::shfl(pl[0], t.own); t.q1 = wv::shfl(pl[1], t.own); t.q2 = wv::shfl(pl[2], t.own); t.qreach = wv::shfl(reach, t.own);
+            const int qi0 = wv::shfl_i(i0, t.own), qj0 = wv::shfl_i(j0, t.own), qwj = wv::shfl_i(wj, t.own), qstart = wv::shfl_i(start, t.own);
+            const int cidx = t.act ? win + task - qstart : 0;
+            const int ci = (int)(((float)cidx + 0.5f) * (1.0f / (float)qwj)); /* cidx / qwj: the quotient's distance from an integer is at least 0.5 / qwj */
+            const int i = qi0 + ci, j = qj0 + (cidx - ci * qwj);
+            t.y0 = -sy + i * dy; t.x0 = -sx + j * dx;
+            const double ey = t.q1 < t.y0 ? t.y0 - t.q1 : (t.q1 > t.y0 + dy ? t.q1 - (t.y0 + dy) : 0.0);
+            const double ex = t.q0 < t.x0 ? t.x0 - t.q0 : (t.q0 > t.x0 + dx ? t.q0 - (t.x0 + dx) : 0.0);
+            t.cull = !t.act || ex * ex + ey * ey > t.qreach * t.qreach;
+            t.h00 = t.h10 = t.h01 = t.h11 = 0.0f;
+            if (!t.cull) { t.h00 = data[i * nc + j]; t.h10 = data[i * nc + j + 1]; t.h01 = data[(i + 1) * nc + j]; t.h11 = data[(i + 1) * nc + j + 1]; }
+        };
+        Task cur, nxt;
+        request(0, cur);
+        for (int base = 0; base < wend; base += WV_WAVE) {
+            if (base + WV_WAVE < wend) request(base + WV_WAVE, nxt); /* (wave-uniform) */
+            else { nxt.act = false; nxt.cull = true; nxt.own = lane; }
+            double best = 1e300, bn[3] = {0, 0, 1};
+            if (!cur.cull) {
+                const double z00 = sz * cur.h00, z10 = sz * cur.h10, z01 = sz * cur.h01, z11 = sz * cur.h11;
+                if (!(cur.q2 - cur.qreach > fmax(fmax(z00, z10), fmax(z01, z11)))) {
+                    const double q[3] = {cur.q0, cur.q1, cur.q2}, x0 = cur.x0, y0 = cur.y0;
+                    const double v00[3] = {x0, y0, z00}, v10[3] = {x0 + dx, y0, z10}, v01[3] = {x0, y0 + dy, z01}, v11[3] = {x0 + dx, y0 + dy, z11};
+                    hfield_triangle(q, v00, v10, v01, best, bn);
+                    hfield_triangle(q, v11, v01, v10, best, bn);
+                }
+            }
+            /* the closest feature among the lanes of one sphere, earlier tasks first: segmented inclusive scan of (distance, lane) */
+            double sv = best;
+            int ssrc = lane;
+            const int seg = cur.act ? cur.own : -1 - lane;
+#pragma unroll
+            for (int dlt = 1; dlt < WV_WAVE; dlt *= 2) {
+                const int from = (lane - dlt) & 63;
+                const double ov = wv::shfl(sv, from);
+                const int osrc = wv::shfl_i(ssrc, from), oseg = wv::shfl_i(seg, from);
+                if (lane >= dlt && oseg == seg && !(sv < ov)) { sv = ov; ssrc = osrc; }
+            }
+            const int nseg = wv::shfl_i(seg, (lane + 1) & 63);
+            const double w0 = wv::shfl(bn[0], ssrc), w1 = wv::shfl(bn[1], ssrc), w2 = wv::shfl(bn[2], ssrc);
+            if (cur.act && (lane == WV_WAVE - 1 || nseg != seg)) {
+                double *const o = work + HF_WINDOW / 8 + 4 * cur.own;
+                if (sv < o[0]) { o[0] = sv; o[1] = w0; o[2] = w1; o[3] = w2; }
+            }
+            wv::sync();
+            cur = nxt;
+        }
+    }
+    wv::sync();
+    const double best = rec[0];
+    if (!mine || best > 1e299) return 0;
+    const double dist = best - r;
+    if (dist > margin) return 0;
+    const double bn[3] = {rec[1], rec[2], rec[3]};
     double nw[3];
     mulmatvec3(nw, mh, bn);
     c.dist = dist;
@@ -2234,9 +2359,16 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
                 RawContact rcs;
                 rcs.dist = 1e300;
                 bool has = false;
-                if (mine) {
+                {
+                    /* (all lanes: the wave shares the cells under the pass's samples; the contact tables are scratch until the
+                     * pair loop below fills them) */
                     double e[3] = {p2[0] + t * axis[0], p2[1] + t * axis[1], p2[2] + t * axis[2]};
-                    has = hfield_sphere(rcs, m, env_hfield, p1, m1, e, s20, margin) != 0;
+                    typedef EnvShared<NVP, LPack<TOPO, NVP>::count, MAXR> SH_T;
+                    static_assert(offsetof(SH_T, c_margin) + sizeof(S.c_margin) - offsetof(SH_T, c_dist) >= HF_WINDOW + sizeof(double) * 4 * WV_WAVE,
+                                  "the contact tables hold the work area of hfield_spheres_wave");
+                    CK_STAMP(44);
+                    has = hfield_spheres_wave(rcs, m, env_hfield, p1, m1, mine, e, s20, margin, lane, &S.c_dist[0]) != 0;
+                    CK_STAMP(45);
                 }
                 /* the samples of this lane's pair: distances (1e300 = no contact) */
                 const int lead = lane - k;
@@ -2287,6 +2419,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
                 }
             }
             wv::sync();
+            CK_STAMP(46);
         }
         if constexpr (!request_early) request_pair(lane, pc);
         for (int p0 = 0; p0 < npass; p0 += WV_WAVE) {

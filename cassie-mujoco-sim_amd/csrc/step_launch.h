@@ -33,6 +33,7 @@ bool launch_step_tray(dim3 grid, dim3 pass_grid, hipStream_t s, PhysIO io, bool 
 /* the 40-dof model's two-wave forms: the fast instantiation (FAST_ROWS_TRAY rows) and the full one (alone, or as the list-walking pass) */
 bool launch_fast_tray_2w(dim3 grid, hipStream_t s, PhysIO io);
 bool launch_fast_tray(dim3 grid, hipStream_t s, PhysIO io);   /* one wave per env, 47 rows, Gram matrix on the matrix core (kernels_tray_fast.hip) */
+bool launch_full_tray_walk(dim3 grid, hipStream_t s, PhysIO io); /* the one-wave full instantiation walking the hand-over list behind it (io.handover_list set) */
 bool launch_full_tray_2w(dim3 grid, hipStream_t s, PhysIO io);
 bool launch_step_generic(dim3 grid, hipStream_t s, PhysIO io, bool wide);           /* <32 | 40, TopoRuntime, FEAT_ALL> */
 

@@ -16,6 +16,10 @@ for n in (int(a) for a in (sys.argv[1:] or ["512", "4096"])):
         b.set_fast_rows(False)      # the stamps of the full instantiation alone (default: the row-capped fast one, where an env fits it)
     WAVES = int(os.environ.get("WAVES", "2"))
     b.set_waves_per_env(WAVES)
+    if m.name == "cassie_hfield":     # the bench's terrain (reference example/test_hfield.py:39-41), every env at the flat centre patch
+        hf = np.random.default_rng(99).random((200, 200)).astype(np.float32)
+        hf[95:105, 95:105] = 0
+        b.set_hfield(hf)
     b.set(P.F_QPOS, np.tile(m.qpos_init(), (n, 1)))
     rng = np.random.default_rng(0)
     b.set(P.F_PD_PTARGET, np.array([0.0045, 0, 0.4973, -1.1997, -1.5968] * 2) + rng.uniform(-0.3, 0.3, (n, 10)))
@@ -74,6 +78,9 @@ for n in (int(a) for a in (sys.argv[1:] or ["512", "4096"])):
         per_cu = np.array([cost[cuid == c].sum() for c in np.unique(cuid)])
         print("  per CU: envs (first 8 CUs) %s, summed env clocks / 4 slots: mean %.0f min %.0f max %.0f (span %.0f)"
               % (np.bincount(np.unique(cuid, return_inverse=True)[1]).tolist()[:8], per_cu.mean() / 4, per_cu.min() / 4, per_cu.max() / 4, t1 - t0))
+    if m.name == "cassie_hfield":
+        d = lambda a, c: (st[:, c] - st[:, a]).astype(float).mean()
+        print("  height-field pre-pass: set-up %.0f, the samples' cells (hfield_spheres_wave) %.0f, capsule rule + records %.0f clocks; pair loop and the rest of the lane pass %.0f" % (d(21, 44), d(44, 45), d(45, 46), d(46, 22)))
     if WAVES == 2 and not os.environ.get("FULL_KERNEL"):
         # two-wave form: wave 0 and wave 1 have timelines of their own, meeting at the barriers F, X and J
         dur = lambda a, c: (st[:, c] - st[:, a]).astype(float).mean()
