@@ -1,4 +1,4 @@
-# round 4, final measurement set (v30: two wavefronts per env for the Cassie instantiations -- mass-matrix group, drive-level pass,
+# round 4, final measurement set (v31: two wavefronts per env for the Cassie instantiations -- mass-matrix group, drive-level pass,
 # factorisations, bias / passive stage and the stages behind the solve on wave 1 --, hand-over list, list-walking two-wave pass).
 # Box clocks differ by up to 30 % between leases: the first bench line decides whether this box is a normal one.
 mkdir -p gpurun_out; nproc > gpurun_out/nproc.txt
@@ -47,3 +47,8 @@ print("$m", {k: (round(v, 4) if isinstance(v, float) else v) for k, v in d.items
 PY
 done
 timeout 900 python bench.py --steps 10000 --warmup 100 --repeats 2 --no-cpu-baseline --no-step-pd --no-other-mode 2> gpurun_out/bench_soak.err | grep '^{"metric"' > gpurun_out/bench_soak_10000_steps_cassie.json; line gpurun_out/bench_soak_10000_steps_cassie.json
+for m in cassie_hfield cassie_tray_box; do
+  timeout 900 python bench.py --model $m --steps 10000 --warmup 100 --repeats 2 --no-cpu-baseline --no-step-pd --no-other-mode 2> gpurun_out/bench_soak_$m.err | grep '^{"metric"' > gpurun_out/bench_soak_10000_steps_$m.json; line gpurun_out/bench_soak_10000_steps_$m.json
+done
+MODEL=cassie_hfield NSUB=50 WAVES=2 python tools/stage_profile.py 4096 > gpurun_out/stage_profile_nsub50_hfield_two_waves.txt 2>&1
+MODEL=cassie_tray_box NSUB=50 WAVES=1 python tools/stage_profile.py 4096 > gpurun_out/stage_profile_nsub50_tray_fast47.txt 2>&1
