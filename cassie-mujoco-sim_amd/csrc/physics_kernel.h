@@ -3491,8 +3491,10 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
 /* WALK: the instantiation is the pass behind the fast kernel in its list-walking form (PhysIO::handover_list): a small grid whose
  * workgroups each finish the handed-over envs blockIdx, blockIdx + gridDim, ... of the list.  (A template parameter and not a
  * run-time branch: env_step is inlined, and two call sites would be two copies of it in one kernel.) */
-template <int NVP, class TOPO, int FEAT = FEAT_ALL, int MAXR = CM_MAXEFC, int NW = 1, bool WALK = false>
-WV_GLOBAL void __launch_bounds__(WV_WAVE * NW) WV_OCC WV_WAVES_PER_SIMD(NW) cassie_step_kernel(PhysIO io) {
+/* WPS: wavefronts per SIMD the registers are budgeted for (NW: 512 / NW registers a lane; 1 with NW = 2: two wavefronts per env with
+ * 512 registers each, for batches that cannot fill the chip anyway -- a single simulator) */
+template <int NVP, class TOPO, int FEAT = FEAT_ALL, int MAXR = CM_MAXEFC, int NW = 1, bool WALK = false, int WPS = NW>
+WV_GLOBAL void __launch_bounds__(WV_WAVE * NW) WV_OCC WV_WAVES_PER_SIMD(WPS) cassie_step_kernel(PhysIO io) {
     WV_SHARED EnvShared<NVP, LPack<TOPO, NVP>::count, MAXR> S;
     const int slot = wv::env_id();
     if constexpr (WALK) {

@@ -28,6 +28,9 @@ bool launch_fast_cassie_hfield_2w(dim3 grid, hipStream_t s, PhysIO io);
  * env range's kernel keeps every SIMD half full (the one-wave full kernel holds 421 registers) */
 bool launch_full_cassie_2w(dim3 grid, hipStream_t s, PhysIO io);
 bool launch_full_cassie_hfield_2w(dim3 grid, hipStream_t s, PhysIO io);
+/* ... and for batches of at most SMALL_BATCH envs alone: two waves of 512 registers (kernels_*_small.hip) */
+bool launch_full_cassie_small(dim3 grid, hipStream_t s, PhysIO io);
+bool launch_full_cassie_hfield_small(dim3 grid, hipStream_t s, PhysIO io);
 bool launch_step_cassie_all(dim3 grid, hipStream_t s, PhysIO io);                   /* <32, TopoCassie32, FEAT_ALL> */
 bool launch_step_tray(dim3 grid, dim3 pass_grid, hipStream_t s, PhysIO io, bool hfield, bool fast, hipEvent_t after_first, int waves); /* <40, TopoCassieTray38, FEAT_WAVEPAIRS | FEAT_ALL> */
 /* the 40-dof model's two-wave forms: the fast instantiation (FAST_ROWS_TRAY rows) and the full one (alone, or as the list-walking pass) */
@@ -37,14 +40,18 @@ bool launch_full_tray_walk(dim3 grid, hipStream_t s, PhysIO io); /* the one-wave
 bool launch_full_tray_2w(dim3 grid, hipStream_t s, PhysIO io);
 bool launch_step_generic(dim3 grid, hipStream_t s, PhysIO io, bool wide);           /* <32 | 40, TopoRuntime, FEAT_ALL> */
 
+constexpr int SMALL_BATCH_NSUB = 4;  /* ... and substeps per launch up to which such a batch skips the row-capped fast kernel + pass pair (two launches) */
 constexpr unsigned SMALL_BATCH = 512; /* envs up to which the full kernel alone runs in its two-wave form (half the chip's workgroup slots) */
 
 template <int NVP, class TOPO, int FEAT>
 inline bool launch_fast_then_full(dim3 grid, dim3 pass_grid, hipStream_t s, PhysIO io, bool fast, hipEvent_t after_first, bool (*fast_2w)(dim3, hipStream_t, PhysIO),
-                                  bool (*full_2w)(dim3, hipStream_t, PhysIO)) {
+                                  bool (*full_2w)(dim3, hipStream_t, PhysIO), bool (*full_small)(dim3, hipStream_t, PhysIO)) {
     /* (measurement aids: CASSIE_DEBUG_SKIP_RESUME_PASS -- what the pass behind the fast kernel costs; handed-over envs are then
      * left unfinished, so only for workloads that hand nothing over; CASSIE_DEBUG_RESUME_ONE_WAVE -- the pass behind a two-wave
      * fast kernel as one-wave workgroups) */
+    /* a small batch stepping a few substeps per launch (somebody's control loop around a handful of envs): one launch of the full
+     * kernel in its small-batch form instead of two -- a launch costs what four substeps' difference between the kernels saves */
+    if (fast && full_small && grid.x <= SMALL_BATCH && io.nsub <= SMALL_BATCH_NSUB) fast = false;
     static const bool skip_resume = getenv("CASSIE_DEBUG_SKIP_RESUME_PASS") != nullptr;
     static const bool resume_one_wave = getenv("CASSIE_DEBUG_RESUME_ONE_WAVE") != nullptr;
     /* the hand-over list is kept only when the pass behind the fast kernel walks it (and clears its count): a fast kernel that
@@ -68,7 +75,7 @@ inline bool launch_fast_then_full(dim3 grid, dim3 pass_grid, hipStream_t s, Phys
         /* the full kernel alone (forward / read-out passes, batches with the read-out enabled such as a cassie_sim_t) on a
          * batch too small to fill the chip: latency is what counts, and two wavefronts per env cut it by a fifth */
         io.handover_list = nullptr;
-        if (!full_2w(grid, s, io)) return false;
+        if (!(full_small ? full_small : full_2w)(grid, s, io)) return false;
     }
     else { /* the one-wave full kernel: one workgroup per env of the launch (no list walk) */
         io.handover_list = nullptr;

@@ -224,7 +224,9 @@ int phys_batch_set_fast_rows(phys_batch_t *b, int on);
  * velocity and constraint-row stages; 1: one wavefront per env.  Same results, bit for bit (a measurement aid). */
 int phys_batch_set_waves_per_env(phys_batch_t *b, int waves);
 /* diagnostics: how many substeps of the last stepping launch the fast kernel completed for every env ([nenv] ints; less than
- * the launch's substep count = the env was handed over to the full kernel there) */
+ * the launch's substep count = the env was handed over to the full kernel there).  Meaningful after a launch that ran the fast
+ * kernel: not with the read-out enabled, fast rows off, or a batch of at most 512 envs stepping at most 4 substeps per launch
+ * (those go through the full kernel alone: one launch instead of two) */
 int phys_batch_download_progress(phys_batch_t *b, int *host);
 
 /* validation aid: fills every CU's LDS with NaN bit patterns before the next launch (LDS is neither initialised nor

@@ -313,6 +313,52 @@ def test_two_wave_form_of_the_fast_kernel_equals_the_one_wave_form_bit_for_bit(b
         assert a.tobytes() == c.tobytes()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("fast_rows", [False, True])
+@pytest.mark.parametrize("name", ["cassie", "cassie_hfield"])
+def test_small_batch_two_wave_kernel_equals_the_one_wave_form_bit_for_bit(built, name, fast_rows):
+    """Batches of at most 512 envs that run the full instantiation alone (a cassie_sim_t: read-out on; here: fast rows off) take it
+    with two wavefronts per env and 512 registers a lane (kernels_*_small.hip): same bits as one wavefront per env.  With fast
+    rows on such a batch still takes that kernel alone for launches of at most 4 substeps (one launch instead of two) and the fast
+    kernel + the list-walking pass for longer ones."""
+    model = Model(name)
+    n, npol = 64, 12
+    hf = G.terrain(name)
+    tg = _stress_targets(np.arange(n), npol)
+    q0 = np.tile(model.qpos_init(), (n, 1))
+    if name == "cassie_hfield":
+        for e in range(n):
+            q0[e, 0], q0[e, 1] = G.start_xy(name, e)
+    out = []
+    for waves in (1, 2):
+        b = Batch(model, n)
+        try:
+            b.set_waves_per_env(waves)
+            b.set_fast_rows(fast_rows)
+            if hf is not None:
+                b.set_hfield(hf)
+            b.set(P.F_QPOS, q0)
+            b.set(P.F_PD_KP, np.tile(bench.PD_KP, (n, 1)))
+            b.set(P.F_PD_KD, np.tile(bench.PD_KD, (n, 1)))
+            b.forward()
+            b.set_drive_mode(P.DRIVE_PD)
+            rows = []
+            for p in range(npol):
+                b.set(P.F_PD_PTARGET, tg[p])
+                b.step((bench.HOLD, 1, 7)[p % 3])
+                rows.append(b.warnings()[1][:, 1].copy())
+            w, info = b.warnings()
+            rec = [b.get(P.F_QPOS), b.get(P.F_QVEL), b.get(P.F_QACC_WARMSTART), b.get(P.F_QACC), b.get(P.F_SENSORDATA), b.get(P.F_TIME), w, info[:, :3].copy(), np.array(rows),
+                   b.get(P.F_MEAS), b.get(P.F_CTRL), b.get(P.F_XPOS), b.get(P.F_XQUAT), b.get(P.F_ACTUATOR_VELOCITY)]
+            rec += [np.frombuffer(b"".join(device_state_bytes(s)), dtype=np.uint8) for s in b.get_drive_state(0, n)]
+            out.append(rec)
+        finally:
+            b.close()
+    assert out[0][8].max() > 20                        # contacts, limits and equality rows all present
+    for a, c in zip(out[0], out[1]):
+        assert a.tobytes() == c.tobytes()
+
+
 def test_device_reset_equals_a_fresh_batch(cassie):
     """phys_batch_reset_envs: envs restarted on the device continue bit for bit like envs of a fresh batch (the benchmark's
     episode restarts; reference src/cassiemujoco.c:1023-1029 / :2008-2034 role), in the drive mode whose state the reset also
