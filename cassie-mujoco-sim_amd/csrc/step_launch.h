@@ -46,12 +46,12 @@ constexpr unsigned SMALL_BATCH = 512; /* envs up to which the full kernel alone 
 template <int NVP, class TOPO, int FEAT>
 inline bool launch_fast_then_full(dim3 grid, dim3 pass_grid, hipStream_t s, PhysIO io, bool fast, hipEvent_t after_first, bool (*fast_2w)(dim3, hipStream_t, PhysIO),
                                   bool (*full_2w)(dim3, hipStream_t, PhysIO), bool (*full_small)(dim3, hipStream_t, PhysIO)) {
-    /* (measurement aids: CASSIE_DEBUG_SKIP_RESUME_PASS -- what the pass behind the fast kernel costs; handed-over envs are then
-     * left unfinished, so only for workloads that hand nothing over; CASSIE_DEBUG_RESUME_ONE_WAVE -- the pass behind a two-wave
-     * fast kernel as one-wave workgroups) */
     /* a small batch stepping a few substeps per launch (somebody's control loop around a handful of envs): one launch of the full
      * kernel in its small-batch form instead of two -- a launch costs what four substeps' difference between the kernels saves */
     if (fast && full_small && grid.x <= SMALL_BATCH && io.nsub <= SMALL_BATCH_NSUB) fast = false;
+    /* (measurement aids: CASSIE_DEBUG_SKIP_RESUME_PASS -- what the pass behind the fast kernel costs; handed-over envs are then
+     * left unfinished, so only for workloads that hand nothing over; CASSIE_DEBUG_RESUME_ONE_WAVE -- the pass behind a two-wave
+     * fast kernel as one-wave workgroups) */
     static const bool skip_resume = getenv("CASSIE_DEBUG_SKIP_RESUME_PASS") != nullptr;
     static const bool resume_one_wave = getenv("CASSIE_DEBUG_RESUME_ONE_WAVE") != nullptr;
     /* the hand-over list is kept only when the pass behind the fast kernel walks it (and clears its count): a fast kernel that
