@@ -869,6 +869,9 @@ def main(argv=None):
                        "envs_per_gpu": n, "envs_total": world * n, "baseline_config": shape, "parallelism": "env-sharded x%d" % world,
                        "obs_allgather_every_steps": HOLD if collect else None,
                        "streams": r["streams"],
+                       # a stepping launch is dispatched as this many workgroups per env, each stepping a share of the substeps
+                       # (phys_batch_set_chunks; launches of fewer than 10 substeps or 2048 envs stay in one piece)
+                       "chunks_per_env_launch": int(os.environ.get("CASSIE_CHUNKS") or (2 if r["streams"] > 1 else 4)),
                        "wavefronts_per_env": (1 if args.model == "cassie_tray_box" or os.environ.get("CASSIE_WAVES_PER_ENV") == "1" else 2),
                        "streams_note": ("the %d envs of a GPU are stepped as %d contiguous ranges, each on its own stream at its own pace "
                                         "(phys_batch_step_range): per policy step every range gets its restarts, its PD targets and one "

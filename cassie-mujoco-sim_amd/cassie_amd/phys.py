@@ -253,6 +253,11 @@ class Batch:
         if lib().phys_batch_set_waves_per_env(self._h, int(waves)) != 0:
             raise ValueError("waves per env: 1 or 2")
 
+    def set_chunks(self, chunks=4):
+        """Stepping launches of the fast kernels as `chunks` workgroups per env (1 = off); results are bit for bit the same."""
+        if lib().phys_batch_set_chunks(self._h, int(chunks)) != 0:
+            raise ValueError("chunks per env-launch: 1 .. 7")
+
     def launch_cost(self):
         """Shader clocks every env's last stepping launch took, first to last instruction (diagnostics; batches >= 2048 envs)."""
         out = np.zeros(self.nenv, dtype=np.uint32)

@@ -8,21 +8,22 @@ bool launch_step_tray(dim3 grid, dim3 pass_grid, hipStream_t s, PhysIO io, bool 
          * env), the full one in its two-wave form behind it, walking the hand-over list -- or alone (two waves per env) */
         if (fast) {
             io.resume = 0;
-            if (!(waves == 2 ? launch_fast_tray_2w(grid, s, io) : launch_fast_tray(grid, s, io))) return false;
+            const dim3 fast_grid = chunked_grid(grid, io);
+            if (!(waves == 2 ? launch_fast_tray_2w(fast_grid, s, io) : launch_fast_tray(fast_grid, s, io))) return false;
             if (after_first) { (void)hipEventRecord(after_first, s); after_first = nullptr; }
-            io.resume = 1;
+            io.resume = 1; io.nchunk = 1;
             /* the pass in the form of the kernel it follows (its workgroups must fit where that kernel's retire); without a
              * hand-over list (allocation failed): one workgroup per env through the two-wave full kernel */
             static const bool pass_2w = getenv("CASSIE_DEBUG_TRAY_PASS_TWO_WAVES") != nullptr; /* (measurement aid) */
             if (!(waves == 2 || !io.handover_list || pass_2w ? launch_full_tray_2w(pass_grid, s, io) : launch_full_tray_walk(pass_grid, s, io))) return false;
         } else {
-            io.progress = nullptr; io.resume = 0; io.handover_list = nullptr;
+            io.progress = nullptr; io.resume = 0; io.handover_list = nullptr; io.nchunk = 1;
             if (!launch_full_tray_2w(grid, s, io)) return false;
         }
         if (after_first) (void)hipEventRecord(after_first, s);
         return true;
     }
-    io.progress = nullptr; io.resume = 0; io.handover_list = nullptr;
+    io.progress = nullptr; io.resume = 0; io.handover_list = nullptr; io.nchunk = 1;
     if (!hfield) hipLaunchKernelGGL((cassie_step_kernel<40, TopoCassieTray38, FEAT_WAVEPAIRS>), grid, dim3(WV_WAVE), 0, s, io);
     else hipLaunchKernelGGL((cassie_step_kernel<40, TopoCassieTray38, FEAT_ALL>), grid, dim3(WV_WAVE), 0, s, io);
     if (after_first) (void)hipEventRecord(after_first, s);

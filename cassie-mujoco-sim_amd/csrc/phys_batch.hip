@@ -24,6 +24,13 @@
 
 void phys_set_last_error(const char *s);
 
+/* stepping launches of the fast instantiations in chunks (PhysIO::nchunk): chunks per env-launch, for launches of at least
+ * CHUNK_MIN_ENVS envs (two jobs per workgroup slot: below that there is no queue whose end could be evened out) and chunks of at
+ * least CHUNK_MIN_SUBSTEPS substeps */
+/* Defaults by measurement (profiles/round4/chunks_ab.txt): a launch over the whole batch has nothing to fill the end of its queue
+ * with: 4 chunks (+7 %); launches over env ranges (phys_batch_step_range: other ranges' launches fill in) gain nothing from more
+ * than 2 in steady state, and as much as the whole-batch launch when they stand alone between two synchronisations. */
+constexpr int DEFAULT_CHUNKS_WHOLE = 4, DEFAULT_CHUNKS_RANGE = 2, CHUNK_MIN_ENVS = 2048, CHUNK_MIN_SUBSTEPS = 5;
 constexpr int DEFAULT_TRAY_WAVES = 1; /* the 40-dof model's default form (decided by measurement, profiles/round4/tray_two_waves_ab.txt) */
 
 struct phys_batch {
@@ -68,6 +75,12 @@ struct phys_batch {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
     size_t ev_used = 0;
     int *d_progress = nullptr;      /* [nenv] substeps completed by the row-capped fast instantiation (PhysIO::progress) */
+    /* stepping launches of the fast instantiations in chunks (PhysIO::nchunk): chunks per env-launch asked for (1 = off), the
+     * words the chunks of an env hand over through, and the tag of the last chunked launch */
+    int chunks = DEFAULT_CHUNKS_WHOLE, chunks_range = DEFAULT_CHUNKS_RANGE; /* (launches over the whole batch / over an env range) */
+    int *d_chunk_flag = nullptr;
+    int chunk_seq = 0;
+    bool chunks_allowed = true;     /* (false: this device does not place workgroup w on XCD w % 8 -- launches stay in one piece) */
     /* the hand-over list (PhysIO::handover_list): env ids per range, [count, ticket] pairs indexed by a range's first env, and
      * -- in pinned host memory the device writes -- the number of envs the last launch of a range handed over */
     int *d_handover_list = nullptr, *d_handover_count = nullptr;
@@ -208,6 +221,20 @@ static int launch(phys_batch *b, int nsub, int integrate, hipStream_t s, bool sc
     auto fast_then_full = [&](bool fast) {
         io.progress = fast ? b->d_progress : nullptr;
         dim3 pass_grid = grid;
+        io.nchunk = 1;
+        if (fast && b->d_chunk_flag && b->chunks_allowed && (n == b->nenv ? b->chunks : b->chunks_range) > 1 && n >= CHUNK_MIN_ENVS && n % 8 == 0 && nsub >= 2 * CHUNK_MIN_SUBSTEPS) {
+            /* (n % 8: workgroup w runs on XCD w % 8, so the chunks of an env -- workgroups n apart -- share an XCD and its L2) */
+            /* the fast kernel's launch as chunks of at least CHUNK_MIN_SUBSTEPS substeps (the launchers size its grid) */
+            const int most = nsub / CHUNK_MIN_SUBSTEPS, asked = n == b->nenv ? b->chunks : b->chunks_range;
+            io.nchunk = asked < most ? asked : most;
+            if (b->chunk_seq >= (1 << 27)) { /* (the tag has 28 bits: start over once nothing is in flight) */
+                (void)quiesce(b);
+                (void)hipMemset(b->d_chunk_flag, 0, sizeof(int) * (size_t)b->nenv);
+                b->chunk_seq = 0;
+            }
+            io.chunk_seq = ++b->chunk_seq;
+            io.chunk_flag = b->d_chunk_flag;
+        }
         if (fast && b->d_handover_list) {
             /* the pass behind the fast kernel walks the hand-over list with a small grid: twice what the range's last launch
              * handed over (the launcher learns that a launch late, through host memory) plus 16, at most one workgroup per env */
@@ -272,6 +299,29 @@ static bool copy_rows(phys_batch *b, int field, void *host, int env0, int n, boo
 
 extern "C" {
 
+/* A launch in chunks hands an env's state from one workgroup to another through the L2 both share (wave.h: publish_global): the
+ * chunks of an env are workgroups a multiple of 8 apart, and workgroup w runs on XCD w % 8.  That assignment is checked here, once
+ * per batch of a size that could be chunked: a grid of 1024 workgroups reports where it ran. */
+__global__ void __launch_bounds__(64) cassie_xcd_probe_kernel(int *xcc) {
+    if (threadIdx.x == 0) xcc[blockIdx.x] = (int)(wv::hw_id() >> 32);
+}
+static bool workgroups_go_round_the_xcds(int device) {
+    static int verdict[64]; /* per device: 0 = not probed, 1 = yes, 2 = no */
+    if (device < 0 || device >= 64) return false;
+    if (verdict[device]) return verdict[device] == 1;
+    constexpr int NWG = 1024;
+    int *d = nullptr, h[NWG];
+    bool ok = hipMalloc((void **)&d, sizeof h) == hipSuccess;
+    if (ok) {
+        hipLaunchKernelGGL(cassie_xcd_probe_kernel, dim3(NWG), dim3(64), 0, 0, d);
+        ok = hipGetLastError() == hipSuccess && hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost) == hipSuccess;
+        for (int w = 8; ok && w < NWG; ++w) ok = h[w] == h[w % 8];
+    }
+    if (d) (void)hipFree(d);
+    verdict[device] = ok ? 1 : 2;
+    return ok;
+}
+
 phys_batch_t *phys_batch_create(const cm_model_t *model, int nenv, int device) {
     if (!model || nenv <= 0) { phys_set_last_error("phys_batch_create: bad arguments"); return nullptr; }
     int ndev = 0;
@@ -315,6 +365,10 @@ phys_batch_t *phys_batch_create(const cm_model_t *model, int nenv, int device) {
     }
     ok = ok && hip_ok(hipMalloc((void **)&b->d_progress, sizeof(int) * (size_t)nenv), "hipMalloc(progress)");
     ok = ok && hip_ok(hipMemset(b->d_progress, 0, sizeof(int) * (size_t)nenv), "hipMemset(progress)");
+    ok = ok && hip_ok(hipMalloc((void **)&b->d_chunk_flag, sizeof(int) * (size_t)nenv), "hipMalloc(chunk words)");
+    ok = ok && hip_ok(hipMemset(b->d_chunk_flag, 0, sizeof(int) * (size_t)nenv), "hipMemset(chunk words)");
+    if (const char *ck = getenv("CASSIE_CHUNKS")) b->chunks = b->chunks_range = atoi(ck) > 1 ? (atoi(ck) < 7 ? atoi(ck) : 7) : 1; /* (A/B switch) */
+    if (ok && nenv >= CHUNK_MIN_ENVS && !workgroups_go_round_the_xcds(device)) b->chunks_allowed = false;
     ok = ok && hip_ok(hipMalloc((void **)&b->d_handover_list, sizeof(int) * (size_t)nenv), "hipMalloc(hand-over list)");
     ok = ok && hip_ok(hipMalloc((void **)&b->d_handover_count, sizeof(int) * 2 * (size_t)nenv), "hipMalloc(hand-over counts)");
     ok = ok && hip_ok(hipMemset(b->d_handover_count, 0, sizeof(int) * 2 * (size_t)nenv), "hipMemset(hand-over counts)");
@@ -347,6 +401,7 @@ void phys_batch_free(phys_batch_t *b) {
     if (b->d_ext) (void)hipFree(b->d_ext);
     if (b->d_scratch_out) (void)hipFree(b->d_scratch_out);
     if (b->d_progress) (void)hipFree(b->d_progress);
+    if (b->d_chunk_flag) (void)hipFree(b->d_chunk_flag);
     if (b->d_handover_list) (void)hipFree(b->d_handover_list);
     if (b->d_handover_count) (void)hipFree(b->d_handover_count);
     if (b->h_handover_seen) (void)hipHostFree(b->h_handover_seen);
@@ -755,6 +810,12 @@ int phys_batch_kernel_timing(phys_batch_t *b, int *launches, double *total_ms) {
 int phys_batch_set_fast_rows(phys_batch_t *b, int on) {
     if (!b) return -1;
     b->fast_rows = on != 0;
+    return 0;
+}
+
+int phys_batch_set_chunks(phys_batch_t *b, int chunks) {
+    if (!b || chunks < 1 || chunks > 7) return -1;
+    b->chunks = b->chunks_range = chunks;
     return 0;
 }
 

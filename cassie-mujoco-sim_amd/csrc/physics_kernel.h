@@ -138,6 +138,14 @@ struct PhysIO {
      * blockIdx + gridDim, ... -- so that a launch that handed nothing over costs a few workgroup placements, not one per env.
      * The last workgroup of the pass to finish (a ticket on handover_count[1]) zeroes the count for the next launch and reports
      * it to *handover_seen (host memory: the launcher sizes the next pass's grid by it). */
+    /* A stepping launch in CHUNKS (nchunk > 1; row-capped fast instantiations only): workgroup w steps env slot w % nenv through
+     * substeps [c (w / nenv), c (w / nenv + 1)), c = ceil(nsub / nchunk) -- an env's launch is nchunk jobs instead of one, so what
+     * the slots wait for at the end of a launch (the last-started jobs running alone) is a quarter as long.  A chunk is a
+     * launch of its own as far as the env is concerned: it loads the state the chunk before it stored and ends like a launch
+     * of c substeps.  chunk_flag[env] = 8 chunk_seq + (chunks of this launch complete); a chunk waits for the one before it
+     * (which has a lower workgroup number, so it was dispatched earlier). */
+    int nchunk, chunk_seq;
+    int *chunk_flag;
     int *handover_list, *handover_count;
     volatile int *handover_seen;
 };
@@ -1740,7 +1748,9 @@ WV_DEVICE void euler_step(SH &S, ModelPtr m, int lane, bool isdof, int k_, int n
  * pairs handled by the whole wave.  The launcher picks the instantiation from the model (phys_batch.hip). */
 
 template <int NVP, class TOPO, int FEAT, int MAXR, int NW>
-WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count, MAXR> &S, int env, int sub_start) {
+WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count, MAXR> &S, int env, int sub_start, int nsub) {
+    /* nsub: the substep this call ends in front of -- io.nsub, or the end of this workgroup's chunk of the launch (PhysIO::nchunk):
+     * the call then ends like a launch of nsub substeps */
     typedef LPack<TOPO, NVP> LP;
     static_assert(NW == 1 || NW == 2, "one or two wavefronts per env");
     static_assert(NW == 1 || TOPO::is_static, "the two-wave form exists for the compile-time topologies");
@@ -1846,7 +1856,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
                 CK_STAMP(38);
                 if (io.drive_mode) {
                     /* the drive-level pass of this substep (ctrl for the passive stage below; the encoder / filter state) */
-                    if (io.integrate) drive_level_io(io, S, m, env, lane, sub1 == io.nsub - 1);
+                    if (io.integrate) drive_level_io(io, S, m, env, lane, sub1 == nsub - 1);
                     wv::sync();
                 }
                 factor_pair_by_height<NVP, TOPO>(m, h, S, col, colh, lane);
@@ -1863,8 +1873,8 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
                 CK_STAMP(39);
                 /* ---- the stages behind wave 0's constraint solve: operands staged now, while wave 0 assembles and solves ---- */
                 {
-                    const bool lastsub = sub1 == io.nsub - 1 || !io.integrate;
-                    const bool need_imu = lastsub || io.all_outputs_every_substep || (io.drive_mode && sub1 + 2 == io.nsub);
+                    const bool lastsub = sub1 == nsub - 1 || !io.integrate;
+                    const bool need_imu = lastsub || io.all_outputs_every_substep || (io.drive_mode && sub1 + 2 == nsub);
                     const bool need_pos = lastsub || io.drive_mode || io.all_outputs_every_substep;
                     const bool issens = lane < m->nsensor && need_pos;
                     const int ls = issens ? lane : 0;
@@ -1944,23 +1954,23 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
                     CK_STAMP(14);
                     wv::block_barrier(); /* E: the substep is complete (qpos / qvel / warm start of the next one are in LDS) */
                 }
-                if (!io.integrate || ++sub1 >= io.nsub) return;
+                if (!io.integrate || ++sub1 >= nsub) return;
             }
         }
     }
 
     bool bailed = false;
     int sub = sub_start;
-    for (; sub < io.nsub; ++sub) {
+    for (; sub < nsub; ++sub) {
         /* Outputs that every substep recomputes (sensordata, qacc, actuator_velocity, xpos / xquat, the solver statistics)
          * are stored only by the LAST substep of a launch: the others' values would be overwritten anyway, and on this
          * hardware vector stores share the loads' completion counter (vmcnt), so a store that is still in flight holds up
          * the next stage's first model read. */
-        const bool lastsub = sub == io.nsub - 1 || !io.integrate;
+        const bool lastsub = sub == nsub - 1 || !io.integrate;
         /* Body quaternions feed only the IMU frame sensor, the site / body orientation read-outs and xquat_out -- all of
          * them values of the last substep (in a drive mode also of the one before it, see the sensors): the other
          * substeps carry rotation matrices only through the kinematic recursion. */
-        const bool need_quat = lastsub || io.ext != nullptr || io.all_outputs_every_substep || (io.drive_mode && sub + 2 == io.nsub);
+        const bool need_quat = lastsub || io.ext != nullptr || io.all_outputs_every_substep || (io.drive_mode && sub + 2 == nsub);
         /* divergence guard (mj_checkPos/mj_checkVel role): sticky flag, state left alone */
         {
             bool badv = false;
@@ -2845,7 +2855,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
         /* The constants of the sensor stage behind the Jacobian loop are requested here, every one of them in one level of
          * unconditional reads (lane = sensor): their round trip through the memory system runs under the loop instead of
          * in front of the sensors. */
-        const bool need_imu = lastsub || io.all_outputs_every_substep || (io.drive_mode && sub + 2 == io.nsub);
+        const bool need_imu = lastsub || io.all_outputs_every_substep || (io.drive_mode && sub + 2 == nsub);
         const bool need_pos = lastsub || io.drive_mode || io.all_outputs_every_substep;
         const bool issens = lane < m->nsensor && need_pos;
         const int ls = issens ? lane : 0;
@@ -2987,7 +2997,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
         }
         /* first constraint row of every contact (lane = contact), for the contact-force read-out */
         int caddr = -1;
-        const bool want_cfrc = io.body_cfrc && (sub == io.nsub - 1 || !io.integrate); /* read out by the last substep only */
+        const bool want_cfrc = io.body_cfrc && (sub == nsub - 1 || !io.integrate); /* read out by the last substep only */
         if (io.ext || want_cfrc) {
             int acc = nefc_before_contacts;
             for (int c = 0; c < ncon; ++c) {
@@ -3448,7 +3458,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
 
     /* ---------------- store state ---------------- */
     if (io.progress && !io.resume && lane == 0) {
-        io.progress[env] = bailed ? sub : io.nsub; /* (the resume pass leaves the record) */
+        io.progress[env] = bailed ? sub : nsub; /* (the resume pass leaves the record) */
         if (bailed && io.handover_list) io.handover_list[io.env0 + wv::atomic_add(io.handover_count, 1)] = env;
     }
     if (io.integrate && io.drive_mode) {
@@ -3504,7 +3514,7 @@ WV_GLOBAL void __launch_bounds__(WV_WAVE * NW) WV_OCC WV_WAVES_PER_SIMD(WPS) cas
         for (int idx = slot; idx < count; idx += wv::grid_size()) {
             const int env = io.handover_list[io.env0 + idx];
             const long long t0 = io.cost ? wv::clock() : 0;
-            env_step<NVP, TOPO, FEAT, MAXR, NW>(io, S, env, io.progress[env]);
+            env_step<NVP, TOPO, FEAT, MAXR, NW>(io, S, env, io.progress[env], io.nsub);
             if (io.cost && wv::lane() == 0 && (NW == 1 || wv::wave_id() == 0)) io.cost[env] += (unsigned)((wv::clock() - t0) >> 6);
             if constexpr (NW == 2) wv::block_barrier(); /* both waves are done with this env before either starts the next */
             else wv::sync();
@@ -3515,20 +3525,37 @@ WV_GLOBAL void __launch_bounds__(WV_WAVE * NW) WV_OCC WV_WAVES_PER_SIMD(WPS) cas
             if (io.handover_seen) *io.handover_seen = count;
         }
     } else {
-    if (slot >= io.nenv) return;
+    /* a launch in chunks (PhysIO::nchunk): workgroup w = chunk w / nenv of env slot w % nenv */
+    const int chunk = io.nchunk > 1 ? wv::env_id() / io.nenv : 0;
+    const int eslot = slot - chunk * io.nenv;
+    if (chunk >= (io.nchunk > 1 ? io.nchunk : 1)) return;
     wv::test_launch_hook(&S, sizeof S); /* CPU emulator only (poisons LDS so that a read-before-write shows); empty on the device */
-    const int env = io.order ? io.order[io.env0 + slot] : io.env0 + slot; /* order holds absolute env ids, sorted range by range */
-    const int sub_start = io.resume ? io.progress[env] : 0;
-    if (sub_start >= io.nsub) return; /* resume pass: the fast instantiation finished this env */
+    const int env = io.order ? io.order[io.env0 + eslot] : io.env0 + eslot; /* order holds absolute env ids, sorted range by range */
+    int sub_start = io.resume ? io.progress[env] : 0, sub_end = io.nsub;
+    if (io.nchunk > 1) {
+        const int per = (io.nsub + io.nchunk - 1) / io.nchunk;
+        sub_start = chunk * per;
+        sub_end = sub_start + per < io.nsub ? sub_start + per : io.nsub;
+    }
+    if (sub_start >= io.nsub) return; /* resume pass: the fast instantiation finished this env; chunks: none left for this one */
+    if (chunk > 0) {
+        /* the chunk before this one has stored the env's state (and, had it met a substep with too many rows, handed the env over) */
+        wv::wait_global<NW>(io.chunk_flag + env, 8 * io.chunk_seq + chunk);
+        if (io.progress[env] != sub_start) {
+            if (sub_end < io.nsub) wv::publish_global<NW>(io.chunk_flag + env, 8 * io.chunk_seq + chunk + 1);
+            return;
+        }
+    }
     const long long t0 = io.cost ? wv::clock() : 0;
-    env_step<NVP, TOPO, FEAT, MAXR, NW>(io, S, env, sub_start);
+    env_step<NVP, TOPO, FEAT, MAXR, NW>(io, S, env, sub_start, sub_end);
+    if (sub_end < io.nsub) wv::publish_global<NW>(io.chunk_flag + env, 8 * io.chunk_seq + chunk + 1);
     if (io.prof && wv::lane() == 0) io.prof[(size_t)env * NSTAMP + 40 + (NW == 2 ? wv::wave_id() : 0)] = wv::hw_id(); /* (profiling aid: the CU / SIMD of the wave) */
     if (io.prof && wv::lane() == 0 && (NW == 1 || wv::wave_id() == 0)) { /* (profiling aid: the shader clock against the 100 MHz wall clock at the env's end) */
         io.prof[(size_t)env * NSTAMP + 42] = wv::clock(); io.prof[(size_t)env * NSTAMP + 43] = wv::wall_clock();
     }
     if (io.cost && wv::lane() == 0 && (NW == 1 || wv::wave_id() == 0)) { /* 64-clock units: 32 bits hold minutes */
         const unsigned c = (unsigned)((wv::clock() - t0) >> 6);
-        io.cost[env] = io.resume ? io.cost[env] + c : c;
+        io.cost[env] = io.resume || chunk > 0 ? io.cost[env] + c : c;
     }
     }
 }

@@ -43,12 +43,16 @@ bool launch_step_generic(dim3 grid, hipStream_t s, PhysIO io, bool wide);       
 constexpr int SMALL_BATCH_NSUB = 4;  /* ... and substeps per launch up to which such a batch skips the row-capped fast kernel + pass pair (two launches) */
 constexpr unsigned SMALL_BATCH = 512; /* envs up to which the full kernel alone runs in its two-wave form (half the chip's workgroup slots) */
 
+/* the grid of a fast kernel whose launch goes in chunks (PhysIO::nchunk): workgroups [k nenv, (k + 1) nenv) are chunk k */
+inline dim3 chunked_grid(dim3 grid, const PhysIO &io) { return dim3(grid.x * (unsigned)(io.nchunk > 1 ? io.nchunk : 1)); }
+
 template <int NVP, class TOPO, int FEAT>
 inline bool launch_fast_then_full(dim3 grid, dim3 pass_grid, hipStream_t s, PhysIO io, bool fast, hipEvent_t after_first, bool (*fast_2w)(dim3, hipStream_t, PhysIO),
                                   bool (*full_2w)(dim3, hipStream_t, PhysIO), bool (*full_small)(dim3, hipStream_t, PhysIO)) {
     /* a small batch stepping a few substeps per launch (somebody's control loop around a handful of envs): one launch of the full
      * kernel in its small-batch form instead of two -- a launch costs what four substeps' difference between the kernels saves */
     if (fast && full_small && grid.x <= SMALL_BATCH && io.nsub <= SMALL_BATCH_NSUB) fast = false;
+    if (!fast) io.nchunk = 1;
     /* (measurement aids: CASSIE_DEBUG_SKIP_RESUME_PASS -- what the pass behind the fast kernel costs; handed-over envs are then
      * left unfinished, so only for workloads that hand nothing over; CASSIE_DEBUG_RESUME_ONE_WAVE -- the pass behind a two-wave
      * fast kernel as one-wave workgroups) */
@@ -60,11 +64,12 @@ inline bool launch_fast_then_full(dim3 grid, dim3 pass_grid, hipStream_t s, Phys
     if (!walk) { io.handover_list = nullptr; pass_grid = grid; }
     if (fast) {
         io.resume = 0;
-        if (fast_2w) { if (!fast_2w(grid, s, io)) return false; }
-        else hipLaunchKernelGGL((cassie_step_kernel<NVP, TOPO, FEAT, FAST_ROWS>), grid, dim3(WV_WAVE), 0, s, io);
+        const dim3 fast_grid = chunked_grid(grid, io);   /* (a launch in chunks: one workgroup per env and chunk) */
+        if (fast_2w) { if (!fast_2w(fast_grid, s, io)) return false; }
+        else hipLaunchKernelGGL((cassie_step_kernel<NVP, TOPO, FEAT, FAST_ROWS>), fast_grid, dim3(WV_WAVE), 0, s, io);
         if (hipGetLastError() != hipSuccess) return false;
         if (after_first) { (void)hipEventRecord(after_first, s); after_first = nullptr; }
-        io.resume = 1;
+        io.resume = 1; io.nchunk = 1;
     } else {
         io.progress = nullptr; io.resume = 0; io.handover_list = nullptr;
         pass_grid = grid;

@@ -47,6 +47,28 @@ WV_DEVICE void block_barrier() {
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
+/* Hand-over between WORKGROUPS of one kernel through a word in device memory (PhysIO::chunk_flag): publish_global() once every
+ * store of the workgroup is on its way (each wave releases its own at agent scope, the waves meet, one lane writes the word);
+ * wait_global() polls the word -- the producer is a workgroup with a lower number, dispatched earlier, so it runs or has run -- and
+ * then drops this CU's cached copies of what the producer wrote (acquire at agent scope) before anybody loads. */
+template <int NW> WV_DEVICE void publish_global(int *flag, int value) {
+#ifdef CK_CHUNK_RELEASE_AGENT
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#else
+    /* (the consumer runs on the same XCD -- workgroup numbers that differ by a multiple of 8, phys_batch.hip -- and so shares this
+     * workgroup's L2: the stores only have to have arrived there, which the counter wait of a workgroup-scope release says;
+     * an agent-scope release would write the XCD's whole L2 back, 25 k clocks a time) */
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+#endif
+    if (NW > 1) __builtin_amdgcn_s_barrier();
+    if (threadIdx.x == 0) __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <int NW> WV_DEVICE void wait_global(const int *flag, int value) {
+    if (threadIdx.x < 64u)
+        while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != value) __builtin_amdgcn_s_sleep(20);
+    if (NW > 1) __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
 /* the lane index recomputed from nothing (two VALU ops) through an asm the optimiser cannot merge or hoist: values
  * derived from it (LDS addresses, lane predicates) then live only inside the stage that asked, instead of being
  * computed once at the top of the kernel and carried -- i.e. spilled -- across everything in between */

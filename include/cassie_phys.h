@@ -223,6 +223,13 @@ int phys_batch_set_fast_rows(phys_batch_t *b, int on);
  * (centres of mass, composite inertias, M, its two factorisations) on the second wave beside the first wave's collision,
  * velocity and constraint-row stages; 1: one wavefront per env.  Same results, bit for bit (a measurement aid). */
 int phys_batch_set_waves_per_env(phys_batch_t *b, int waves);
+/* Stepping launches of the row-capped fast kernels in CHUNKS (1 = off .. 7; default: 4 for launches over the whole batch, 2 for
+ * launches over an env range, whose neighbours' launches fill the end of its queue anyway): a launch of at least 2048 envs and 10 substeps is
+ * dispatched as `chunks` workgroups per env, each stepping a share of the substeps (5 at least) from the state the chunk before it
+ * stored -- the jobs the GPU's workgroup slots queue up are that much shorter, and so is the time the slots stand idle at the
+ * end of a launch while the last-started jobs finish.  Same results, bit for bit (a chunk ends and the next begins exactly
+ * like two launches). */
+int phys_batch_set_chunks(phys_batch_t *b, int chunks);
 /* diagnostics: how many substeps of the last stepping launch the fast kernel completed for every env ([nenv] ints; less than
  * the launch's substep count = the env was handed over to the full kernel there).  Meaningful after a launch that ran the fast
  * kernel: not with the read-out enabled, fast rows off, or a batch of at most 512 envs stepping at most 4 substeps per launch

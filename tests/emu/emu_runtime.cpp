@@ -213,6 +213,10 @@ extern "C" void emu_two_waves(int on) { g_two_waves = on; }
 extern "C" void emu_wave_schedule(int mode) { g_wave_schedule = mode; }
 /* the row-capped fast instantiation ahead of the full one, as phys_batch.hip launches them (PhysIO::progress / resume);
  * g_fast_bails counts the envs the fast instantiation handed over */
+namespace wv { void emu_fail(const char *what) { fprintf(stderr, "emu: %s\n", what); abort(); } }
+/* a launch in chunks (PhysIO::nchunk): the fast instantiation's workgroups in launch order, chunk by chunk */
+static int g_chunks = 1, g_chunk_seq = 0;
+extern "C" void emu_chunks(int k) { g_chunks = k > 1 ? k : 1; }
 static int g_fast_rows = 0, g_fast_bails = 0;
 extern "C" void emu_fast_rows(int on) { g_fast_rows = on; }
 extern "C" int emu_fast_bails(void) { return g_fast_bails; }
@@ -267,13 +271,17 @@ extern "C" int emu_phys_run(const cm_model_t *model, int nenv, int nsub, int int
         static volatile int seen;
         count[0] = count[1] = 0; seen = -1;
         g_io.progress = progress; g_io.resume = 0; g_io.handover_list = list; g_io.handover_count = count; g_io.handover_seen = &seen;
-        g_grid = nenv;
-        for (int e = 0; e < nenv; ++e) {
-            g_env = e;
+        static int chunk_flag[1 << 16];
+        const int nchunk = (g_chunks > 1 && nsub >= 2) ? g_chunks : 1;
+        g_io.nchunk = nchunk; g_io.chunk_seq = ++g_chunk_seq; g_io.chunk_flag = chunk_flag;
+        g_grid = nenv * nchunk;
+        for (int wg = 0; wg < nenv * nchunk; ++wg) {
+            g_env = wg;
             if (tray38) run_block(body40s_fast);
             else if (g_two_waves) run_block(body32s_fast_2w, 2); else run_block(body32s_fast);
-            if (progress[e] < nsub) ++g_fast_bails;
         }
+        for (int e = 0; e < nenv; ++e) if (progress[e] < nsub) ++g_fast_bails;
+        g_io.nchunk = 1;
         const int handed = count[0];
         g_io.resume = 1;
         g_grid = g_resume_grid;

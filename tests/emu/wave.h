@@ -24,6 +24,7 @@
 #define __launch_bounds__(x)
 #define WV_WAVES_PER_SIMD(n)
 
+#include <cstdio>
 namespace wv {
 int lane();
 int wave_id();
@@ -57,6 +58,13 @@ template <int DST> inline double writelane(double v, double s) { return lane() =
 unsigned long long ballot(bool p);
 double wave_sum(double v);
 float wave_sum_f32(float v);
+/* workgroups run one after the other here, in launch order: the word a chunk waits for must be there already */
+template <int NW> inline void publish_global(int *flag, int value) { if (NW > 1) block_barrier(); if (lane() == 0 && (NW == 1 || wave_id() == 0)) *flag = value; }
+void emu_fail(const char *what);
+template <int NW> inline void wait_global(const int *flag, int value) {
+    if (*flag != value) { fprintf(stderr, "emu: chunk flag %d, expected %d\n", *flag, value); emu_fail("a chunk of a launch started before the chunk in front of it had finished"); }
+    if (NW > 1) block_barrier(); else sync(); /* (as on the device: nobody moves on -- and publishes -- before every lane of every wave has looked) */
+}
 inline long long clock() { return 0; }
 inline long long wall_clock() { return 0; }
 inline long long hw_id() { return 0; }

@@ -314,6 +314,66 @@ def test_two_wave_form_of_the_fast_kernel_equals_the_one_wave_form_bit_for_bit(b
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name,waves", [("cassie", 2), ("cassie", 1), ("cassie_hfield", 2), ("cassie_tray_box", 1)])
+def test_launch_in_chunks_equals_the_launch_in_one_piece_bit_for_bit(built, name, waves):
+    """phys_batch_set_chunks: a stepping launch of the fast kernel dispatched as several workgroups per env, each stepping a share
+    of the substeps from the state the chunk before it stored (a word per env in device memory orders them).  State, outputs, solver
+    statistics, measurement block and drive state must be BIT FOR BIT those of the launch in one piece -- under the stress targets
+    (envs handed over to the full kernel in the middle of chunks), with launch lengths that chunk differently (50: 4 chunks, 20: 4,
+    11: 2, 7: none) and two env ranges on two streams."""
+    import torch
+    model = Model(name)
+    n, npol = 4096, 28
+    hf = G.terrain(name)
+    tg = _stress_targets(np.arange(n), npol) if name != "cassie_tray_box" else bench.pd_targets(np.arange(n), npol)
+    q0 = np.tile(model.qpos_init(), (n, 1))
+    if name == "cassie_hfield":
+        for e in range(n):
+            q0[e, 0], q0[e, 1] = G.start_xy(name, e)
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    out = []
+    for chunks in (1, 4, 3):
+        b = Batch(model, n)
+        try:
+            b.set_waves_per_env(waves)
+            b.set_chunks(chunks)
+            if hf is not None:
+                b.set_hfield(hf)
+            b.set(P.F_QPOS, q0)
+            b.set(P.F_PD_KP, np.tile(bench.PD_KP, (n, 1)))
+            b.set(P.F_PD_KD, np.tile(bench.PD_KD, (n, 1)))
+            b.forward()
+            b.set_drive_mode(P.DRIVE_PD)
+            handed = 0
+            for p in range(npol):
+                b.set(P.F_PD_PTARGET, tg[p])
+                nsub = (bench.HOLD, 20, 11, 7)[p % 4]
+                if p % 2:
+                    b.step(nsub)
+                else:
+                    b.sync()
+                    for (first, cnt), st in zip(bench.half_ranges(n, 2), streams):
+                        b.step_range(first, cnt, nsub, st.cuda_stream)
+                    b.sync()
+                handed += int(np.count_nonzero(b.fast_rows_progress() < nsub))
+                assert b.handover_pending() == 0
+            w, info = b.warnings()
+            rec = [b.get(P.F_QPOS), b.get(P.F_QVEL), b.get(P.F_QACC_WARMSTART), b.get(P.F_QACC), b.get(P.F_SENSORDATA), b.get(P.F_TIME), w, info[:, :3].copy(),
+                   b.get(P.F_MEAS), b.get(P.F_CTRL), b.get(P.F_XPOS), b.get(P.F_XQUAT), b.get(P.F_ACTUATOR_VELOCITY)]
+            rec += [np.frombuffer(b"".join(device_state_bytes(s)), dtype=np.uint8) for s in b.get_drive_state(0, 64)]
+            out.append((rec, handed))
+        finally:
+            b.close()
+    print("%s, %d wave(s): %s env-launches handed over (1 / 4 / 3 chunks)" % (name, waves, [o[1] for o in out]))
+    assert out[0][1] == out[1][1] == out[2][1]
+    if name != "cassie_tray_box":
+        assert out[0][1] > 20
+    for k in (1, 2):
+        for a, c in zip(out[0][0], out[k][0]):
+            assert a.tobytes() == c.tobytes(), k
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("fast_rows", [False, True])
 @pytest.mark.parametrize("name", ["cassie", "cassie_hfield"])
 def test_small_batch_two_wave_kernel_equals_the_one_wave_form_bit_for_bit(built, name, fast_rows):

@@ -479,3 +479,27 @@ def test_tray_fast_instantiation_is_bit_for_bit_the_full_one(built):
     finally:
         emu_py.lib().emu_resume_grid(2)
     assert got == ref and bails > before
+
+
+@pytest.mark.parametrize("name", ["cassie", "cassie_hfield", "cassie_tray_box"])
+def test_launch_in_chunks_is_bit_for_bit_the_launch_in_one_piece(name, built):
+    """PhysIO::nchunk: the fast instantiation's launch as chunks of substeps, one workgroup per (env, chunk), a chunk loading what
+    the chunk before it stored and ending like a launch of its own -- state, outputs, solver statistics and drive-level state must
+    be those of the launch in one piece, with envs handed over to the full instantiation in the middle of chunks (stress
+    targets), in both wave forms, with chunk counts that do and do not divide the substep count."""
+    from cassie_amd import Model
+    import emu_py
+    model = Model(name)
+    lib = emu_py.lib()
+    for stress in ((False, True) if name != "cassie_tray_box" else (False,)):   # (the 40-dof model's 47-row instantiation is not left under these targets: covered above)
+        ref, rows, before = _two_wave_workload(model, True, fast=True, two_waves=False, schedule=0, nlaunch=3, nsub=11, stress=stress)
+        for chunks, two_waves in ((4, False), (3, True), (2, True)):
+            lib.emu_chunks(chunks)
+            try:
+                got, _, bails = _two_wave_workload(model, True, fast=True, two_waves=two_waves, schedule=1, poison=True, nlaunch=3, nsub=11, stress=stress)
+            finally:
+                lib.emu_chunks(1)
+            assert got == ref, (chunks, two_waves, stress)
+            if stress:
+                assert bails > before
+            before = bails
