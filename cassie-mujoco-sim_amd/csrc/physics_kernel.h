@@ -195,8 +195,10 @@ struct EnvShared {
     /* two-wave form (NW = 2): cmd[0] = what the waves tell each other at the workgroup barriers -- 0 = carry on, 1 = this env's
      * launch ends here (wave 0: diverged state, or the row-capped instantiation hands the substep over), 2 = wave 1 found a
      * diverged qacc; cmd[1] = the substep (+ 1) whose body forces wave 0's velocity stage has put in LDS, cmd[2] = the substep
-     * (+ 1) whose staged matrix Y wave 0 has put in LDS (wave 1 waits for either) */
-    int cmd[4];
+     * (+ 1) whose staged matrix Y wave 0 has put in LDS (wave 1 waits for either); cmd[3] = the substep (+ 1) whose mass-matrix group
+     * wave 1 has finished (com, cinert, cdof in LDS, the buf tile free again: wave 0's velocity stage waits for it), cmd[4] = the
+     * substep (+ 1) whose collision verdict wave 0 has reached (cmd[0] = 1: handed over; wave 1's drive-level pass waits for it) */
+    int cmd[6];
 };
 
 /* ------------------------------------------------------------ small math --- */
@@ -1758,9 +1760,11 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
      * except for the stages wave 1 runs beside it (wave 1's program, ahead of the substep loop): the mass-matrix group (centres
      * of mass, cinert, cdof, composite inertias, M's columns), the drive-level pass, the two factorisations and the bias /
      * passive stage beside wave 0's collision, velocity and constraint-row stages; then qacc, the accelerometers, the substep's
-     * outputs and the Euler step behind wave 0's solve, with their operands staged while wave 0 solves.  Five workgroup
-     * barriers per substep (F: poses in LDS; X: com / cinert / cdof and the contact list; J: the factors and qfrc_smooth; P: the
-     * row forces; E: the substep is complete) and two one-directional flags (cmd[1], cmd[2]).  Every value is computed by the
+     * outputs and the Euler step behind wave 0's solve, with their operands staged while wave 0 solves.  Four workgroup
+     * barriers per substep (F: poses in LDS; J: the factors and qfrc_smooth; P: the row forces; E: the substep is complete) and four
+     * one-directional flags: cmd[3] / cmd[4] where a barrier X used to be (com / cinert / cdof for wave 0's velocity stage, the
+     * collision verdict for wave 1's drive-level pass: its factorisations in between do not wait for wave 0's collision stage),
+     * cmd[1] (body forces), cmd[2] (the staged matrix).  Every value is computed by the
      * same instructions from the same operands as in the one-wave form, so the results are bit for bit the same. */
     const int wid = NW == 2 ? wv::wave_id() : 0;
 
@@ -1774,7 +1778,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
 
     /* ---------------- load state (coalesced, env-major) ---------------- */
     if (NW == 1 || wid == 0) {
-    if (lane == 0) { S.cmd[0] = 0; S.cmd[1] = 0; S.cmd[2] = 0; }
+    if (lane == 0) { S.cmd[0] = 0; S.cmd[1] = 0; S.cmd[2] = 0; S.cmd[3] = 0; S.cmd[4] = 0; }
     if (lane < nq) S.qpos[lane] = io.qpos[(size_t)env * io.sq + lane];
     if (lane < nv) {
         S.qvel[lane] = io.qvel[(size_t)env * io.sqv + lane];
@@ -1851,15 +1855,18 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
                 }
                 double col[NVP], colh[NVP];
                 mass_matrix_columns<NVP, TOPO, FEAT, NW>(io, S, m, env, ids, mass, iner, ximat, col, colh);
-                wv::block_barrier(); /* X: com, cinert and cdof are in LDS (wave 0's velocity and row stages read them) */
-                if (wv::opaque(S.cmd[0])) return; /* (the row-capped instantiation hands this substep over) */
+                /* X as two one-directional flags: com, cinert and cdof are in LDS and the buf tile is free again (wave 0's velocity
+                 * stage waits for that); the factorisations -- which touch nothing wave 0's collision stage does -- do not wait for
+                 * wave 0's collision verdict, only the drive-level pass (it changes the drive state) does */
+                wv::publish(&S.cmd[3], sub1 + 1);
                 CK_STAMP(38);
+                factor_pair_by_height<NVP, TOPO>(m, h, S, col, colh, lane);
+                wv::wait_for(&S.cmd[4], sub1 + 1);
+                if (wv::opaque(S.cmd[0])) return; /* (the row-capped instantiation hands this substep over) */
                 if (io.drive_mode) {
-                    /* the drive-level pass of this substep (ctrl for the passive stage below; the encoder / filter state) */
                     if (io.integrate) drive_level_io(io, S, m, env, lane, sub1 == nsub - 1);
                     wv::sync();
                 }
-                factor_pair_by_height<NVP, TOPO>(m, h, S, col, colh, lane);
                 CK_STAMP(4);
                 {
                     const int kd = isdof ? k_ : 0;
@@ -2607,7 +2614,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
             const int need = 3 * wv::popc64(wv::ballot(eact)) + wv::popc64(lob) + wv::popc64(hib) + 4 * ncon;
             if (need > MAXR) {
                 bailed = true;
-                if constexpr (NW == 2) { if (lane == 0) S.cmd[0] = 1; wv::block_barrier(); } /* (X) */
+                if constexpr (NW == 2) { if (lane == 0) S.cmd[0] = 1; wv::publish(&S.cmd[4], sub + 1); } /* (X) */
                 break;
             }
             if constexpr (NW == 1) if (io.drive_mode) {
@@ -2615,7 +2622,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
                 wv::sync();
             }
         }
-        if constexpr (NW == 2) { CK_STAMP(33); wv::block_barrier(); } /* X */
+        if constexpr (NW == 2) { CK_STAMP(33); wv::publish(&S.cmd[4], sub + 1); wv::wait_for(&S.cmd[3], sub + 1); } /* X */
         CK_STAMP(5);
 
         /* ================= P6 velocities and bias forces ================= */
