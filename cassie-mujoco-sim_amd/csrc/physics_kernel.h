@@ -1006,7 +1006,9 @@ WV_DEVICE void factor_pair_in_registers(ModelPtr m, double h, double (&col)[NVP]
  * matrix gives L[k][:] in every lane at once), parks them in the packed LDS factors -- where the solves want them
  * anyway -- and then applies the rank-one updates with L[k][i] fetched back as LDS broadcast reads: two FMAs and two
  * reads per ancestor pair, no scalar registers, one LDS round trip per height instead of one per dof. */
-template <int NVP, class TOPO, class SH>
+/* WHICH: 2 = both factorisations, interleaved (their chains hide each other's latency); 0 = that of M alone, 1 = that of M + hB alone
+ * (the two-wave form runs the second one behind the barrier J, while wave 0 solves: only the Euler step reads it) */
+template <int NVP, class TOPO, int WHICH = 2, class SH>
 WV_DEVICE void factor_pair_by_height(ModelPtr m, double h, SH &S, double (&col)[NVP], double (&colh)[NVP], int lane) {
     /* The trunk dofs (the floating base: each one's ancestors are all the lower ones) come last and one to a height: a
      * round through LDS for a single dof is all latency.  They are eliminated in registers instead (below), with
@@ -1019,12 +1021,11 @@ WV_DEVICE void factor_pair_by_height(ModelPtr m, double h, SH &S, double (&col)[
         for (int k = NVP - 1; k >= 0; --k) {
             if (TOPO::height[k] != s) continue;
             const double arm = m->dof_armature[k]; /* diagonal terms, see the mass-matrix stage */
-            const double inv = fast_rcp(wv::readlane(col[k], k) + arm), invh = fast_rcp(wv::readlane(colh[k], k) + (arm + h * m->dof_damping[k]));
-            S.dinv[k] = inv; S.dinvH[k] = invh; /* every lane holds the same value: an unpredicated same-address store */
-            /* lanes at or past the diagonal all land on one unused slot: an unpredicated store */
+            /* every lane holds the same 1/D: an unpredicated same-address store; lanes at or past the diagonal all land on one
+             * unused slot of the row: an unpredicated store too */
             const int at = LPack<TOPO, NVP>::row_slot(k, lane);
-            S.Lp[at] = col[k] * inv;
-            S.LHp[at] = colh[k] * invh;
+            if constexpr (WHICH != 1) { const double inv = fast_rcp(wv::readlane(col[k], k) + arm); S.dinv[k] = inv; S.Lp[at] = col[k] * inv; }
+            if constexpr (WHICH != 0) { const double invh = fast_rcp(wv::readlane(colh[k], k) + (arm + h * m->dof_damping[k])); S.dinvH[k] = invh; S.LHp[at] = colh[k] * invh; }
         }
         wv::sync();
 #pragma unroll
@@ -1036,15 +1037,15 @@ WV_DEVICE void factor_pair_by_height(ModelPtr m, double h, SH &S, double (&col)[
 #pragma unroll
             for (int i = k - 1; i >= 0; --i) {
                 if (!((TOPO::table[k] >> i) & 1ull)) continue;
-                t[i] = S.Lp[LPack<TOPO, NVP>::idx(k, i)];
-                th[i] = S.LHp[LPack<TOPO, NVP>::idx(k, i)];
+                if constexpr (WHICH != 1) t[i] = S.Lp[LPack<TOPO, NVP>::idx(k, i)];
+                if constexpr (WHICH != 0) th[i] = S.LHp[LPack<TOPO, NVP>::idx(k, i)];
             }
             wv::sched_fence();
 #pragma unroll
             for (int i = k - 1; i >= 0; --i) {
                 if (!((TOPO::table[k] >> i) & 1ull)) continue;
-                col[i] -= t[i] * col[k];
-                colh[i] -= th[i] * colh[k];
+                if constexpr (WHICH != 1) col[i] -= t[i] * col[k];
+                if constexpr (WHICH != 0) colh[i] -= th[i] * colh[k];
             }
             wv::sched_fence();
         }
@@ -1053,19 +1054,30 @@ WV_DEVICE void factor_pair_by_height(ModelPtr m, double h, SH &S, double (&col)[
 #pragma unroll
     for (int k = TOPO::trunk - 1; k >= 0; --k) {
         const double arm = m->dof_armature[k];
-        const double inv = fast_rcp(wv::readlane(col[k], k) + arm), invh = fast_rcp(wv::readlane(colh[k], k) + (arm + h * m->dof_damping[k]));
-        S.dinv[k] = inv; S.dinvH[k] = invh;
         const int at = LPack<TOPO, NVP>::row_slot(k, lane);
-        S.Lp[at] = col[k] * inv;
-        S.LHp[at] = colh[k] * invh;
-        double t[TOPO::trunk], th[TOPO::trunk];
+        if constexpr (WHICH != 1) {
+            const double inv = fast_rcp(wv::readlane(col[k], k) + arm);
+            S.dinv[k] = inv;
+            S.Lp[at] = col[k] * inv;
+            double t[TOPO::trunk];
 #pragma unroll
-        for (int i = k - 1; i >= 0; --i) { t[i] = wv::readlane(col[k], i) * inv; th[i] = wv::readlane(colh[k], i) * invh; }
+            for (int i = k - 1; i >= 0; --i) t[i] = wv::readlane(col[k], i) * inv;
 #pragma unroll
-        for (int i = k - 1; i >= 0; --i) { col[i] -= t[i] * col[k]; colh[i] -= th[i] * colh[k]; }
+            for (int i = k - 1; i >= 0; --i) col[i] -= t[i] * col[k];
+        }
+        if constexpr (WHICH != 0) {
+            const double invh = fast_rcp(wv::readlane(colh[k], k) + (arm + h * m->dof_damping[k]));
+            S.dinvH[k] = invh;
+            S.LHp[at] = colh[k] * invh;
+            double th[TOPO::trunk];
+#pragma unroll
+            for (int i = k - 1; i >= 0; --i) th[i] = wv::readlane(colh[k], i) * invh;
+#pragma unroll
+            for (int i = k - 1; i >= 0; --i) colh[i] -= th[i] * colh[k];
+        }
     }
     wv::sync();
-    if (lane < TOPO::nv) S.rsd[lane] = sqrt(S.dinv[lane]);
+    if constexpr (WHICH != 1) if (lane < TOPO::nv) S.rsd[lane] = sqrt(S.dinv[lane]);
 }
 
 /* Projected Gauss-Seidel sweeps, one constraint row per lane.  The per-row state is the SCALED residual
@@ -1860,7 +1872,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
                  * wave 0's collision verdict, only the drive-level pass (it changes the drive state) does */
                 wv::publish(&S.cmd[3], sub1 + 1);
                 CK_STAMP(38);
-                factor_pair_by_height<NVP, TOPO>(m, h, S, col, colh, lane);
+                factor_pair_by_height<NVP, TOPO, 0>(m, h, S, col, colh, lane); /* (that of M + hB: behind the barrier J) */
                 wv::wait_for(&S.cmd[4], sub1 + 1);
                 if (wv::opaque(S.cmd[0])) return; /* (the row-capped instantiation hands this substep over) */
                 if (io.drive_mode) {
@@ -1876,8 +1888,11 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
                     wv::wait_for(&S.cmd[1], sub1 + 1); /* wave 0's velocity stage has the body forces (cfrc) in LDS */
                     bias_forces_and_qfrc_smooth<NVP>(io, S, m, env, ids, kdamp, kstiff, kref, kgear, klo, khi, kq, ka);
                 }
-                wv::block_barrier(); /* J: the factors of M and M + hB and qfrc_smooth are in LDS */
+                wv::block_barrier(); /* J: the factor of M and qfrc_smooth are in LDS */
                 CK_STAMP(39);
+                /* the factorisation of M + hB, which only this wave's Euler step reads: here, in the time this wave would otherwise
+                 * wait for wave 0's solve, instead of on the way to the barrier J, where wave 0 waited for it (+4.6 %) */
+                factor_pair_by_height<NVP, TOPO, 1>(m, h, S, col, colh, lane);
                 /* ---- the stages behind wave 0's constraint solve: operands staged now, while wave 0 assembles and solves ---- */
                 {
                     const bool lastsub = sub1 == nsub - 1 || !io.integrate;
