@@ -231,7 +231,16 @@ def launch_io_bytes_per_env(pod, drive=True):
     return 8 * (load + store)
 
 
-def pmc_traffic(env_steps_per_launch, model_name="cassie", envs_per_launch=None, pod=None):
+def launch_chunks(envs_per_launch, substeps_per_launch, whole_batch):
+    """Workgroups per env a stepping launch of this shape is dispatched as (phys_batch.hip: launches in chunks -- 4 for a launch
+    over the whole batch, 2 for one over an env range, chunks of at least 5 substeps, launches of at least 2048 envs)."""
+    asked = int(os.environ.get("CASSIE_CHUNKS") or (4 if whole_batch else 2))
+    if envs_per_launch < 2048 or envs_per_launch % 8 or substeps_per_launch < 10:
+        return 1
+    return max(1, min(asked, int(substeps_per_launch) // 5))
+
+
+def pmc_traffic(env_steps_per_launch, model_name="cassie", envs_per_launch=None, pod=None, chunks=1):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (tools/gpu_pmc_all.sh: FETCH_SIZE and WRITE_SIZE in
     separate --pmc runs, corrected as MI355X_MICROARCH.md prescribes), brought to this run's launch shape: the passes
     profile 50-substep launches, and a launch's traffic is a per-env part that does not depend on the substep count (state
@@ -253,9 +262,9 @@ def pmc_traffic(env_steps_per_launch, model_name="cassie", envs_per_launch=None,
             if envs_per_launch is None or pod is None:
                 return total / es * env_steps_per_launch, os.path.relpath(path, REPO)
             envs_pmc = d.get("envs_per_launch", 4096)
-            fixed = launch_io_bytes_per_env(pod)
-            per_env_step = max(0.0, total - fixed * envs_pmc) / es
-            return fixed * envs_per_launch + per_env_step * env_steps_per_launch, os.path.relpath(path, REPO)
+            fixed = launch_io_bytes_per_env(pod)      # per env and CHUNK: every chunk of a launch loads and stores like a launch
+            per_env_step = max(0.0, total - fixed * envs_pmc * d.get("chunks_per_env_launch", 1)) / es
+            return fixed * envs_per_launch * chunks + per_env_step * env_steps_per_launch, os.path.relpath(path, REPO)
         except (KeyError, ValueError, OSError):
             continue
     return None, None
@@ -843,7 +852,8 @@ def main(argv=None):
         rate = lambda sec: world * n * args.steps / sec
         value = rate(elapsed)
         # (per launch of the dominant kernel, like `achieved_one_launch`: one env range's launch)
-        traffic, traffic_src = pmc_traffic(n * steps_per_launch / r["streams"], args.model, envs_per_launch=n / r["streams"], pod=pod)
+        chunks = launch_chunks(n // r["streams"], steps_per_launch, r["streams"] == 1)
+        traffic, traffic_src = pmc_traffic(n * steps_per_launch / r["streams"], args.model, envs_per_launch=n / r["streams"], pod=pod, chunks=chunks)
         api = {"drive-pd": "phys_batch_step in CM_DRIVE_PD mode (device-resident, include/cassie_phys.h): pd_input's motor PD on the encoder "
                            "measurements + motor model with torque delay + physics in one kernel -- cassie_sim_step_pd's drive-level semantics "
                            "without the Agility safety layer / estimator",
@@ -871,7 +881,7 @@ def main(argv=None):
                        "streams": r["streams"],
                        # a stepping launch is dispatched as this many workgroups per env, each stepping a share of the substeps
                        # (phys_batch_set_chunks; launches of fewer than 10 substeps or 2048 envs stay in one piece)
-                       "chunks_per_env_launch": int(os.environ.get("CASSIE_CHUNKS") or (2 if r["streams"] > 1 else 4)),
+                       "chunks_per_env_launch": chunks,
                        "wavefronts_per_env": (1 if args.model == "cassie_tray_box" or os.environ.get("CASSIE_WAVES_PER_ENV") == "1" else 2),
                        "streams_note": ("the %d envs of a GPU are stepped as %d contiguous ranges, each on its own stream at its own pace "
                                         "(phys_batch_step_range): per policy step every range gets its restarts, its PD targets and one "
@@ -895,11 +905,11 @@ def main(argv=None):
                                            "order / restart kernels)" % (r["streams"], launch_env_steps, achieved_one or 0.0)) if r["streams"] > 1 else
                                           "algorithmic bytes of one launch / the dominant kernel's mean duration (a HIP event pair around every launch on the launch stream)",
                          "achieved_one_launch": achieved_one, "stream_ms_per_policy_step": r["stream_ms"], "kernel_launches_timed": r["kernel_launches"],
-                         "kernel": {"cassie": "ck::cassie_step_kernel<32, ck::TopoCassie32, 0, 31, 2, false> (row-capped fast instantiation, TWO wavefronts per env; "
+                         "kernel": {"cassie": "ck::cassie_step_kernel<32, ck::TopoCassie32, 0, 31, 2, false, 2> (row-capped fast instantiation, TWO wavefronts per env; "
                                               "<..., 63, 2, true> walks the list of handed-over envs behind it)",
-                                    "cassie_hfield": "ck::cassie_step_kernel<32, ck::TopoCassie32, 1, 31, 2, false> (row-capped fast instantiation, two wavefronts per env; "
+                                    "cassie_hfield": "ck::cassie_step_kernel<32, ck::TopoCassie32, 1, 31, 2, false, 2> (row-capped fast instantiation, two wavefronts per env; "
                                                      "<..., 63, 2, true> walks the list of handed-over envs behind it)",
-                                    "cassie_tray_box": "ck::cassie_step_kernel<40, ck::TopoCassieTray38, 2, 47, 1, false> (row-capped instantiation of 47 rows, ONE wavefront "
+                                    "cassie_tray_box": "ck::cassie_step_kernel<40, ck::TopoCassieTray38, 2, 47, 1, false, 1> (row-capped instantiation of 47 rows, ONE wavefront "
                                                        "per env and 512 registers, Gram matrix on the matrix core; <..., 63, 2, true> walks the list of handed-over envs "
                                                        "behind it; the two-wave form of the 40-dof instantiation spills and is slower, profiles/round4)"}[args.model], "kernel_ms": kern_ms, "algorithmic_bytes_per_env_step": algo_bytes, "env_steps_per_launch": launch_env_steps,
                          "note": "latency-bound by design: ~2 KB of state vs ~0.22 MFLOP of serially dependent fp64 per env-step"},

@@ -1,4 +1,4 @@
-# round 4, final measurement set (v31: two wavefronts per env for the Cassie instantiations -- mass-matrix group, drive-level pass,
+# round 4, final measurement set (v32: two wavefronts per env for the Cassie instantiations -- mass-matrix group, drive-level pass,
 # factorisations, bias / passive stage and the stages behind the solve on wave 1 --, hand-over list, list-walking two-wave pass).
 # Box clocks differ by up to 30 % between leases: the first bench line decides whether this box is a normal one.
 mkdir -p gpurun_out; nproc > gpurun_out/nproc.txt
