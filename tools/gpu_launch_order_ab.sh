@@ -1,6 +1,6 @@
 #!/bin/bash
-# round 4, call u: does the launch order (expensive envs of the last launch first) still pay?  CASSIE_NO_BALANCE=1 against the default
-mkdir -p gpurun_out/r4u
+# round 4: does the launch order (expensive envs of the last launch first) still pay?  CASSIE_NO_BALANCE=1 against the default
+mkdir -p gpurun_out/ab
 show() { python - "$1" "$2" <<'PY'
 import json, sys
 d=json.loads(open(sys.argv[1]).read().strip().split("\n")[-1]); w=d.get("workgroup_slots") or {}
@@ -11,7 +11,7 @@ for rep in 1 2; do
 for m in cassie cassie_tray_box; do
 for v in order noorder; do
   if [ $v = noorder ]; then export CASSIE_NO_BALANCE=1; else unset CASSIE_NO_BALANCE; fi
-  timeout 300 python bench.py --model $m --steps 500 --warmup 50 --no-cpu-baseline --no-step-pd > gpurun_out/r4u/${m}_${v}_$rep.json 2> gpurun_out/r4u/${m}_${v}_$rep.err; show gpurun_out/r4u/${m}_${v}_$rep.json "$m $v run $rep"
+  timeout 300 python bench.py --model $m --steps 500 --warmup 50 --no-cpu-baseline --no-step-pd > gpurun_out/ab/${m}_${v}_$rep.json 2> gpurun_out/ab/${m}_${v}_$rep.err; show gpurun_out/ab/${m}_${v}_$rep.json "$m $v run $rep"
 done
 done
 done
