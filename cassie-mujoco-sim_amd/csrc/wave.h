@@ -59,6 +59,8 @@ template <int NW> WV_DEVICE void publish_global(int *flag, int value) {
      * workgroup's L2: the stores only have to have arrived there, which the counter wait of a workgroup-scope release says;
      * an agent-scope release would write the XCD's whole L2 back, 25 k clocks a time) */
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    /* (EVERY wave's stores, before the waves meet: at workgroup scope the compiler waits for the publishing wave's only) */
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
     if (NW > 1) __builtin_amdgcn_s_barrier();
     if (threadIdx.x == 0) __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -68,6 +70,7 @@ template <int NW> WV_DEVICE void wait_global(const int *flag, int value) {
         while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != value) __builtin_amdgcn_s_sleep(20);
     if (NW > 1) __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __builtin_amdgcn_s_dcache_inv(); /* (the scalar cache too, should the compiler ever read a wave-uniform word of the env's state through it) */
 }
 /* the lane index recomputed from nothing (two VALU ops) through an asm the optimiser cannot merge or hoist: values
  * derived from it (LDS addresses, lane predicates) then live only inside the stage that asked, instead of being
