@@ -16,6 +16,9 @@ for n in (int(a) for a in (sys.argv[1:] or ["512", "4096"])):
         b.set_fast_rows(False)      # the stamps of the full instantiation alone (default: the row-capped fast one, where an env fits it)
     WAVES = int(os.environ.get("WAVES", "2"))
     b.set_waves_per_env(WAVES)
+    # launches in one piece by default here (CHUNKS=4 for the product's whole-batch default): the slot analysis below takes an env's
+    # start as its end minus its cost, which holds for one workgroup per env only
+    b.set_chunks(int(os.environ.get("CHUNKS", "1")))
     if m.name == "cassie_hfield":     # the bench's terrain (reference example/test_hfield.py:39-41), every env at the flat centre patch
         hf = np.random.default_rng(99).random((200, 200)).astype(np.float32)
         hf[95:105, 95:105] = 0
