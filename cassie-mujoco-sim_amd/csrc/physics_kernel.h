@@ -43,7 +43,7 @@
  * for the batched getters; a longest-job-first launch order.
  *
  * Round 4: the two-wave form (wave 1: mass-matrix group, drive-level pass, factorisations, bias / passive stage, the stages
- * behind the solve; five workgroup barriers and two LDS flags per substep; bit for bit the one-wave form); the hand-over list
+ * behind the solve; four workgroup barriers and four LDS flags per substep; bit for bit the one-wave form); the hand-over list
  * and the list-walking pass behind the row-capped fast instantiation.
  *
  * Numerically this follows the same algorithm as oracle/cassie_oracle.c but with
@@ -2007,7 +2007,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
         if (io.drive_mode) {
             /* (the row-capped instantiation runs this pass after it knows that the substep fits its rows, see below: a
              * substep it hands over must not have advanced the filter histories and delay lines) */
-            if constexpr (MAXR == CM_MAXEFC && NW == 1) { /* (two-wave form: wave 1, behind the barrier X) */
+            if constexpr (MAXR == CM_MAXEFC && NW == 1) { /* (two-wave form: wave 1, once wave 0's collision verdict is in) */
                 if (io.integrate) drive_level_io(io, S, m, env, lane, lastsub); /* mj_forward leaves the drive-level state alone */
                 wv::sync();
             }
@@ -2629,7 +2629,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
             const int need = 3 * wv::popc64(wv::ballot(eact)) + wv::popc64(lob) + wv::popc64(hib) + 4 * ncon;
             if (need > MAXR) {
                 bailed = true;
-                if constexpr (NW == 2) { if (lane == 0) S.cmd[0] = 1; wv::publish(&S.cmd[4], sub + 1); } /* (X) */
+                if constexpr (NW == 2) { if (lane == 0) S.cmd[0] = 1; wv::publish(&S.cmd[4], sub + 1); } /* (the verdict: handed over) */
                 break;
             }
             if constexpr (NW == 1) if (io.drive_mode) {
@@ -2637,7 +2637,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
                 wv::sync();
             }
         }
-        if constexpr (NW == 2) { CK_STAMP(33); wv::publish(&S.cmd[4], sub + 1); wv::wait_for(&S.cmd[3], sub + 1); } /* X */
+        if constexpr (NW == 2) { CK_STAMP(33); wv::publish(&S.cmd[4], sub + 1); wv::wait_for(&S.cmd[3], sub + 1); } /* the verdict for wave 1; wave 1's com / cinert / cdof for the stage below */
         CK_STAMP(5);
 
         /* ================= P6 velocities and bias forces ================= */

@@ -265,7 +265,7 @@ def test_row_capped_fast_kernel_equals_the_full_kernel_bit_for_bit(built, name, 
 @pytest.mark.parametrize("name", ["cassie", "cassie_hfield", "cassie_tray_box"])
 def test_two_wave_form_of_the_fast_kernel_equals_the_one_wave_form_bit_for_bit(built, name):
     """phys_batch_set_waves_per_env: the row-capped fast kernels run as two wavefronts per env (wave 1: the mass-matrix stage
-    group beside wave 0's collision / velocity / row stages, three workgroup barriers per substep).  Every value is computed by
+    group, the factorisations and the stages behind the solve beside wave 0's collision / velocity / row / solve stages).  Every value is computed by
     the same instructions from the same operands, so state, outputs, solver statistics, measurement block and drive state
     must be BIT FOR BIT those of the one-wave form -- under the stress targets, i.e. with envs handed over to the (one-wave)
     full kernel in the middle of fused launches, and with substeps of every length of launch (1 .. HOLD)."""
