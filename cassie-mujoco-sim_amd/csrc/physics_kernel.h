@@ -3338,10 +3338,16 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
                     const double mydelta = fmax(mys, lo_f);
                     const double change = (r_ < nrows) ? mydelta * (halfAii * mydelta - Aii * mys) : 0.0;
                     /* The guarded sweep adds the rows' cost changes in row order, and the sum only feeds the convergence test.
-                     * A single-precision tree sum (issued before the guard ballot, so the two latencies overlap) decides it
+                     * A single-precision tree sum decides it
                      * unless it lands within a factor two of the tolerance -- far outside what precision or the order of
                      * summation can move -- and only then is the ordered double-precision sum formed. */
-                    const float est = -wv::wave_sum_f32((float)change) * (float)scale, tol = (float)tolerance;
+                    /* One row whose own cost decrease is past 2.5 x the tolerance settles "not converged" without the sum: the other
+                     * rows' changes are decreases too (or at most +1e-10 each, else the guard fires), so the sum is past the 2 x band
+                     * below whatever they are.  Most sweeps before the last two or three end here: a compare and a ballot instead
+                     * of the six-step tree sum on the sweep's dependent chain. */
+                    const float tol = (float)tolerance;
+                    const bool one_row_decides = wv::ballot(-(float)change * (float)scale > 2.5f * tol) != 0ull;
+                    const float est = one_row_decides ? 4.0f * tol : -wv::wave_sum_f32((float)change) * (float)scale;
                     if (wv::ballot(change > 1e-10) != 0ull || wv::debug_force_guarded()) { /* some row would have raised the cost: redo guarded */
                         double improvement = 0;
                         f = f0; sres = s0; ++nguarded;
