@@ -3335,7 +3335,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
                     double mys = 0;
                     const double lo_f = flo - f;
                     pgs_rows_fast<0, MAXR>(arow, nrows, r_, lo_f, sres, mys);
-                    const double mydelta = fmax(mys, lo_f);
+                    const double mydelta = wv::max_raw(mys, lo_f); /* (the very instruction the row chain took its step with) */
                     const double change = (r_ < nrows) ? mydelta * (halfAii * mydelta - Aii * mys) : 0.0;
                     /* The guarded sweep adds the rows' cost changes in row order, and the sum only feeds the convergence test.
                      * A single-precision tree sum decides it
