@@ -503,3 +503,13 @@ def test_launch_in_chunks_is_bit_for_bit_the_launch_in_one_piece(name, built):
             if stress:
                 assert bails > before
             before = bails
+    # more chunks than substeps (the trailing chunks have nothing to do), and a chunk of a single substep
+    if name == "cassie":
+        for nsub in (2, 5):
+            ref, _, _ = _two_wave_workload(model, True, fast=True, two_waves=True, schedule=0, nlaunch=4, nsub=nsub, stress=False)
+            lib.emu_chunks(4)
+            try:
+                got, _, _ = _two_wave_workload(model, True, fast=True, two_waves=True, schedule=2, nlaunch=4, nsub=nsub, stress=False)
+            finally:
+                lib.emu_chunks(1)
+            assert got == ref, nsub
