@@ -1648,8 +1648,9 @@ WV_DEVICE void stage_factor_row(const SH &S, int k_, bool isdof, double (&lrow)[
         } else lrow[i] = (isdof && i < k_) ? S.Lp[CK_TRI(k_, i)] : 0.0;
     }
 }
-/* this lane's column and row of the factor of M + hB (the Euler step's two substitutions) */
-template <int NVP, class TOPO, class SH>
+/* this lane's column and row of the factor of M + hB (the Euler step's two substitutions); WHICH: 2 = both, 0 = the column only
+ * (the backward substitution's operand, the first of the two), 1 = the row only */
+template <int NVP, class TOPO, int WHICH = 2, class SH>
 WV_DEVICE void stage_factor_h(const SH &S, int k_, bool isdof, int nv, double (&lcol)[NVP], double (&lrowh)[NVP]) {
     typedef LPack<TOPO, NVP> LP;
     const typename LP::Row myrow = LP::row_of(k_);
@@ -1657,13 +1658,19 @@ WV_DEVICE void stage_factor_h(const SH &S, int k_, bool isdof, int nv, double (&
     for (int k = 0; k < NVP; ++k) {
         const bool inrange = TOPO::is_static ? k < TOPO::nv : k < nv;
         if constexpr (LP::packed) {
-            const bool hasc = inrange && isdof && k > k_ && LP::col_has(k, k_), hasr = isdof && k < k_ && LP::row_has(myrow, k);
-            const double vc = S.LHp[hasc ? LP::col_idx(k, k_) : 0], vr = S.LHp[hasr ? LP::row_idx(myrow, k) : 0];
-            lcol[k] = hasc ? vc : 0.0;
-            lrowh[k] = hasr ? vr : 0.0;
+            if constexpr (WHICH != 1) {
+                const bool hasc = inrange && isdof && k > k_ && LP::col_has(k, k_);
+                const double vc = S.LHp[hasc ? LP::col_idx(k, k_) : 0];
+                lcol[k] = hasc ? vc : 0.0;
+            }
+            if constexpr (WHICH != 0) {
+                const bool hasr = isdof && k < k_ && LP::row_has(myrow, k);
+                const double vr = S.LHp[hasr ? LP::row_idx(myrow, k) : 0];
+                lrowh[k] = hasr ? vr : 0.0;
+            }
         } else {
-            lcol[k] = (inrange && isdof && k > k_) ? S.LHp[CK_TRI(k, k_)] : 0.0;
-            lrowh[k] = (isdof && k < k_) ? S.LHp[CK_TRI(k_, k)] : 0.0;
+            if constexpr (WHICH != 1) lcol[k] = (inrange && isdof && k > k_) ? S.LHp[CK_TRI(k, k_)] : 0.0;
+            if constexpr (WHICH != 0) lrowh[k] = (isdof && k < k_) ? S.LHp[CK_TRI(k_, k)] : 0.0;
         }
     }
 }
@@ -1908,6 +1915,10 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
                     const double *const fbuf = &S.c_solimp[0][0];
                     double lrow[NVP];
                     stage_factor_row<NVP, TOPO>(S, k_, isdof, lrow);
+                    /* ... and its column of the factor of M + hB (this wave formed it right behind J): the Euler step's first
+                     * substitution then starts without the column's 32 address computations and reads in front of it */
+                    double lcol[NVP], lrowh[NVP];
+                    stage_factor_h<NVP, TOPO, 0>(S, k_, isdof, nv, lcol, lrowh);
                     const double rsdk = isdof ? S.rsd[k_] : 0.0;
                     const int kk = isdof ? k_ : 0;
                     /* this lane's column of the staged matrix (row MAXR = the qfrc_smooth column), once wave 0 has put it in LDS: the
@@ -1952,8 +1963,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
                     if (!isdof) z = 0.0;
                     if (isdof) z *= rsdk;
                     /* (the Euler step's operands are requested here: their LDS latency runs under the substitution below) */
-                    double lcol[NVP], lrowh[NVP];
-                    stage_factor_h<NVP, TOPO>(S, k_, isdof, nv, lcol, lrowh);
+                    stage_factor_h<NVP, TOPO, 1>(S, k_, isdof, nv, lcol, lrowh); /* (the row: its registers were the staged column of Y until here) */
                     const double dih = isdof ? S.dinvH[k_] : 0.0;
                     wv::sched_fence();
                     const double qacc = solve_forward<NVP, TOPO>(z, lrow, lane, nv);
