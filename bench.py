@@ -674,8 +674,10 @@ def device_rollout(model, mode, n, steps, warmup, rank, world, local_rank, subst
     # that keep a launch order) -> how full the GPU's workgroup slots were over the timed regions, see main()
     try:
         res["env_clocks_per_substep"] = float(np.mean(b.launch_cost())) / max(1, last_launch["nsub"])
+        res["shader_clock_hz"] = b.measured_shader_clock() if hasattr(b, "measured_shader_clock") else None
     except (RuntimeError, AttributeError):
         res["env_clocks_per_substep"] = None
+        res["shader_clock_hz"] = None
     # ---- the metric's second half: sampled envs of EVERY rank against the CPU reference, same schedule ----
     ids_sample = torch.from_numpy(env_ids[sample].astype(np.int64)).to(dev)
     if collect and world > 1:
@@ -705,20 +707,24 @@ def device_rollout(model, mode, n, steps, warmup, rank, world, local_rank, subst
 
 
 SLOTS_PER_GPU = 256 * 4        # one env per workgroup, 40 KB of LDS each: four workgroups per CU
-SHADER_CLOCK_HZ = 2.4e9        # MI355X peak engine clock; measured under this kernel: 2.38 - 2.39 GHz (profiles/round4/clock_and_slots.txt)
+SHADER_CLOCK_HZ = 2.4e9        # MI355X peak engine clock: the fallback when the launch did not measure its own (slot_occupancy)
 
 
-def slot_occupancy(env_clocks_per_substep, n, substeps, elapsed_s):
+def slot_occupancy(env_clocks_per_substep, n, substeps, elapsed_s, clock_hz=None):
     """Where a timed region's time goes, one level above the kernel: every env-step occupies one of the GPU's 1024 workgroup
     slots for `env_clocks_per_substep`; busy_frac = slot time used / slot time available over the region.  The rest is slots
     waiting for work: the drain at the end of each range's launch (no env of a launch may start the next one before all have
     finished this one) and the gaps between a range's launches."""
     if not env_clocks_per_substep or not elapsed_s:
         return None
-    busy = n * substeps * env_clocks_per_substep / SHADER_CLOCK_HZ / (SLOTS_PER_GPU * elapsed_s)
-    return {"env_clocks_per_substep": env_clocks_per_substep, "slots": SLOTS_PER_GPU, "clock_hz_assumed": SHADER_CLOCK_HZ,
+    # the shader clock under THIS load, measured by the last launch itself (every env's span in s_memtime clocks over the same span
+    # on the constant 100 MHz clock: phys_batch_measured_shader_clock); the nominal peak only where the launch could not measure it
+    hz = clock_hz or SHADER_CLOCK_HZ
+    busy = n * substeps * env_clocks_per_substep / hz / (SLOTS_PER_GPU * elapsed_s)
+    return {"env_clocks_per_substep": env_clocks_per_substep, "slots": SLOTS_PER_GPU, "clock_hz": hz,
+            "clock_source": "measured by the last launch (s_memtime over s_memrealtime, all envs)" if clock_hz else "assumed (nominal peak)",
             "busy_frac": busy,
-            "rate_with_every_slot_busy": SLOTS_PER_GPU * SHADER_CLOCK_HZ / env_clocks_per_substep,
+            "rate_with_every_slot_busy": SLOTS_PER_GPU * hz / env_clocks_per_substep,
             "note": "per GPU, from the LAST launch's per-env clocks (first to last instruction of the fast kernel + the pass behind it)"}
 
 
@@ -897,6 +903,9 @@ def main(argv=None):
             "parity": r["parity"],
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         # `achieved`, `peak`, `frac`, `traffic` and `kernel_ms` are PER GPU at every N (a rank's env-steps over the
+                         # region against ONE GPU's HBM peak); the node moves n_gpus x `achieved` against n_gpus x `peak`
+                         "scope": "per GPU", "achieved_node": achieved * world, "peak_node": HBM_PEAK_GBS * world,
                          "concurrent_launches": r["streams"],
                          "achieved_note": ("per GPU: algorithmic bytes of all env-steps of a timed region / the region's time.  The %d env ranges' launches "
                                            "overlap; ONE launch of the dominant kernel (%d env-steps, `kernel_ms` = its mean duration from a HIP "
@@ -917,7 +926,7 @@ def main(argv=None):
             "roofline_fp64": {"bound": "fp64-valu", "achieved": value * 0.22e6 / 1e12, "peak": 78.6 * world, "unit": "TFLOP/s",
                               "frac": value * 0.22e6 / 1e12 / (78.6 * world),
                               "note": "algorithmic flops (SURVEY.md 8a estimate), not counting lanes that idle or recompute"},
-            "workgroup_slots": slot_occupancy(r["env_clocks_per_substep"], n, r["steps"], r["elapsed"]),
+            "workgroup_slots": slot_occupancy(r["env_clocks_per_substep"], n, r["steps"], r["elapsed"], r.get("shader_clock_hz")),
             "envs_with_warnings": r["envs_with_warnings"],
             **({"obs_allgather_ok": r.get("gather_ok")} if collect else {}),   # rank 0's rows of the last gathered block = its snapshot
             "frac_envs_handed_over_to_the_full_kernel_in_the_last_launch": r["frac_envs_handed_over_last_launch"],
@@ -961,7 +970,14 @@ def main(argv=None):
             out["true_reference"] = true_reference(args.model, model.qpos_init(), pd_targets(tsample, EPISODE // HOLD + 1), EPISODE)
         elif world == 1 and args.total_envs is None and not args.dry_run_cpu and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model, hfield=hfield)      # configs 4 / 5: the oracle on this box's cores, same workload
+        elif world > 1 and not args.no_cpu_baseline:
+            # N > 1 (a SCALE line): rank 0 alone times the CPU oracle on the node's host cores, after the timed regions, while the
+            # other ranks wait at the barrier below -- the line must not read as unmeasured for want of the key
+            out["cpu_baseline"] = cpu_baseline(model, budget_s=1.0 if args.dry_run_cpu else 12.0, hfield=hfield)
+            out["cpu_baseline"]["note"] = "rank 0 only, all host cores of the node, timed behind the GPU regions with the other ranks idle"
         print(json.dumps(out), flush=True)
+    if collect and world > 1:
+        dist.barrier()      # (the ranks leave together: rank 0 may still be in its CPU leg)
     if collect:
         dist.destroy_process_group()
     return 0

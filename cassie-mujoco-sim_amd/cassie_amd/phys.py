@@ -265,6 +265,15 @@ class Batch:
             raise RuntimeError("cost download failed (balancing is off or the batch is small)")
         return out.astype(np.float64) * 64.0
 
+    def measured_shader_clock(self):
+        """Hz the last stepping launch ran at: the envs' spans in shader clocks over the same spans on the 100 MHz clock
+        (None where the launch-cost arrays do not exist: small batches, balancing off)."""
+        import ctypes
+        hz = ctypes.c_double(0.0)
+        if lib().phys_batch_measured_shader_clock(self._h, ctypes.byref(hz)) != 0:
+            return None
+        return float(hz.value)
+
     def handover_pending(self):
         """Validation aid: entries left in the hand-over lists once the batch's streams are idle (0 in every mode)."""
         r = lib().phys_batch_debug_handover_pending(self._h)

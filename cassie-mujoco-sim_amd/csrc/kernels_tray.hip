@@ -14,7 +14,7 @@ bool launch_step_tray(dim3 grid, dim3 pass_grid, hipStream_t s, PhysIO io, bool 
             io.resume = 1; io.nchunk = 1;
             /* the pass in the form of the kernel it follows (its workgroups must fit where that kernel's retire); without a
              * hand-over list (allocation failed): one workgroup per env through the two-wave full kernel */
-            static const bool pass_2w = getenv("CASSIE_DEBUG_TRAY_PASS_TWO_WAVES") != nullptr; /* (measurement aid) */
+            static const bool pass_2w = measurement_switch("CASSIE_DEBUG_TRAY_PASS_TWO_WAVES"); /* (measurement aid) */
             if (!(waves == 2 || !io.handover_list || pass_2w ? launch_full_tray_2w(pass_grid, s, io) : launch_full_tray_walk(pass_grid, s, io))) return false;
         } else {
             io.progress = nullptr; io.resume = 0; io.handover_list = nullptr; io.nchunk = 1;

@@ -60,7 +60,7 @@ struct phys_batch {
     /* launch-order balancing (see ck::cassie_order_kernel) */
     bool all_outputs = false;       /* measurement aid: see PhysIO::all_outputs_every_substep */
     bool balance = true;
-    unsigned *d_cost = nullptr;
+    unsigned *d_cost = nullptr, *d_cost_wall = nullptr; /* per-env span of the last launch in 64 shader clocks / in 100 MHz ticks */
     int *d_order = nullptr;
     /* d_order holds a permutation of the env ids of every range it was last sorted for (the order kernel sorts one launch's
      * range [env0, env0 + n) at a time) and the identity everywhere else.  A launch may use the array only for a range that is
@@ -81,6 +81,13 @@ struct phys_batch {
     int *d_chunk_flag = nullptr;
     int chunk_seq = 0;
     bool chunks_allowed = true;     /* (false: this device does not place workgroup w on XCD w % 8 -- launches stay in one piece) */
+    /* the placement rule is a property of the QUEUE a launch goes to (a CU-masked stream, another partition mode ...): every stream
+     * is probed the first time a chunked launch is about to go to it -- with the step kernel's own workgroup shape -- and the
+     * kernel checks every hand-over besides (PhysIO::chunk_fault: a word in pinned host memory a consumer sets when it finds its
+     * producer on another XCD; launches stay in one piece from then on) */
+    std::vector<std::pair<hipStream_t, bool>> probed_streams;
+    int *h_chunk_fault = nullptr, *d_chunk_fault = nullptr;
+    bool chunk_fault_reported = false;
     /* the hand-over list (PhysIO::handover_list): env ids per range, [count, ticket] pairs indexed by a range's first env, and
      * -- in pinned host memory the device writes -- the number of envs the last launch of a range handed over */
     int *d_handover_list = nullptr, *d_handover_count = nullptr;
@@ -98,6 +105,8 @@ static bool hip_ok(hipError_t e, const char *what) {
     fprintf(stderr, "cassie_phys: %s\n", msg.c_str());
     return false;
 }
+
+static bool stream_may_chunk(phys_batch *b, hipStream_t s);
 
 static ck::PhysIO make_io(phys_batch *b, int nsub, int integrate) {
     ck::PhysIO io;
@@ -136,7 +145,7 @@ static ck::PhysIO make_io(phys_batch *b, int nsub, int integrate) {
     io.all_outputs_every_substep = b->all_outputs ? 1 : 0;
     io.prof = b->d_prof;
     io.ext = b->d_ext;
-    if (b->balance && b->d_order) { io.order = b->d_order; io.cost = b->d_cost; }
+    if (b->balance && b->d_order) { io.order = b->d_order; io.cost = b->d_cost; io.cost_wall = b->d_cost_wall; }
     return io;
 }
 
@@ -176,10 +185,10 @@ static int launch(phys_batch *b, int nsub, int integrate, hipStream_t s, bool sc
     if (n < 0) n = b->nenv;
     io.env0 = env0; io.nenv = n;
     phys_batch::OrderSeg *seg = nullptr;
-    if (io.order && !integrate) { io.order = nullptr; io.cost = nullptr; } /* forward / read-out passes: one substep, nothing to balance (identity order) */
+    if (io.order && !integrate) { io.order = nullptr; io.cost = nullptr; io.cost_wall = nullptr; } /* forward / read-out passes: one substep, nothing to balance (identity order) */
     if (io.order) {
         seg = order_segment_for(b, env0, n, s);
-        if (!seg) { io.order = nullptr; io.cost = nullptr; }
+        if (!seg) { io.order = nullptr; io.cost = nullptr; io.cost_wall = nullptr; }
     }
     if (scratch_outputs) {
         /* a read-out pass: the step outputs the caller's fields hold (sensordata and actuator_velocity of the last STEP feed
@@ -222,18 +231,23 @@ static int launch(phys_batch *b, int nsub, int integrate, hipStream_t s, bool sc
         io.progress = fast ? b->d_progress : nullptr;
         dim3 pass_grid = grid;
         io.nchunk = 1;
-        if (fast && b->d_chunk_flag && b->chunks_allowed && (n == b->nenv ? b->chunks : b->chunks_range) > 1 && n >= CHUNK_MIN_ENVS && n % 8 == 0 && nsub >= 2 * CHUNK_MIN_SUBSTEPS) {
+        if (fast && b->d_chunk_flag && b->chunks_allowed && (n == b->nenv ? b->chunks : b->chunks_range) > 1 && n >= CHUNK_MIN_ENVS && n % 8 == 0 && nsub >= 2 * CHUNK_MIN_SUBSTEPS &&
+            stream_may_chunk(b, s)) {
             /* (n % 8: workgroup w runs on XCD w % 8, so the chunks of an env -- workgroups n apart -- share an XCD and its L2) */
             /* the fast kernel's launch as chunks of at least CHUNK_MIN_SUBSTEPS substeps (the launchers size its grid) */
             const int most = nsub / CHUNK_MIN_SUBSTEPS, asked = n == b->nenv ? b->chunks : b->chunks_range;
             io.nchunk = asked < most ? asked : most;
-            if (b->chunk_seq >= (1 << 27)) { /* (the tag has 28 bits: start over once nothing is in flight) */
-                (void)quiesce(b);
-                (void)hipMemset(b->d_chunk_flag, 0, sizeof(int) * (size_t)b->nenv);
+            if (b->chunk_seq >= (1 << 24)) { /* (the tag has 25 bits: start over once NOTHING is in flight on the device -- the words of
+                                               * envs in flight on a stream this batch does not remember must not be cleared under them --
+                                               * and the clearing itself is complete before the next chunk can publish) */
+                (void)hipDeviceSynchronize();
+                (void)hipMemsetAsync(b->d_chunk_flag, 0, sizeof(int) * (size_t)b->nenv, s);
+                (void)hipStreamSynchronize(s);
                 b->chunk_seq = 0;
             }
             io.chunk_seq = ++b->chunk_seq;
             io.chunk_flag = b->d_chunk_flag;
+            io.chunk_fault = b->d_chunk_fault;
         }
         if (fast && b->d_handover_list) {
             /* the pass behind the fast kernel walks the hand-over list with a small grid: twice what the range's last launch
@@ -302,23 +316,37 @@ extern "C" {
 /* A launch in chunks hands an env's state from one workgroup to another through the L2 both share (wave.h: publish_global): the
  * chunks of an env are workgroups a multiple of 8 apart, and workgroup w runs on XCD w % 8.  That assignment is checked here, once
  * per batch of a size that could be chunked: a grid of 1024 workgroups reports where it ran. */
-__global__ void __launch_bounds__(64) cassie_xcd_probe_kernel(int *xcc) {
-    if (threadIdx.x == 0) xcc[blockIdx.x] = (int)(wv::hw_id() >> 32);
+__global__ void __launch_bounds__(128) cassie_xcd_probe_kernel(int *xcc) {
+    if (threadIdx.x == 0) xcc[blockIdx.x] = (int)(wv::hw_id() >> 32) & 7;
 }
-static bool workgroups_go_round_the_xcds(int device) {
-    static int verdict[64]; /* per device: 0 = not probed, 1 = yes, 2 = no */
-    if (device < 0 || device >= 64) return false;
-    if (verdict[device]) return verdict[device] == 1;
+/* does the queue behind stream s place workgroup w on XCD w % 8 (in the sense that workgroups 8 apart share an XCD)?  A grid of 1024
+ * workgroups of the step kernel's shape (128 threads) reports where it ran. */
+static bool workgroups_go_round_the_xcds(hipStream_t s) {
     constexpr int NWG = 1024;
     int *d = nullptr, h[NWG];
     bool ok = hipMalloc((void **)&d, sizeof h) == hipSuccess;
     if (ok) {
-        hipLaunchKernelGGL(cassie_xcd_probe_kernel, dim3(NWG), dim3(64), 0, 0, d);
-        ok = hipGetLastError() == hipSuccess && hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost) == hipSuccess;
+        hipLaunchKernelGGL(cassie_xcd_probe_kernel, dim3(NWG), dim3(128), 0, s, d);
+        ok = hipGetLastError() == hipSuccess && hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
         for (int w = 8; ok && w < NWG; ++w) ok = h[w] == h[w % 8];
     }
     if (d) (void)hipFree(d);
-    verdict[device] = ok ? 1 : 2;
+    return ok;
+}
+static bool stream_may_chunk(phys_batch *b, hipStream_t s) {
+    if (!b->chunks_allowed) return false;
+    if (b->h_chunk_fault && *(volatile int *)b->h_chunk_fault) {
+        b->chunks_allowed = false;
+        if (!b->chunk_fault_reported) {
+            b->chunk_fault_reported = true;
+            fprintf(stderr, "cassie_phys: a chunk of a stepping launch ran on another XCD than the chunk before it (a CU-masked stream or a partition mode that "
+                            "breaks the round-robin placement): the envs concerned carry warning bit 16, launches go in one piece from now on\n");
+        }
+        return false;
+    }
+    for (const auto &ps : b->probed_streams) if (ps.first == s) return ps.second;
+    const bool ok = workgroups_go_round_the_xcds(s);
+    if (b->probed_streams.size() < 64) b->probed_streams.emplace_back(s, ok);
     return ok;
 }
 
@@ -362,13 +390,17 @@ phys_batch_t *phys_batch_create(const cm_model_t *model, int nenv, int device) {
         ok = ok && hip_ok(hipMemcpy(b->d_order, b->order_ident.data(), sizeof(int) * (size_t)nenv, hipMemcpyHostToDevice), "hipMemcpy(order)");
         ok = ok && hip_ok(hipMalloc((void **)&b->d_cost, sizeof(unsigned) * (size_t)nenv), "hipMalloc(cost)");
         ok = ok && hip_ok(hipMemset(b->d_cost, 0, sizeof(unsigned) * (size_t)nenv), "hipMemset(cost)");
+        ok = ok && hip_ok(hipMalloc((void **)&b->d_cost_wall, sizeof(unsigned) * (size_t)nenv), "hipMalloc(cost, wall clock)");
+        ok = ok && hip_ok(hipMemset(b->d_cost_wall, 0, sizeof(unsigned) * (size_t)nenv), "hipMemset(cost, wall clock)");
     }
     ok = ok && hip_ok(hipMalloc((void **)&b->d_progress, sizeof(int) * (size_t)nenv), "hipMalloc(progress)");
     ok = ok && hip_ok(hipMemset(b->d_progress, 0, sizeof(int) * (size_t)nenv), "hipMemset(progress)");
     ok = ok && hip_ok(hipMalloc((void **)&b->d_chunk_flag, sizeof(int) * (size_t)nenv), "hipMalloc(chunk words)");
     ok = ok && hip_ok(hipMemset(b->d_chunk_flag, 0, sizeof(int) * (size_t)nenv), "hipMemset(chunk words)");
     if (const char *ck = getenv("CASSIE_CHUNKS")) b->chunks = b->chunks_range = atoi(ck) > 1 ? (atoi(ck) < 7 ? atoi(ck) : 7) : 1; /* (A/B switch) */
-    if (ok && nenv >= CHUNK_MIN_ENVS && !workgroups_go_round_the_xcds(device)) b->chunks_allowed = false;
+    ok = ok && hip_ok(hipHostMalloc((void **)&b->h_chunk_fault, sizeof(int), hipHostMallocMapped), "hipHostMalloc(chunk fault word)");
+    if (ok) *b->h_chunk_fault = 0;
+    ok = ok && hip_ok(hipHostGetDevicePointer((void **)&b->d_chunk_fault, b->h_chunk_fault, 0), "hipHostGetDevicePointer");
     ok = ok && hip_ok(hipMalloc((void **)&b->d_handover_list, sizeof(int) * (size_t)nenv), "hipMalloc(hand-over list)");
     ok = ok && hip_ok(hipMalloc((void **)&b->d_handover_count, sizeof(int) * 2 * (size_t)nenv), "hipMalloc(hand-over counts)");
     ok = ok && hip_ok(hipMemset(b->d_handover_count, 0, sizeof(int) * 2 * (size_t)nenv), "hipMemset(hand-over counts)");
@@ -405,10 +437,12 @@ void phys_batch_free(phys_batch_t *b) {
     if (b->d_handover_list) (void)hipFree(b->d_handover_list);
     if (b->d_handover_count) (void)hipFree(b->d_handover_count);
     if (b->h_handover_seen) (void)hipHostFree(b->h_handover_seen);
+    if (b->h_chunk_fault) (void)hipHostFree(b->h_chunk_fault);
     for (auto &e : b->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (b->d_drive) (void)hipFree(b->d_drive);
     if (b->d_order) (void)hipFree(b->d_order);
     if (b->d_cost) (void)hipFree(b->d_cost);
+    if (b->d_cost_wall) (void)hipFree(b->d_cost_wall);
     if (b->ev0) (void)hipEventDestroy(b->ev0);
     if (b->ev1) (void)hipEventDestroy(b->ev1);
     if (b->ev_mark) (void)hipEventDestroy(b->ev_mark);
@@ -830,6 +864,19 @@ int phys_batch_download_cost(phys_batch_t *b, unsigned *host) {
     if (!b || !host || !b->d_cost) return -1;
     (void)hipSetDevice(b->device);
     return quiesce(b) && hip_ok(hipMemcpy(host, b->d_cost, sizeof(unsigned) * (size_t)b->nenv, hipMemcpyDeviceToHost), "cost download") ? 0 : -1;
+}
+
+int phys_batch_measured_shader_clock(phys_batch_t *b, double *hz) {
+    if (!b || !hz || !b->d_cost || !b->d_cost_wall) return -1;
+    (void)hipSetDevice(b->device);
+    std::vector<unsigned> c((size_t)b->nenv), w((size_t)b->nenv);
+    if (!quiesce(b) || !hip_ok(hipMemcpy(c.data(), b->d_cost, sizeof(unsigned) * c.size(), hipMemcpyDeviceToHost), "cost download") ||
+        !hip_ok(hipMemcpy(w.data(), b->d_cost_wall, sizeof(unsigned) * w.size(), hipMemcpyDeviceToHost), "cost download")) return -1;
+    double sc = 0, sw = 0;
+    for (size_t i = 0; i < c.size(); ++i) if (w[i] > 1000u) { sc += 64.0 * c[i]; sw += w[i]; } /* (envs that spanned at least 10 us) */
+    if (sw <= 0) return -1;
+    *hz = sc / sw * 1e8;
+    return 0;
 }
 
 int phys_batch_debug_handover_pending(phys_batch_t *b) {

@@ -74,7 +74,8 @@ constexpr int NSTAMP = 48;   /* 0..15 stage boundaries, 16..32 sub-stage stamps,
 #define CK_FRESH() do { lane = wv::fresh_lane(); b = lane; k_ = lane; isbody = b < nbody; isdof = k_ < nv; } while (0)
 
 /* warning bits reported per env */
-enum { WARN_CONTACT_FULL = 1, WARN_CONSTRAINT_FULL = 2, WARN_UNSUPPORTED_PAIR = 4, WARN_DIVERGED = 8 };
+enum { WARN_CONTACT_FULL = 1, WARN_CONSTRAINT_FULL = 2, WARN_UNSUPPORTED_PAIR = 4, WARN_DIVERGED = 8,
+       WARN_CHUNK_PLACEMENT = 16 /* a chunk of a launch found the chunk before it on another XCD (cassie_step_kernel): state possibly stale */ };
 
 #ifndef WV_OCC
 #define WV_OCC
@@ -123,6 +124,7 @@ struct PhysIO {
      * shader clocks its launch took; the launcher sorts the next launch's order by that cost, most expensive first */
     const int *order;
     unsigned *cost;
+    unsigned *cost_wall;        /* (may be null) the same span in ticks of the constant 100 MHz clock: cost / cost_wall = the shader clock under load */
     /* non-zero: every substep of a launch evaluates every output (IMU sensors, body quaternions) although only the last
      * substep's can be read -- a measurement aid (bench.py reports the rate with it as a side figure) */
     int all_outputs_every_substep;
@@ -142,10 +144,12 @@ struct PhysIO {
      * substeps [c (w / nenv), c (w / nenv + 1)), c = ceil(nsub / nchunk) -- an env's launch is nchunk jobs instead of one, so what
      * the slots wait for at the end of a launch (the last-started jobs running alone) is a quarter as long.  A chunk is a
      * launch of its own as far as the env is concerned: it loads the state the chunk before it stored and ends like a launch
-     * of c substeps.  chunk_flag[env] = 8 chunk_seq + (chunks of this launch complete); a chunk waits for the one before it
-     * (which has a lower workgroup number, so it was dispatched earlier). */
+     * of c substeps.  chunk_flag[env] = 64 chunk_seq + 8 (XCD of the chunk that wrote the word) + (chunks of this launch
+     * complete); a chunk waits for the one before it (which has a lower workgroup number, so it was dispatched earlier) and checks
+     * that it ran on the same XCD (wave.h: publish_global / wait_global); *chunk_fault (host memory, may be null) is set if not. */
     int nchunk, chunk_seq;
     int *chunk_flag;
+    volatile int *chunk_fault;
     int *handover_list, *handover_count;
     volatile int *handover_seen;
 };
@@ -3337,6 +3341,10 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
             const double cdiag = isrow ? rR * ninvAii : 0.0; /* the R part of B_jj = -(Y Y^T + R)_jj / A_jj, see above */
             const int maxiter = m->iterations;
             const double tolerance = m->tolerance;
+            /* (the one-row shortcut below rests on the other rows raising the cost sum by at most 1e-10 each: that must stay inside
+             * the half tolerance between its 2.5 x threshold and the 2 x band -- true of any tolerance a model is likely to ask for,
+             * checked because the tolerance is the model's to set) */
+            const bool shortcut_ok = 0.5 * tolerance > (double)MAXR * 1e-10 * scale;
             while (iters < maxiter) {
                 const int nrows = wv::opaque(nefc); /* keeps the row-bound tests out of loop-invariant hoisting */
                 bool converged;
@@ -3356,7 +3364,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
                      * below whatever they are.  Most sweeps before the last two or three end here: a compare and a ballot instead
                      * of the six-step tree sum on the sweep's dependent chain. */
                     const float tol = (float)tolerance;
-                    const bool one_row_decides = wv::ballot(-(float)change * (float)scale > 2.5f * tol) != 0ull;
+                    const bool one_row_decides = shortcut_ok && wv::ballot(-(float)change * (float)scale > 2.5f * tol) != 0ull;
                     const float est = one_row_decides ? 4.0f * tol : -wv::wave_sum_f32((float)change) * (float)scale;
                     if (wv::ballot(change > 1e-10) != 0ull || wv::debug_force_guarded()) { /* some row would have raised the cost: redo guarded */
                         double improvement = 0;
@@ -3551,9 +3559,12 @@ WV_GLOBAL void __launch_bounds__(WV_WAVE * NW) WV_OCC WV_WAVES_PER_SIMD(WPS) cas
         const int count = wv::opaque(wv::shfl_i(wv::lane() == 0 ? wv::atomic_add(io.handover_count, 0) : 0, 0));
         for (int idx = slot; idx < count; idx += wv::grid_size()) {
             const int env = io.handover_list[io.env0 + idx];
-            const long long t0 = io.cost ? wv::clock() : 0;
+            const long long t0 = io.cost ? wv::clock() : 0, t0w = io.cost_wall ? wv::wall_clock() : 0;
             env_step<NVP, TOPO, FEAT, MAXR, NW>(io, S, env, io.progress[env], io.nsub);
-            if (io.cost && wv::lane() == 0 && (NW == 1 || wv::wave_id() == 0)) io.cost[env] += (unsigned)((wv::clock() - t0) >> 6);
+            if (io.cost && wv::lane() == 0 && (NW == 1 || wv::wave_id() == 0)) {
+                io.cost[env] += (unsigned)((wv::clock() - t0) >> 6);
+                if (io.cost_wall) io.cost_wall[env] += (unsigned)(wv::wall_clock() - t0w);
+            }
             if constexpr (NW == 2) wv::block_barrier(); /* both waves are done with this env before either starts the next */
             else wv::sync();
         }
@@ -3578,15 +3589,19 @@ WV_GLOBAL void __launch_bounds__(WV_WAVE * NW) WV_OCC WV_WAVES_PER_SIMD(WPS) cas
     if (sub_start >= io.nsub) return; /* resume pass: the fast instantiation finished this env; chunks: none left for this one */
     if (chunk > 0) {
         /* the chunk before this one has stored the env's state (and, had it met a substep with too many rows, handed the env over) */
-        wv::wait_global<NW>(io.chunk_flag + env, 8 * io.chunk_seq + chunk);
+        if (!wv::wait_global<NW>(io.chunk_flag + env, io.chunk_seq, chunk)) {
+            /* the producer's stores sit in ANOTHER XCD's L2 (wave.h): what this chunk is about to load may be stale.  The env is
+             * flagged -- its results are not to be trusted -- and the launcher told, which launches in one piece from then on */
+            if (wv::lane() == 0) { wv::atomic_or(io.warn + env, WARN_CHUNK_PLACEMENT); if (io.chunk_fault) *io.chunk_fault = 1; }
+        }
         if (io.progress[env] != sub_start) {
-            if (sub_end < io.nsub) wv::publish_global<NW>(io.chunk_flag + env, 8 * io.chunk_seq + chunk + 1);
+            if (sub_end < io.nsub) wv::publish_global<NW>(io.chunk_flag + env, io.chunk_seq, chunk + 1);
             return;
         }
     }
-    const long long t0 = io.cost ? wv::clock() : 0;
+    const long long t0 = io.cost ? wv::clock() : 0, t0w = io.cost_wall ? wv::wall_clock() : 0;
     env_step<NVP, TOPO, FEAT, MAXR, NW>(io, S, env, sub_start, sub_end);
-    if (sub_end < io.nsub) wv::publish_global<NW>(io.chunk_flag + env, 8 * io.chunk_seq + chunk + 1);
+    if (sub_end < io.nsub) wv::publish_global<NW>(io.chunk_flag + env, io.chunk_seq, chunk + 1);
     if (io.prof && wv::lane() == 0) io.prof[(size_t)env * NSTAMP + 40 + (NW == 2 ? wv::wave_id() : 0)] = wv::hw_id(); /* (profiling aid: the CU / SIMD of the wave) */
     if (io.prof && wv::lane() == 0 && (NW == 1 || wv::wave_id() == 0)) { /* (profiling aid: the shader clock against the 100 MHz wall clock at the env's end) */
         io.prof[(size_t)env * NSTAMP + 42] = wv::clock(); io.prof[(size_t)env * NSTAMP + 43] = wv::wall_clock();
@@ -3594,6 +3609,7 @@ WV_GLOBAL void __launch_bounds__(WV_WAVE * NW) WV_OCC WV_WAVES_PER_SIMD(WPS) cas
     if (io.cost && wv::lane() == 0 && (NW == 1 || wv::wave_id() == 0)) { /* 64-clock units: 32 bits hold minutes */
         const unsigned c = (unsigned)((wv::clock() - t0) >> 6);
         io.cost[env] = io.resume || chunk > 0 ? io.cost[env] + c : c;
+        if (io.cost_wall) { const unsigned cw = (unsigned)(wv::wall_clock() - t0w); io.cost_wall[env] = io.resume || chunk > 0 ? io.cost_wall[env] + cw : cw; }
     }
     }
 }

@@ -9,6 +9,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
 #include <cstdlib>
 
 #include "physics_kernel.h"
@@ -40,6 +41,15 @@ bool launch_full_tray_walk(dim3 grid, hipStream_t s, PhysIO io); /* the one-wave
 bool launch_full_tray_2w(dim3 grid, hipStream_t s, PhysIO io);
 bool launch_step_generic(dim3 grid, hipStream_t s, PhysIO io, bool wide);           /* <32 | 40, TopoRuntime, FEAT_ALL> */
 
+/* measurement switches read from the environment (A/B runs on one GPU box): a switch that is set says so on stderr, once per
+ * process -- CASSIE_DEBUG_SKIP_RESUME_PASS leaves handed-over envs unfinished, which must not happen silently */
+inline bool measurement_switch(const char *name) {
+    const bool on = getenv(name) != nullptr;
+    if (on) fprintf(stderr, "cassie_phys: measurement switch %s is set -- results are not the product's%s\n", name,
+                    name[13] == 'S' ? " (envs handed over by the fast kernel stay UNFINISHED)" : "");
+    return on;
+}
+
 constexpr int SMALL_BATCH_NSUB = 4;  /* ... and substeps per launch up to which such a batch skips the row-capped fast kernel + pass pair (two launches) */
 constexpr unsigned SMALL_BATCH = 512; /* envs up to which the full kernel alone runs in its two-wave form (half the chip's workgroup slots) */
 
@@ -56,8 +66,8 @@ inline bool launch_fast_then_full(dim3 grid, dim3 pass_grid, hipStream_t s, Phys
     /* (measurement aids: CASSIE_DEBUG_SKIP_RESUME_PASS -- what the pass behind the fast kernel costs; handed-over envs are then
      * left unfinished, so only for workloads that hand nothing over; CASSIE_DEBUG_RESUME_ONE_WAVE -- the pass behind a two-wave
      * fast kernel as one-wave workgroups) */
-    static const bool skip_resume = getenv("CASSIE_DEBUG_SKIP_RESUME_PASS") != nullptr;
-    static const bool resume_one_wave = getenv("CASSIE_DEBUG_RESUME_ONE_WAVE") != nullptr;
+    static const bool skip_resume = measurement_switch("CASSIE_DEBUG_SKIP_RESUME_PASS");
+    static const bool resume_one_wave = measurement_switch("CASSIE_DEBUG_RESUME_ONE_WAVE");
     /* the hand-over list is kept only when the pass behind the fast kernel walks it (and clears its count): a fast kernel that
      * appended to a list nobody clears would run past the list's end after a few launches */
     const bool walk = fast && full_2w && !resume_one_wave && !skip_resume;

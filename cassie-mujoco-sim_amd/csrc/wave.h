@@ -48,29 +48,45 @@ WV_DEVICE void block_barrier() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 /* Hand-over between WORKGROUPS of one kernel through a word in device memory (PhysIO::chunk_flag): publish_global() once every
- * store of the workgroup is on its way (each wave releases its own at agent scope, the waves meet, one lane writes the word);
- * wait_global() polls the word -- the producer is a workgroup with a lower number, dispatched earlier, so it runs or has run -- and
- * then drops this CU's cached copies of what the producer wrote (acquire at agent scope) before anybody loads. */
-template <int NW> WV_DEVICE void publish_global(int *flag, int value) {
+ * store of the workgroup is on its way (each wave waits for its own, the waves meet, one lane writes the word); wait_global()
+ * polls the word -- the producer is a workgroup with a lower number, dispatched earlier, so it runs or has run -- and then drops
+ * this CU's cached copies of what the producer wrote before anybody loads.
+ * The word is 64 tag + 8 XCC + done: the producer states WHICH XCD's L2 its stores went to (they are released at workgroup scope:
+ * they have arrived in that L2, nothing writes it back), and the consumer, who runs on the same XCD when workgroup w is placed on
+ * XCD w % 8 (phys_batch.hip probes that, per stream), CHECKS it: wait_global returns false when the producer's XCD is not this
+ * workgroup's -- the caller then flags the env and tells the launcher, which stops chunking (a CU-masked stream or another
+ * partition mode broke the placement rule). */
+WV_DEVICE int xcc_id() { unsigned x; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x)); return (int)(x & 7u); }
+template <int NW> WV_DEVICE void publish_global(int *flag, int tag, int done) {
 #ifdef CK_CHUNK_RELEASE_AGENT
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
 #else
-    /* (the consumer runs on the same XCD -- workgroup numbers that differ by a multiple of 8, phys_batch.hip -- and so shares this
-     * workgroup's L2: the stores only have to have arrived there, which the counter wait of a workgroup-scope release says;
-     * an agent-scope release would write the XCD's whole L2 back, 25 k clocks a time) */
+    /* (the consumer runs on the same XCD and so shares this workgroup's L2: the stores only have to have arrived there, which the
+     * counter wait of a workgroup-scope release says; an agent-scope release would write the XCD's whole L2 back, 25 k clocks a time) */
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     /* (EVERY wave's stores, before the waves meet: at workgroup scope the compiler waits for the publishing wave's only) */
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
     if (NW > 1) __builtin_amdgcn_s_barrier();
-    if (threadIdx.x == 0) __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) __hip_atomic_store(flag, 64 * tag + 8 * xcc_id() + done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-template <int NW> WV_DEVICE void wait_global(const int *flag, int value) {
-    if (threadIdx.x < 64u)
-        while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != value) __builtin_amdgcn_s_sleep(20);
+template <int NW> WV_DEVICE bool wait_global(const int *flag, int tag, int done) {
+    int word = 0;
+    if (threadIdx.x < 64u) {
+        for (;;) {
+            word = __builtin_amdgcn_readfirstlane(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            if ((word >> 6) == tag && (word & 7) == done) break;
+            __builtin_amdgcn_s_sleep(20);
+        }
+    }
     if (NW > 1) __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     __builtin_amdgcn_s_dcache_inv(); /* (the scalar cache too, should the compiler ever read a wave-uniform word of the env's state through it) */
+#ifdef CK_CHUNK_RELEASE_AGENT
+    return true;
+#else
+    return threadIdx.x >= 64u || ((word >> 3) & 7) == xcc_id(); /* (wave 0 holds the verdict) */
+#endif
 }
 /* the lane index recomputed from nothing (two VALU ops) through an asm the optimiser cannot merge or hoist: values
  * derived from it (LDS addresses, lane predicates) then live only inside the stage that asked, instead of being
@@ -84,6 +100,7 @@ WV_DEVICE int env_id() { return (int)blockIdx.x; }
 WV_DEVICE int grid_size() { return (int)gridDim.x; }
 /* device-scope atomic add on an int in global memory, returns the old value */
 WV_DEVICE int atomic_add(int *p, int v) { return atomicAdd(p, v); }
+WV_DEVICE int atomic_or(int *p, int v) { return atomicOr(p, v); }
 
 /* Orders LDS traffic between the lanes of the wave.  The workgroup IS one wave, whose LDS instructions are issued and
  * executed in program order, so a later read already sees an earlier write of any lane: all that is needed is that

@@ -205,6 +205,10 @@ int phys_batch_set_balance(phys_batch_t *b, int on);
 /* diagnostics (batches of 2048 envs and more, balancing on): what the last stepping launch cost every env, in units of 64
  * shader clocks from the env's first to its last instruction ([nenv] unsigned) -- the figure the launch order is sorted by */
 int phys_batch_download_cost(phys_batch_t *b, unsigned *host);
+/* the shader clock the last stepping launch ran at, measured by the kernel itself: every env's span in shader clocks (s_memtime)
+ * over the same span on the constant 100 MHz clock (s_memrealtime), summed over the envs.  -1 where the launch-cost arrays do not
+ * exist (batches under 2048 envs, balancing off). */
+int phys_batch_measured_shader_clock(phys_batch_t *b, double *hz);
 /* validation aid: entries (and walker tickets) left in the hand-over lists of the batch's env ranges once its streams are idle
  * -- 0 whatever the mode: the pass behind the fast kernel clears what it walked, and a fast kernel whose pass does not walk the
  * list is not given one; -1 on error */

@@ -68,3 +68,38 @@ void mjh_get_consts(const mjh_t *h, double *body_invweight0 /* [nbody][2] */, do
     memcpy(dof_invweight0, h->m->dof_invweight0, sizeof(double) * h->m->nv);
     *meaninertia = h->m->stat.meaninertia;
 }
+
+/* ---- per-stage quantities of the last mj_forward / mj_step (the arrays of the forward pass the step integrated from), so that the
+ * first run against a genuine MuJoCo localises which constant of the restatement differs ("the least
+ * certain part"): tests/test_true_reference_stages.py ---- */
+/* out[4]: ncon, nefc, nv, 1 if the constraint Jacobian is stored sparse (then efc_J is not dumped) */
+void mjh_stage_sizes(const mjh_t *h, int *out)
+{
+    out[0] = h->d->ncon; out[1] = h->d->nefc; out[2] = h->m->nv; out[3] = mj_isSparse(h->m);
+}
+/* qM[nv][nv] dense; efc_*[nefc] (efc_J[nefc][nv], dense storage only); con[ncon][13] = dist, pos[3], frame[9];
+ * con_i[ncon][3] = geom1, geom2, dim.  Any pointer may be null. */
+void mjh_get_stages(const mjh_t *h, double *qM, double *efc_J, double *efc_aref, double *efc_R, double *efc_force, double *efc_pos,
+                    double *efc_diagApprox, double *efc_b, int *efc_type, int *efc_id, double *con, int *con_i, double *qacc_smooth)
+{
+    const mjModel *m = h->m;
+    const mjData *d = h->d;
+    const int nv = m->nv, nefc = d->nefc;
+    if (qM) mj_fullM(m, qM, d->qM);
+    if (efc_J && !mj_isSparse(m)) memcpy(efc_J, d->efc_J, sizeof(double) * (size_t)nefc * nv);
+    if (efc_aref) memcpy(efc_aref, d->efc_aref, sizeof(double) * nefc);
+    if (efc_R) memcpy(efc_R, d->efc_R, sizeof(double) * nefc);
+    if (efc_force) memcpy(efc_force, d->efc_force, sizeof(double) * nefc);
+    if (efc_pos) memcpy(efc_pos, d->efc_pos, sizeof(double) * nefc);
+    if (efc_diagApprox) memcpy(efc_diagApprox, d->efc_diagApprox, sizeof(double) * nefc);
+    if (efc_b) memcpy(efc_b, d->efc_b, sizeof(double) * nefc);
+    if (efc_type) for (int i = 0; i < nefc; ++i) efc_type[i] = d->efc_type[i];
+    if (efc_id) for (int i = 0; i < nefc; ++i) efc_id[i] = d->efc_id[i];
+    for (int i = 0; i < d->ncon; ++i) {
+        const mjContact *c = d->contact + i;
+        if (con) { con[13 * i] = c->dist; memcpy(con + 13 * i + 1, c->pos, sizeof(double) * 3); memcpy(con + 13 * i + 4, c->frame, sizeof(double) * 9); }
+        if (con_i) { con_i[3 * i] = c->geom1; con_i[3 * i + 1] = c->geom2; con_i[3 * i + 2] = c->dim; }
+    }
+    if (qacc_smooth) memcpy(qacc_smooth, d->qacc_smooth, sizeof(double) * nv);
+}
+void mjh_set_ctrl(mjh_t *h, const double *ctrl) { memcpy(h->d->ctrl, ctrl, sizeof(double) * h->m->nu); }

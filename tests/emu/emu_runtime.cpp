@@ -217,6 +217,13 @@ namespace wv { void emu_fail(const char *what) { fprintf(stderr, "emu: %s\n", wh
 /* a launch in chunks (PhysIO::nchunk): the fast instantiation's workgroups in launch order, chunk by chunk */
 static int g_chunks = 1, g_chunk_seq = 0;
 extern "C" void emu_chunks(int k) { g_chunks = k > 1 ? k : 1; }
+/* test hook: the "XCD" a chunk says it ran on when it publishes (consumers run on 0: anything else makes the consumer's placement
+ * check fire), and the word the kernel sets then (PhysIO::chunk_fault) */
+static int g_producer_xcc = 0;
+static volatile int g_chunk_fault = 0;
+namespace wv { int emu_xcc() { return g_producer_xcc; } }
+extern "C" void emu_producer_xcc(int x) { g_producer_xcc = x & 7; g_chunk_fault = 0; }
+extern "C" int emu_chunk_fault(void) { return g_chunk_fault; }
 static int g_fast_rows = 0, g_fast_bails = 0;
 extern "C" void emu_fast_rows(int on) { g_fast_rows = on; }
 extern "C" int emu_fast_bails(void) { return g_fast_bails; }
@@ -273,7 +280,7 @@ extern "C" int emu_phys_run(const cm_model_t *model, int nenv, int nsub, int int
         g_io.progress = progress; g_io.resume = 0; g_io.handover_list = list; g_io.handover_count = count; g_io.handover_seen = &seen;
         static int chunk_flag[1 << 16];
         const int nchunk = (g_chunks > 1 && nsub >= 2) ? g_chunks : 1;
-        g_io.nchunk = nchunk; g_io.chunk_seq = ++g_chunk_seq; g_io.chunk_flag = chunk_flag;
+        g_io.nchunk = nchunk; g_io.chunk_seq = ++g_chunk_seq; g_io.chunk_flag = chunk_flag; g_io.chunk_fault = &g_chunk_fault;
         g_grid = nenv * nchunk;
         for (int wg = 0; wg < nenv * nchunk; ++wg) {
             g_env = wg;

@@ -31,6 +31,7 @@ int wave_id();
 int env_id();
 int grid_size();
 inline int atomic_add(int *p, int v) { const int old = *p; *p = old + v; return old; } /* (lanes run one at a time) */
+inline int atomic_or(int *p, int v) { const int old = *p; *p = old | v; return old; }
 void sync();
 void block_barrier();
 void spin_yield();
@@ -59,11 +60,16 @@ unsigned long long ballot(bool p);
 double wave_sum(double v);
 float wave_sum_f32(float v);
 /* workgroups run one after the other here, in launch order: the word a chunk waits for must be there already */
-template <int NW> inline void publish_global(int *flag, int value) { if (NW > 1) block_barrier(); if (lane() == 0 && (NW == 1 || wave_id() == 0)) *flag = value; }
+/* (the word is 64 tag + 8 XCC + done, wave.h of the product; the emulator has one "XCD", number emu_xcc(): a test hook that lets
+ * a test place a producer elsewhere and see the consumer's check fire) */
+int emu_xcc();
+template <int NW> inline void publish_global(int *flag, int tag, int done) { if (NW > 1) block_barrier(); if (lane() == 0 && (NW == 1 || wave_id() == 0)) *flag = 64 * tag + 8 * emu_xcc() + done; }
 void emu_fail(const char *what);
-template <int NW> inline void wait_global(const int *flag, int value) {
-    if (*flag != value) { fprintf(stderr, "emu: chunk flag %d, expected %d\n", *flag, value); emu_fail("a chunk of a launch started before the chunk in front of it had finished"); }
+template <int NW> inline bool wait_global(const int *flag, int tag, int done) {
+    const int word = *flag;
+    if ((word >> 6) != tag || (word & 7) != done) { fprintf(stderr, "emu: chunk flag %d, expected tag %d done %d\n", word, tag, done); emu_fail("a chunk of a launch started before the chunk in front of it had finished"); }
     if (NW > 1) block_barrier(); else sync(); /* (as on the device: nobody moves on -- and publishes -- before every lane of every wave has looked) */
+    return ((word >> 3) & 7) == 0; /* (consumers run on "XCD" 0) */
 }
 inline long long clock() { return 0; }
 inline long long wall_clock() { return 0; }

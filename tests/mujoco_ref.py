@@ -69,6 +69,9 @@ class _CHarness:
             getattr(self.L, fn).argtypes = [ctypes.c_void_p] * args
             getattr(self.L, fn).restype = None
         self.L.mjh_set_hfield.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+        for fn, args in (("mjh_stage_sizes", 2), ("mjh_get_stages", 14), ("mjh_set_ctrl", 2)):
+            getattr(self.L, fn).argtypes = [ctypes.c_void_p] * args
+            getattr(self.L, fn).restype = None
         self.kind = "libmujoco210"
         self.version = "mj_version() = %d" % self.L.mjh_version_number()
 
@@ -107,6 +110,26 @@ class _CSim:
         sd, av, cnt = np.zeros(self.nsensordata), np.zeros(self.nu), (ctypes.c_int * 3)()
         self.L.mjh_get(self.h, q.ctypes.data, v.ctypes.data, a.ctypes.data, sd.ctypes.data, av.ctypes.data, cnt)
         return dict(qpos=q, qvel=v, qacc=a, sensordata=sd, actuator_velocity=av, counts=tuple(cnt))
+
+    def set_ctrl(self, ctrl):
+        c = np.ascontiguousarray(ctrl, dtype=np.float64)
+        self.L.mjh_set_ctrl(self.h, c.ctypes.data)
+
+    def stages(self):
+        """Per-stage quantities of the last forward pass (mj_forward, or the one inside the last step): qM, the constraint rows
+        (efc_J when stored dense, aref, R, force, pos, diagApprox, b, type, id), the contact list, qacc_smooth."""
+        sz = (ctypes.c_int * 4)()
+        self.L.mjh_stage_sizes(self.h, sz)
+        ncon, nefc, nv, sparse = sz[0], sz[1], sz[2], sz[3]
+        qM, J = np.zeros((nv, nv)), np.zeros((nefc, nv))
+        vec = {k: np.zeros(nefc) for k in ("aref", "R", "force", "pos", "diagApprox", "b")}
+        typ, eid = np.zeros(nefc, dtype=np.int32), np.zeros(nefc, dtype=np.int32)
+        con, coni, qs = np.zeros((ncon, 13)), np.zeros((ncon, 3), dtype=np.int32), np.zeros(nv)
+        self.L.mjh_get_stages(self.h, qM.ctypes.data, J.ctypes.data, vec["aref"].ctypes.data, vec["R"].ctypes.data, vec["force"].ctypes.data,
+                              vec["pos"].ctypes.data, vec["diagApprox"].ctypes.data, vec["b"].ctypes.data, typ.ctypes.data, eid.ctypes.data,
+                              con.ctypes.data, coni.ctypes.data, qs.ctypes.data)
+        return dict(ncon=ncon, nefc=nefc, qM=qM, efc_J=None if sparse else J, efc_type=typ, efc_id=eid, contact_dist=con[:, 0], contact_pos=con[:, 1:4],
+                    contact_frame=con[:, 4:13], contact_geom=coni[:, :2], contact_dim=coni[:, 2], qacc_smooth=qs, **{"efc_" + k: v for k, v in vec.items()})
 
     def close(self):
         if self.h:
@@ -151,6 +174,24 @@ class _WheelSim:
         d = self.d
         return dict(qpos=d.qpos.copy(), qvel=d.qvel.copy(), qacc=d.qacc.copy(), sensordata=d.sensordata.copy(),
                     actuator_velocity=d.actuator_velocity.copy(), counts=(int(d.ncon), int(d.nefc), int(d.solver_iter[0]) if np.ndim(d.solver_iter) else int(d.solver_iter)))
+
+    def set_ctrl(self, ctrl):
+        self.d.ctrl[:] = ctrl
+
+    def stages(self):
+        m, d, mj = self.m, self.d, self.mj
+        nv, nefc, ncon = m.nv, int(d.nefc), int(d.ncon)
+        qM = np.zeros((nv, nv))
+        mj.mj_fullM(m, qM, d.qM)
+        sparse = bool(mj.mj_isSparse(m))
+        J = None if sparse else np.array(d.efc_J, dtype=float).reshape(-1)[: nefc * nv].reshape(nefc, nv)
+        g = lambda name: np.array(getattr(d, name), dtype=float).reshape(-1)[:nefc]
+        geoms = np.array([[(c.geom[0] if hasattr(c, "geom") else c.geom1), (c.geom[1] if hasattr(c, "geom") else c.geom2)] for c in d.contact[:ncon]], dtype=np.int32).reshape(ncon, 2)
+        return dict(ncon=ncon, nefc=nefc, qM=qM, efc_J=J, efc_type=np.array(d.efc_type, dtype=np.int32).reshape(-1)[:nefc], efc_id=np.array(d.efc_id, dtype=np.int32).reshape(-1)[:nefc],
+                    efc_aref=g("efc_aref"), efc_R=g("efc_R"), efc_force=g("efc_force"), efc_pos=g("efc_pos"), efc_diagApprox=g("efc_diagApprox"), efc_b=g("efc_b"),
+                    contact_dist=np.array([c.dist for c in d.contact[:ncon]]), contact_pos=np.array([c.pos for c in d.contact[:ncon]]).reshape(ncon, 3),
+                    contact_frame=np.array([c.frame for c in d.contact[:ncon]]).reshape(ncon, 9), contact_geom=geoms,
+                    contact_dim=np.array([c.dim for c in d.contact[:ncon]], dtype=np.int32), qacc_smooth=np.array(d.qacc_smooth, dtype=float))
 
     def close(self):
         pass

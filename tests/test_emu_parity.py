@@ -513,3 +513,24 @@ def test_launch_in_chunks_is_bit_for_bit_the_launch_in_one_piece(name, built):
             finally:
                 lib.emu_chunks(1)
             assert got == ref, nsub
+
+
+def test_a_chunk_that_finds_its_producer_on_another_xcd_flags_the_env_and_tells_the_launcher(cassie):
+    """A launch in chunks hands an env's state over through the L2 of ONE XCD (csrc/wave.h: publish_global at workgroup scope): the
+    word carries the producer's XCD and the consumer checks it.  With the emulator's producers publishing from "XCD 3" (consumers
+    run on 0) every env must carry WARN_CHUNK_PLACEMENT (16) and the launcher's fault word must be set; with producers on 0 neither."""
+    import emu_py
+    lib = emu_py.lib()
+    lib.emu_chunks(3)
+    try:
+        lib.emu_producer_xcc(0)
+        got, _, _ = _two_wave_workload(cassie, True, fast=True, two_waves=True, schedule=1, nlaunch=2, nsub=9, stress=False)
+        warn = np.frombuffer(got[7], dtype=np.int32)
+        assert not (warn & 16).any() and lib.emu_chunk_fault() == 0
+        lib.emu_producer_xcc(3)
+        got, _, _ = _two_wave_workload(cassie, True, fast=True, two_waves=True, schedule=1, nlaunch=2, nsub=9, stress=False)
+        warn = np.frombuffer(got[7], dtype=np.int32)
+        assert (warn & 16).all() and lib.emu_chunk_fault() == 1
+    finally:
+        lib.emu_producer_xcc(0)
+        lib.emu_chunks(1)

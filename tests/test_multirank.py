@@ -235,6 +235,13 @@ def test_bench_main_starts_its_own_ranks_and_prints_one_line_for_all_of_them():
     assert d["max_qpos_err"] == 0.0 and all(v == 0.0 for v in per_rank.values())
     assert d["value"] > 0 and d["value_min"] <= d["value"] <= d["value_max"]
     assert "stand-in" in d["data"]                     # nobody can mistake this line for a measurement
+    # an N > 1 line is complete: rank 0 times the CPU oracle behind the regions (the other ranks wait), and the roofline object says
+    # that its figures are per GPU
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and "sample" in cb
+    rf = d["roofline"]
+    assert rf["scope"] == "per GPU" and rf["peak_node"] == 2 * rf["peak"] and abs(rf["achieved_node"] - 2 * rf["achieved"]) < 1e-9 * rf["achieved_node"]
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(rf)
 
 
 def test_bench_refuses_a_rank_count_that_is_not_the_launchers():

@@ -48,7 +48,15 @@ derived = {
     "frac_wait_any": g("SQ_WAIT_ANY") / g("SQ_WAVE_CYCLES"),
     "frac_valu_active": g("SQ_ACTIVE_INST_VALU") / g("SQ_WAVE_CYCLES"),
     "frac_wait_lds": g("SQ_WAIT_INST_LDS") / g("SQ_WAVE_CYCLES"),
-    "frac_wait_inst_fetch": g("SQ_WAIT_INST_ANY") / g("SQ_WAVE_CYCLES"),
+    # SQ_WAIT_INST_ANY = wave cycles spent waiting for ANY instruction to issue (issue arbitration between the waves of a SIMD,
+    # dependency stalls that are not counted under a specific unit) -- NOT instruction fetch (round 4 mislabelled it so).  What
+    # fetch costs is bounded by the instruction-cache misses: a miss is a trip to L2 of a few hundred clocks that a wave at the end
+    # of its fetch window waits out
+    "frac_wait_issue": g("SQ_WAIT_INST_ANY") / g("SQ_WAVE_CYCLES"),
+    "ifetch_requests_per_env_step": g("SQ_IFETCH") / n_env_steps,
+    "icache_misses_per_env_step": g("SQC_ICACHE_MISSES") / n_env_steps,
+    # upper bound of the fetch stall: every miss waited out in full by one wave at ~500 shader clocks (125 quad-cycles) a miss
+    "frac_fetch_stall_upper_bound": 125.0 * g("SQC_ICACHE_MISSES") / g("SQ_WAVE_CYCLES"),
     "lds_bank_conflict_frac_of_lds_active": g("SQ_LDS_BANK_CONFLICT") / g("SQ_ACTIVE_INST_LDS"),
     "icache_hit": g("SQC_ICACHE_HITS") / g("SQC_ICACHE_REQ"),
     "hbm_read_bytes_per_launch": 2 * 1024 * g("FETCH_SIZE"),
