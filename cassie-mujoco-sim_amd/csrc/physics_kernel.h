@@ -67,7 +67,7 @@ constexpr int FAST_ROWS = 31;  /* rows of the row-capped fast instantiation (+ t
 constexpr int FAST_ROWS_TRAY = 47; /* the 40-dof model's fast instantiation: Cassie + tray + cube at rest use 32 .. 40 rows (+ the qfrc_smooth row: three blocks of 16) */
 constexpr int NSTAMP = 48;   /* 0..15 stage boundaries, 16..32 sub-stage stamps, 33..39 the two-wave form's barrier arrivals / departures,
                                 40..41 where the hardware placed the env's wave(s), 42..43 shader clock and 100 MHz clock at the env's end,
-                                44..46 the height-field pre-pass (tools/stage_profile.py names them) */
+                                44..46 the height-field pre-pass, 47 wave 1's sensor stage (tools/stage_profile.py names them) */
 #define CK_TRI(k, i) ((k) * ((k) + 1) / 2 + (i))
 #define CK_STAMP(i) do { if (io.prof && lane == 0) io.prof[(size_t)env * NSTAMP + (i)] = wv::clock(); CK_FRESH(); } while (0)
 /* stage boundary: re-derive the lane index and its aliases (see wv::fresh_lane) */
@@ -1678,11 +1678,83 @@ WV_DEVICE void stage_factor_h(const SH &S, int k_, bool isdof, int nv, double (&
         }
     }
 }
+/* ---- sensors, part 1 (lane = sensor): everything that does not need qacc is final here; the accelerometer parks its partial
+ *      results in LDS (S.accel) because the body tiles are about to be recycled.  One-wave form: in line behind the Jacobian rows.
+ *      Two-wave form: wave 1, in front of the barrier J -- in the time it used to wait there for wave 0's Jacobian rows (its own
+ *      drive-level pass has read the previous substep's sensor words by then; poses, body velocities and bias accelerations are
+ *      in LDS since F / cmd[1]); behind J, where wave 0 ran it until round 5, it was 4.7 k clocks of wave 0's critical path.
+ *      (Placed behind J on wave 1 -- beside wave 0's half solve, with a flag before the staged matrix overwrites the body tiles --
+ *      it sits between the mass matrix's columns, which wave 1 keeps for the factorisation of M + hB, and their use: 850 values
+ *      went to scratch.) ---- */
+/* Who reads a substep's sensors: the launch's caller (the last substep's), and in a drive mode the next substep's
+ * encoder models (the joint / actuator positions) and the measurement block the LAST substep's drive pass writes
+ * (the IMU words of the substep before it).  The IMU sensors -- frame quaternion, gyro, magnetometer and the
+ * accelerometer with its second part after the solve -- are therefore evaluated by the last two substeps only. */
+struct SensorConsts { int stype, slot, sqadr, sb, sroot, sdim, sadr; double sgain, scut; };
+WV_DEVICE SensorConsts request_sensor_consts(ModelPtr m, int ls) {
+    SensorConsts c;
+    c.stype = m->sensor_type[ls]; c.slot = m->sensor_slot[ls];
+    c.sqadr = m->sensor_qadr[ls]; c.sb = m->sensor_body[ls]; c.sroot = m->sensor_root[ls];
+    c.sdim = m->sensor_dim[ls]; c.sadr = m->sensor_adr[ls];
+    c.sgain = m->sensor_gain[ls]; c.scut = m->sensor_cutoff[ls];
+    return c;
+}
+/* returns which accelerometer this lane is (-1: none) */
+template <class SH>
+WV_DEVICE int sensors_before_solve(const PhysIO &io, SH &S, ModelPtr m, int env, bool issens, int ls, SensorConsts sc, bool need_imu, bool lastsub) {
+    int stype = sc.stype, slot_ = sc.slot;
+    const int sqadr = sc.sqadr, sb = sc.sb, sroot = sc.sroot, sdim = sc.sdim, sadr = sc.sadr;
+    const double sgain = sc.sgain, scut = sc.scut;
+    wv::keep(stype); wv::keep(slot_);
+    if (!issens) stype = -1;
+    const int aslot = (stype == CM_SENS_ACCELEROMETER) ? slot_ : -1; /* which accelerometer this lane is */
+    if (issens) {
+        double sout[4] = {0, 0, 0, 0};
+        if (sqadr >= 0) sout[0] = sgain * S.qpos[sqadr]; /* actuatorpos (gear * q) and jointpos */
+        else if (need_imu && stype >= CM_SENS_FRAMEQUAT && stype <= CM_SENS_MAGNETOMETER) {
+            double sq[4] = {m->sensor_squat[ls][0], m->sensor_squat[ls][1], m->sensor_squat[ls][2], m->sensor_squat[ls][3]};
+            double q[4], sxmat[9], scvel[6];
+            mulquat(q, S.x.s.xquat[sb], sq);
+            quat2mat(sxmat, q);
+            for (int i = 0; i < 6; ++i) scvel[i] = S.x.s.cvel[sb][i];
+            if (stype == CM_SENS_FRAMEQUAT) { for (int i = 0; i < 4; ++i) sout[i] = q[i]; }
+            else if (stype == CM_SENS_GYRO) mulmatTvec3(sout, sxmat, scvel);
+            else if (stype == CM_SENS_MAGNETOMETER) {
+                double mg[3] = {m->magnetic[0], m->magnetic[1], m->magnetic[2]};
+                mulmatTvec3(sout, sxmat, mg);
+            } else if (aslot >= 0) {
+                /* accelerometer: velocity-product part of the body's com-frame acceleration (incl. -gravity)
+                 * = the body's bias acceleration, which the velocity stage left in the buf tile */
+                double acc_ang[3] = {S.x.s.buf[sb][0], S.x.s.buf[sb][1], S.x.s.buf[sb][2]};
+                double acc_lin[3] = {S.x.s.buf[sb][3], S.x.s.buf[sb][4], S.x.s.buf[sb][5]};
+                double sp[3] = {m->sensor_spos[ls][0], m->sensor_spos[ls][1], m->sensor_spos[ls][2]}, t[3];
+                mulmatvec3(t, S.x.s.xmat[sb], sp);
+                const double *c = S.com[sroot];
+                double *pa = S.accel[aslot];
+                for (int i = 0; i < 3; ++i) { pa[i] = acc_ang[i]; pa[3 + i] = acc_lin[i]; pa[6 + i] = t[i] + S.x.s.xpos[sb][i] - c[i]; }
+                for (int i = 0; i < 9; ++i) pa[9 + i] = sxmat[i];
+                for (int i = 0; i < 6; ++i) pa[18 + i] = scvel[i];
+            }
+        }
+        if (stype != CM_SENS_ACCELEROMETER && (need_imu || sqadr >= 0)) {
+            for (int i = 0; i < 4; ++i) {
+                if (i >= sdim) continue;
+                double v = sout[i];
+                if (scut > 0 && stype != CM_SENS_FRAMEQUAT) v = clampd(v, -scut, scut);
+                if (lastsub) io.sensordata[(size_t)env * io.ssd + sadr + i] = v;
+                if (io.drive_mode) S.sens[sadr + i] = v;
+            }
+        }
+    }
+    return aslot;
+}
 /* what a substep still owes once qacc is in LDS: the accelerometers (they need qacc), the actuator velocities, and -- in the last
  * substep of a launch -- the outputs in HBM.  aslot / sb: which accelerometer this lane is (-1: none) and its body. */
 template <class SH>
 WV_DEVICE void outputs_after_qacc(const PhysIO &io, SH &S, ModelPtr m, int env, int lane, bool isdof, int k_, int nu, double qacc, int aslot, int sb, bool need_imu,
-                                  bool lastsub, double pf_agear, int pf_adof, int ncon, int nefc, int iters, int nguarded) {
+                                  bool lastsub, double av, int ncon, int nefc, int iters, int nguarded) {
+    /* av: this lane's actuator velocity, gear * qvel of the state the substep started from (the caller reads it ahead of the Euler
+     * step: in the two-wave form this function runs BEHIND the Euler step, beside wave 0's next kinematics stage) */
     if (aslot >= 0 && need_imu) {
         const double *pa = S.accel[aslot];
         double acc_ang[3] = {pa[0], pa[1], pa[2]}, acc_lin[3] = {pa[3], pa[4], pa[5]}, acc_dif[3] = {pa[6], pa[7], pa[8]};
@@ -1708,7 +1780,6 @@ WV_DEVICE void outputs_after_qacc(const PhysIO &io, SH &S, ModelPtr m, int env, 
         }
     }
     if (lane < nu) {
-        const double av = pf_agear * S.qvel[pf_adof];
         if (lastsub) io.actuator_velocity[(size_t)env * io.su + lane] = av;
         if (io.drive_mode) S.actvel[lane] = av;
     }
@@ -1899,20 +1970,26 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
                     wv::wait_for(&S.cmd[1], sub1 + 1); /* wave 0's velocity stage has the body forces (cfrc) in LDS */
                     bias_forces_and_qfrc_smooth<NVP>(io, S, m, env, ids, kdamp, kstiff, kref, kgear, klo, khi, kq, ka);
                 }
-                wv::block_barrier(); /* J: the factor of M and qfrc_smooth are in LDS */
+                /* (the sensor stage's constants: requested ahead of the barrier) */
+                const bool lastsub1 = sub1 == nsub - 1 || !io.integrate;
+                const bool need_imu1 = lastsub1 || io.all_outputs_every_substep || (io.drive_mode && sub1 + 2 == nsub);
+                const bool issens1 = lane < m->nsensor && (lastsub1 || io.drive_mode || io.all_outputs_every_substep);
+                const int ls1 = issens1 ? lane : 0;
+                const SensorConsts sens_c1 = request_sensor_consts(m, ls1);
+                /* the sensor stage, in the time this wave used to wait at J for wave 0's Jacobian rows: everything it reads is in LDS
+                 * (poses since F, body velocities and bias accelerations since cmd[1]) and its own drive-level pass has read the
+                 * previous substep's sensor words */
+                const int aslot1 = sensors_before_solve(io, S, m, env, issens1, ls1, sens_c1, need_imu1, lastsub1);
+                CK_STAMP(47);
+                wv::block_barrier(); /* J: the factor of M and qfrc_smooth are in LDS, the sensor stage is done with the body tiles */
                 CK_STAMP(39);
                 /* the factorisation of M + hB, which only this wave's Euler step reads: here, in the time this wave would otherwise
                  * wait for wave 0's solve, instead of on the way to the barrier J, where wave 0 waited for it (+4.6 %) */
                 factor_pair_by_height<NVP, TOPO, 1>(m, h, S, col, colh, lane);
                 /* ---- the stages behind wave 0's constraint solve: operands staged now, while wave 0 assembles and solves ---- */
                 {
-                    const bool lastsub = sub1 == nsub - 1 || !io.integrate;
-                    const bool need_imu = lastsub || io.all_outputs_every_substep || (io.drive_mode && sub1 + 2 == nsub);
-                    const bool need_pos = lastsub || io.drive_mode || io.all_outputs_every_substep;
-                    const bool issens = lane < m->nsensor && need_pos;
-                    const int ls = issens ? lane : 0;
-                    const int stype = issens ? m->sensor_type[ls] : -1, sb = m->sensor_body[ls];
-                    const int aslot = stype == CM_SENS_ACCELEROMETER ? m->sensor_slot[ls] : -1; /* which accelerometer this lane is */
+                    const bool lastsub = lastsub1, need_imu = need_imu1;
+                    const int sb = sens_c1.sb, aslot = aslot1;
                     const int pf_u = lane < nu ? lane : 0, pf_ej = lane < njnt ? lane : 0;
                     const double pf_agear = m->act_gear[pf_u], pf_kdamp = m->dof_damping[isdof ? k_ : 0];
                     const int pf_adof = m->act_dofid[pf_u], pf_ejt = m->jnt_type[pf_ej], pf_eqa = m->jnt_qposadr[pf_ej], pf_eda = m->jnt_dofadr[pf_ej];
@@ -1980,15 +2057,20 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
                         }
                     }
                     if (isdof) S.qacc[k_] = qacc;
+                    const double av = pf_agear * S.qvel[pf_adof]; /* (the actuator velocity of the state the substep started from) */
                     wv::sync();
                     CK_STAMP(12);
-                    outputs_after_qacc(io, S, m, env, lane, isdof, k_, nu, qacc, aslot, sb, need_imu, lastsub, pf_agear, pf_adof, ncon, nefc, iters, nguarded);
-                    CK_STAMP(13);
+                    /* Euler first: wave 0's next substep waits for qpos / qvel / the warm start only, so the barrier E sits right
+                     * behind them and the substep's outputs -- the accelerometers (they read qacc, the partials parked in S.accel and
+                     * cdof, none of which wave 0 touches before the next barrier F), the actuator velocities, the last substep's
+                     * stores -- run beside wave 0's guard and kinematics stage instead of in front of them */
                     if (io.integrate) {
                         euler_step<NVP, TOPO>(S, m, lane, isdof, k_, nv, njnt, h, qacc, lcol, lrowh, dih, pf_kdamp, pf_ejt, pf_eqa, pf_eda);
                     }
+                    CK_STAMP(13);
+                    wv::block_barrier(); /* E: the state of the next substep is in LDS (qpos / qvel / warm start) */
+                    outputs_after_qacc(io, S, m, env, lane, isdof, k_, nu, qacc, aslot, sb, need_imu, lastsub, av, ncon, nefc, iters, nguarded);
                     CK_STAMP(14);
-                    wv::block_barrier(); /* E: the substep is complete (qpos / qvel / warm start of the next one are in LDS) */
                 }
                 if (!io.integrate || ++sub1 >= nsub) return;
             }
@@ -2895,10 +2977,9 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
         const bool need_pos = lastsub || io.drive_mode || io.all_outputs_every_substep;
         const bool issens = lane < m->nsensor && need_pos;
         const int ls = issens ? lane : 0;
-        int stype = m->sensor_type[ls], slot_ = m->sensor_slot[ls];
-        const int sqadr = m->sensor_qadr[ls], sb = m->sensor_body[ls], sroot = m->sensor_root[ls];
-        const int sdim = m->sensor_dim[ls], sadr = m->sensor_adr[ls];
-        const double sgain = m->sensor_gain[ls], scut = m->sensor_cutoff[ls];
+        SensorConsts sens_c;
+        if constexpr (NW == 1) sens_c = request_sensor_consts(m, ls);
+        const int sb = NW == 1 ? sens_c.sb : 0;
         /* this lane's Jacobian row, one dof at a time, straight into registers; lane 63 carries qfrc_smooth */
         double ycol[NVP];
         double jvel = 0, jws = 0;
@@ -2949,53 +3030,9 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
         }
         const double raref = rtype >= 0 ? -rB * jvel - rK * rimp * (rpos - rmargin) : 0.0;
 
-        /* ---- sensors, part 1 (lane = sensor): everything that does not need qacc is final here; the
-         *      accelerometer parks its partial results in LDS because the body tiles are about to be recycled ---- */
-        /* Who reads a substep's sensors: the launch's caller (the last substep's), and in a drive mode the next substep's
-         * encoder models (the joint / actuator positions) and the measurement block the LAST substep's drive pass writes
-         * (the IMU words of the substep before it).  The IMU sensors -- frame quaternion, gyro, magnetometer and the
-         * accelerometer with its second part after the solve -- are therefore evaluated by the last two substeps only. */
-        wv::keep(stype); wv::keep(slot_);
-        if (!issens) stype = -1;
-        const int aslot = (stype == CM_SENS_ACCELEROMETER) ? slot_ : -1; /* which accelerometer this lane is */
-        if (issens) {
-            double sout[4] = {0, 0, 0, 0};
-            if (sqadr >= 0) sout[0] = sgain * S.qpos[sqadr]; /* actuatorpos (gear * q) and jointpos */
-            else if (need_imu && stype >= CM_SENS_FRAMEQUAT && stype <= CM_SENS_MAGNETOMETER) {
-                double sq[4] = {m->sensor_squat[ls][0], m->sensor_squat[ls][1], m->sensor_squat[ls][2], m->sensor_squat[ls][3]};
-                double q[4], sxmat[9], scvel[6];
-                mulquat(q, S.x.s.xquat[sb], sq);
-                quat2mat(sxmat, q);
-                for (int i = 0; i < 6; ++i) scvel[i] = S.x.s.cvel[sb][i];
-                if (stype == CM_SENS_FRAMEQUAT) { for (int i = 0; i < 4; ++i) sout[i] = q[i]; }
-                else if (stype == CM_SENS_GYRO) mulmatTvec3(sout, sxmat, scvel);
-                else if (stype == CM_SENS_MAGNETOMETER) {
-                    double mg[3] = {m->magnetic[0], m->magnetic[1], m->magnetic[2]};
-                    mulmatTvec3(sout, sxmat, mg);
-                } else if (aslot >= 0) {
-                    /* accelerometer: velocity-product part of the body's com-frame acceleration (incl. -gravity)
-                     * = the body's bias acceleration, which the velocity stage left in the buf tile */
-                    double acc_ang[3] = {S.x.s.buf[sb][0], S.x.s.buf[sb][1], S.x.s.buf[sb][2]};
-                    double acc_lin[3] = {S.x.s.buf[sb][3], S.x.s.buf[sb][4], S.x.s.buf[sb][5]};
-                    double sp[3] = {m->sensor_spos[ls][0], m->sensor_spos[ls][1], m->sensor_spos[ls][2]}, t[3];
-                    mulmatvec3(t, S.x.s.xmat[sb], sp);
-                    const double *c = S.com[sroot];
-                    double *pa = S.accel[aslot];
-                    for (int i = 0; i < 3; ++i) { pa[i] = acc_ang[i]; pa[3 + i] = acc_lin[i]; pa[6 + i] = t[i] + S.x.s.xpos[sb][i] - c[i]; }
-                    for (int i = 0; i < 9; ++i) pa[9 + i] = sxmat[i];
-                    for (int i = 0; i < 6; ++i) pa[18 + i] = scvel[i];
-                }
-            }
-            if (stype != CM_SENS_ACCELEROMETER && (need_imu || sqadr >= 0)) {
-                for (int i = 0; i < 4; ++i) {
-                    if (i >= sdim) continue;
-                    double v = sout[i];
-                    if (scut > 0 && stype != CM_SENS_FRAMEQUAT) v = clampd(v, -scut, scut);
-                    if (lastsub) io.sensordata[(size_t)env * io.ssd + sadr + i] = v;
-                    if (io.drive_mode) S.sens[sadr + i] = v;
-                }
-            }
-        }
+        /* ---- sensors, part 1 (sensors_before_solve; two-wave form: wave 1 runs it behind the barrier J) ---- */
+        int aslot = -1;
+        if constexpr (NW == 1) aslot = sensors_before_solve(io, S, m, env, issens, ls, sens_c, need_imu, lastsub);
         CK_STAMP(29);
         if (io.xpos_out && isbody && lastsub) {
             for (int i = 0; i < 3; ++i) io.xpos_out[((size_t)env * io.sb + b) * 3 + i] = S.x.s.xpos[b][i];
@@ -3487,7 +3524,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
         CK_STAMP(12);
 
         /* ---- sensors, part 2 (the accelerometer needs qacc), actuator velocities, the last substep's outputs ---- */
-        outputs_after_qacc(io, S, m, env, lane, isdof, k_, nu, qacc, aslot, sb, need_imu, lastsub, pf_agear, pf_adof, ncon, nefc, iters, nguarded);
+        outputs_after_qacc(io, S, m, env, lane, isdof, k_, nu, qacc, aslot, sb, need_imu, lastsub, pf_agear * S.qvel[pf_adof], ncon, nefc, iters, nguarded);
         if (!io.integrate) break;
         CK_STAMP(13);
 

@@ -91,11 +91,11 @@ for n in (int(a) for a in (sys.argv[1:] or ["512", "4096"])):
         print("nenv %d, %d substeps per launch, TWO WAVES PER ENV: %.3f ms/step; wave 0's last substep %.0f cycles; nefc mean %.1f iters mean %.1f"
               % (n, NSUB, ms, tot0, info[:, 1].mean(), info[:, 2].mean()))
         for nm, a, c in [("w0 drive io + kinematics (incl. F)", 0, 1), ("w0 geoms", 1, 17), ("w0 collision (+ drive io)", 17, 33), ("w0 WAIT at X", 33, 5),
-                         ("w0 velocity -> cfrc", 5, 24), ("w0 rows+J", 24, 34), ("w0 WAIT at J + sensors1", 34, 8), ("w0 halfsolve", 8, 9),
+                         ("w0 velocity -> cfrc", 5, 24), ("w0 rows+J", 24, 34), ("w0 WAIT at J (+ read-outs)", 34, 8), ("w0 halfsolve", 8, 9),
                          ("w0 A", 9, 10), ("w0 pgs", 10, 11), ("w0 hand f over, WAIT for wave 1's qacc + Euler", 11, 37),
-                         ("w1 stage L row / Y column, WAIT at P", 39, 12), ("w1 qacc", 39, 12), ("w1 accelerometers + outputs", 12, 13), ("w1 euler", 13, 14),
+                         ("w1 factor M+hB, stage L row / Y column, WAIT at P, qacc", 39, 12), ("w1 euler (then E)", 12, 13), ("w1 accelerometers + outputs (behind E)", 13, 14),
                          ("w1 WAIT at F", 35, 36), ("w1 com+cinert+cdof", 36, 2), ("w1 crba + M columns", 2, 3), ("w1 WAIT at X", 3, 38),
-                         ("w1 drive io + factor", 38, 4), ("w1 wait cfrc + bias proj", 4, 6), ("w1 qfrc_smooth", 6, 7), ("w1 WAIT at J", 7, 39), ("w1 busy (F..factor done)", 36, 4), ("w0 F -> J (its parallel part)", 1, 8)]:
+                         ("w1 drive io + factor", 38, 4), ("w1 wait cfrc + bias proj", 4, 6), ("w1 qfrc_smooth", 6, 7), ("w1 sensors1", 7, 47), ("w1 WAIT at J", 47, 39), ("w1 busy (F..factor done)", 36, 4), ("w0 F -> J (its parallel part)", 1, 8)]:
             print("  %-36s %9.0f cycles  %5.1f%%" % (nm, dur(a, c), 100 * dur(a, c) / tot0))
         hw0, hw1 = st[:, 40], st[:, 41]
         simd = lambda h: (h >> 4) & 3
