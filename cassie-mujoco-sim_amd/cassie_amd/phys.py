@@ -27,7 +27,7 @@ DRIVE_OFF, DRIVE_TORQUE, DRIVE_PD = 0, 1, 2
 MEAS_DRIVE_POS, MEAS_DRIVE_VEL, MEAS_DRIVE_TORQUE, MEAS_JOINT_POS, MEAS_JOINT_VEL = 0, 10, 20, 30, 36
 MEAS_ORIENTATION, MEAS_ANGVEL, MEAS_LINACC, MEAS_MAG, MEAS_DIM = 42, 46, 49, 52, 56
 
-FLAG_EULERDAMP, FLAG_WARMSTART, FLAG_REFSAFE, FLAG_HFDENSE, FLAG_HFMULTI = 1, 2, 4, 8, 16      # CM_FLAG_* (cm_model.h)
+FLAG_EULERDAMP, FLAG_WARMSTART, FLAG_REFSAFE, FLAG_HFDENSE, FLAG_HFMULTI, FLAG_HFPRISM = 1, 2, 4, 8, 16, 32      # CM_FLAG_* (cm_model.h)
 WARN_CONTACT_FULL, WARN_CONSTRAINT_FULL, WARN_UNSUPPORTED_PAIR, WARN_DIVERGED = 1, 2, 4, 8
 
 # joint configuration the reference writes at init (reference src/cassiemujoco.c:1023-1028)

@@ -661,6 +661,7 @@ void cassie_sim_set_hfield_size(cassie_sim_t *c, double size[4]) { memcpy(phys_m
 float *cassie_sim_hfielddata(cassie_sim_t *c) { return phys_model_hfield_data(c->m); }
 void cassie_sim_set_hfield_dense_sampling(cassie_sim_t *c, bool on) { if (c) phys_model_set_flag(c->m, CM_FLAG_HFDENSE, on ? 1 : 0); }
 void cassie_sim_set_hfield_multi_contact(cassie_sim_t *c, bool on) { if (c) phys_model_set_flag(c->m, CM_FLAG_HFMULTI, on ? 1 : 0); }
+void cassie_sim_set_hfield_prism_contacts(cassie_sim_t *c, bool on) { if (c) phys_model_set_flag(c->m, CM_FLAG_HFPRISM, on ? 1 : 0); }
 void cassie_sim_set_hfielddata(cassie_sim_t *c, float *data)
 {
     float *a = phys_model_hfield_data(c->m);

@@ -41,15 +41,22 @@ extern "C" {
 #define CM_HF_SLOTS  6       /* sample spheres per height-field pair: two ends + at most four interior ones */
 #define CM_HF_MAXC    4      /* contacts per capsule / height-field pair with CM_FLAG_HFMULTI */
 #define CM_HF_SLOTS_DENSE 10 /* the same with CM_FLAG_HFDENSE: two ends + at most eight interior ones (six pairs per wave pass) */
-/* (CM_MAXCON / CM_MAXEFC can be raised from the command line for ORACLE-ONLY studies of what the caps and the collision
- * definitions cost in fidelity -- tests/collision_fidelity_study.py; the kernel's row stages are built around 63 = one row per lane) */
+/* CAPACITIES of the contact list and of the constraint rows of an env-step (the oracle's arrays, the read-out block, the widest
+ * kernel instantiation).  What a MODEL may use of them is cm_model_t::maxcon / maxefc: 32 contacts and 127 rows for models on the
+ * 32-dof Cassie dof tree (cassie.xml, cassie_hfield.xml: the step kernel has a 127-row instantiation whose solve is spread over
+ * both wavefronts of an env for them), 16 and 63 -- one constraint row per lane of ONE wavefront -- for every other model.  Past a
+ * model's caps later contacts / rows are dropped and a warning bit is raised, in oracle and kernel alike.
+ * (Both can be raised from the command line for ORACLE-ONLY studies: tests/collision_fidelity_study.py.) */
 #ifndef CM_MAXCON
-#define CM_MAXCON    16      /* contacts kept per env-step */
+#define CM_MAXCON    32      /* contacts kept per env-step, at most */
 #endif
 #define CM_MAXSLIDE  3       /* slide joints ahead of a body's rotational joint (kin_simple) */
 #ifndef CM_MAXEFC
-#define CM_MAXEFC    63      /* constraint rows per env-step (lane 63 is the qfrc_smooth column) */
+#define CM_MAXEFC    127     /* constraint rows per env-step, at most (two wavefronts of 64 lanes: 127 rows + the qfrc_smooth column) */
 #endif
+#define CM_MAXCON_NARROW 16  /* the caps of models without a 127-row kernel instantiation (and of the one-wavefront instantiations) */
+#define CM_MAXEFC_NARROW 63
+#define CM_HP_MAXS   16      /* CM_FLAG_HFPRISM: sample spheres along a capsule's axis, at most */
 
 /* joint types (same numbering as MuJoCo's mjtJoint) */
 enum { CM_JNT_FREE = 0, CM_JNT_BALL = 1, CM_JNT_SLIDE = 2, CM_JNT_HINGE = 3 };
@@ -71,6 +78,12 @@ enum { CM_CNSTR_EQUALITY = 0, CM_CNSTR_LIMIT_JOINT = 3, CM_CNSTR_CONTACT_FRICTIO
                                    (ties: lower sample index) -- instead of the two-contact rule; towards MuJoCo's one contact per
                                    penetrated prism.  Off by default: a Cassie standing on both feet then needs 44 constraint rows
                                    instead of 28 */
+#define CM_FLAG_HFPRISM   32u   /* sphere / capsule vs height field: ONE CONTACT PER PENETRATED GRID TRIANGLE (MuJoCo reports one per penetrated
+                                   prism, which is why model/cassie_hfield.xml:4 asks for nconmax = 300) instead of at most two per capsule: the
+                                   capsule's axis is sampled no further apart than its radius, every grid triangle under the capsule keeps its
+                                   deepest sample sphere (ties: the sample nearer the +axis end), and every triangle whose deepest sample is within
+                                   the margin gives a contact, in grid order.  Off by default: a Cassie standing on rough terrain
+                                   then needs 36 rows on average and up to the 127 of the widest instantiation.  Overrides HFMULTI / HFDENSE. */
 #define CM_FLAG_HFDENSE    8u   /* capsule vs height field: up to CM_HF_SLOTS_DENSE - 2 interior samples instead of CM_HF_SLOTS - 2 (a grid
                                    cell apart along Cassie's 0.43 m shin on the 5 cm grid of example/test_hfield.py); off by default: -10 % on
                                    BASELINE config 4 */
@@ -102,6 +115,7 @@ typedef struct cm_model {
     int hfield_nrow, hfield_ncol;
     int npair_always;      /* simple pairs [0, npair_always) are always tested; [npair_always, npair_simple) involve a static
                             * non-plane geom (stairs ...) and are skipped as a block while all of those are out of reach */
+    int maxcon, maxefc;    /* contacts / constraint rows an env-step of this model may use (<= CM_MAXCON / CM_MAXEFC, see there) */
     int npair_simple;      /* pairs [0, npair_simple) give <= 2 contacts and are tested one per lane; the rest
                             * (plane-box, box-box) are tested by the whole wave, one pair at a time */
     double timestep, tolerance, meaninertia;

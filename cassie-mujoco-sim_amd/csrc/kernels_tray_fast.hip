@@ -11,7 +11,7 @@ bool launch_fast_tray(dim3 grid, hipStream_t s, PhysIO io) {
  * wherever a workgroup of the fast kernel has retired (the two-wave form of the pass wants two SIMDs with 256 free registers each
  * on one CU, and waited 4 ms for them behind the other env range's one-wave workgroups) */
 bool launch_full_tray_walk(dim3 grid, hipStream_t s, PhysIO io) {
-    hipLaunchKernelGGL((cassie_step_kernel<40, TopoCassieTray38, FEAT_WAVEPAIRS, CM_MAXEFC, 1, true>), grid, dim3(WV_WAVE), 0, s, io);
+    hipLaunchKernelGGL((cassie_step_kernel<40, TopoCassieTray38, FEAT_WAVEPAIRS, MID_ROWS, 1, true>), grid, dim3(WV_WAVE), 0, s, io);
     return hipGetLastError() == hipSuccess;
 }
 }  // namespace ck

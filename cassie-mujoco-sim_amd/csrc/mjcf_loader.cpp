@@ -12,6 +12,7 @@
  * outside the subset fails loudly instead of simulating something else.
  */
 #include "host_model.h"
+#include "topo_static.h"
 
 #include <algorithm>
 #include <cmath>
@@ -1363,6 +1364,12 @@ bool HostModel::compile(cm_model_t *o, std::string *err) const {
             o->sensor_slot[s] = slot;
         }
     }
+    /* what an env-step of this model may use of the contact list and of the constraint rows (cm_model.h: CM_MAXCON / CM_MAXEFC): the
+     * 127-row instantiation of the step kernel exists for the 32-dof Cassie dof tree */
+    bool cassie32 = nv == ck::TopoCassie32::nv && o->kin_simple && o->maxdepth <= ck::TopoCassie32::body_levels;
+    for (int k = 0; cassie32 && k < nv; ++k) cassie32 = o->dof_ancmask[k] == ck::TopoCassie32::table[k];
+    o->maxcon = cassie32 ? CM_MAXCON : CM_MAXCON_NARROW;
+    o->maxefc = cassie32 ? CM_MAXEFC : CM_MAXEFC_NARROW;
     return true;
 }
 

@@ -92,6 +92,9 @@ struct phys_batch {
      * -- in pinned host memory the device writes -- the number of envs the last launch of a range handed over */
     int *d_handover_list = nullptr, *d_handover_count = nullptr;
     int *h_handover_seen = nullptr, *d_handover_seen = nullptr;
+    /* ... and the same for the second list: what the 63-row pass hands on to the 127-row pass (models on the Cassie dof tree) */
+    int *d_handover_list2 = nullptr, *d_handover_count2 = nullptr;
+    int *h_handover_seen2 = nullptr, *d_handover_seen2 = nullptr;
     bool fast_rows = true;          /* use the row-capped fast instantiation where one exists (phys_batch_set_fast_rows) */
     int waves_per_env = 2;          /* two-wave form of the fast instantiations (phys_batch_set_waves_per_env) */
     int waves_per_env_tray = DEFAULT_TRAY_WAVES; /* ... of the 40-dof instantiations (CASSIE_TRAY_TWO_WAVES=0/1 overrides the default: A/B aid) */
@@ -225,11 +228,12 @@ static int launch(phys_batch *b, int nsub, int integrate, hipStream_t s, bool sc
             ++b->ev_used;
         }
     }
-    /* a row-capped fast instantiation with the full one behind it: the fast kernel's record of completed substeps, and the
-     * hand-over list the pass behind it walks -> the grid of that pass */
-    auto fast_then_full = [&](bool fast) {
+    /* a row-capped fast instantiation with the passes behind it: the fast kernel's record of completed substeps, the launch in
+     * chunks, and the hand-over lists the passes walk -> their grids */
+    ck::HandoverLists hl = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    ck::TierGrids tg = {grid, grid};
+    auto tiers = [&](bool fast) {
         io.progress = fast ? b->d_progress : nullptr;
-        dim3 pass_grid = grid;
         io.nchunk = 1;
         if (fast && b->d_chunk_flag && b->chunks_allowed && (n == b->nenv ? b->chunks : b->chunks_range) > 1 && n >= CHUNK_MIN_ENVS && n % 8 == 0 && nsub >= 2 * CHUNK_MIN_SUBSTEPS &&
             stream_may_chunk(b, s)) {
@@ -249,33 +253,35 @@ static int launch(phys_batch *b, int nsub, int integrate, hipStream_t s, bool sc
             io.chunk_flag = b->d_chunk_flag;
             io.chunk_fault = b->d_chunk_fault;
         }
-        if (fast && b->d_handover_list) {
+        if (fast && b->d_handover_list && b->d_handover_list2) {
             /* the pass behind the fast kernel walks the hand-over list with a small grid: twice what the range's last launch
-             * handed over (the launcher learns that a launch late, through host memory) plus 16, at most one workgroup per env */
-            io.handover_list = b->d_handover_list; io.handover_count = b->d_handover_count + 2 * (size_t)env0;
-            io.handover_seen = b->d_handover_seen + env0;
-            const int seen = b->h_handover_seen[env0];
-            const long want = 2L * (seen > 0 ? seen : 0) + 16;
-            pass_grid = dim3((unsigned)(want < n ? want : n));
+             * handed over (the launcher learns that a launch late, through host memory) plus 16, at most one workgroup per env;
+             * the 127-row pass behind that one likewise, plus 8 */
+            hl.list1 = b->d_handover_list; hl.count1 = b->d_handover_count + 2 * (size_t)env0; hl.seen1 = b->d_handover_seen + env0;
+            hl.list2 = b->d_handover_list2; hl.count2 = b->d_handover_count2 + 2 * (size_t)env0; hl.seen2 = b->d_handover_seen2 + env0;
+            const int seen = b->h_handover_seen[env0], seen2 = b->h_handover_seen2[env0];
+            const long want = 2L * (seen > 0 ? seen : 0) + 16, want2 = 2L * (seen2 > 0 ? seen2 : 0) + 8;
+            tg.mid = dim3((unsigned)(want < n ? want : n));
+            tg.wide = dim3((unsigned)(want2 < n ? want2 : n));
         }
-        return pass_grid;
     };
     if (matches(ck::TopoCassie32::table, ck::TopoCassie32::nv, ck::TopoCassie32::body_levels)) {
-        /* stepping launches of the two Cassie instantiations go through the row-capped fast instantiation first; the full one
-         * behind it finishes the envs that met a substep with more rows (and is the only one for forward / read-out passes) */
+        /* stepping launches of the two Cassie instantiations go through the row-capped fast instantiation first; the 63-row pass
+         * behind it finishes the envs that met a substep with more rows, the 127-row pass behind that one what is left; forward /
+         * read-out passes and small batches take the 127-row instantiation alone */
         const bool fast = b->fast_rows && integrate && !wp && !io.ext && b->d_progress;
-        const dim3 pass_grid = fast_then_full(fast);
-        if (!hf && !wp) { launched = ck::launch_step_cassie(grid, pass_grid, s, io, fast, ev_after, b->waves_per_env); ev_after = nullptr; }
-        else if (hf && !wp) { launched = ck::launch_step_cassie_hfield(grid, pass_grid, s, io, fast, ev_after, b->waves_per_env); ev_after = nullptr; }
+        tiers(fast);
+        if (!hf && !wp) { launched = ck::launch_step_cassie(grid, tg, s, io, hl, fast, ev_after, b->waves_per_env); ev_after = nullptr; }
+        else if (hf && !wp) { launched = ck::launch_step_cassie_hfield(grid, tg, s, io, hl, fast, ev_after, b->waves_per_env); ev_after = nullptr; }
         else launched = ck::launch_step_cassie_all(grid, s, io);
     } else if (matches(ck::TopoCassieTray38::table, ck::TopoCassieTray38::nv, ck::TopoCassieTray38::body_levels)) {
         /* the 40-dof model: a fast instantiation of 47 rows (the boxes resting on the tray take it to 32 .. 40 routinely) -- one wave
-         * per env and the Gram matrix on the matrix core by default, or the two-wave form -- with the full one behind it */
+         * per env and the Gram matrix on the matrix core by default, or the two-wave form -- with the 63-row one behind it */
         const bool plain = integrate && !io.ext && !hf;
         const bool two = plain && b->waves_per_env_tray == 2;
         const bool fast = plain && b->fast_rows && b->d_progress;
-        const dim3 pass_grid = fast_then_full(fast);
-        launched = ck::launch_step_tray(grid, pass_grid, s, io, hf, fast, ev_after, two ? 2 : 1); ev_after = nullptr;
+        tiers(fast);
+        launched = ck::launch_step_tray(grid, tg.mid, s, io, hl, hf, fast, ev_after, two ? 2 : 1); ev_after = nullptr;
     }
     else launched = ck::launch_step_generic(grid, s, io, hm.nv > 32);
     if (ev_after) (void)hipEventRecord(ev_after, s);
@@ -407,6 +413,12 @@ phys_batch_t *phys_batch_create(const cm_model_t *model, int nenv, int device) {
     ok = ok && hip_ok(hipHostMalloc((void **)&b->h_handover_seen, sizeof(int) * (size_t)nenv, hipHostMallocMapped), "hipHostMalloc(hand-over seen)");
     if (ok) memset(b->h_handover_seen, 0, sizeof(int) * (size_t)nenv);
     ok = ok && hip_ok(hipHostGetDevicePointer((void **)&b->d_handover_seen, b->h_handover_seen, 0), "hipHostGetDevicePointer");
+    ok = ok && hip_ok(hipMalloc((void **)&b->d_handover_list2, sizeof(int) * (size_t)nenv), "hipMalloc(second hand-over list)");
+    ok = ok && hip_ok(hipMalloc((void **)&b->d_handover_count2, sizeof(int) * 2 * (size_t)nenv), "hipMalloc(second hand-over counts)");
+    ok = ok && hip_ok(hipMemset(b->d_handover_count2, 0, sizeof(int) * 2 * (size_t)nenv), "hipMemset(second hand-over counts)");
+    ok = ok && hip_ok(hipHostMalloc((void **)&b->h_handover_seen2, sizeof(int) * (size_t)nenv, hipHostMallocMapped), "hipHostMalloc(second hand-over seen)");
+    if (ok) memset(b->h_handover_seen2, 0, sizeof(int) * (size_t)nenv);
+    ok = ok && hip_ok(hipHostGetDevicePointer((void **)&b->d_handover_seen2, b->h_handover_seen2, 0), "hipHostGetDevicePointer");
     ok = ok && hip_ok(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking), "hipStreamCreate");
     ok = ok && hip_ok(hipEventCreate(&b->ev0), "hipEventCreate") && hip_ok(hipEventCreate(&b->ev1), "hipEventCreate");
     ok = ok && hip_ok(hipEventCreateWithFlags(&b->ev_mark, hipEventDisableTiming), "hipEventCreate");
@@ -437,6 +449,9 @@ void phys_batch_free(phys_batch_t *b) {
     if (b->d_handover_list) (void)hipFree(b->d_handover_list);
     if (b->d_handover_count) (void)hipFree(b->d_handover_count);
     if (b->h_handover_seen) (void)hipHostFree(b->h_handover_seen);
+    if (b->d_handover_list2) (void)hipFree(b->d_handover_list2);
+    if (b->d_handover_count2) (void)hipFree(b->d_handover_count2);
+    if (b->h_handover_seen2) (void)hipHostFree(b->h_handover_seen2);
     if (b->h_chunk_fault) (void)hipHostFree(b->h_chunk_fault);
     for (auto &e : b->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (b->d_drive) (void)hipFree(b->d_drive);
@@ -884,10 +899,22 @@ int phys_batch_debug_handover_pending(phys_batch_t *b) {
     if (!b->d_handover_count) return 0;
     (void)hipSetDevice(b->device);
     std::vector<int> h(2 * (size_t)b->nenv);
-    if (!quiesce(b) || !hip_ok(hipMemcpy(h.data(), b->d_handover_count, sizeof(int) * h.size(), hipMemcpyDeviceToHost), "hand-over count download")) return -1;
     long total = 0;
-    for (int v : h) total += v < 0 ? -(long)v : v;
+    if (!quiesce(b)) return -1;
+    for (int *d : {b->d_handover_count, b->d_handover_count2}) {
+        if (!d) continue;
+        if (!hip_ok(hipMemcpy(h.data(), d, sizeof(int) * h.size(), hipMemcpyDeviceToHost), "hand-over count download")) return -1;
+        for (int v : h) total += v < 0 ? -(long)v : v;
+    }
     return total > 0x7fffffff ? 0x7fffffff : (int)total;
+}
+
+/* envs the 63-row pass of the last stepping launch over [env0, ...) handed on to the 127-row pass (what that pass reported) */
+int phys_batch_wide_pass_envs(phys_batch_t *b, int env0) {
+    if (!b || env0 < 0 || env0 >= b->nenv || !b->h_handover_seen2) return -1;
+    (void)hipSetDevice(b->device);
+    if (!quiesce(b)) return -1;
+    return *(volatile int *)(b->h_handover_seen2 + env0);
 }
 
 int phys_batch_set_balance(phys_batch_t *b, int on) {

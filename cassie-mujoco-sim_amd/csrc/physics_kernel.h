@@ -63,6 +63,8 @@ namespace ck {
 constexpr int NB = CM_MAXBODY;
 constexpr int NG = CM_MAXGEOM;
 constexpr int NROW = 64;       /* rows 0..62 constraints, column 63 = qfrc_smooth */
+constexpr int MID_ROWS = CM_MAXEFC_NARROW;  /* 63: one constraint row per lane of one wavefront (+ the qfrc_smooth column in lane 63) */
+constexpr int WIDE_ROWS = CM_MAXEFC;        /* 127: the solve spread over both wavefronts of an env (rows 64 .. 126 + the qfrc_smooth column on wave 1) */
 constexpr int FAST_ROWS = 31;  /* rows of the row-capped fast instantiation (+ the qfrc_smooth column: half of the full tile) */
 constexpr int FAST_ROWS_TRAY = 47; /* the 40-dof model's fast instantiation: Cassie + tray + cube at rest use 32 .. 40 rows (+ the qfrc_smooth row: three blocks of 16) */
 constexpr int NSTAMP = 48;   /* 0..15 stage boundaries, 16..32 sub-stage stamps, 33..39 the two-wave form's barrier arrivals / departures,
@@ -152,24 +154,52 @@ struct PhysIO {
     volatile int *chunk_fault;
     int *handover_list, *handover_count;
     volatile int *handover_seen;
+    /* Three tiers since round 5: fast (31 / 47 rows) -> mid (63 rows, 16 contacts) -> wide (127 rows, 32 contacts; models whose
+     * cm_model_t::maxefc allows it).  has_next: an instantiation with more rows runs behind this one -- a substep that needs more
+     * rows or contacts than this one holds is handed over instead of being capped; handover_out_list / handover_out_count: where this
+     * pass appends the envs it hands over (the list the pass behind it walks; same layout as handover_list / handover_count). */
+    int has_next;
+    int *handover_out_list, *handover_out_count;
 };
 
-/* MAXR: constraint rows this instantiation can hold (CM_MAXEFC, or fewer in the row-capped fast instantiation, see
+/* MAXR: constraint rows this instantiation can hold (WIDE_ROWS, MID_ROWS, or fewer in the row-capped fast instantiations, see
  * cassie_step_kernel); the Y tile has one more row, the qfrc_smooth column */
-template <int NVP, int NL = NVP * (NVP + 1) / 2, int MAXR = CM_MAXEFC>
+template <int NVP>
+struct BodyTiles { /* position / velocity stage tiles */
+    double xpos[NB][3], xquat[NB][4], xmat[NB][9], xipos[NB][3];
+    double xanchor[CM_MAXJNT][3], xaxis[CM_MAXJNT][3];
+    double cinert[NB][10], crb[NB][10];
+    double cvel[NB][6], cfrc[NB][6];
+    double cdof_dot[NVP][6], buf[NVP][6];
+    double geom_xpos[NG][3], geom_xmat[NG][9];
+};
+/* the body tiles and the staged matrix Y share their LDS (the tiles are dead once the Jacobian rows are formed) -- except in the
+ * 127-row instantiation, whose rows 64 .. 126 are formed in a second pass while the staged rows of the first are already parked */
+template <int NVP, int MAXR, bool SEPARATE> struct TilesAndY {
+    static constexpr int YP = NVP + 2;
+    union { BodyTiles<NVP> s; double Yr[MAXR + 1][YP]; };
+};
+template <int NVP, int MAXR> struct TilesAndY<NVP, MAXR, true> {
+    static constexpr int YP = NVP + 2;
+    BodyTiles<NVP> s;
+    double Yr[MAXR + 1][YP];
+    /* what the row stages hand to the solve per row (the rows of the second pass are wave 1's in the solve): regulariser R,
+     * reference acceleration, J . qacc_warmstart, and 1.0 for rows that are clamped at zero / 0.0 for equality rows / -1.0 for no row */
+    double rowt[MAXR + 1][4];
+    /* the exchange between the two waves' halves of a Gauss-Seidel sweep: v[w] = sum over wave w's rows of (row of Y) x (its step),
+     * the joint-space image of the steps -- the other wave's residuals take it in through their own rows of Y; sums[] = the waves'
+     * parts of the warm start's cost and of a sweep's cost change, verdict words */
+    double vx[2][NVP];
+    double sums[8];
+    int turn[4];
+};
+template <int NVP, int NL = NVP * (NVP + 1) / 2, int MAXR = MID_ROWS>
 struct EnvShared {
     static constexpr int YP = NVP + 2; /* leading dimension of the Y staging tile: 16-byte aligned rows, conflict-free */
-    union {
-        struct { /* position / velocity stage tiles */
-            double xpos[NB][3], xquat[NB][4], xmat[NB][9], xipos[NB][3];
-            double xanchor[CM_MAXJNT][3], xaxis[CM_MAXJNT][3];
-            double cinert[NB][10], crb[NB][10];
-            double cvel[NB][6], cfrc[NB][6];
-            double cdof_dot[NVP][6], buf[NVP][6];
-            double geom_xpos[NG][3], geom_xmat[NG][9];
-        } s;
-        double Yr[MAXR + 1][YP];    /* Y staged row-major by constraint row for broadcast reads; row MAXR = the qfrc_smooth column */
-    } x;
+    static constexpr bool WIDE = MAXR > MID_ROWS;
+    static constexpr int MAXC = WIDE ? CM_MAXCON : CM_MAXCON_NARROW; /* contacts the instantiation's list holds */
+    /* x.s: the body-stage tiles; x.Yr: Y staged row-major by constraint row for broadcast reads, row MAXR = the qfrc_smooth column */
+    TilesAndY<NVP, MAXR, WIDE> x;
     /* L^T D L factors of M and of M + hB, rows stored as LPack<TOPO, NVP> says (NL entries): a full lower triangle,
      * entry (k, i <= k) at k(k+1)/2 + i, or block-dense rows for a compile-time topology that asks for them */
     double Lp[NL], LHp[NL];
@@ -190,12 +220,12 @@ struct EnvShared {
      * speed in rad/s, encoder counts and scale; the launch's command (torque + STO, or PD targets and gains) */
     double drv_c[CM_NUM_DRIVES][10], drv_jc[CM_NUM_JOINTS][2];
     /* contacts */
-    double c_dist[CM_MAXCON], c_pos[CM_MAXCON][3], c_frame[CM_MAXCON][9], c_fri[CM_MAXCON][3];
-    double c_solref[CM_MAXCON][2], c_solimp[CM_MAXCON][5], c_margin[CM_MAXCON];
-    int c_dim[CM_MAXCON], c_g1[CM_MAXCON], c_g2[CM_MAXCON], c_pair[CM_MAXCON];
-    int c_root[CM_MAXCON][2];               /* tree roots of the two bodies, their dof chains, summed inverse weights */
-    unsigned long long c_dofmask[CM_MAXCON][2];
-    double c_tran[CM_MAXCON];
+    double c_dist[MAXC], c_pos[MAXC][3], c_frame[MAXC][9], c_fri[MAXC][3];
+    double c_solref[MAXC][2], c_solimp[MAXC][5], c_margin[MAXC];
+    int c_dim[MAXC], c_g1[MAXC], c_g2[MAXC], c_pair[MAXC];
+    int c_root[MAXC][2];               /* tree roots of the two bodies, their dof chains, summed inverse weights */
+    unsigned long long c_dofmask[MAXC][2];
+    double c_tran[MAXC];
     /* two-wave form (NW = 2): cmd[0] = what the waves tell each other at the workgroup barriers -- 0 = carry on, 1 = this env's
      * launch ends here (wave 0: diverged state, or the row-capped instantiation hands the substep over), 2 = wave 1 found a
      * diverged qacc; cmd[1] = the substep (+ 1) whose body forces wave 0's velocity stage has put in LDS, cmd[2] = the substep
@@ -850,6 +880,121 @@ WV_DEVICE void write_raw_contact(SH &S, int slot, int pair, const RawContact &r)
     S.c_dist[slot] = r.dist;
     S.c_pair[slot] = pair;
     for (int i = 0; i < 3; ++i) { S.c_pos[slot][i] = r.pos[i]; S.c_frame[slot][i] = r.normal[i]; S.c_frame[slot][3 + i] = r.tangent[i]; }
+}
+
+/* CM_FLAG_HFPRISM (same definition, same candidate order as oracle/cassie_oracle.c hfield_prism_contacts): ONE CONTACT PER
+ * PENETRATED GRID TRIANGLE under every sphere / capsule that has a height-field pair.  Lane = pair first (its capsule in the
+ * height field's frame, the cells under its bounding rectangle, its sample count -> a record in `hp`), then lane = (pair, cell,
+ * triangle) KEY in the oracle's order -- pair order, cells row-major, the triangle (v00, v10, v01) of a cell before (v11, v01, v10) --
+ * 64 keys to a round: a key's lane walks the capsule's sample spheres (no further apart than the radius; exact culls by plan
+ * distance and by the cell's highest corner skip most), keeps the deepest, and a key whose deepest sample is within the margin is a
+ * contact.  Ballots put the contacts into the list in key order, which is the oracle's.  Returns the number of contacts FOUND;
+ * those past the list's `room` slots are not written (the caller caps or hands the substep over).
+ * hp: scratch, HP_REC doubles per height-field pair of the model (the idle velocity tiles). */
+constexpr int HP_REC = 16;
+template <class SH>
+WV_DEVICE int hfield_prism_wave(SH &S, ModelPtr m, const float *data, int lane, double *hp, int room) {
+    const int nhf = m->nhfpair, nc = m->hfield_ncol, nr = m->hfield_nrow;
+    if (!data || nr < 2 || nc < 2) return 0;
+    const double sx = m->hfield_size[0], sy = m->hfield_size[1], sz = m->hfield_size[2];
+    const double dx = 2 * sx / (nc - 1), dy = 2 * sy / (nr - 1);
+    /* ---- lane = pair ---- */
+    int nkeys = 0;
+    if (lane < nhf) {
+        const int p = m->hfpair[lane];
+        const int g1 = m->pair_geom1[p], g2 = m->pair_geom2[p], t2 = m->pair_type[p] >> 8;
+        const double margin = m->pair_margin[p], r = m->pair_size[p][3], h = t2 == CM_GEOM_CAPSULE ? m->pair_size[p][4] : 0.0;
+        const double *ph = S.x.s.geom_xpos[g1], *mh = S.x.s.geom_xmat[g1], *pc = S.x.s.geom_xpos[g2], *mc = S.x.s.geom_xmat[g2];
+        const double axw[3] = {mc[2], mc[5], mc[8]}, d[3] = {pc[0] - ph[0], pc[1] - ph[1], pc[2] - ph[2]};
+        double p0[3], ax[3];
+        mulmatTvec3(p0, mh, d);
+        mulmatTvec3(ax, mh, axw);
+        const double reach = r + (margin > 0 ? margin : 0);
+        int i0 = 0, j0 = 0, wj = 1, ncell = 0;
+        if (!(p0[2] - h * fabs(ax[2]) - r > sz + margin)) {
+            const double xa = p0[0] - h * fabs(ax[0]) - reach, xb = p0[0] + h * fabs(ax[0]) + reach;
+            const double ya = p0[1] - h * fabs(ax[1]) - reach, yb = p0[1] + h * fabs(ax[1]) + reach;
+            int j1 = (int)floor((xb + sx) / dx), i1 = (int)floor((yb + sy) / dy);
+            j0 = (int)floor((xa + sx) / dx); i0 = (int)floor((ya + sy) / dy);
+            if (j0 < 0) j0 = 0;
+            if (i0 < 0) i0 = 0;
+            if (j1 > nc - 2) j1 = nc - 2;
+            if (i1 > nr - 2) i1 = nr - 2;
+            if (j1 >= j0 && i1 >= i0) { wj = j1 - j0 + 1; ncell = wj * (i1 - i0 + 1); }
+        }
+        int ns = h > 0 ? 1 + (int)ceil(2 * h / r) : 1;
+        if (ns > CM_HP_MAXS) ns = CM_HP_MAXS;
+        double *rec = hp + HP_REC * lane;
+        for (int i = 0; i < 3; ++i) { rec[i] = p0[i]; rec[3 + i] = ax[i]; }
+        rec[6] = r; rec[7] = h; rec[8] = margin; rec[9] = (double)ns; rec[10] = (double)i0; rec[11] = (double)j0; rec[12] = (double)wj;
+        rec[13] = (double)p; rec[14] = (double)g2;
+        nkeys = 2 * ncell;
+    }
+    int endx = nkeys;
+#pragma unroll
+    for (int dlt = 1; dlt < WV_WAVE; dlt *= 2) { const int t = wv::shfl_i(endx, (lane - dlt) & 63); if (lane >= dlt) endx += t; }
+    const int total = wv::shfl_i(endx, WV_WAVE - 1);
+    const int start = endx - nkeys;
+    wv::sync();
+    /* ---- lane = key ---- */
+    int ncon = 0;
+    const int g1h = m->hfield_geom;
+    for (int base = 0; base < total; base += WV_WAVE) {
+        const int t = base + lane;
+        const bool act = t < total;
+        int h = 0, hstart = 0;
+        for (int hh = 0; hh < nhf; ++hh) {
+            const int st = wv::shfl_i(start, hh), en = wv::shfl_i(endx, hh);
+            if (t >= st && t < en) { h = hh; hstart = st; }
+        }
+        const double *rec = hp + HP_REC * h;
+        const double p0[3] = {rec[0], rec[1], rec[2]}, ax[3] = {rec[3], rec[4], rec[5]}, r = rec[6], hl = rec[7], margin = rec[8];
+        const int ns = act ? (int)rec[9] : 0, i0 = (int)rec[10], j0 = (int)rec[11], wj = (int)rec[12], pidx = (int)rec[13], g2 = (int)rec[14];
+        const int q = act ? t - hstart : 0, cell = q >> 1, tri = q & 1;
+        const int ci = (int)(((float)cell + 0.5f) * (1.0f / (float)wj)); /* cell / wj: the quotient's distance from an integer is at least 0.5 / wj */
+        const int i = i0 + ci, j = j0 + (cell - ci * wj);
+        const double x0 = -sx + j * dx, y0 = -sy + i * dy, reach = r + (margin > 0 ? margin : 0);
+        double z00 = 0, z10 = 0, z01 = 0, z11 = 0;
+        if (act) { z00 = sz * data[i * nc + j]; z10 = sz * data[i * nc + j + 1]; z01 = sz * data[(i + 1) * nc + j]; z11 = sz * data[(i + 1) * nc + j + 1]; }
+        const double zmax = fmax(fmax(z00, z10), fmax(z01, z11));
+        const double v00[3] = {x0, y0, z00}, v10[3] = {x0 + dx, y0, z10}, v01[3] = {x0, y0 + dy, z01}, v11[3] = {x0 + dx, y0 + dy, z11};
+        double best = 1e300, bn[3] = {0, 0, 1}, bt = 0;
+        for (int k = 0; k < CM_HP_MAXS; ++k) {
+            if (wv::ballot(k < ns) == 0ull) break; /* (wave-uniform: no lane has a k-th sample) */
+            if (k >= ns) continue;
+            const double tk = ns > 1 ? hl * (1.0 - 2.0 * k / (ns - 1)) : 0.0;
+            const double p[3] = {p0[0] + tk * ax[0], p0[1] + tk * ax[1], p0[2] + tk * ax[2]};
+            /* exact culls: a sample further from the cell's rectangle than the reach in plan, or more than the reach above the
+             * cell's highest corner, is not within contact distance of either of its triangles */
+            const double ex = p[0] < x0 ? x0 - p[0] : (p[0] > x0 + dx ? p[0] - (x0 + dx) : 0.0);
+            const double ey = p[1] < y0 ? y0 - p[1] : (p[1] > y0 + dy ? p[1] - (y0 + dy) : 0.0);
+            if (ex * ex + ey * ey > reach * reach || p[2] - reach > zmax) continue;
+            double cur = 1e300, cn[3] = {0, 0, 1};
+            if (tri == 0) hfield_triangle(p, v00, v10, v01, cur, cn); else hfield_triangle(p, v11, v01, v10, cur, cn);
+            if (cur < best) { best = cur; bt = tk; bn[0] = cn[0]; bn[1] = cn[1]; bn[2] = cn[2]; }
+        }
+        const double dist = best - r;
+        const bool hit = act && best < 1e299 && !(dist > margin);
+        const unsigned long long hb = wv::ballot(hit);
+        const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+        const int slot = ncon + wv::popc64(hb & below);
+        if (hit && slot < room) {
+            const double *mh = S.x.s.geom_xmat[g1h], *pc = S.x.s.geom_xpos[g2], *mc = S.x.s.geom_xmat[g2];
+            const double axw[3] = {mc[2], mc[5], mc[8]};
+            double nw[3];
+            mulmatvec3(nw, mh, bn);
+            RawContact rc;
+            rc.dist = dist;
+            for (int x = 0; x < 3; ++x) {
+                const double psw = pc[x] + bt * axw[x];
+                rc.normal[x] = nw[x]; rc.pos[x] = psw - nw[x] * (r + 0.5 * dist); rc.tangent[x] = hl > 0 ? axw[x] : 0.0;
+            }
+            write_raw_contact(S, slot, pidx, rc);
+        }
+        ncon += wv::popc64(hb);
+    }
+    wv::sync();
+    return ncon;
 }
 
 /* lane = contact: contact frame from (normal, tangent hint) and the pair's pre-mixed parameters (model compile
@@ -1838,6 +1983,290 @@ WV_DEVICE void euler_step(SH &S, ModelPtr m, int lane, bool isdof, int k_, int n
     wv::sync();
 }
 
+/* ---------------- the solve of the 127-row instantiation (MAXR = WIDE_ROWS, two wavefronts): both waves call it behind the barrier
+ * J, wave w for the rows 64 w .. 64 w + 63 (row 127 = the qfrc_smooth column, wave 1's lane 63).  The row stages (wave 0, one or two
+ * passes) have parked every row's raw Jacobian row in x.Yr and its parameters in x.rowt; here every lane takes its row from there,
+ * runs the half solve, puts the staged row back (barrier Y: the staged matrix is complete), forms ITS WAVE'S 64 x 64 block of
+ * A = Y Y^T in registers, and solves:
+ *   - a substep of at most 64 rows lives on wave 0 alone: the very chain of operations of the 63-row instantiation (so a substep that
+ *     fits both gives the same bits in both), wave 1 returns at once;
+ *   - with more rows a Gauss-Seidel sweep is wave 0's rows, then wave 1's, in row order -- the oracle's order.  The waves never run
+ *     at the same time, so the chain crosses them twice per sweep, not once per row: a wave that has finished its half hands over
+ *     v = sum over its rows of (staged row of Y) x (the row's step), the steps' image in joint space (NVP numbers through LDS), and
+ *     the other wave's residuals take it in through their own staged rows, res_j += Y_j . v -- which is A_jI step_I summed over the
+ *     other wave's rows I without the off-diagonal blocks of A existing anywhere.  The guard (never accept a cost increase) is
+ *     local to a half; the sweep's cost change is summed in row order across both halves, as the oracle sums it.
+ * Returns this lane's row force; iters / nguarded: the sweeps taken (valid in both waves when the substep has more than 64 rows,
+ * in wave 0 otherwise). ---------------- */
+template <int NVP, class TOPO, class SH>
+WV_DEVICE double wide_solve(SH &S, ModelPtr m, const int wid, const int nefc, const int sub, int &iters, int &nguarded) {
+    constexpr int H = NROW, MAXR = WIDE_ROWS;
+    static_assert(TOPO::is_static, "the 127-row instantiation exists for the compile-time topologies");
+    const int lane = wv::fresh_lane();
+    const int g = H * wid + lane;                    /* this lane's row (127: the qfrc_smooth column) */
+    const bool hasrow = g < nefc, qcol = g == MAXR;
+    const int nown = wid == 0 ? (nefc < H ? nefc : H) : (nefc > H ? nefc - H : 0);
+    iters = 0; nguarded = 0;
+    double rR = 1.0, raref = 0.0, jws = 0.0, code = -1.0;
+    {
+        const double *rt = S.x.rowt[hasrow ? g : 0];
+        const double t0 = rt[0], t1 = rt[1], t2 = rt[2], t3 = rt[3];
+        if (hasrow) { rR = t0; raref = t1; jws = t2; code = t3; }
+    }
+    const bool isrow = hasrow && code >= 0.0, clampf = isrow && code > 0.5;
+    double ycol[NVP];
+#pragma unroll
+    for (int k = 0; k < NVP; ++k) {
+        const double raw = S.x.Yr[hasrow ? g : 0][k], qs = S.qfrc_smooth[k < TOPO::nv ? k : 0];
+        ycol[k] = hasrow ? raw : ((qcol && k < TOPO::nv) ? qs : 0.0);
+    }
+    /* ---- half solve in registers: Y = D^-1/2 L^-T [J^T | qfrc_smooth] (env_step's, for a compile-time topology) ---- */
+    {
+        double ta[NVP], tb[NVP], ra = 0, rb = 0;
+        auto fetch = [&](int k, double (&t)[NVP], double &rs) {
+#pragma unroll
+            for (int i = k - 1; i >= 0; --i) if ((TOPO::table[k] >> i) & 1ull) t[i] = S.Lp[LPack<TOPO, NVP>::idx(k, i)];
+            rs = S.rsd[k];
+        };
+        fetch(TOPO::nv - 1, ((TOPO::nv - 1) & 1) ? ta : tb, ((TOPO::nv - 1) & 1) ? ra : rb);
+#pragma unroll
+        for (int k = NVP - 1; k >= 0; --k) {
+            if (k >= TOPO::nv) continue;
+            if (k > 0) fetch(k - 1, ((k - 1) & 1) ? ta : tb, ((k - 1) & 1) ? ra : rb);
+            wv::sched_fence();
+            const double (&t)[NVP] = (k & 1) ? ta : tb;
+            const double xk = ycol[k];
+#pragma unroll
+            for (int i = k - 1; i >= 0; --i) if ((TOPO::table[k] >> i) & 1ull) ycol[i] -= t[i] * xk;
+            ycol[k] = xk * ((k & 1) ? ra : rb);
+            wv::sched_fence();
+        }
+    }
+    {   /* (every lane: the lanes that hold no row store zeros, so that all 128 rows of the tile are defined) */
+#pragma unroll
+        for (int k = 0; k < NVP; ++k) S.x.Yr[g][k] = ycol[k];
+    }
+    wv::block_barrier(); /* Y: the staged matrix is complete -- both waves' rows and the qfrc_smooth column */
+    if (nefc <= H && wid == 1) return 0.0; /* (no rows on this wave) */
+
+    /* ---- this lane's row of its wave's block of A = Y Y^T (one FMA chain per product over the dofs in index order, as everywhere),
+     *      b = Y y_q - aref, the diagonal ---- */
+    double arow[H];
+    const int rbase = H * wid;
+#pragma unroll
+    for (int r = 0; r < H; r += 2) {
+        double acc0 = 0, acc1 = 0;
+        if (rbase + r < nefc) {
+            double ya[NVP], yb[NVP];
+#pragma unroll
+            for (int k = 0; k < NVP; ++k) ya[k] = S.x.Yr[rbase + r][k];
+#pragma unroll
+            for (int k = 0; k < NVP; ++k) yb[k] = S.x.Yr[rbase + r + 1][k];
+            wv::sched_fence();
+#pragma unroll
+            for (int k = 0; k < NVP; ++k) { acc0 = fma(ya[k], ycol[k], acc0); acc1 = fma(yb[k], ycol[k], acc1); }
+        }
+        arow[r] = acc0;
+        arow[r + 1] = rbase + r + 1 < nefc ? acc1 : 0.0; /* (row 127 is the qfrc_smooth column, not a row) */
+    }
+    double rb;
+    {
+        double acc = 0;
+#pragma unroll
+        for (int k = 0; k < NVP; ++k) acc = fma(S.x.Yr[MAXR][k], ycol[k], acc);
+        rb = acc - raref;
+    }
+    double Aii = 1.0;
+    if (isrow) {
+        double d = 0;
+#pragma unroll
+        for (int k = 0; k < NVP; ++k) d = fma(ycol[k], ycol[k], d);
+        Aii = d + rR;
+    }
+    const double invAii = 1.0 / Aii;
+    double f = 0, res = isrow ? rb : 0.0;
+    const int r_ = lane; /* the row's index within its wave */
+    const int nvs = TOPO::nv;
+    const double scale = 1.0 / (m->meaninertia * (nvs > 1 ? nvs : 1));
+    const double halfAii = 0.5 * Aii;
+    const double flo = clampf ? 0.0 : -1e300;
+    const double ninvAii = -invAii;
+    const int maxiter = m->iterations;
+    const double tolerance = m->tolerance;
+    const int kk = lane < NVP ? lane : 0;
+
+    if (nefc <= H) {
+        /* ======== at most 64 rows: wave 0 alone, the 63-row instantiation's chain of operations ======== */
+        if (m->flags & CM_FLAG_WARMSTART) {
+            if (isrow) {
+                f = -(jws - raref) / rR;
+                if (clampf && f < 0) f = 0;
+            }
+            double af0 = 0, af1 = 0, af2 = 0, af3 = 0;
+#pragma unroll
+            for (int t = 0; t < H; t += 4) {
+                if (t < nefc) {
+                    af0 += arow[t] * wv::readlane(f, t);
+                    af1 += arow[t + 1] * wv::readlane(f, t + 1);
+                    af2 += arow[t + 2] * wv::readlane(f, t + 2);
+                    af3 += arow[t + 3] * wv::readlane(f, t + 3);
+                }
+            }
+            const double af = ((af0 + af1) + (af2 + af3)) + (isrow ? rR * f : 0.0);
+            double cost = wv::wave_sum(isrow ? f * (rb + 0.5 * af) : 0.0);
+            if (cost > 0) f = 0;
+            else if (isrow) res = rb + af;
+        }
+        double sres = res * ninvAii;
+#pragma unroll
+        for (int t = 0; t < H; ++t) arow[t] *= ninvAii;
+        const double cdiag = isrow ? rR * ninvAii : 0.0;
+        const bool shortcut_ok = 0.5 * tolerance > (double)MID_ROWS * 1e-10 * scale;
+        while (iters < maxiter) {
+            const int nrows = wv::opaque(nefc);
+            bool converged;
+            {
+                const double f0 = f, s0 = sres;
+                double mys = 0;
+                const double lo_f = flo - f;
+                pgs_rows_fast<0, H>(arow, nrows, r_, lo_f, sres, mys);
+                const double mydelta = wv::max_raw(mys, lo_f);
+                const double change = (r_ < nrows) ? mydelta * (halfAii * mydelta - Aii * mys) : 0.0;
+                const float tol = (float)tolerance;
+                const bool one_row_decides = shortcut_ok && wv::ballot(-(float)change * (float)scale > 2.5f * tol) != 0ull;
+                const float est = one_row_decides ? 4.0f * tol : -wv::wave_sum_f32((float)change) * (float)scale;
+                if (wv::ballot(change > 1e-10) != 0ull || wv::debug_force_guarded()) {
+                    double improvement = 0;
+                    f = f0; sres = s0; ++nguarded;
+                    pgs_rows<0, H>(arow, nrows, r_, Aii, halfAii, flo, f, sres, improvement);
+                    sres = fma(cdiag, f - f0, sres);
+                    converged = improvement * scale < tolerance;
+                } else {
+                    if (r_ < nrows) { f += mydelta; sres = fma(cdiag, mydelta, sres); }
+                    if (est < 0.5f * tol) converged = true;
+                    else if (est > 2.0f * tol) converged = false;
+                    else {
+                        const double tree = -wv::wave_sum(change) * scale, tolv = tolerance;
+                        if (fabs(tree - tolv) > 1e-9 * tolv) converged = tree < tolv;
+                        else {
+                            double improvement = 0;
+                            for (int t = 0; t < nrows; ++t) improvement -= wv::readlane(change, t);
+                            converged = improvement * scale < tolerance;
+                        }
+                    }
+                }
+            }
+            ++iters;
+            if (converged) break;
+        }
+        return f;
+    }
+
+    /* ======== more than 64 rows: the sweep crosses the waves ======== */
+    /* v[wid] = sum over this wave's rows t < nown of (staged row) x val_t, lane = dof (four partial sums, rows four to a branch) */
+    auto image_of = [&](double val) {
+        double v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+#pragma unroll
+        for (int t = 0; t < H; t += 4) {
+            if (t < nown) {
+                v0 = fma(S.x.Yr[rbase + t][kk], wv::readlane(val, t), v0);
+                v1 = fma(S.x.Yr[rbase + t + 1][kk], wv::readlane(val, t + 1), v1);
+                v2 = fma(S.x.Yr[rbase + t + 2][kk], wv::readlane(val, t + 2), v2);
+                v3 = fma(S.x.Yr[rbase + t + 3][kk], wv::readlane(val, t + 3), v3); /* (val is 0 in lanes that are not rows; their rows of the tile are zeros) */
+            }
+        }
+        if (lane < NVP) S.x.vx[wid][lane] = (v0 + v1) + (v2 + v3);
+    };
+    /* this lane's staged row times the other wave's image: what the other wave's values contribute to this row's A x */
+    auto cross = [&]() {
+        double d = 0;
+#pragma unroll
+        for (int k = 0; k < NVP; ++k) d = fma(ycol[k], S.x.vx[1 - wid][k], d);
+        return d;
+    };
+    if (m->flags & CM_FLAG_WARMSTART) {
+        if (isrow) {
+            f = -(jws - raref) / rR;
+            if (clampf && f < 0) f = 0;
+        }
+        image_of(f);
+        wv::block_barrier();
+        double af0 = 0, af1 = 0, af2 = 0, af3 = 0;
+#pragma unroll
+        for (int t = 0; t < H; t += 4) {
+            if (t < nown) {
+                af0 += arow[t] * wv::readlane(f, t);
+                af1 += arow[t + 1] * wv::readlane(f, t + 1);
+                af2 += arow[t + 2] * wv::readlane(f, t + 2);
+                af3 += arow[t + 3] * wv::readlane(f, t + 3);
+            }
+        }
+        const double af = (((af0 + af1) + (af2 + af3)) + cross()) + (isrow ? rR * f : 0.0);
+        const double part = wv::wave_sum(isrow ? f * (rb + 0.5 * af) : 0.0);
+        if (lane == 0) S.x.sums[wid] = part;
+        wv::block_barrier();
+        const double cost = S.x.sums[0] + S.x.sums[1];
+        if (cost > 0) f = 0;
+        else if (isrow) res = rb + af;
+        wv::block_barrier(); /* (vx and sums are free again) */
+    }
+    double sres = res * ninvAii;
+#pragma unroll
+    for (int t = 0; t < H; ++t) arow[t] *= ninvAii;
+    const double cdiag = isrow ? rR * ninvAii : 0.0;
+    /* the turn word: base + 2 s + 1 = wave 0 has finished its half of sweep s, base + 2 s + 2 = wave 1 has (and has left its verdict) */
+    const int base = (sub + 1) << 12;
+    const int sweeps_max = maxiter < 2000 ? maxiter : 2000;
+    for (int sweep = 0;; ++sweep) {
+        double carried = 0.0; /* the sweep's cost change summed in row order up to this wave's first row */
+        if (wid == 0) {
+            if (sweep > 0) {
+                wv::wait_for(&S.x.turn[1], base + 2 * sweep);
+                if (wv::opaque(S.x.turn[2])) break; /* (wave 1's verdict on the sweep before: converged, or out of sweeps) */
+                sres = fma(ninvAii, cross(), sres);
+            }
+        } else {
+            wv::wait_for(&S.x.turn[1], base + 2 * sweep + 1);
+            sres = fma(ninvAii, cross(), sres);
+            carried = S.x.sums[2];
+        }
+        const int nrows = wv::opaque(nown);
+        double improvement = carried, dstep;
+        {
+            const double f0 = f, s0 = sres;
+            double mys = 0;
+            const double lo_f = flo - f;
+            pgs_rows_fast<0, H>(arow, nrows, r_, lo_f, sres, mys);
+            const double mydelta = wv::max_raw(mys, lo_f);
+            const double change = (r_ < nrows) ? mydelta * (halfAii * mydelta - Aii * mys) : 0.0;
+            if (wv::ballot(change > 1e-10) != 0ull || wv::debug_force_guarded()) { /* some row of this half would have raised the cost: redo it guarded */
+                f = f0; sres = s0;
+                ++nguarded;
+                pgs_rows<0, H>(arow, nrows, r_, Aii, halfAii, flo, f, sres, improvement);
+                sres = fma(cdiag, f - f0, sres);
+                dstep = f - f0;
+            } else {
+                dstep = (r_ < nrows) ? mydelta : 0.0;
+                if (r_ < nrows) { f += mydelta; sres = fma(cdiag, mydelta, sres); }
+                for (int t = 0; t < nrows; ++t) improvement -= wv::readlane(change, t);
+            }
+        }
+        image_of(dstep);
+        if (wid == 0) {
+            if (lane == 0) S.x.sums[2] = improvement;
+            wv::publish(&S.x.turn[1], base + 2 * sweep + 1);
+        } else {
+            iters = sweep + 1;
+            const bool stop = improvement * scale < tolerance || iters >= sweeps_max;
+            if (lane == 0) { S.x.turn[2] = stop ? 1 : 0; S.x.turn[3] = iters; S.x.sums[3] = (double)nguarded; }
+            wv::publish(&S.x.turn[1], base + 2 * sweep + 2);
+            if (stop) break;
+        }
+    }
+    if (wid == 0) { iters = wv::opaque(S.x.turn[3]); nguarded += (int)S.x.sums[3]; }
+    return f;
+}
+
 /* ======================================================== the env step ==== */
 /* FEAT selects the collision code a model needs, so that the instantiation for plain cassie.xml does not carry the
  * register pressure of paths it never takes: FEAT_HFIELD = height-field pairs, FEAT_WAVEPAIRS = plane-box / box-box
@@ -1863,10 +2292,19 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
     const int wid = NW == 2 ? wv::wave_id() : 0;
 
     static_assert(LP::covers() && LP::distinct(), "packed factor rows must hold every ancestor pair, each in its own slot");
+    typedef EnvShared<NVP, LPack<TOPO, NVP>::count, MAXR> SH_T;
+    constexpr int MAXC = SH_T::MAXC;
+    constexpr bool WIDE = SH_T::WIDE;
+    static_assert(!WIDE || (NW == 2 && MAXR == WIDE_ROWS), "the 127-row instantiation spreads its solve over the two wavefronts of an env");
     const ModelPtr m_launch = (ModelPtr)(io.models + (size_t)env * io.model_stride);
     ModelPtr m = m_launch;
     int lane = wv::lane();
     const int nq = m->nq, nv = m->nv, nu = m->nu, nbody = m->nbody, njnt = m->njnt;
+    /* rows / contacts a substep may use: what this instantiation holds, within the model's caps (cm_model_t::maxefc / maxcon) */
+    const int capr = m->maxefc < MAXR ? m->maxefc : MAXR, capc = m->maxcon < MAXC ? m->maxcon : MAXC;
+    /* an instantiation with more rows / contacts runs behind this one (PhysIO::has_next) and the model may use them: a substep
+     * that does not fit is handed over, from its start, instead of being capped */
+    const bool can_hand_over = MAXR < WIDE_ROWS && io.has_next != 0 && io.progress != nullptr && (MAXR < m->maxefc || MAXC < m->maxcon);
     const double h = m->timestep;
     int warn = 0;
 
@@ -1983,6 +2421,13 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
                 CK_STAMP(47);
                 wv::block_barrier(); /* J: the factor of M and qfrc_smooth are in LDS, the sensor stage is done with the body tiles */
                 CK_STAMP(39);
+                if constexpr (WIDE) {
+                    /* the 127-row instantiation: this wave's rows 64 .. 126 and the qfrc_smooth column (wide_solve); its row forces
+                     * go to LDS for the barrier P like wave 0's */
+                    int it1 = 0, ng1 = 0;
+                    const double f1 = wide_solve<NVP, TOPO>(S, m, 1, wv::opaque(S.x.turn[0]), sub1, it1, ng1);
+                    (&S.c_solimp[0][0])[NROW + lane] = f1;
+                }
                 /* the factorisation of M + hB, which only this wave's Euler step reads: here, in the time this wave would otherwise
                  * wait for wave 0's solve, instead of on the way to the barrier J, where wave 0 waited for it (+4.6 %) */
                 factor_pair_by_height<NVP, TOPO, 1>(m, h, S, col, colh, lane);
@@ -2012,8 +2457,9 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
                         for (int r = 0; r <= MAXR; ++r) ycolk[r] = S.x.Yr[r][kk];
                     }
                     wv::block_barrier(); /* P: wave 0's row forces and solver statistics are in LDS */
-                    const double f = fbuf[lane];
-                    const int ncon = (int)fbuf[64], nefc = (int)fbuf[65], iters = (int)fbuf[66], nguarded = (int)fbuf[67];
+                    const double f = fbuf[lane], f_hi = WIDE ? fbuf[NROW + lane] : 0.0; /* (rows 64 .. 126 of the 127-row instantiation) */
+                    constexpr int FB = WIDE ? 2 * NROW : NROW;
+                    const int ncon = (int)fbuf[FB], nefc = (int)fbuf[FB + 1], iters = (int)fbuf[FB + 2], nguarded = (int)fbuf[FB + 3];
                     /* ================= qacc = L^-1 D^-1/2 (y63 + Y f)  (lane = dof) ================= */
                     double z, z1 = 0, z2 = 0, z3 = 0;
                     if constexpr (stage_y) {
@@ -2032,13 +2478,15 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
                         }
                     } else {
                         z = isdof ? S.x.Yr[MAXR][k_] : 0.0;
+                        /* (row r's force: lane r of f, or -- rows 64 .. 126 of the 127-row instantiation -- lane r - 64 of f_hi) */
+                        auto frow = [&](int r) { if constexpr (WIDE) return r < NROW ? wv::readlane(f, r) : wv::readlane(f_hi, r - NROW); else return wv::readlane(f, r); };
                         int r = 0;
                         for (; r + 4 <= nefc; r += 4) {
                             const double y0 = S.x.Yr[r][kk], y1 = S.x.Yr[r + 1][kk], y2 = S.x.Yr[r + 2][kk], y3 = S.x.Yr[r + 3][kk];
-                            z += y0 * wv::readlane(f, r); z1 += y1 * wv::readlane(f, r + 1);
-                            z2 += y2 * wv::readlane(f, r + 2); z3 += y3 * wv::readlane(f, r + 3);
+                            z += y0 * frow(r); z1 += y1 * frow(r + 1);
+                            z2 += y2 * frow(r + 2); z3 += y3 * frow(r + 3);
                         }
-                        for (; r < nefc; ++r) z += S.x.Yr[r][kk] * wv::readlane(f, r);
+                        for (; r < nefc; ++r) z += S.x.Yr[r][kk] * frow(r);
                     }
                     z = (z + z1) + (z2 + z3);
                     if (!isdof) z = 0.0;
@@ -2103,10 +2551,8 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
         if (io.drive_mode) {
             /* (the row-capped instantiation runs this pass after it knows that the substep fits its rows, see below: a
              * substep it hands over must not have advanced the filter histories and delay lines) */
-            if constexpr (MAXR == CM_MAXEFC && NW == 1) { /* (two-wave form: wave 1, once wave 0's collision verdict is in) */
-                if (io.integrate) drive_level_io(io, S, m, env, lane, lastsub); /* mj_forward leaves the drive-level state alone */
-                wv::sync();
-            }
+            /* (behind the collision verdict, below: a substep this instantiation hands over must not have advanced the filter
+             * histories and delay lines.  Two-wave form: wave 1, once wave 0's collision verdict is in) */
         } else if (io.pd_ptarget) {
             if (lane < nu) {
                 const size_t o = (size_t)env * io.su + lane;
@@ -2460,7 +2906,16 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
         static_assert(CM_HF_PASS * CM_HF_SLOTS <= WV_WAVE && CM_HF_SLOTS_DENSE <= WV_WAVE, "a pass of the height-field pre-pass is one wave");
         double *const hfres = &S.x.s.cvel[0][0];
         const bool hf_on = (FEAT & FEAT_HFIELD) != 0 && env_hfield != nullptr && m->nhfpair > 0;
-        if constexpr ((FEAT & FEAT_HFIELD) != 0) if (hf_on) {
+        const bool hf_prism = (FEAT & FEAT_HFIELD) != 0 && hf_on && (m->flags & CM_FLAG_HFPRISM) != 0;
+        int ncon_prism = 0;
+        if constexpr ((FEAT & FEAT_HFIELD) != 0) if (hf_prism) {
+            /* CM_FLAG_HFPRISM: one contact per penetrated grid triangle, straight into the contact list ahead of the other pairs' */
+            static_assert(CM_MAXHFPAIR * HP_REC <= NB * 12 + NVP * 12, "the per-pair records of the prism pass fit the idle velocity tiles");
+            CK_STAMP(44);
+            ncon_prism = hfield_prism_wave(S, m, env_hfield, lane, hfres, MAXC);
+            CK_STAMP(46);
+        }
+        if constexpr ((FEAT & FEAT_HFIELD) != 0) if (hf_on && !hf_prism) {
             /* CM_FLAG_HFDENSE: ten sample slots per pair (six pairs per pass) instead of six (ten pairs per pass) */
             const bool dense = (m->flags & CM_FLAG_HFDENSE) != 0;
             const int slots = dense ? CM_HF_SLOTS_DENSE : CM_HF_SLOTS, per_pass = dense ? WV_WAVE / CM_HF_SLOTS_DENSE : CM_HF_PASS;
@@ -2491,7 +2946,6 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
                     /* (all lanes: the wave shares the cells under the pass's samples; the contact tables are scratch until the
                      * pair loop below fills them) */
                     double e[3] = {p2[0] + t * axis[0], p2[1] + t * axis[1], p2[2] + t * axis[2]};
-                    typedef EnvShared<NVP, LPack<TOPO, NVP>::count, MAXR> SH_T;
                     static_assert(offsetof(SH_T, c_margin) + sizeof(S.c_margin) - offsetof(SH_T, c_dist) >= HF_WINDOW + sizeof(double) * 4 * WV_WAVE,
                                   "the contact tables hold the work area of hfield_spheres_wave");
                     CK_STAMP(44);
@@ -2550,6 +3004,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
             CK_STAMP(46);
         }
         if constexpr (!request_early) request_pair(lane, pc);
+        if constexpr ((FEAT & FEAT_HFIELD) != 0) ncon = ncon_prism; /* (the prism pass's contacts come first) */
         for (int p0 = 0; p0 < npass; p0 += WV_WAVE) {
             const int p = p0 + lane;
             int n = 0;
@@ -2561,7 +3016,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
                 const int slot = p < npass ? m->pair_hfslot[p] : -1;
                 if (slot >= 0) {
                     from_spread = true;
-                    if (hf_on) {
+                    if (hf_on && !hf_prism) {
                         const double *rec = hfres + (size_t)slot * HF_REC;
                         n = (int)rec[0];
                         hfs = slot;     /* (contacts 3 and 4 of a CM_FLAG_HFMULTI pair go from the table straight to the contact list) */
@@ -2643,7 +3098,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
                 slot += wv::popc64(m3b & below) + wv::popc64(m4b & below);
                 more = wv::popc64(m3b) + wv::popc64(m4b);
                 for (int extra = 2; extra < CM_HF_MAXC; ++extra)
-                    if (n > extra && slot + extra < CM_MAXCON) {
+                    if (n > extra && slot + extra < MAXC) {
                         const double *c = hfres + (size_t)hfs * HF_REC + 1 + 10 * extra;
                         RawContact rx;
                         rx.dist = c[0];
@@ -2651,8 +3106,8 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
                         write_raw_contact(S, slot + extra, p, rx);
                     }
             }
-            if (n >= 1 && slot < CM_MAXCON) write_raw_contact(S, slot, p, rc0);
-            if (n >= 2 && slot + 1 < CM_MAXCON) write_raw_contact(S, slot + 1, p, rc1);
+            if (n >= 1 && slot < MAXC) write_raw_contact(S, slot, p, rc0);
+            if (n >= 2 && slot + 1 < MAXC) write_raw_contact(S, slot + 1, p, rc1);
             ncon += wv::popc64(m1b) + wv::popc64(m2b) + more;
         }
         CK_STAMP(22);
@@ -2698,11 +3153,12 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
             const unsigned long long hb = wv::ballot(hit);
             const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
             const int rank = wv::popc64(hb & below);
-            if (hit && rank < 4 && ncon + rank < CM_MAXCON) write_raw_contact(S, ncon + rank, p, rc);
+            if (hit && rank < 4 && ncon + rank < MAXC) write_raw_contact(S, ncon + rank, p, rc);
             const int nh = wv::popc64(hb);
             ncon += nh < 4 ? nh : 4;
         }
-        if (ncon > CM_MAXCON) { ncon = CM_MAXCON; warn |= WARN_CONTACT_FULL; }
+        const int ncon_found = ncon;
+        if (ncon > capc) ncon = capc; /* (the warning bit: below, unless the substep is handed over) */
         wv::sync();
         finish_contacts(S, m, lane, ncon);
         /* joint limits: lane = joint evaluates its own violation (the ballots give the row slots in joint order below) */
@@ -2717,21 +3173,24 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
             }
             lob = wv::ballot(lo); hib = wv::ballot(hi);
         }
-        if constexpr (MAXR < CM_MAXEFC) {
+        if constexpr (MAXR < WIDE_ROWS) {
             /* an upper bound of the rows this substep needs (the caps of the row assignment can only lower it): past this
-             * instantiation's capacity the env is handed to the full instantiation, from the start of this substep */
-            const int neq = m->neq;
-            const bool eact = lane < neq && m->eq_active[lane < neq ? lane : 0] != 0;
-            const int need = 3 * wv::popc64(wv::ballot(eact)) + wv::popc64(lob) + wv::popc64(hib) + 4 * ncon;
-            if (need > MAXR) {
-                bailed = true;
-                if constexpr (NW == 2) { if (lane == 0) S.cmd[0] = 1; wv::publish(&S.cmd[4], sub + 1); } /* (the verdict: handed over) */
-                break;
+             * instantiation's capacity -- rows or contacts -- the env is handed to the next instantiation, from the start of this substep */
+            if (can_hand_over) {
+                const int neq = m->neq;
+                const bool eact = lane < neq && m->eq_active[lane < neq ? lane : 0] != 0;
+                const int need = 3 * wv::popc64(wv::ballot(eact)) + wv::popc64(lob) + wv::popc64(hib) + 4 * ncon;
+                if (need > capr || ncon_found > capc) {
+                    bailed = true;
+                    if constexpr (NW == 2) { if (lane == 0) S.cmd[0] = 1; wv::publish(&S.cmd[4], sub + 1); } /* (the verdict: handed over) */
+                    break;
+                }
             }
-            if constexpr (NW == 1) if (io.drive_mode) {
-                if (io.integrate) drive_level_io(io, S, m, env, lane, lastsub);
-                wv::sync();
-            }
+        }
+        if (ncon_found > capc) warn |= WARN_CONTACT_FULL;
+        if constexpr (NW == 1) if (io.drive_mode) {
+            if (io.integrate) drive_level_io(io, S, m, env, lane, lastsub); /* mj_forward leaves the drive-level state alone */
+            wv::sync();
         }
         if constexpr (NW == 2) { CK_STAMP(33); wv::publish(&S.cmd[4], sub + 1); wv::wait_for(&S.cmd[3], sub + 1); } /* the verdict for wave 1; wave 1's com / cinert / cdof for the stage below */
         CK_STAMP(5);
@@ -2832,21 +3291,39 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
 
         /* ================= P5 constraint rows: lane = row ================= */
         /* row descriptor assignment is wave-uniform bookkeeping; every lane keeps its own row */
-        const int r_ = lane;
+        /* (The 127-row instantiation forms its rows in TWO PASSES of this wave -- rows 0 .. 63, then, if the substep has them, rows
+         * 64 .. 126 -- and parks every row's raw Jacobian row and solver parameters in LDS (x.Yr, x.rowt); behind the barrier J each
+         * wave picks up its 64 rows from there: wide_solve.  Every other instantiation runs the loop below once.) */
+        int r_ = lane;
         int rtype = -1, rid = 0, rsub = 0;
-        int nefc = 0;
+        int nefc = 0, nefc_before_contacts = 0;
+        double rpos = 0, rmargin = 0, rR = 1.0, rK = 0, rB = 0, rimp = 1.0;
+        const bool need_imu = lastsub || io.all_outputs_every_substep || (io.drive_mode && sub + 2 == nsub);
+        const bool need_pos = lastsub || io.drive_mode || io.all_outputs_every_substep;
+        const bool issens = lane < m->nsensor && need_pos;
+        const int ls = issens ? lane : 0;
+        SensorConsts sens_c;
+        double ycol[NVP]; /* this lane's Jacobian row, one dof at a time, straight into registers; lane 63 carries qfrc_smooth */
+        double jvel = 0, jws = 0;
+        const bool lastcol = !WIDE && lane == NROW - 1;
+        for (int pass = 0; pass < (WIDE ? 2 : 1); ++pass) {
+        if constexpr (WIDE) {
+            if (pass == 1 && nefc <= NROW) break; /* (wave-uniform: no second pass) */
+            r_ = NROW * pass + lane; rtype = -1; rid = 0; rsub = 0; nefc = 0; jvel = 0; jws = 0;
+            rpos = 0; rmargin = 0; rR = 1.0; rK = 0; rB = 0; rimp = 1.0;
+        }
         {
             /* all equalities active and within the cap (the usual case): three rows each, in order, in closed form */
             const int neq = m->neq;
             const bool eact = lane < neq && m->eq_active[lane < neq ? lane : 0] != 0;
             const unsigned long long eall = neq >= 64 ? ~0ull : (1ull << neq) - 1;
-            if (wv::ballot(eact) == eall && 3 * neq <= CM_MAXEFC) {
+            if (wv::ballot(eact) == eall && 3 * neq <= capr) {
                 if (r_ < 3 * neq) { rtype = CM_CNSTR_EQUALITY; rid = r_ / 3; rsub = r_ - 3 * rid; }
                 nefc = 3 * neq;
             } else
             for (int e = 0; e < neq; ++e) {
                 if (!m->eq_active[e]) continue;
-                if (nefc + 3 > CM_MAXEFC) { warn |= WARN_CONSTRAINT_FULL; continue; }
+                if (nefc + 3 > capr) { warn |= WARN_CONSTRAINT_FULL; continue; }
                 if (r_ >= nefc && r_ < nefc + 3) { rtype = CM_CNSTR_EQUALITY; rid = e; rsub = r_ - nefc; }
                 nefc += 3;
             }
@@ -2857,16 +3334,16 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
                 const int j = wv::popc64((any & (0ull - any)) - 1);
                 for (int side = 0; side < 2; ++side) {
                     if (!(((side == 0 ? lob : hib) >> j) & 1ull)) continue;
-                    if (nefc >= CM_MAXEFC) { warn |= WARN_CONSTRAINT_FULL; continue; }
+                    if (nefc >= capr) { warn |= WARN_CONSTRAINT_FULL; continue; }
                     if (r_ == nefc) { rtype = CM_CNSTR_LIMIT_JOINT; rid = j; rsub = side; }
                     ++nefc;
                 }
             }
         }
-        const int nefc_before_contacts = nefc;
+        nefc_before_contacts = nefc;
         /* every contact a friction pyramid of four rows and all of them within the cap (the usual case): closed form */
         const bool cpyr = lane < ncon && S.c_dim[lane < ncon ? lane : 0] == 3;
-        if (wv::ballot(cpyr) == (ncon >= 64 ? ~0ull : (1ull << ncon) - 1) && nefc + 4 * ncon <= CM_MAXEFC) {
+        if (wv::ballot(cpyr) == (ncon >= 64 ? ~0ull : (1ull << ncon) - 1) && nefc + 4 * ncon <= capr) {
             if (r_ >= nefc && r_ < nefc + 4 * ncon) { rtype = CM_CNSTR_CONTACT_PYRAMIDAL; rid = (r_ - nefc) >> 2; rsub = (r_ - nefc) & 3; }
             nefc += 4 * ncon;
         } else
@@ -2874,7 +3351,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
             const int dim = S.c_dim[c];
             if (dim != 1 && dim != 3) { warn |= WARN_UNSUPPORTED_PAIR; continue; }
             const int nrow = dim == 1 ? 1 : 2 * (dim - 1);
-            if (nefc + nrow > CM_MAXEFC) { warn |= WARN_CONSTRAINT_FULL; continue; }
+            if (nefc + nrow > capr) { warn |= WARN_CONSTRAINT_FULL; continue; }
             if (r_ >= nefc && r_ < nefc + nrow) {
                 rtype = dim == 1 ? CM_CNSTR_CONTACT_FRICTIONLESS : CM_CNSTR_CONTACT_PYRAMIDAL;
                 rid = c; rsub = r_ - nefc;
@@ -2887,7 +3364,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
         double u3[3] = {0, 0, 0}, wp[3] = {0, 0, 0}, wm[3] = {0, 0, 0};
         unsigned long long maskp = 0, maskm = 0;
         int limdof = -1;
-        double limsgn = 0, rpos = 0, rmargin = 0, rdiag = 0, imp_pos = 0, rRscale = 1.0;
+        double limsgn = 0, rdiag = 0, imp_pos = 0, rRscale = 1.0;
         double solref0 = 0.02, solref1 = 1, solimp[5] = {0.9, 0.95, 0.001, 0.5, 2};
         if (rtype == CM_CNSTR_EQUALITY) {
             if (rid != pf_eq) { /* (an inactive equality ahead of this one: the constants requested in advance are another row's) */
@@ -2953,7 +3430,6 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
             for (int i = 0; i < 5; ++i) solimp[i] = S.c_solimp[c][i];
         }
         CK_STAMP(26);
-        double rR = 1.0, rK = 0, rB = 0, rimp = 1.0;
         if (rtype >= 0) {
             rimp = impedance(solimp, imp_pos, rmargin);
             rR = fmax(CM_MINVAL, (1 - rimp) * rdiag / rimp);
@@ -2973,17 +3449,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
         /* The constants of the sensor stage behind the Jacobian loop are requested here, every one of them in one level of
          * unconditional reads (lane = sensor): their round trip through the memory system runs under the loop instead of
          * in front of the sensors. */
-        const bool need_imu = lastsub || io.all_outputs_every_substep || (io.drive_mode && sub + 2 == nsub);
-        const bool need_pos = lastsub || io.drive_mode || io.all_outputs_every_substep;
-        const bool issens = lane < m->nsensor && need_pos;
-        const int ls = issens ? lane : 0;
-        SensorConsts sens_c;
         if constexpr (NW == 1) sens_c = request_sensor_consts(m, ls);
-        const int sb = NW == 1 ? sens_c.sb : 0;
-        /* this lane's Jacobian row, one dof at a time, straight into registers; lane 63 carries qfrc_smooth */
-        double ycol[NVP];
-        double jvel = 0, jws = 0;
-        const bool lastcol = r_ == NROW - 1;
 #pragma unroll
         for (int k0 = 0; k0 < NVP; k0 += 4) {
             /* stage four motion axes and the matching qvel / qacc_warmstart / qfrc_smooth entries, then compute */
@@ -3017,10 +3483,30 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
                 ycol[k] = v;
             }
         }
+        if constexpr (WIDE) {
+            /* the row goes to LDS: its raw Jacobian row (the half solve behind the barrier J takes it from there) and what the solve
+             * needs of it -- R, the reference acceleration, J . qacc_warmstart, and 1 / 0 / -1 for clamped row / equality row / no row */
+            if (r_ < MAXR) {
+#pragma unroll
+                for (int k = 0; k < NVP; ++k) S.x.Yr[r_][k] = ycol[k];
+                double *rt = S.x.rowt[r_];
+                rt[0] = rR; rt[1] = rtype >= 0 ? -rB * jvel - rK * rimp * (rpos - rmargin) : 0.0; rt[2] = jws;
+                rt[3] = rtype < 0 ? -1.0 : (rtype == CM_CNSTR_EQUALITY ? 0.0 : 1.0);
+            }
+            if (io.ext && pass == 0 && rtype == CM_CNSTR_EQUALITY && r_ < CM_MAXEQROW) {
+                cm_ext_t *ex = io.ext + env;
+                ex->eq_pos[r_] = rpos; ex->eq_id[r_] = rid;
+#pragma unroll
+                for (int k = 0; k < NVP; ++k) if (k < nv) ex->eq_J[r_][k] = ycol[k];
+            }
+        }
+        } /* (pass) */
+        const int sb = NW == 1 ? sens_c.sb : 0;
         CK_STAMP(28);
         if constexpr (NW == 2) {
             /* J: wave 1 is done with this substep -- the factors of M and M + hB and qfrc_smooth are in LDS, and its drive-level pass
              * has read the previous substep's sensor words, which the sensor stage below replaces */
+            if constexpr (WIDE) { if (lane == 0) S.x.turn[0] = nefc; } /* (wave 1 takes its rows by it) */
             CK_STAMP(34); wv::block_barrier();
             /* lane 63's column of the staged matrix is qfrc_smooth */
             if (lastcol) {
@@ -3054,12 +3540,12 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
                 for (int i = 0; i < 9; ++i) ex->site_xmat[lane][i] = mm[i];
             }
             if (isdof) for (int i = 0; i < 6; ++i) { ex->cdof[k_][i] = S.cdof[k_][i]; ex->cdof_dot[k_][i] = S.x.s.cdof_dot[k_][i]; }
-            if (rtype == CM_CNSTR_EQUALITY && r_ < CM_MAXEQROW) {
+            if (!WIDE && rtype == CM_CNSTR_EQUALITY && r_ < CM_MAXEQROW) {
                 ex->eq_pos[r_] = rpos; ex->eq_id[r_] = rid;
 #pragma unroll
                 for (int k = 0; k < NVP; ++k) if (k < nv) ex->eq_J[r_][k] = ycol[k];
             }
-            if (lane == 0) { int ne = 0; for (int e = 0; e < m->neq; ++e) if (m->eq_active[e] && ne + 3 <= CM_MAXEFC) ne += 3; ex->ne = ne; }
+            if (lane == 0) { int ne = 0; for (int e = 0; e < m->neq; ++e) if (m->eq_active[e] && ne + 3 <= capr) ne += 3; ex->ne = ne; }
             if (lane < ncon) {
                 ex->con_geom1[lane] = m->geom_fullid[S.c_g1[lane]]; ex->con_geom2[lane] = m->geom_fullid[S.c_g2[lane]];
                 ex->con_body1[lane] = m->geom_bodyid[S.c_g1[lane]]; ex->con_body2[lane] = m->geom_bodyid[S.c_g2[lane]];
@@ -3077,7 +3563,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
                 const int dim = S.c_dim[c];
                 if (dim != 1 && dim != 3) continue;
                 const int nrow = dim == 1 ? 1 : 2 * (dim - 1);
-                if (acc + nrow > CM_MAXEFC) continue;
+                if (acc + nrow > capr) continue;
                 if (c == lane) caddr = acc;
                 acc += nrow;
             }
@@ -3085,6 +3571,59 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
         wv::sync(); /* every reader of the body-stage tiles is done: region x becomes the Y staging tile */
         CK_STAMP(8);
 
+        if constexpr (WIDE) {
+            /* the 127-row instantiation: half solve, A and the sweeps for this wave's rows 0 .. 63 (wide_solve; wave 1 is in the same
+             * function for rows 64 .. 126 and the qfrc_smooth column), the row forces of both waves through LDS at the barrier P,
+             * the read-outs from there */
+            int iters = 0, nguarded = 0;
+            const double f = wide_solve<NVP, TOPO>(S, m, 0, nefc, sub, iters, nguarded);
+            CK_STAMP(11);
+            static_assert(sizeof(S.c_solimp) >= (2 * NROW + 4) * sizeof(double), "the row forces are handed over through the contacts' solimp slots");
+            double *const fbuf = &S.c_solimp[0][0];
+            fbuf[lane] = f;
+            if (lane == 0) { fbuf[2 * NROW] = (double)ncon; fbuf[2 * NROW + 1] = (double)nefc; fbuf[2 * NROW + 2] = (double)iters; fbuf[2 * NROW + 3] = (double)nguarded; }
+            wv::block_barrier(); /* P */
+            if (io.ext || want_cfrc) {
+                /* decode the pyramid: normal = sum of the edge forces, tangents = mu (f+ - f-); the rows' forces from LDS */
+                const int a0 = caddr >= 0 ? caddr : 0;
+                double fn = 0, ft1 = 0, ft2 = 0;
+                if (lane < ncon && caddr >= 0) {
+                    const double f0 = fbuf[a0];
+                    if (S.c_dim[lane] == 1) fn = f0;
+                    else { const double f1 = fbuf[a0 + 1], f2 = fbuf[a0 + 2], f3 = fbuf[a0 + 3], mu = S.c_fri[lane][0]; fn = f0 + f1 + f2 + f3; ft1 = mu * (f0 - f1); ft2 = mu * (f2 - f3); }
+                }
+                if (io.ext) {
+                    cm_ext_t *ex = io.ext + env;
+                    if (lane < ncon) { ex->con_force[lane][0] = fn; ex->con_force[lane][1] = ft1; ex->con_force[lane][2] = ft2; }
+                    if (lane == 0) { ex->ncon = ncon; ex->nefc = nefc; ex->solver_iter = iters; }
+                }
+                if (want_cfrc) {
+                    if (lane < ncon) {
+                        const double *fr = S.c_frame[lane];
+                        double fw[3];
+                        for (int j = 0; j < 3; ++j) fw[j] = fr[j] * fn + fr[3 + j] * ft1 + fr[6 + j] * ft2;
+                        for (int j = 0; j < 3; ++j) S.c_pos[lane][j] = fw[j];
+                    }
+                    wv::sync();
+                    if (isbody) {
+                        double acc[3] = {0, 0, 0};
+                        for (int c = 0; c < ncon; ++c) {
+                            const int b1 = m->geom_bodyid[S.c_g1[c]], b2 = m->geom_bodyid[S.c_g2[c]];
+                            const double sg = (b2 == b ? 1.0 : 0.0) - (b1 == b ? 1.0 : 0.0);
+                            for (int j = 0; j < 3; ++j) acc[j] += sg * S.c_pos[c][j];
+                        }
+                        for (int j = 0; j < 3; ++j) io.body_cfrc[((size_t)env * io.sb + b) * 3 + j] = acc[j];
+                    }
+                    wv::sync();
+                }
+            }
+            wv::block_barrier(); /* E */
+            CK_STAMP(37);
+            if (wv::opaque(S.cmd[0])) { warn |= WARN_DIVERGED; break; }
+            if (!io.integrate) break;
+            time += h;
+            continue;
+        }
         /* ================= half solve in registers: Y = D^-1/2 L^-T [J^T | qfrc_smooth], lane = column ================= */
         if constexpr (TOPO::is_static) {
             /* The multipliers do not depend on the solve, so dof k - 1's row of L is fetched (LDS broadcast reads) while
@@ -3540,9 +4079,11 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
     }
 
     /* ---------------- store state ---------------- */
-    if (io.progress && !io.resume && lane == 0) {
-        io.progress[env] = bailed ? sub : nsub; /* (the resume pass leaves the record) */
-        if (bailed && io.handover_list) io.handover_list[io.env0 + wv::atomic_add(io.handover_count, 1)] = env;
+    if (io.progress && lane == 0 && (!io.resume || bailed)) {
+        /* (a pass behind the fast kernel leaves the record of an env it completes; one that hands the env on -- the 63-row pass of a
+         * model that may use 127 -- moves it to the substep the next pass starts from) */
+        io.progress[env] = bailed ? sub : nsub;
+        if (bailed && io.handover_out_list) io.handover_out_list[io.env0 + wv::atomic_add(io.handover_out_count, 1)] = env;
     }
     if (io.integrate && io.drive_mode) {
         drive_state_store(io, S, env, lane);
@@ -3586,7 +4127,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
  * run-time branch: env_step is inlined, and two call sites would be two copies of it in one kernel.) */
 /* WPS: wavefronts per SIMD the registers are budgeted for (NW: 512 / NW registers a lane; 1 with NW = 2: two wavefronts per env with
  * 512 registers each, for batches that cannot fill the chip anyway -- a single simulator) */
-template <int NVP, class TOPO, int FEAT = FEAT_ALL, int MAXR = CM_MAXEFC, int NW = 1, bool WALK = false, int WPS = NW>
+template <int NVP, class TOPO, int FEAT = FEAT_ALL, int MAXR = MID_ROWS, int NW = 1, bool WALK = false, int WPS = NW>
 WV_GLOBAL void __launch_bounds__(WV_WAVE * NW) WV_OCC WV_WAVES_PER_SIMD(WPS) cassie_step_kernel(PhysIO io) {
     WV_SHARED EnvShared<NVP, LPack<TOPO, NVP>::count, MAXR> S;
     const int slot = wv::env_id();

@@ -209,6 +209,9 @@ int phys_batch_download_cost(phys_batch_t *b, unsigned *host);
  * over the same span on the constant 100 MHz clock (s_memrealtime), summed over the envs.  -1 where the launch-cost arrays do not
  * exist (batches under 2048 envs, balancing off). */
 int phys_batch_measured_shader_clock(phys_batch_t *b, double *hz);
+/* diagnostics: envs that the last stepping launch over the env range starting at env0 passed on to the 127-row instantiation (the
+ * count its pass reported: envs that met a substep with more than 63 constraint rows or 16 contacts) */
+int phys_batch_wide_pass_envs(phys_batch_t *b, int env0);
 /* validation aid: entries (and walker tickets) left in the hand-over lists of the batch's env ranges once its streams are idle
  * -- 0 whatever the mode: the pass behind the fast kernel clears what it walked, and a fast kernel whose pass does not walk the
  * list is not given one; -1 on error */

@@ -805,6 +805,82 @@ static int hfield_capsule_per_triangle(raw_contact_t *c, const cm_model_t *m, co
     return n;
 }
 #endif
+/* CM_FLAG_HFPRISM: ONE CONTACT PER PENETRATED GRID TRIANGLE under a sphere / capsule (a sphere is a capsule of half length 0).
+ * MuJoCo decomposes the terrain under a geom into one prism per grid triangle and reports one contact per penetrated prism
+ * (why reference model/cassie_hfield.xml:4 asks for nconmax = 300); this definition keeps that shape with the repository's
+ * closest-feature rule per triangle (hfield_triangle above):
+ *   - the capsule's axis carries ns = 1 + ceil(2 h / r) sample spheres (at most CM_HP_MAXS), t_k = h (1 - 2 k / (ns - 1)): no
+ *     further apart than the radius, so the union of the spheres sags at most 0.134 r below the capsule's surface;
+ *   - every grid triangle under the capsule's bounding rectangle (grown by the reach r + margin), cells in row-major scan order,
+ *     the triangle (v00, v10, v01) of a cell before (v11, v01, v10), keeps the DEEPEST of the samples -- smallest closest-feature
+ *     distance, ties to the lower k -- and gives a contact when that distance minus r is within the margin: position on the
+ *     sample sphere's surface, normal = that sample's closest-feature direction, tangent hint = the capsule's axis;
+ *   - contacts in that order; the caller's buffer bounds them (co_collision: the model's contact cap, with the warning bit).
+ * Returns the number of contacts found (which may exceed `room`: only the first `room` are written). */
+static int hfield_prism_contacts(raw_contact_t *c, int room, const cm_model_t *m, const float *data, const double *ph, const double *mh,
+                                 const double *pc, const double *axw, double r, double h, double margin) {
+    if (!data || m->hfield_nrow < 2 || m->hfield_ncol < 2) return 0;
+    const double sx = m->hfield_size[0], sy = m->hfield_size[1], sz = m->hfield_size[2];
+    double d[3] = {pc[0] - ph[0], pc[1] - ph[1], pc[2] - ph[2]}, p0[3], ax[3];
+    mulmatTvec3(p0, mh, d);
+    mulmatTvec3(ax, mh, axw);
+    const int nc = m->hfield_ncol, nr = m->hfield_nrow;
+    const double dx = 2 * sx / (nc - 1), dy = 2 * sy / (nr - 1), reach = r + (margin > 0 ? margin : 0);
+    if (p0[2] - h * fabs(ax[2]) - r > sz + margin) return 0;     /* the whole capsule above the highest possible terrain */
+    const double xa = p0[0] - h * fabs(ax[0]) - reach, xb = p0[0] + h * fabs(ax[0]) + reach;
+    const double ya = p0[1] - h * fabs(ax[1]) - reach, yb = p0[1] + h * fabs(ax[1]) + reach;
+    int j0 = (int)floor((xa + sx) / dx), j1 = (int)floor((xb + sx) / dx), i0 = (int)floor((ya + sy) / dy), i1 = (int)floor((yb + sy) / dy);
+    if (j0 < 0) j0 = 0;
+    if (i0 < 0) i0 = 0;
+    if (j1 > nc - 2) j1 = nc - 2;
+    if (i1 > nr - 2) i1 = nr - 2;
+    int ns = h > 0 ? 1 + (int)ceil(2 * h / r) : 1;
+    if (ns > CM_HP_MAXS) ns = CM_HP_MAXS;
+    int n = 0;
+    for (int i = i0; i <= i1; ++i)
+        for (int j = j0; j <= j1; ++j) {
+            const double x0 = -sx + j * dx, y0 = -sy + i * dy;
+            const double v00[3] = {x0, y0, sz * data[i * nc + j]}, v10[3] = {x0 + dx, y0, sz * data[i * nc + j + 1]};
+            const double v01[3] = {x0, y0 + dy, sz * data[(i + 1) * nc + j]}, v11[3] = {x0 + dx, y0 + dy, sz * data[(i + 1) * nc + j + 1]};
+            for (int tri = 0; tri < 2; ++tri) {
+                double best = 1e300, bn[3] = {0, 0, 1}, bt = 0;
+                for (int k = 0; k < ns; ++k) {
+                    const double t = ns > 1 ? h * (1.0 - 2.0 * k / (ns - 1)) : 0.0;
+                    const double p[3] = {p0[0] + t * ax[0], p0[1] + t * ax[1], p0[2] + t * ax[2]};
+                    double cur = 1e300, cn[3] = {0, 0, 1};
+                    if (tri == 0) hfield_triangle(p, v00, v10, v01, &cur, cn); else hfield_triangle(p, v11, v01, v10, &cur, cn);
+                    if (cur < best) { best = cur; bt = t; for (int q = 0; q < 3; ++q) bn[q] = cn[q]; }
+                }
+                if (best > 1e299) continue;
+                const double dist = best - r;
+                if (dist > margin) continue;
+                if (n < room) {
+                    raw_contact_t *rc = &c[n];
+                    double nw[3];
+                    mulmatvec3(nw, mh, bn);
+                    rc->dist = dist;
+                    for (int q = 0; q < 3; ++q) {
+                        const double psw = pc[q] + bt * axw[q];          /* the sample's centre, world frame */
+                        rc->normal[q] = nw[q]; rc->pos[q] = psw - nw[q] * (r + 0.5 * dist); rc->tangent[q] = h > 0 ? axw[q] : 0.0;
+                    }
+                }
+                ++n;
+            }
+        }
+    return n;
+}
+/* test hook: sphere (halflen 0) / capsule against the height field geom by the CM_FLAG_HFPRISM rule; out[max][7] = dist, pos, normal */
+int co_test_hfield_prism(const cm_model_t *m, const double *pc, const double *mc, double radius, double halflen, double margin, int max, double *out) {
+    if (m->hfield_geom < 0) return 0;
+    raw_contact_t c[CM_MAXCON];
+    double mh[9];
+    const double axw[3] = {mc[2], mc[5], mc[8]};
+    quat2mat(mh, m->geom_quat[m->hfield_geom]);
+    if (max > CM_MAXCON) max = CM_MAXCON;
+    const int n = hfield_prism_contacts(c, max, m, g_hfield, m->geom_pos[m->hfield_geom], mh, pc, axw, radius, halflen, margin);
+    for (int k = 0; k < n && k < max; ++k) { out[7 * k] = c[k].dist; for (int i = 0; i < 3; ++i) { out[7 * k + 1 + i] = c[k].pos[i]; out[7 * k + 4 + i] = c[k].normal[i]; } }
+    return n;
+}
 /* test hook: one sphere (world centre ps, radius r) against the height field geom of the model; out = dist, pos, normal */
 int co_test_hfield_sphere(const cm_model_t *m, const double *ps, double r, double margin, double *out) {
     if (m->hfield_geom < 0) return 0;
@@ -905,9 +981,16 @@ static void make_frame(double *frame) {
 
 void co_collision(const cm_model_t *m, co_data_t *d) {
     d->ncon = 0;
+    const int maxcon = m->maxcon > 0 && m->maxcon < CM_MAXCON ? m->maxcon : CM_MAXCON;
+    const int prism = (m->flags & CM_FLAG_HFPRISM) != 0;
+    /* CM_FLAG_HFPRISM: the height-field pairs' contacts come FIRST (pair order, grid order within a pair), then the other pairs'
+     * in pair order -- the kernel forms them in a pass of its own ahead of its pair loop */
+    for (int pass = prism ? 0 : 1; pass < 2; ++pass)
     for (int p = 0; p < m->npair; ++p) {
         int g1 = m->pair_geom1[p], g2 = m->pair_geom2[p];
         int t1 = m->geom_type[g1], t2 = m->geom_type[g2];
+        const int hfpair = t1 == CM_GEOM_HFIELD && (t2 == CM_GEOM_SPHERE || t2 == CM_GEOM_CAPSULE);
+        if (prism && (pass == 0) != (hfpair != 0)) continue;
         double margin = fmax(m->geom_margin[g1], m->geom_margin[g2]);
         double gap = fmax(m->geom_gap[g1], m->geom_gap[g2]);
         const double *p1 = d->geom_xpos[g1], *p2 = d->geom_xpos[g2];
@@ -922,7 +1005,7 @@ void co_collision(const cm_model_t *m, co_data_t *d) {
             double dif[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
             if (dot3(dif, n) > margin + m->geom_rbound[g2]) continue;
         }
-        raw_contact_t rc[CO_RC_MAX];
+        raw_contact_t rc[CO_RC_MAX > CM_MAXCON ? CO_RC_MAX : CM_MAXCON];
         (void)mulmat3;
         int n = 0;
         if (t1 == CM_GEOM_PLANE && t2 == CM_GEOM_SPHERE) n = plane_sphere(rc, p1, m1, p2, m->geom_size[g2][0], margin);
@@ -936,6 +1019,12 @@ void co_collision(const cm_model_t *m, co_data_t *d) {
             n = hfield_capsule_per_triangle(rc, m, g_hfield, p1, m1, p2, axw, m->geom_size[g2][0], t2 == CM_GEOM_CAPSULE ? m->geom_size[g2][1] : 0.0, margin);
         }
 #endif
+        else if (hfpair && prism) {
+            const double axw[3] = {m2[2], m2[5], m2[8]};
+            const int room = maxcon - d->ncon;
+            n = hfield_prism_contacts(rc, room, m, g_hfield, p1, m1, p2, axw, m->geom_size[g2][0], t2 == CM_GEOM_CAPSULE ? m->geom_size[g2][1] : 0.0, margin);
+            if (n > room) { d->warn_contact_full = 1; n = room; }
+        }
         else if (t1 == CM_GEOM_HFIELD && t2 == CM_GEOM_SPHERE) n = hfield_sphere(rc, m, g_hfield, p1, m1, p2, m->geom_size[g2][0], margin);
         else if (t1 == CM_GEOM_HFIELD && t2 == CM_GEOM_CAPSULE) n = hfield_capsule(rc, m, g_hfield, p1, m1, p2, m2, m->geom_size[g2], margin);
         else if (t1 == CM_GEOM_SPHERE && t2 == CM_GEOM_BOX) n = sphere_box(rc, p1, m->geom_size[g1][0], p2, m2, m->geom_size[g2], margin);
@@ -944,7 +1033,7 @@ void co_collision(const cm_model_t *m, co_data_t *d) {
         else if (t1 == CM_GEOM_BOX && t2 == CM_GEOM_BOX) n = box_box(rc, p1, m1, m->geom_size[g1], p2, m2, m->geom_size[g2], margin);
         else { d->warn_unsupported_pair = 1; continue; }
         for (int k = 0; k < n; ++k) {
-            if (d->ncon >= CM_MAXCON) { d->warn_contact_full = 1; break; }
+            if (d->ncon >= maxcon) { d->warn_contact_full = 1; break; }
             co_contact_t *c = &d->contact[d->ncon++];
             memset(c, 0, sizeof *c);
             c->dist = rc[k].dist;
@@ -993,8 +1082,8 @@ static void impedance(const double *solimp, double pos, double margin, double *i
     *imp = dmin + y * (dmax - dmin);
 }
 
-static int add_row(co_data_t *d, int type, int id, const double *J, int nv, double pos, double margin, double diag) {
-    if (d->nefc >= CM_MAXEFC) { d->warn_constraint_full = 1; return 0; }
+static int add_row(co_data_t *d, int maxefc, int type, int id, const double *J, int nv, double pos, double margin, double diag) {
+    if (d->nefc >= maxefc) { d->warn_constraint_full = 1; return 0; }
     int r = d->nefc++;
     d->efc_type[r] = type; d->efc_id[r] = id;
     for (int k = 0; k < nv; ++k) d->efc_J[r][k] = J[k];
@@ -1005,6 +1094,7 @@ static int add_row(co_data_t *d, int type, int id, const double *J, int nv, doub
 void co_make_constraint(const cm_model_t *m, co_data_t *d) {
     int nv = m->nv;
     d->nefc = d->ne = d->nl = 0;
+    const int maxefc = m->maxefc > 0 && m->maxefc < CM_MAXEFC ? m->maxefc : CM_MAXEFC;
     double jp1[3][NV_], jr1[3][NV_], jp2[3][NV_], jr2[3][NV_], J[NV_];
 
     /* equality: connect (3 rows each): residual = anchor1_world - anchor2_world */
@@ -1018,10 +1108,10 @@ void co_make_constraint(const cm_model_t *m, co_data_t *d) {
         co_jac(m, d, b1, a1, jp1, jr1);
         co_jac(m, d, b2, a2, jp2, jr2);
         double diag = m->body_invweight0[b1][0] + m->body_invweight0[b2][0];
-        if (d->nefc + 3 > CM_MAXEFC) { d->warn_constraint_full = 1; continue; }
+        if (d->nefc + 3 > maxefc) { d->warn_constraint_full = 1; continue; }
         for (int i = 0; i < 3; ++i) {
             for (int k = 0; k < nv; ++k) J[k] = jp1[i][k] - jp2[i][k];
-            add_row(d, CM_CNSTR_EQUALITY, e, J, nv, a1[i] - a2[i], 0.0, diag);
+            add_row(d, maxefc, CM_CNSTR_EQUALITY, e, J, nv, a1[i] - a2[i], 0.0, diag);
         }
     }
     d->ne = d->nefc;
@@ -1036,7 +1126,7 @@ void co_make_constraint(const cm_model_t *m, co_data_t *d) {
             if (dist < margin) {
                 for (int k = 0; k < nv; ++k) J[k] = 0;
                 J[m->jnt_dofadr[j]] = -(double)side;
-                add_row(d, CM_CNSTR_LIMIT_JOINT, j, J, nv, dist, margin, m->dof_invweight0[m->jnt_dofadr[j]]);
+                add_row(d, maxefc, CM_CNSTR_LIMIT_JOINT, j, J, nv, dist, margin, m->dof_invweight0[m->jnt_dofadr[j]]);
             }
         }
     }
@@ -1049,7 +1139,7 @@ void co_make_constraint(const cm_model_t *m, co_data_t *d) {
         int nrow = c->dim == 1 ? 1 : 2 * (c->dim - 1);
         c->efc_address = -1;
         if (c->dim != 1 && c->dim != 3) { d->warn_unsupported_pair = 1; continue; }
-        if (d->nefc + nrow > CM_MAXEFC) { d->warn_constraint_full = 1; continue; }
+        if (d->nefc + nrow > maxefc) { d->warn_constraint_full = 1; continue; }
         co_jac(m, d, b1, c->pos, jp1, jr1);
         co_jac(m, d, b2, c->pos, jp2, jr2);
         double Jf[3][NV_]; /* relative translational Jacobian in the contact frame */
@@ -1062,15 +1152,15 @@ void co_make_constraint(const cm_model_t *m, co_data_t *d) {
         double tran = m->body_invweight0[b1][0] + m->body_invweight0[b2][0];
         c->efc_address = d->nefc;
         if (c->dim == 1) {
-            add_row(d, CM_CNSTR_CONTACT_FRICTIONLESS, ci, Jf[0], nv, c->dist, c->includemargin, tran);
+            add_row(d, maxefc, CM_CNSTR_CONTACT_FRICTIONLESS, ci, Jf[0], nv, c->dist, c->includemargin, tran);
         } else {
             for (int a = 1; a < c->dim; ++a) {
                 double mu = c->friction[a - 1];
                 double diag = tran + mu * mu * tran;
                 for (int k = 0; k < nv; ++k) J[k] = Jf[0][k] + mu * Jf[a][k];
-                add_row(d, CM_CNSTR_CONTACT_PYRAMIDAL, ci, J, nv, c->dist, c->includemargin, diag);
+                add_row(d, maxefc, CM_CNSTR_CONTACT_PYRAMIDAL, ci, J, nv, c->dist, c->includemargin, diag);
                 for (int k = 0; k < nv; ++k) J[k] = Jf[0][k] - mu * Jf[a][k];
-                add_row(d, CM_CNSTR_CONTACT_PYRAMIDAL, ci, J, nv, c->dist, c->includemargin, diag);
+                add_row(d, maxefc, CM_CNSTR_CONTACT_PYRAMIDAL, ci, J, nv, c->dist, c->includemargin, diag);
             }
         }
     }

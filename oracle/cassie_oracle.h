@@ -94,6 +94,7 @@ unsigned long co_sizeof_data(void);
 int co_test_box_box(const double *p1, const double *m1, const double *s1, const double *p2, const double *m2, const double *s2, double margin, double *out);
 int co_test_hfield_capsule(const cm_model_t *m, const double *pc, const double *mc, double radius, double halflen, double margin, double *out);
 int co_test_hfield_sphere(const cm_model_t *m, const double *ps, double r, double margin, double *out);
+int co_test_hfield_prism(const cm_model_t *m, const double *pc, const double *mc, double radius, double halflen, double margin, int max, double *out);
 /* joint PD -> motor-side ctrl (pd_input motor law + reference motor() speed-torque limit, no delay line) */
 void co_pd_ctrl(const cm_model_t *m, co_data_t *d, const double *ptarget, const double *kp, const double *kd);
 /* OpenMP over independent envs: nsteps of co_step (optionally with the PD law) for each of n envs */

@@ -201,12 +201,16 @@ static int g_force_runtime_topology = 0;
 static void body32s() { ck::cassie_step_kernel<32, ck::TopoCassie32>(g_io); }
 static void body32s_fast() { ck::cassie_step_kernel<32, ck::TopoCassie32, ck::FEAT_ALL, ck::FAST_ROWS>(g_io); }
 /* the two-wave forms (wave 1 runs the mass-matrix stage group beside wave 0's collision / velocity / row stages) */
-static void body32s_2w() { ck::cassie_step_kernel<32, ck::TopoCassie32, ck::FEAT_ALL, CM_MAXEFC, 2>(g_io); }
+static void body32s_2w() { ck::cassie_step_kernel<32, ck::TopoCassie32, ck::FEAT_ALL, ck::MID_ROWS, 2>(g_io); }
 /* the full instantiation as the list-walking pass behind the fast kernel */
-static void body32s_walk() { ck::cassie_step_kernel<32, ck::TopoCassie32, ck::FEAT_ALL, CM_MAXEFC, 1, true>(g_io); }
-static void body32s_2w_walk() { ck::cassie_step_kernel<32, ck::TopoCassie32, ck::FEAT_ALL, CM_MAXEFC, 2, true>(g_io); }
+static void body32s_walk() { ck::cassie_step_kernel<32, ck::TopoCassie32, ck::FEAT_ALL, ck::MID_ROWS, 1, true>(g_io); }
+static void body32s_2w_walk() { ck::cassie_step_kernel<32, ck::TopoCassie32, ck::FEAT_ALL, ck::MID_ROWS, 2, true>(g_io); }
+/* the 127-row instantiation (two wavefronts; the solve of a substep with more than 64 rows is spread over both): alone, and as the
+ * pass that walks the list of envs the 63-row pass handed on */
+static void body32s_wide() { ck::cassie_step_kernel<32, ck::TopoCassie32, ck::FEAT_ALL, ck::WIDE_ROWS, 2, false, 1>(g_io); }
+static void body32s_wide_walk() { ck::cassie_step_kernel<32, ck::TopoCassie32, ck::FEAT_ALL, ck::WIDE_ROWS, 2, true, 1>(g_io); }
 static void body32s_fast_2w() { ck::cassie_step_kernel<32, ck::TopoCassie32, ck::FEAT_ALL, ck::FAST_ROWS, 2>(g_io); }
-static void body40s_2w() { ck::cassie_step_kernel<40, ck::TopoCassieTray38, ck::FEAT_WAVEPAIRS, CM_MAXEFC, 2>(g_io); } /* (no height-field pairs) */
+static void body40s_2w() { ck::cassie_step_kernel<40, ck::TopoCassieTray38, ck::FEAT_WAVEPAIRS, ck::MID_ROWS, 2>(g_io); } /* (no height-field pairs) */
 static int g_two_waves = 0, g_resume_grid = 2;
 extern "C" void emu_resume_grid(int n) { g_resume_grid = n > 0 ? n : 1; }
 extern "C" void emu_two_waves(int on) { g_two_waves = on; }
@@ -224,15 +228,16 @@ static volatile int g_chunk_fault = 0;
 namespace wv { int emu_xcc() { return g_producer_xcc; } }
 extern "C" void emu_producer_xcc(int x) { g_producer_xcc = x & 7; g_chunk_fault = 0; }
 extern "C" int emu_chunk_fault(void) { return g_chunk_fault; }
-static int g_fast_rows = 0, g_fast_bails = 0;
+static int g_fast_rows = 0, g_fast_bails = 0, g_wide_envs = 0;
 extern "C" void emu_fast_rows(int on) { g_fast_rows = on; }
 extern "C" int emu_fast_bails(void) { return g_fast_bails; }
+extern "C" int emu_wide_envs(void) { return g_wide_envs; } /* envs the 63-row pass handed on to the 127-row pass, so far */
 static void body40s() { ck::cassie_step_kernel<40, ck::TopoCassieTray38>(g_io); }
 /* the 40-dof model's row-capped instantiation (47 rows, one wave per env: the Gram matrix through the staged tile's own LDS) and
  * the full one as the list-walking pass behind it (no height-field pairs) */
 static void body40s_fast() { ck::cassie_step_kernel<40, ck::TopoCassieTray38, ck::FEAT_WAVEPAIRS, ck::FAST_ROWS_TRAY>(g_io); }
-static void body40s_walk() { ck::cassie_step_kernel<40, ck::TopoCassieTray38, ck::FEAT_WAVEPAIRS, CM_MAXEFC, 1, true>(g_io); }
-static void body40s_2w_walk() { ck::cassie_step_kernel<40, ck::TopoCassieTray38, ck::FEAT_WAVEPAIRS, CM_MAXEFC, 2, true>(g_io); }
+static void body40s_walk() { ck::cassie_step_kernel<40, ck::TopoCassieTray38, ck::FEAT_WAVEPAIRS, ck::MID_ROWS, 1, true>(g_io); }
+static void body40s_2w_walk() { ck::cassie_step_kernel<40, ck::TopoCassieTray38, ck::FEAT_WAVEPAIRS, ck::MID_ROWS, 2, true>(g_io); }
 static void body32() { ck::cassie_step_kernel<32, ck::TopoRuntime>(g_io); }
 static void body40() { ck::cassie_step_kernel<40, ck::TopoRuntime>(g_io); }
 extern "C" void emu_force_runtime_topology(int on) { g_force_runtime_topology = on; }
@@ -274,10 +279,15 @@ extern "C" int emu_phys_run(const cm_model_t *model, int nenv, int nsub, int int
     if ((cassie32 || tray38) && g_fast_rows && integrate && nenv <= (1 << 16)) {
         /* as phys_batch.hip launches them: the row-capped fast instantiation for every env (it appends the envs it hands over to
          * the hand-over list), then the full instantiation as ONE small grid walking that list (here: g_resume_grid workgroups) */
-        static int progress[1 << 16], list[1 << 16], count[2];
-        static volatile int seen;
-        count[0] = count[1] = 0; seen = -1;
-        g_io.progress = progress; g_io.resume = 0; g_io.handover_list = list; g_io.handover_count = count; g_io.handover_seen = &seen;
+        static int progress[1 << 16], list[1 << 16], count[2], list2[1 << 16], count2[2];
+        static volatile int seen, seen2;
+        count[0] = count[1] = 0; seen = -1; count2[0] = count2[1] = 0; seen2 = -1;
+        /* the fast kernel appends to `list`; the 63-row pass walks it and -- for models that may use 127 rows -- appends what it cannot
+         * hold to `list2`, which the 127-row pass walks */
+        const bool third = cassie32 && model->maxefc > ck::MID_ROWS;
+        g_io.progress = progress; g_io.resume = 0; g_io.has_next = 1;
+        g_io.handover_list = nullptr; g_io.handover_count = nullptr; g_io.handover_seen = nullptr;
+        g_io.handover_out_list = list; g_io.handover_out_count = count;
         static int chunk_flag[1 << 16];
         const int nchunk = (g_chunks > 1 && nsub >= 2) ? g_chunks : 1;
         g_io.nchunk = nchunk; g_io.chunk_seq = ++g_chunk_seq; g_io.chunk_flag = chunk_flag; g_io.chunk_fault = &g_chunk_fault;
@@ -290,22 +300,38 @@ extern "C" int emu_phys_run(const cm_model_t *model, int nenv, int nsub, int int
         for (int e = 0; e < nenv; ++e) if (progress[e] < nsub) ++g_fast_bails;
         g_io.nchunk = 1;
         const int handed = count[0];
-        g_io.resume = 1;
+        g_io.resume = 1; g_io.has_next = third ? 1 : 0;
+        g_io.handover_list = list; g_io.handover_count = count; g_io.handover_seen = &seen;
+        g_io.handover_out_list = third ? list2 : nullptr; g_io.handover_out_count = third ? count2 : nullptr;
         g_grid = g_resume_grid;
         for (int wg = 0; wg < g_resume_grid; ++wg) {
             g_env = wg;
             if (tray38) { if (g_two_waves) run_block(body40s_2w_walk, 2); else run_block(body40s_walk); }
             else if (g_two_waves) run_block(body32s_2w_walk, 2); else run_block(body32s_walk);
         }
-        g_grid = 1;
-        g_io.progress = nullptr; g_io.resume = 0; g_io.handover_list = nullptr; g_io.handover_count = nullptr; g_io.handover_seen = nullptr;
         if (count[0] != 0 || count[1] != 0 || seen != handed) { fprintf(stderr, "emu: the pass behind the fast kernel left count %d ticket %d seen %d (handed %d)\n", count[0], count[1], (int)seen, handed); abort(); }
+        if (third) {
+            const int handed2 = count2[0];
+            g_wide_envs += handed2;
+            g_io.has_next = 0;
+            g_io.handover_list = list2; g_io.handover_count = count2; g_io.handover_seen = &seen2;
+            g_io.handover_out_list = nullptr; g_io.handover_out_count = nullptr;
+            const int grid2 = g_resume_grid > 1 ? g_resume_grid - 1 : 1;
+            g_grid = grid2;
+            for (int wg = 0; wg < grid2; ++wg) { g_env = wg; run_block(body32s_wide_walk, 2); }
+            if (count2[0] != 0 || count2[1] != 0 || seen2 != handed2) { fprintf(stderr, "emu: the 127-row pass left count %d ticket %d seen %d (handed %d)\n", count2[0], count2[1], (int)seen2, handed2); abort(); }
+        }
+        g_grid = 1;
+        g_io.progress = nullptr; g_io.resume = 0; g_io.has_next = 0; g_io.handover_list = nullptr; g_io.handover_count = nullptr; g_io.handover_seen = nullptr;
         return 0;
     }
     for (int e = 0; e < nenv; ++e) {
         g_env = e;
         if (cassie32) {
-            if (g_two_waves) run_block(body32s_2w, 2); else run_block(body32s);
+            /* (alone -- forward / read-out passes, the fast kernel switched off: the 127-row instantiation for models that may use
+             * its rows, the 63-row one for per-env models capped there) */
+            if (model->maxefc > ck::MID_ROWS) run_block(body32s_wide, 2);
+            else if (g_two_waves) run_block(body32s_2w, 2); else run_block(body32s);
         }
         else if (!g_force_runtime_topology && topo_matches(model, ck::TopoCassieTray38::table, ck::TopoCassieTray38::nv, ck::TopoCassieTray38::body_levels)) {
             if (g_two_waves && model->nhfpair == 0 && model->hfield_geom < 0) run_block(body40s_2w, 2); else run_block(body40s);
