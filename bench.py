@@ -673,11 +673,13 @@ def device_rollout(model, mode, n, steps, warmup, rank, world, local_rank, subst
     # what the last launch cost an env, first to last instruction, in shader clocks per substep (phys_batch_download_cost: batches
     # that keep a launch order) -> how full the GPU's workgroup slots were over the timed regions, see main()
     try:
+        res["wide_pass_envs_last_launch"] = sum(b.wide_pass_envs(first) for first, _ in ranges) if hasattr(b, "wide_pass_envs") else None
         res["env_clocks_per_substep"] = float(np.mean(b.launch_cost())) / max(1, last_launch["nsub"])
         res["shader_clock_hz"] = b.measured_shader_clock() if hasattr(b, "measured_shader_clock") else None
     except (RuntimeError, AttributeError):
         res["env_clocks_per_substep"] = None
         res["shader_clock_hz"] = None
+        res.setdefault("wide_pass_envs_last_launch", None)
     # ---- the metric's second half: sampled envs of EVERY rank against the CPU reference, same schedule ----
     ids_sample = torch.from_numpy(env_ids[sample].astype(np.int64)).to(dev)
     if collect and world > 1:
@@ -785,6 +787,9 @@ def main(argv=None):
                     help="physics steps fused into one kernel launch (at most up to the next PD-target re-draw)")
     ap.add_argument("--model", default="cassie", choices=["cassie", "cassie_hfield", "cassie_tray_box"],
                     help="cassie = BASELINE configs[1] (the headline); the other two are configs[3] / configs[4], for the record")
+    ap.add_argument("--hfield-contacts", default="default", choices=["default", "prism"],
+                    help="cassie_hfield only: `prism` = CM_FLAG_HFPRISM, one contact per penetrated grid triangle (the MuJoCo-shaped contact set; "
+                         "up to 32 contacts / 127 rows, envs pass through the 31 / 63 / 127-row instantiations); default = at most two per capsule")
     ap.add_argument("--parity-envs", type=int, default=64, help="envs of the timed batch replayed on the CPU reference (spread over all ranks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-step-pd", action="store_true")
@@ -833,6 +838,11 @@ def main(argv=None):
     from cassie_amd import Model
 
     model = Model(args.model)
+    if args.hfield_contacts == "prism":
+        if args.model != "cassie_hfield":
+            raise SystemExit("--hfield-contacts prism applies to --model cassie_hfield")
+        from cassie_amd import phys as _P
+        model.set_flag(_P.FLAG_HFPRISM, True)
     pod = model.pod
     n, scaling, shape = resolve_envs(world, args.envs_per_gpu, args.total_envs)
     repeats = max(1, args.repeats)
@@ -882,6 +892,7 @@ def main(argv=None):
                                    "each (value_min / value_max: the slowest / fastest region)"
                                    % (r["streams"], r["streams"], n, world, world * n, shape, args.model, EPISODE, PREROLL, HOLD, repeats, args.steps),
                        "api_of_value": api, "mode": args.mode,
+                       "hfield_contacts": args.hfield_contacts if args.model == "cassie_hfield" else None,
                        "envs_per_gpu": n, "envs_total": world * n, "baseline_config": shape, "parallelism": "env-sharded x%d" % world,
                        "obs_allgather_every_steps": HOLD if collect else None,
                        "streams": r["streams"],
@@ -930,6 +941,8 @@ def main(argv=None):
             "envs_with_warnings": r["envs_with_warnings"],
             **({"obs_allgather_ok": r.get("gather_ok")} if collect else {}),   # rank 0's rows of the last gathered block = its snapshot
             "frac_envs_handed_over_to_the_full_kernel_in_the_last_launch": r["frac_envs_handed_over_last_launch"],
+            # ... and of those, the envs the 63-row pass passed on to the 127-row instantiation (rank 0's batch)
+            "frac_envs_in_the_127_row_pass_in_the_last_launch": (r.get("wide_pass_envs_last_launch") / float(n)) if r.get("wide_pass_envs_last_launch") is not None else None,
             "mean_constraint_rows": r["mean_constraint_rows"], "mean_pgs_iterations": r["mean_pgs_iterations"], "mean_pgs_guarded_sweeps": r["mean_pgs_guarded_sweeps"],
         }
         if world == 1 and args.model == "cassie" and args.total_envs is None and not args.dry_run_cpu:

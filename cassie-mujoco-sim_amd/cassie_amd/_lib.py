@@ -98,6 +98,7 @@ def _declare(L):
     L.phys_batch_set_waves_per_env.argtypes = [vp, c.c_int]
     L.phys_batch_download_cost.argtypes = [vp, vp]
     L.phys_batch_measured_shader_clock.argtypes = [vp, vp]
+    L.phys_batch_wide_pass_envs.argtypes = [vp, c.c_int]
     L.phys_batch_set_chunks.argtypes = [vp, c.c_int]
     L.phys_batch_debug_handover_pending.argtypes = [vp]
     L.phys_batch_debug_handover_pending.restype = c.c_int

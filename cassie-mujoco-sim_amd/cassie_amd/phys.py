@@ -274,6 +274,14 @@ class Batch:
             return None
         return float(hz.value)
 
+    def wide_pass_envs(self, env0=0):
+        """Envs that the last stepping launch over the env range starting at env0 passed on to the 127-row instantiation (they met a
+        substep with more than 63 constraint rows or 16 contacts); waits for the batch's streams."""
+        r = lib().phys_batch_wide_pass_envs(self._h, int(env0))
+        if r < 0:
+            raise RuntimeError("phys_batch_wide_pass_envs failed")
+        return r
+
     def handover_pending(self):
         """Validation aid: entries left in the hand-over lists once the batch's streams are idle (0 in every mode)."""
         r = lib().phys_batch_debug_handover_pending(self._h)

@@ -25,7 +25,7 @@ def cassie_model(name):
     return Model(name)
 
 
-def _pd_rollout(model, n, sample, nsteps=1000, hfield=None, q0_of=None, generic=False):
+def _pd_rollout(model, n, sample, nsteps=1000, hfield=None, q0_of=None, generic=False, allow_caps=False):
     """n envs under the bench workload on the GPU (PD mode, HOLD fused substeps per launch); envs `sample` also on
     the oracle; returns the worst relative qpos error over all policy steps."""
     pod = model.pod
@@ -68,6 +68,8 @@ def _pd_rollout(model, n, sample, nsteps=1000, hfield=None, q0_of=None, generic=
             worst = max(worst, float(np.max(np.abs(q[sample] - qo) / np.maximum(1.0, np.abs(qo)))))
             rows_seen = max(rows_seen, int(cnt[:, 1].max()))
             assert worst <= REL_TOL, (p, worst)
+        if allow_caps:          # (rows / contacts past the model's caps are dropped alike by oracle and kernel, and the counts above agree)
+            w = w & ~(P.WARN_CONTACT_FULL | P.WARN_CONSTRAINT_FULL)
         assert not w.any(), "warning bits raised: %s" % np.unique(w)
         assert np.all(np.isfinite(q))
         return worst, rows_seen, q
@@ -314,3 +316,22 @@ def test_multi_contact_heightfield_flag_on_the_gpu(built):
         return q
     worst, rows, q = _pd_rollout(hf, 256, np.arange(0, 256, 8), nsteps=600, hfield=h, q0_of=place)
     assert rows >= 40
+
+
+def test_prism_contacts_heightfield_flag_on_the_gpu(built):
+    """CM_FLAG_HFPRISM (optional: one contact per penetrated grid triangle, up to 32 contacts and 127 rows -- the solve of a substep with
+    more than 64 rows spread over both wavefronts of its env): robots standing on the flat patch and robots tipped over on the rough
+    part, in exact-PD mode; GPU against the oracle with the same flag, counts equal at every policy step, rows well past one
+    wavefront's."""
+    hf = Model("cassie_hfield")
+    hf.set_flag(P.FLAG_HFPRISM, True)
+    h = np.random.default_rng(99).random((200, 200)).astype(np.float32)
+    h[95:105, 95:105] = 0
+
+    def place(e, q):
+        if e % 2:
+            q[0], q[1], q[2] = 0.6 + 0.07 * (e % 16), 0.9 - 0.05 * (e // 16 % 16), 0.75
+            q[3:7] = [0.924, 0.0, 0.383, 0.0]
+        return q
+    worst, rows, q = _pd_rollout(hf, 256, np.arange(0, 256, 8), nsteps=600, hfield=h, q0_of=place, allow_caps=True)
+    assert rows > 64

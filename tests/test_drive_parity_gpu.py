@@ -31,7 +31,7 @@ FLIP_SAFE_COUNTS = 1e-6
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _drive_pd_rollout(model, name, n, nsteps, nsample=64, spread_on_terrain=False):
+def _drive_pd_rollout(model, name, n, nsteps, nsample=64, spread_on_terrain=False, caps_report=None):
     """n envs in CM_DRIVE_PD mode under the benchmark's PD workload, HOLD fused substeps per launch; `nsample` of them replayed
     through HostChainEnvs and compared at EVERY policy step.  Returns (worst relative error, smallest flip margin, rows seen)."""
     pod = model.pod
@@ -41,6 +41,9 @@ def _drive_pd_rollout(model, name, n, nsteps, nsample=64, spread_on_terrain=Fals
     tg = bench.pd_targets(sample, npol)                  # seeds depend on the env id only ...
     q0 = np.tile(model.qpos_init(), (n, 1))
     if spread_on_terrain:
+        if caps_report is not None:                      # (every env somewhere on the terrain: the cap statistics are the batch's)
+            for e in range(n):
+                q0[e, 0], q0[e, 1] = G.start_xy(name, e)
         for i, e in enumerate(sample):
             q0[e, 0], q0[e, 1] = G.start_xy(name, i)
     tg_all = np.tile(bench.PD_OFFSET, (npol, n, 1))      # ... the other envs get targets too (cheaply: a per-env phase of one stream)
@@ -61,12 +64,22 @@ def _drive_pd_rollout(model, name, n, nsteps, nsample=64, spread_on_terrain=Fals
         b.set(P.F_PD_KD, np.tile(bench.PD_KD, (n, 1)))
         b.set_drive_mode(P.DRIVE_PD)
         worst, rows = 0.0, 0
+        capped_windows = wide_envs = 0
+        rows_all = []
         for p in range(npol):
             b.set(P.F_PD_PTARGET, tg_all[p])
+            if caps_report is not None:
+                b.clear_warnings()
             b.step(bench.HOLD)
             ref.step(bench.HOLD, tg[p])
             q = b.get(P.F_QPOS)[sample]
             w, info = b.warnings()
+            if caps_report is not None:
+                capped_windows += int(np.count_nonzero(w & (P.WARN_CONTACT_FULL | P.WARN_CONSTRAINT_FULL)))
+                wide_envs += b.wide_pass_envs()
+                rows_all.append(info[:, 1].copy())
+                assert not (w & ~(P.WARN_CONTACT_FULL | P.WARN_CONSTRAINT_FULL)).any(), np.unique(w)
+                w = w * 0                                # (rows past the cap are dropped alike by oracle and kernel: compared like the others)
             qr, cnt = ref.qpos(), ref.counts()
             bad = np.nonzero(np.any(info[sample][:, :3] != cnt, axis=1))[0]
             assert bad.size == 0, (name, p, sample[bad][:8].tolist(), info[sample][bad][:8].tolist(), cnt[bad][:8].tolist())
@@ -86,6 +99,14 @@ def _drive_pd_rollout(model, name, n, nsteps, nsample=64, spread_on_terrain=Fals
             if ref.flip_margin[i] > FLIP_SAFE_COUNTS:
                 dev, host = device_state_bytes(states[int(e)]), ref.chains[i].state_bytes()
                 assert dev[0] == host[0], (name, "drive FIR history (int32 counts)", int(e))
+        if caps_report is not None:
+            ra = np.array(rows_all)
+            caps_report.update({"envs": n, "steps": npol * bench.HOLD, "env_windows_of_50_steps": n * npol,
+                                "frac_env_windows_with_a_cap_warning": capped_windows / float(n * npol),
+                                "frac_env_launches_passed_on_to_the_127_row_instantiation": wide_envs / float(n * npol),
+                                "rows_at_the_ends_of_the_windows": {"mean": float(ra.mean()), "p99": float(np.percentile(ra, 99)), "max": int(ra.max()),
+                                                                    "frac_over_31": float((ra > 31).mean()), "frac_over_63": float((ra > 63).mean())},
+                                "worst_rel_qpos_err_sampled_envs": worst, "sampled_envs": int(len(sample)), "caps": {"contacts": int(pod.maxcon), "rows": int(pod.maxefc)}})
         return worst, float(ref.flip_margin.min()), rows
     finally:
         b.close()
@@ -101,6 +122,23 @@ def test_drive_pd_4096_envs_1000_steps(built, name):
     print("drive-pd %s: worst rel err %.2e over 64 envs x 20 policy steps, closest encoder input to a count boundary %.2e counts, up to %d rows"
           % (name, worst, margin, rows))
     assert rows >= 20
+
+
+def test_drive_pd_prism_contacts_4096_envs_1000_steps(built):
+    """BASELINE config 4 with CM_FLAG_HFPRISM -- one contact per penetrated grid triangle, the MuJoCo-shaped contact set that
+    reference model/cassie_hfield.xml:4 sizes nconmax = 300 for -- on the terrain of example/test_hfield.py:39-41, every env somewhere
+    on it: 64 sampled envs replayed through oracle + host chain at every policy step ((ncon, nefc, sweeps) equal, qpos 1e-9), envs
+    passing through all three tiers (31 -> 63 -> 127 rows) in the middle of fused launches.  The cap statistics of the batch --
+    env-windows with a warning bit, launches that reached the 127-row pass, rows -- go to gpurun_out/prism_caps_cassie_hfield.json."""
+    model = Model("cassie_hfield")
+    model.set_flag(P.FLAG_HFPRISM, True)
+    report = {"model": "cassie_hfield", "flag": "CM_FLAG_HFPRISM"}
+    worst, margin, rows = _drive_pd_rollout(model, "cassie_hfield", 4096, 1000, 64, spread_on_terrain=True, caps_report=report)
+    print(json.dumps(report))
+    os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(REPO, "gpurun_out", "prism_caps_cassie_hfield.json"), "w") as f:
+        json.dump(report, f, indent=1)
+    assert rows > 63 and report["frac_env_launches_passed_on_to_the_127_row_instantiation"] > 0
 
 
 def test_config3_per_rank_shape_8192_envs(cassie):
@@ -197,7 +235,7 @@ def test_stress_variant_pm10_rad_targets(built, name):
                   "frac_windows_constraint_cap": hits["constraint_full"] / total, "frac_windows_diverged": hits["diverged"] / total,
                   "unsupported_pair_warnings": hits["unsupported"], "max_rows_last_step": max_rows, "max_contacts_last_step": max_con,
                   "sampled_env_windows_compared": compared, "sampled_env_windows_excluded_for_a_cap": excluded,
-                  "worst_rel_qpos_err_over_a_window": worst, "caps": {"CM_MAXCON": 16, "CM_MAXEFC": 63}}
+                  "worst_rel_qpos_err_over_a_window": worst, "caps": {"contacts": int(pod.maxcon), "rows": int(pod.maxefc)}}
         print(json.dumps(report))
         os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
         with open(os.path.join(REPO, "gpurun_out", "stress_caps_%s.json" % name), "w") as f:

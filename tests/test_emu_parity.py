@@ -550,3 +550,67 @@ def test_a_chunk_that_finds_its_producer_on_another_xcd_flags_the_env_and_tells_
     finally:
         lib.emu_producer_xcc(0)
         lib.emu_chunks(1)
+
+
+def test_127_row_instantiation_is_the_63_row_one_bit_for_bit_where_both_hold_the_substep(cassie):
+    """The 127-row instantiation parks every row in LDS, picks it up again, and runs a substep of at most 64 rows on wave 0 alone
+    through the 63-row instantiation's chain of operations (physics_kernel.h, wide_solve): a workload that never needs more than
+    63 rows must come out of it bit for bit as out of the 63-row instantiation -- which is what lets an env move between the tiers
+    in the middle of a launch, and a launch go in chunks, without a trace in the results."""
+    pod = cassie.pod
+    keep = (pod.maxcon, pod.maxefc)
+    try:
+        wide, rows, _ = _two_wave_workload(cassie, True, fast=False, two_waves=True, schedule=1, poison=True, nlaunch=3)
+        assert 31 < rows[:, :, 1].max() <= 63
+        pod.maxcon, pod.maxefc = 16, 63
+        for two_waves in (True, False):
+            mid, _, _ = _two_wave_workload(cassie, True, fast=False, two_waves=two_waves, schedule=2, nlaunch=3)
+            assert mid == wide, two_waves
+    finally:
+        pod.maxcon, pod.maxefc = keep
+
+
+def test_three_tiers_equal_the_127_row_instantiation_alone_bit_for_bit(built):
+    """fast (31 rows) -> mid (63 rows, walks the first hand-over list, hands on to the second) -> wide (127 rows, walks the second):
+    on the rough terrain with one contact per penetrated grid triangle (CM_FLAG_HFPRISM) robots dropped into the ground pass through
+    all three in the middle of fused launches.  State, outputs, solver statistics and drive-level state must be those of the 127-row
+    instantiation stepping every env alone -- under all three wave schedules, with NaN-poisoned LDS, in one-wave and two-wave form of
+    the first two tiers, and with the launch in chunks."""
+    from cassie_amd import Model
+    from cassie_amd import phys as P
+    import emu_py
+    lib = emu_py.lib()
+    model = Model("cassie_hfield")
+    model.set_flag(P.FLAG_HFPRISM, True)
+    ref, rows, _ = _two_wave_workload(model, True, fast=False, two_waves=True, schedule=0, nlaunch=3, nsub=12, stress=False)
+    assert rows[:, :, 1].max() > 63 and rows[:, :, 1].min() <= 31, (rows[:, :, 1].min(), rows[:, :, 1].max())
+    for schedule, two_waves, chunks in ((0, True, 1), (1, True, 1), (2, True, 1), (1, False, 1), (2, True, 3)):
+        before = lib.emu_wide_envs()
+        lib.emu_resume_grid((2, 1, 3)[schedule]); lib.emu_chunks(chunks)
+        try:
+            got, _, _ = _two_wave_workload(model, True, fast=True, two_waves=two_waves, schedule=schedule, poison=True, nlaunch=3, nsub=12, stress=False)
+        finally:
+            lib.emu_resume_grid(2); lib.emu_chunks(1)
+        assert lib.emu_wide_envs() > before, "no env reached the 127-row pass"
+        assert got == ref, (schedule, two_waves, chunks)
+
+
+def test_guarded_sweeps_across_both_waves_reproduce_the_fast_ones(cassie):
+    """The guard (never accept a cost increase) of a sweep that crosses the waves is local to each wave's half: forcing every half
+    through its guarded form must give the trajectory of the unguarded sweeps to rounding, on the pose that needs 80 rows."""
+    import emu_py
+    pod = cassie.pod
+    q0 = cassie.qpos_init().copy()
+    q0[2] = 0.0
+    a, b = EmuBatch(pod, 1), EmuBatch(pod, 1)
+    for x in (a, b):
+        x.qpos[:] = q0
+    a.step(10)
+    emu_py.lib().emu_force_guarded_pgs(1)
+    try:
+        b.step(10)
+    finally:
+        emu_py.lib().emu_force_guarded_pgs(0)
+    assert a.info[0, 1] > 64 and a.info[0, 3] == 0 and b.info[0, 3] > 0
+    assert tuple(a.info[0, :3]) == tuple(b.info[0, :3])
+    assert np.abs(a.qpos - b.qpos).max() < 1e-11 and np.abs(a.qvel - b.qvel).max() < 1e-9

@@ -377,3 +377,163 @@ def test_emulated_kernel_matches_oracle_with_multi_contact(built, dense):
             assert np.max(np.abs(emu.qpos[e] - o.qpos) / np.maximum(1, np.abs(o.qpos))) < 1e-7
     finally:
         oracle_py.set_hfield(None)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# CM_FLAG_HFPRISM: one contact per penetrated grid triangle (MuJoCo reports one per penetrated prism: reference
+# model/cassie_hfield.xml:4 asks for nconmax = 300 for that reason)
+def _prism(model, pc, mc, radius, halflen, margin=0.0, room=32):
+    import ctypes
+    L = oracle_py.lib()
+    L.co_test_hfield_prism.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_void_p]
+    out = np.zeros(7 * room)
+    pc, mc = np.ascontiguousarray(pc, dtype=float), np.ascontiguousarray(mc, dtype=float)
+    n = L.co_test_hfield_prism(ctypes.byref(model.pod), pc.ctypes.data, mc.ctypes.data, radius, halflen, margin, room, out.ctypes.data)
+    return n, out.reshape(room, 7)[: min(n, room)]
+
+
+def _grid():
+    nc = 200
+    return -5 + 10.0 * np.arange(nc) / (nc - 1)      # sample coordinates of the 200 x 200 grid over [-5, 5]
+
+
+def test_prism_rule_one_contact_per_penetrated_triangle_geometry(hf):
+    """Geometric facts of the definition, on terrains where the answer can be written down:
+      - a sphere pressed into flat ground over the INTERIOR of a grid triangle touches that triangle alone: one contact, straight
+        down, at the plane model's depth; none when it floats above;
+      - over a grid VERTEX all six triangles that meet there are penetrated: six contacts, same depth, vertical normals;
+      - a capsule lying along a grid line reports a contact for every triangle within its radius along its whole length, in
+        row-major cell order, the (v00, v10, v01) triangle of a cell before the other;
+      - over a spike the spike's triangles come out deeper than the flat ones, with normals leaning away from the spike."""
+    xs = _grid()
+    dx = xs[1] - xs[0]
+    eye = np.array([1.0, 0, 0, 0, 1, 0, 0, 0, 1])
+    oracle_py.set_hfield(np.zeros((200, 200), dtype=np.float32))
+    try:
+        j, i = 120, 110
+        inside = np.array([xs[j] + dx / 3, xs[i] + dx / 3, -0.1 + 0.018])            # centroid of the lower-left triangle of cell (i, j), 2 mm deep at r = 2 cm
+        n, c = _prism(hf, inside, eye, 0.02, 0.0)                                      # (the sphere cuts the ground in a circle of 8.7 mm; the triangle's edges are 11.8 mm away)
+        assert n == 1 and abs(c[0, 0] + 0.002) < 1e-12 and np.allclose(c[0, 4:7], [0, 0, 1]) and np.allclose(c[0, 1:3], inside[:2])
+        assert abs(c[0, 3] - (-0.1 - 0.001)) < 1e-12                                   # position: midway between the surfaces
+        n, _ = _prism(hf, inside + [0, 0, 0.003], eye, 0.02, 0.0)
+        assert n == 0
+        # pressed 5 mm in, the circle (13.2 mm) reaches over the triangle's edges: the neighbours across them are penetrated too, at
+        # their closest points on the shared edges -- shallower, with normals leaning towards the centre (the prism-shaped answer)
+        n, c = _prism(hf, inside - [0, 0, 0.003], eye, 0.02, 0.0)
+        assert n >= 2 and abs(c[:, 0].min() + 0.005) < 1e-12 and np.sum(np.isclose(c[:, 0], -0.005)) == 1 and np.all(c[:, 6] > 0.7)
+        n, c = _prism(hf, [xs[j], xs[i], -0.1 + 0.015], eye, 0.02, 0.0)
+        assert n == 6 and np.allclose(c[:, 0], -0.005) and np.allclose(c[:, 4:7], [0, 0, 1])
+        # a foot-like capsule (r = 2 cm, half length 8 cm) along x, 1 cm above a grid line y = xs[i]: every triangle whose closest
+        # point to the axis is within the radius -- the two rows of cells on either side of the line, both triangles of a cell
+        # where the diagonal comes close enough
+        along_x = np.array([0.0, 0, 1, 0, 1, 0, -1, 0, 0])                           # capsule axis (third column) = world x
+        pc = np.array([xs[j] + 0.5 * dx, xs[i], -0.1 + 0.015])
+        n, c = _prism(hf, pc, along_x, 0.02, 0.08)
+        # (triangles with an EDGE on the line have a sample straight above that edge: 5 mm; those with only a VERTEX on it take the nearest
+        # of the samples, which are 2 cm apart: up to 1 cm off, a little shallower and leaning)
+        assert n >= 8 and np.sum(np.isclose(c[:, 0], -0.005)) >= 8 and np.all(c[:, 0] <= -0.004) and np.all(c[:, 0] >= -0.005 - 1e-12) and np.all(c[:, 6] > 0.9)
+        assert np.all(np.abs(c[:, 1] - pc[0]) <= 0.08 + 0.02) and np.all(np.abs(c[:, 2] - pc[1]) < 0.01)   # contact points along the axis' foot line
+        # the default rule reports the two ends only
+        import ctypes
+        L = oracle_py.lib()
+        L.co_test_hfield_capsule.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_void_p]
+        out = np.zeros(28)
+        assert L.co_test_hfield_capsule(ctypes.byref(hf.pod), pc.ctypes.data, along_x.ctypes.data, 0.02, 0.08, 0.0, out.ctypes.data) == 2
+        # a 5 cm spike at the vertex under the capsule's middle
+        h = np.zeros((200, 200), dtype=np.float32)
+        h[i, j] = 0.25
+        oracle_py.set_hfield(h)
+        pc2 = np.array([xs[j], xs[i] + 0.4 * dx, -0.1 + 0.04])
+        n, c = _prism(hf, pc2, along_x, 0.02, 0.08)
+        assert n >= 2 and c[:, 0].min() < -0.01 and np.any(c[:, 5] > 0.3)              # the spike's flank pushes towards +y
+    finally:
+        oracle_py.set_hfield(None)
+
+
+def test_prism_rule_is_the_dense_limit_of_point_samples(hf):
+    """Against brute force on the random terrain: for every grid triangle under a capsule, the smallest closest-feature distance
+    over the rule's sample spheres, computed here in numpy from the definition's own triangle rule (closest point of the triangle
+    when the centre is above its plane, signed plane distance inside its prism otherwise) -- contact count, order, depth."""
+    h = terrain()
+    oracle_py.set_hfield(h)
+    try:
+        xs = _grid()
+        dx = xs[1] - xs[0]
+        rng = np.random.default_rng(3)
+        gpos = np.array([0.0, 0.0, -0.1])
+        for trial in range(12):
+            r, hl = (0.02, 0.08) if trial % 2 else (0.04, 0.21)
+            ax = rng.standard_normal(3); ax[2] *= 0.3; ax /= np.linalg.norm(ax)
+            b1 = np.cross(ax, [0, 0, 1.0]); b1 /= np.linalg.norm(b1)
+            mc = np.stack([b1, np.cross(ax, b1), ax], axis=1).ravel()               # third column = axis
+            pc = np.array([rng.uniform(0.5, 1.5), rng.uniform(-1.0, 1.0), -0.1 + rng.uniform(0.05, 0.16)])
+            n, c = _prism(hf, pc, mc, r, hl, room=32)
+            ns = min(16, 1 + int(np.ceil(2 * hl / r)))
+            ts = [hl * (1.0 - 2.0 * k / (ns - 1)) for k in range(ns)]
+            p0 = pc - gpos
+            reach = r
+            j0 = int(np.floor((p0[0] - hl * abs(ax[0]) - reach + 5) / dx)); j1 = int(np.floor((p0[0] + hl * abs(ax[0]) + reach + 5) / dx))
+            i0 = int(np.floor((p0[1] - hl * abs(ax[1]) - reach + 5) / dx)); i1 = int(np.floor((p0[1] + hl * abs(ax[1]) + reach + 5) / dx))
+            want = []
+            for i in range(i0, i1 + 1):
+                for j in range(j0, j1 + 1):
+                    x0, y0 = xs[j], xs[i]
+                    v = {(0, 0): np.array([x0, y0, 0.2 * h[i, j]]), (1, 0): np.array([x0 + dx, y0, 0.2 * h[i, j + 1]]),
+                         (0, 1): np.array([x0, y0 + dx, 0.2 * h[i + 1, j]]), (1, 1): np.array([x0 + dx, y0 + dx, 0.2 * h[i + 1, j + 1]])}
+                    for tri in ((v[0, 0], v[1, 0], v[0, 1]), (v[1, 1], v[0, 1], v[1, 0])):
+                        best = np.inf
+                        for t in ts:
+                            p = p0 + t * ax
+                            a, b_, c_ = tri
+                            nrm = np.cross(b_ - a, c_ - a)
+                            if nrm[2] < 0:
+                                nrm = -nrm
+                            nrm /= np.linalg.norm(nrm)
+                            s = nrm @ (p - a)
+                            if s >= 0:
+                                d = np.linalg.norm(p - _closest_on_triangle_np(p, a, b_, c_))
+                            else:
+                                e = [(q2[0] - q1[0]) * (p[1] - q1[1]) - (q2[1] - q1[1]) * (p[0] - q1[0]) for q1, q2 in ((a, b_), (b_, c_), (c_, a))]
+                                d = s if (all(x >= 0 for x in e) or all(x <= 0 for x in e)) else np.inf
+                            best = min(best, d)
+                        if best - r <= 0:
+                            want.append(best - r)
+            assert n == len(want), (trial, n, len(want))
+            assert np.allclose(c[:, 0], want[:32], atol=1e-12), trial
+    finally:
+        oracle_py.set_hfield(None)
+
+
+def test_emulated_kernel_matches_oracle_with_prism_contacts(built):
+    """CM_FLAG_HFPRISM in the kernel (hfield_prism_wave: lane = (pair, cell, triangle) key in the oracle's order, the contacts into the
+    list by ballot) against the oracle: a robot dropped on the flat patch, one straddling its edge, and one tipped over on the rough
+    part, where a lying Cassie needs more rows than one wavefront has lanes -- counts, sweeps and warning bits equal at every step."""
+    from cassie_amd import phys as P
+    m = _flag_model(P.FLAG_HFPRISM)
+    h = terrain()
+    oracle_py.set_hfield(h)
+    try:
+        pod = m.pod
+        qs = [m.qpos_init(), m.qpos_init(), m.qpos_init()]
+        qs[1][0] = 0.35
+        qs[2][0], qs[2][1], qs[2][2] = 0.6, 0.9, 0.75
+        qs[2][3:7] = [0.924, 0.0, 0.383, 0.0]
+        orcs = [Oracle(pod, q) for q in qs]
+        emu = EmuBatch(pod, 3)
+        for e, q in enumerate(qs):
+            emu.qpos[e] = q
+        emu.hfield = h.ravel().copy()
+        most, rows = [0, 0, 0], [0, 0, 0]
+        for s in range(300):
+            emu.step()
+            for e, o in enumerate(orcs):
+                o.step()
+                assert (emu.info[e, 0], emu.info[e, 1], emu.info[e, 2]) == (o.d.ncon, o.d.nefc, o.d.solver_iter), (s, e)
+                want = (1 if o.d.warn_contact_full else 0) | (2 if o.d.warn_constraint_full else 0)
+                assert int(emu.warn[e]) & 3 == want or (int(emu.warn[e]) & 3) | want == int(emu.warn[e]) & 3, (s, e)   # (the kernel's bits are sticky)
+                most[e], rows[e] = max(most[e], o.d.ncon), max(rows[e], o.d.nefc)
+        assert most[0] >= 6 and rows[2] > 64, (most, rows)     # several triangles under each foot; the lying robot is past one wavefront's rows
+        for e, o in enumerate(orcs):
+            assert np.max(np.abs(emu.qpos[e] - o.qpos) / np.maximum(1, np.abs(o.qpos))) < 1e-7
+    finally:
+        oracle_py.set_hfield(None)

@@ -16,20 +16,22 @@ sys.path.insert(0, os.path.join(REPO, "tests"))
 
 def main():
     import golden_physics as G
-    from cassie_amd import Model
-    if os.path.exists(G.PATH) and "--force" not in sys.argv:
-        raise SystemExit("%s exists: a changed definition needs a new VERSION in tests/golden_physics.py (or --force to overwrite)" % G.PATH)
-    out = {"meta/version": np.array(G.VERSION), "meta/checkpoints": np.array(G.CHECKPOINTS), "meta/nenv": np.array(G.NENV)}
-    for name in G.MODELS:
-        model = Model(name)
+    # `--v2`: the file of the round-5 option (CM_FLAG_HFPRISM); default: the v1 file of the default definitions
+    v2 = "--v2" in sys.argv
+    path, version, models = (G.PATH2, G.VERSION2, G.MODELS2) if v2 else (G.PATH, G.VERSION, G.MODELS)
+    if os.path.exists(path) and "--force" not in sys.argv:
+        raise SystemExit("%s exists: a changed definition needs a new VERSION in tests/golden_physics.py (or --force to overwrite)" % path)
+    out = {"meta/version": np.array(version), "meta/checkpoints": np.array(G.CHECKPOINTS), "meta/nenv": np.array(G.NENV)}
+    for name in models:
+        model = G.model_of(name)
         for mode in G.MODES:
             rec = G.oracle_rollout(model, name, mode)
             for field, v in rec.items():
                 out[G.key(name, mode, field)] = v
-            print("%-16s %-9s rows at step 1000: %s  sweeps: %s" % (name, mode, rec["counts"][-1][:, 1], rec["counts"][-1][:, 2]), flush=True)
-    os.makedirs(os.path.dirname(G.PATH), exist_ok=True)
-    np.savez_compressed(G.PATH, **out)
-    print("wrote", G.PATH, os.path.getsize(G.PATH), "bytes")
+            print("%-20s %-9s rows at step 1000: %s  sweeps: %s  most rows at a checkpoint: %d" % (name, mode, rec["counts"][-1][:, 1], rec["counts"][-1][:, 2], rec["counts"][:, :, 1].max()), flush=True)
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes")
 
 
 if __name__ == "__main__":
