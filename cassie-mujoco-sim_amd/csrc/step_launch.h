@@ -87,17 +87,25 @@ inline bool launch_three_tiers(dim3 grid, const TierGrids &tg, hipStream_t s, Ph
         if (after_first) (void)hipEventRecord(after_first, s);
         return hipGetLastError() == hipSuccess;
     }
+    /* (measurement aid: CASSIE_DEBUG_SKIP_MID_PASS -- two tiers, the fast kernel handing over straight to the 127-row pass) */
+    static const bool skip_mid = measurement_switch("CASSIE_DEBUG_SKIP_MID_PASS");
     /* the fast kernel: every env of the launch (in chunks, perhaps) */
     const bool walk1 = mid_2w != nullptr && hl.list1 != nullptr;   /* (the one-wave form's 63-row pass looks every env's record up instead) */
     io.resume = 0; io.has_next = 1;
     io.handover_list = nullptr; io.handover_count = nullptr; io.handover_seen = nullptr;
     io.handover_out_list = walk1 ? hl.list1 : nullptr; io.handover_out_count = walk1 ? hl.count1 : nullptr;
+    if (skip_mid) { io.handover_out_list = hl.list2; io.handover_out_count = hl.count2; }
     const dim3 fast_grid = chunked_grid(grid, io);
     if (fast_2w) { if (!fast_2w(fast_grid, s, io)) return false; }
     else hipLaunchKernelGGL((cassie_step_kernel<NVP, TOPO, FEAT, FAST_ROWS>), fast_grid, dim3(WV_WAVE), 0, s, io);
     if (hipGetLastError() != hipSuccess) return false;
     if (after_first) (void)hipEventRecord(after_first, s);
     if (skip_passes) return true;
+    if (skip_mid) {
+        io.resume = 1; io.nchunk = 1; io.has_next = 0; io.handover_out_list = nullptr; io.handover_out_count = nullptr;
+        io.handover_list = hl.list2; io.handover_count = hl.count2; io.handover_seen = hl.seen2;
+        return wide(tg.mid, s, io);    /* (sized like the pass it replaces) */
+    }
     /* the 63-row pass: walks the first list (two-wave form), or one workgroup per env that looks its env's record up (one-wave form);
      * hands on to the second list */
     io.resume = 1; io.nchunk = 1; io.has_next = 1;
