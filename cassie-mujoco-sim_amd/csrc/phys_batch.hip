@@ -31,7 +31,7 @@ void phys_set_last_error(const char *s);
  * with: 4 chunks (+7 %); launches over env ranges (phys_batch_step_range: other ranges' launches fill in) gain nothing from more
  * than 2 in steady state, and as much as the whole-batch launch when they stand alone between two synchronisations. */
 constexpr int DEFAULT_CHUNKS_WHOLE = 4, DEFAULT_CHUNKS_RANGE = 2, CHUNK_MIN_ENVS = 2048, CHUNK_MIN_SUBSTEPS = 5;
-constexpr int DEFAULT_TRAY_WAVES = 1; /* the 40-dof model's default form (decided by measurement, profiles/round4/tray_two_waves_ab.txt) */
+constexpr int DEFAULT_TRAY_WAVES = 2; /* the 40-dof model's default form (by measurement: round 5, 17.77 against 15.72 M with one wave, profiles/round5/tray_two_waves_ab.txt; round 4 had it at -7.5 %) */
 
 struct phys_batch {
     int nenv = 0, device = 0;

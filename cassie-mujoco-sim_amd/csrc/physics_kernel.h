@@ -1694,7 +1694,7 @@ WV_DEVICE void mass_matrix_columns(const PhysIO &io, SH &S, ModelPtr m, int env,
 /* ---------------- bias forces projected on the motion axes, passive forces, actuation -> qfrc_smooth (lane = dof).  Reads the
  * cfrc tile the velocity stage left, cdof, qpos / qvel / ctrl; writes S.qfrc_smooth.  One-wave form: in line behind the
  * velocity stage.  Two-wave form: wave 1, behind its factorisations, once wave 0 has published the cfrc tile. ---------------- */
-template <int NVP, class SH>
+template <int NVP, bool ROLLED = false, class SH>
 WV_DEVICE void bias_forces_and_qfrc_smooth(const PhysIO &io, SH &S, ModelPtr m, int env, const LaneIds &ids, const double kdamp, const double kstiff,
                                            const double kref, const double kgear, const double klo, const double khi, const int kq, const int ka) {
     const int nbody = ids.nbody, nv = ids.nv, kbody = ids.kbody, kbend = ids.kbend;
@@ -1727,7 +1727,9 @@ WV_DEVICE void bias_forces_and_qfrc_smooth(const PhysIO &io, SH &S, ModelPtr m, 
     } else {
         double acc[6] = {0, 0, 0, 0, 0, 0};
         const unsigned ksub = isdof ? (unsigned)(((1ull << kbend) - 1ull) ^ ((1ull << kbody) - 1ull)) : 0u; /* bodies [kbody, kbend) */
-#pragma unroll
+        /* (ROLLED: the 40-dof instantiation at 256 registers -- unrolled, the compiler requests all 32 bodies' forces at once, 384
+         * registers' worth, and spills a hundred of them around the wait for wave 0's velocity stage) */
+#pragma unroll(ROLLED ? 1 : NB / 4)
         for (int c0 = 0; c0 < NB; c0 += 4) {
             double ff[4][6];
 #pragma unroll
@@ -2393,6 +2395,22 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
                 wv::publish(&S.cmd[3], sub1 + 1);
                 CK_STAMP(38);
                 factor_pair_by_height<NVP, TOPO, 0>(m, h, S, col, colh, lane); /* (that of M + hB: behind the barrier J) */
+                /* The columns of M + hB wait for their factorisation behind J.  With 40 dofs and 256 registers they cannot wait in
+                 * registers (80 of them, across the drive-level pass, the bias stage and the sensor stage: the model constants those
+                 * stages request went to scratch one by one): they wait in LDS, in the slots their factor will take -- entry (i, j)
+                 * of the lower triangle in the factor's slot (i, j), the diagonal in dinvH -- and come back behind J. */
+                constexpr bool park_colh = NVP > 32;
+                if constexpr (park_colh) {
+                    if (isdof) {
+#pragma unroll
+                        for (int i = 0; i < NVP; ++i) {
+                            if (i >= TOPO::nv) continue;
+                            if (i == k_) S.dinvH[k_] = colh[i];
+                            else if (i > k_ && LP::col_has(i, k_)) S.LHp[LP::col_idx(i, k_)] = colh[i]; /* (entries outside the slots are zero) */
+                        }
+                    }
+                    wv::sync();
+                }
                 wv::wait_for(&S.cmd[4], sub1 + 1);
                 if (wv::opaque(S.cmd[0])) return; /* (the row-capped instantiation hands this substep over) */
                 if (io.drive_mode) {
@@ -2406,7 +2424,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
                     const double kgear = m->dof_gear[kd], klo = m->dof_ctrl_lo[kd], khi = m->dof_ctrl_hi[kd];
                     const int kq = m->dof_qadr[kd], ka = m->dof_act[kd];
                     wv::wait_for(&S.cmd[1], sub1 + 1); /* wave 0's velocity stage has the body forces (cfrc) in LDS */
-                    bias_forces_and_qfrc_smooth<NVP>(io, S, m, env, ids, kdamp, kstiff, kref, kgear, klo, khi, kq, ka);
+                    bias_forces_and_qfrc_smooth<NVP, (NVP > 32)>(io, S, m, env, ids, kdamp, kstiff, kref, kgear, klo, khi, kq, ka);
                 }
                 /* (the sensor stage's constants: requested ahead of the barrier) */
                 const bool lastsub1 = sub1 == nsub - 1 || !io.integrate;
@@ -2430,6 +2448,18 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
                 }
                 /* the factorisation of M + hB, which only this wave's Euler step reads: here, in the time this wave would otherwise
                  * wait for wave 0's solve, instead of on the way to the barrier J, where wave 0 waited for it (+4.6 %) */
+                if constexpr (park_colh) {
+#pragma unroll
+                    for (int i = 0; i < NVP; ++i) {
+                        double v = 0.0;
+                        if (i < TOPO::nv && isdof) {
+                            if (i == k_) v = S.dinvH[k_];
+                            else if (i > k_ && LP::col_has(i, k_)) v = S.LHp[LP::col_idx(i, k_)];
+                        }
+                        colh[i] = v;
+                    }
+                    wv::sync();
+                }
                 factor_pair_by_height<NVP, TOPO, 1>(m, h, S, col, colh, lane);
                 /* ---- the stages behind wave 0's constraint solve: operands staged now, while wave 0 assembles and solves ---- */
                 {
@@ -2440,11 +2470,15 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
                     const int pf_adof = m->act_dofid[pf_u], pf_ejt = m->jnt_type[pf_ej], pf_eqa = m->jnt_qposadr[pf_ej], pf_eda = m->jnt_dofadr[pf_ej];
                     const double *const fbuf = &S.c_solimp[0][0];
                     double lrow[NVP];
-                    stage_factor_row<NVP, TOPO>(S, k_, isdof, lrow);
+                    constexpr bool stage_h_early = NVP <= 32;
+                    if constexpr (stage_h_early) stage_factor_row<NVP, TOPO>(S, k_, isdof, lrow);
                     /* ... and its column of the factor of M + hB (this wave formed it right behind J): the Euler step's first
                      * substitution then starts without the column's 32 address computations and reads in front of it */
                     double lcol[NVP], lrowh[NVP];
-                    stage_factor_h<NVP, TOPO, 0>(S, k_, isdof, nv, lcol, lrowh);
+                    /* (the 40-dof instantiation at 256 registers cannot hold its row of L, this column and -- from the qacc stage on -- the row of
+                     * the factor of M + hB at once: 240 registers, which went to scratch and came back on the tail; there every operand
+                     * is fetched right in front of its use, 120 LDS reads on the tail instead) */
+                    if constexpr (stage_h_early) stage_factor_h<NVP, TOPO, 0>(S, k_, isdof, nv, lcol, lrowh);
                     const double rsdk = isdof ? S.rsd[k_] : 0.0;
                     const int kk = isdof ? k_ : 0;
                     /* this lane's column of the staged matrix (row MAXR = the qfrc_smooth column), once wave 0 has put it in LDS: the
@@ -2492,8 +2526,9 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
                     if (!isdof) z = 0.0;
                     if (isdof) z *= rsdk;
                     /* (the Euler step's operands are requested here: their LDS latency runs under the substitution below) */
-                    stage_factor_h<NVP, TOPO, 1>(S, k_, isdof, nv, lcol, lrowh); /* (the row: its registers were the staged column of Y until here) */
+                    if constexpr (stage_h_early) stage_factor_h<NVP, TOPO, 1>(S, k_, isdof, nv, lcol, lrowh); /* (the row: its registers were the staged column of Y until here) */
                     const double dih = isdof ? S.dinvH[k_] : 0.0;
+                    if constexpr (!stage_h_early) stage_factor_row<NVP, TOPO>(S, k_, isdof, lrow);
                     wv::sched_fence();
                     const double qacc = solve_forward<NVP, TOPO>(z, lrow, lane, nv);
                     {
@@ -2513,6 +2548,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
                      * cdof, none of which wave 0 touches before the next barrier F), the actuator velocities, the last substep's
                      * stores -- run beside wave 0's guard and kinematics stage instead of in front of them */
                     if (io.integrate) {
+                        if constexpr (!stage_h_early) stage_factor_h<NVP, TOPO>(S, k_, isdof, nv, lcol, lrowh);
                         euler_step<NVP, TOPO>(S, m, lane, isdof, k_, nv, njnt, h, qacc, lcol, lrowh, dih, pf_kdamp, pf_ejt, pf_eqa, pf_eda);
                     }
                     CK_STAMP(13);
@@ -3683,7 +3719,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
          *     body-stage region behind the staged tile) so that every lane ends up with its own row in registers;
          *   - the full instantiation forms the same chains on the vector unit, two rows at a time. */
         constexpr bool gram_on_matrix_core = MAXR == 31 && NVP % 4 == 0;
-        constexpr bool gram_in_place = MAXR == 47 && NVP == 40 && NW == 1; /* (the same on the matrix core, through the staged tile's own LDS: see there) */
+        constexpr bool gram_in_place = MAXR == 47 && NVP == 40; /* (the same on the matrix core, through the staged tile's own LDS: see there) */
         if constexpr (gram_on_matrix_core) {
             constexpr int YP = EnvShared<NVP, LPack<TOPO, NVP>::count, MAXR>::YP;
             static_assert(2 * (MAXR + 1) * YP * sizeof(double) <= sizeof(S.x), "the Gram matrix is parked behind the staged tile");
@@ -3751,11 +3787,15 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
             }
             wv::sync();
             const int myrow = lane < AR ? lane : AR - 1; /* (lanes past the staged rows hold no row: they take one and never use it) */
+            rb = Am[myrow][MAXR] - raref;
+            diag_yy = Am[myrow][myrow];
+            /* every lane takes its row of A, and the lanes store their rows of the tile once more (they still hold them).  (Leaving A
+             * in LDS through the sweeps instead -- one ds_read_b64 per row of the chain, requested eight rows ahead -- frees the 94
+             * registers of the row, but the chain is slower by more than the spills cost: round 5, 15.8 against 17.8 M in the two-wave
+             * form, 13.7 against 15.6 M with one wave.) */
 #pragma unroll
             for (int t = 0; t < MAXR; ++t) arow[t] = Am[myrow][t];
-            rb = Am[myrow][MAXR] - raref;
             wv::sync();
-            /* the staged tile as it was: the staging store over again */
             if (r_ < MAXR || lastcol) {
                 const int yrow = lastcol ? MAXR : r_;
 #pragma unroll
@@ -3862,7 +3902,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
          * R part of a row's action on its own residual is applied once per sweep (cdiag below): a row's residual is not
          * read again between its own turn and the end of the sweep. */
         double Aii = 1.0;
-        if constexpr (gram_on_matrix_core) { if (isrow) Aii = diag_yy + rR; }
+        if constexpr (gram_on_matrix_core || gram_in_place) { if (isrow) Aii = diag_yy + rR; }
         else if (isrow) {
             if constexpr (NVP == 32 || NVP == 40) { /* (the instantiations with a matrix-core form: its chain) */
                 double d = 0;
