@@ -60,7 +60,7 @@ $(OBJD)/%.o: $(CSRC)/%.cpp $(wildcard $(CSRC)/*.h) $(wildcard include/*.h)
 $(OBJD)/%.o: $(CSRC)/%.c $(wildcard $(CSRC)/*.h) $(wildcard include/*.h)
 	@mkdir -p $(OBJD)
 	gcc $(CFLAGS) -c $< -o $@
-$(OBJD)/%.hip.o: $(CSRC)/%.hip $(wildcard $(CSRC)/*.h) $(wildcard include/*.h)
+$(OBJD)/%.hip.o: $(CSRC)/%.hip $(wildcard $(CSRC)/*.h) $(wildcard $(CSRC)/*.inc) $(wildcard include/*.h)
 	@mkdir -p $(OBJD)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
@@ -76,7 +76,7 @@ $(PKG)/bin/cassiesim: $(PKG)/apps/cassiesim.c $(PRODUCT)
 oracle/libcassie_oracle.so: oracle/cassie_oracle.c oracle/cassie_oracle.h $(CSRC)/cm_model.h
 	gcc -O2 -std=gnu11 -fPIC -shared -fopenmp -I$(CSRC) -Ioracle oracle/cassie_oracle.c -o $@ -lm
 
-tests/emu/libcassie_emu.so: tests/emu/emu_runtime.cpp tests/emu/wave.h $(CSRC)/physics_kernel.h $(CSRC)/small_kernels.h $(CSRC)/cm_model.h
+tests/emu/libcassie_emu.so: tests/emu/emu_runtime.cpp tests/emu/wave.h $(wildcard $(CSRC)/*.h) $(wildcard $(CSRC)/*.inc)
 	g++ -O2 -std=c++17 -fPIC -shared -Wl,-Bsymbolic -Itests/emu -I$(CSRC) tests/emu/emu_runtime.cpp -o $@
 
 models: product
