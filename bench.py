@@ -67,11 +67,14 @@ PD_KP = np.array([70, 70, 100, 100, 50] * 2, dtype=np.float64)
 PD_KD = np.array([7, 7, 8, 8, 5] * 2, dtype=np.float64)
 
 
+TARGET_SPREAD = 0.3                 # rad; --target-spread 10 is the stress workload (reference example/cassietest_jac.py:106)
+
+
 def pd_targets(env_ids, npolicy):
     """[npolicy][len(env_ids)][10] targets; env e uses numpy.random.default_rng(1234 + e)."""
     out = np.empty((npolicy, len(env_ids), 10))
     for i, e in enumerate(env_ids):
-        out[:, i, :] = PD_OFFSET + np.random.default_rng(1234 + int(e)).uniform(-0.3, 0.3, (npolicy, 10))
+        out[:, i, :] = PD_OFFSET + np.random.default_rng(1234 + int(e)).uniform(-TARGET_SPREAD, TARGET_SPREAD, (npolicy, 10))
     return out
 
 
@@ -790,6 +793,9 @@ def main(argv=None):
     ap.add_argument("--hfield-contacts", default="default", choices=["default", "prism"],
                     help="cassie_hfield only: `prism` = CM_FLAG_HFPRISM, one contact per penetrated grid triangle (the MuJoCo-shaped contact set; "
                          "up to 32 contacts / 127 rows, envs pass through the 31 / 63 / 127-row instantiations); default = at most two per capsule")
+    ap.add_argument("--target-spread", type=float, default=TARGET_SPREAD,
+                    help="half-width in rad of the uniform PD targets around the standing pose (0.3: the metric's workload; 10: the "
+                         "stress targets of reference example/cassietest_jac.py:106, joints driven into their limits)")
     ap.add_argument("--parity-envs", type=int, default=64, help="envs of the timed batch replayed on the CPU reference (spread over all ranks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-step-pd", action="store_true")
@@ -802,6 +808,7 @@ def main(argv=None):
                     help="TEST INFRASTRUCTURE (tests/test_multirank.py): run main()'s launch / sharding / gather / reduction path on CPU "
                          "ranks (gloo) with a stand-in for the GPU batch (tests/bench_standin.py); no physics, nothing is measured")
     args = ap.parse_args(argv)
+    globals()["TARGET_SPREAD"] = args.target_spread
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # started the way the driver starts N = 1: no launcher around us -- start the ranks ourselves
@@ -893,13 +900,14 @@ def main(argv=None):
                                    % (r["streams"], r["streams"], n, world, world * n, shape, args.model, EPISODE, PREROLL, HOLD, repeats, args.steps),
                        "api_of_value": api, "mode": args.mode,
                        "hfield_contacts": args.hfield_contacts if args.model == "cassie_hfield" else None,
+                       "pd_target_spread_rad": args.target_spread,
                        "envs_per_gpu": n, "envs_total": world * n, "baseline_config": shape, "parallelism": "env-sharded x%d" % world,
                        "obs_allgather_every_steps": HOLD if collect else None,
                        "streams": r["streams"],
                        # a stepping launch is dispatched as this many workgroups per env, each stepping a share of the substeps
                        # (phys_batch_set_chunks; launches of fewer than 10 substeps or 2048 envs stay in one piece)
                        "chunks_per_env_launch": chunks,
-                       "wavefronts_per_env": (1 if args.model == "cassie_tray_box" or os.environ.get("CASSIE_WAVES_PER_ENV") == "1" else 2),
+                       "wavefronts_per_env": (1 if os.environ.get("CASSIE_WAVES_PER_ENV") == "1" or (args.model == "cassie_tray_box" and os.environ.get("CASSIE_TRAY_TWO_WAVES") == "0") else 2),
                        "streams_note": ("the %d envs of a GPU are stepped as %d contiguous ranges, each on its own stream at its own pace "
                                         "(phys_batch_step_range): per policy step every range gets its restarts, its PD targets and one "
                                         "launch, and nothing on the device joins the ranges between policy steps, so one range's workgroups "
@@ -926,12 +934,12 @@ def main(argv=None):
                                           "algorithmic bytes of one launch / the dominant kernel's mean duration (a HIP event pair around every launch on the launch stream)",
                          "achieved_one_launch": achieved_one, "stream_ms_per_policy_step": r["stream_ms"], "kernel_launches_timed": r["kernel_launches"],
                          "kernel": {"cassie": "ck::cassie_step_kernel<32, ck::TopoCassie32, 0, 31, 2, false, 2> (row-capped fast instantiation, TWO wavefronts per env; "
-                                              "<..., 63, 2, true> walks the list of handed-over envs behind it)",
+                                              "<..., 63, 2, true, 2> walks the list of handed-over envs behind it and <..., 127, 2, true, 1> the list of those it passes on)",
                                     "cassie_hfield": "ck::cassie_step_kernel<32, ck::TopoCassie32, 1, 31, 2, false, 2> (row-capped fast instantiation, two wavefronts per env; "
-                                                     "<..., 63, 2, true> walks the list of handed-over envs behind it)",
-                                    "cassie_tray_box": "ck::cassie_step_kernel<40, ck::TopoCassieTray38, 2, 47, 1, false, 1> (row-capped instantiation of 47 rows, ONE wavefront "
-                                                       "per env and 512 registers, Gram matrix on the matrix core; <..., 63, 2, true> walks the list of handed-over envs "
-                                                       "behind it; the two-wave form of the 40-dof instantiation spills and is slower, profiles/round4)"}[args.model], "kernel_ms": kern_ms, "algorithmic_bytes_per_env_step": algo_bytes, "env_steps_per_launch": launch_env_steps,
+                                                     "<..., 63, 2, true, 2> walks the list of handed-over envs behind it and <..., 127, 2, true, 1> the list of those it passes on)",
+                                    "cassie_tray_box": "ck::cassie_step_kernel<40, ck::TopoCassieTray38, 2, 47, 2, false, 2> (row-capped instantiation of 47 rows, TWO wavefronts "
+                                                       "per env, Gram matrix on the matrix core; <..., 63, 2, true, 2> walks the list of handed-over envs behind it; "
+                                                       "CASSIE_TRAY_TWO_WAVES=0: the one-wave form of round 4, profiles/round5/tray_two_waves_ab.txt)"}[args.model], "kernel_ms": kern_ms, "algorithmic_bytes_per_env_step": algo_bytes, "env_steps_per_launch": launch_env_steps,
                          "note": "latency-bound by design: ~2 KB of state vs ~0.22 MFLOP of serially dependent fp64 per env-step"},
             # the more telling bound: ~0.22 MFLOP of algorithmic fp64 work per env-step against the fp64 vector peak
             "roofline_fp64": {"bound": "fp64-valu", "achieved": value * 0.22e6 / 1e12, "peak": 78.6 * world, "unit": "TFLOP/s",

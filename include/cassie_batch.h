@@ -80,6 +80,11 @@ void cassie_sim_set_hfield_dense_sampling(struct cassie_sim *c, bool on);
 /* extension: up to four contacts per capsule / height-field pair (its deepest sample spheres) instead of two -- towards
  * MuJoCo's one contact per penetrated prism; a Cassie standing on both feet then needs 44 constraint rows instead of 28 */
 void cassie_sim_set_hfield_multi_contact(struct cassie_sim *c, bool on);
+/* extension: the MuJoCo-shaped contact set -- ONE CONTACT PER PENETRATED GRID TRIANGLE under every sphere / capsule that has a
+ * height-field pair (the deepest of the capsule's sample spheres over that triangle), the set reference model/cassie_hfield.xml:4
+ * sizes nconmax = 300 for.  Up to 32 contacts / 127 constraint rows per env (a warning bit past that); substeps with more than
+ * 31 / 63 rows are finished by the 63- / 127-row passes.  Off by default: about 3.3 x the cost on the bench terrain. */
+void cassie_sim_set_hfield_prism_contacts(struct cassie_sim *c, bool on);
 
 /* cores this process may really use: min(affinity mask, cgroup CPU quota) */
 int cassie_host_cpu_count(void);

@@ -37,7 +37,7 @@ void phys_model_set_const(phys_model_t *m);
 /* derive the pointer-free kernel model; returns 0 on success */
 int phys_model_compile(const phys_model_t *m, cm_model_t *out, char *err, int errlen);
 /* option flags of the model (CM_FLAG_* in csrc/cm_model.h: implicit joint damping, warm start, refsafe -- the mjOption
- * disable / enable bits the in-scope models use -- and CM_FLAG_HFDENSE, the denser capsule sampling against height fields);
+ * disable / enable bits the in-scope models use -- and the height-field contact options CM_FLAG_HFDENSE / HFMULTI / HFPRISM);
  * a change takes effect with the next compile / the next step of a cassie_sim_t */
 unsigned phys_model_flags(const phys_model_t *m);
 int phys_model_set_flag(phys_model_t *m, unsigned flag, int on);

@@ -100,6 +100,19 @@ def _drive_pd_rollout(model, name, n, nsteps, nsample=64, spread_on_terrain=Fals
                 dev, host = device_state_bytes(states[int(e)]), ref.chains[i].state_bytes()
                 assert dev[0] == host[0], (name, "drive FIR history (int32 counts)", int(e))
         if caps_report is not None:
+            # per ENV-STEP statistics: 200 more steps of the batch in one-step launches (the warning word is per launch)
+            capped_steps, rows_steps = 0, []
+            for s_ in range(200):
+                b.clear_warnings()
+                b.step(1)
+                w1, info1 = b.warnings()
+                capped_steps += int(np.count_nonzero(w1 & (P.WARN_CONTACT_FULL | P.WARN_CONSTRAINT_FULL)))
+                rows_steps.append(info1[:, 1].copy())
+            rs = np.array(rows_steps)
+            caps_report["env_steps_in_one_step_launches"] = {
+                "env_steps": int(rs.size), "frac_with_a_cap_warning": capped_steps / float(rs.size),
+                "rows": {"mean": float(rs.mean()), "p99": float(np.percentile(rs, 99)), "max": int(rs.max()),
+                         "frac_over_31": float((rs > 31).mean()), "frac_over_63": float((rs > 63).mean())}}
             ra = np.array(rows_all)
             caps_report.update({"envs": n, "steps": npol * bench.HOLD, "env_windows_of_50_steps": n * npol,
                                 "frac_env_windows_with_a_cap_warning": capped_windows / float(n * npol),
