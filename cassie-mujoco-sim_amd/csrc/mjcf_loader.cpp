@@ -1364,12 +1364,17 @@ bool HostModel::compile(cm_model_t *o, std::string *err) const {
             o->sensor_slot[s] = slot;
         }
     }
-    /* what an env-step of this model may use of the contact list and of the constraint rows (cm_model.h: CM_MAXCON / CM_MAXEFC): the
-     * 127-row instantiation of the step kernel exists for the 32-dof Cassie dof tree */
+    /* what an env-step of this model may use of the contact list and of the constraint rows (cm_model.h: CM_MAXCON / CM_MAXEFC).  The
+     * caps follow the contact definition: 16 contacts / 63 rows (never reached by the shipped definitions: 0 of 163 840 stress
+     * windows, profiles/round4) -- and 32 / 127 with CM_FLAG_HFPRISM, whose contact sets need them; the 127-row instantiation of the
+     * step kernel exists for the 32-dof Cassie dof tree.  (Round 5 first gave every model on that tree the wide caps: the 127-row
+     * pass then sits behind every launch, and its workgroups -- two empty SIMDs, 84 KB of LDS -- wait for the other env range's
+     * kernel to drain even when their list is empty: -4 % on config 2, profiles/round5/wide_pass_ab.txt.) */
     bool cassie32 = nv == ck::TopoCassie32::nv && o->kin_simple && o->maxdepth <= ck::TopoCassie32::body_levels;
     for (int k = 0; cassie32 && k < nv; ++k) cassie32 = o->dof_ancmask[k] == ck::TopoCassie32::table[k];
-    o->maxcon = cassie32 ? CM_MAXCON : CM_MAXCON_NARROW;
-    o->maxefc = cassie32 ? CM_MAXEFC : CM_MAXEFC_NARROW;
+    const bool wide_caps = cassie32 && (o->flags & CM_FLAG_HFPRISM) != 0 && o->nhfpair > 0;
+    o->maxcon = wide_caps ? CM_MAXCON : CM_MAXCON_NARROW;
+    o->maxefc = wide_caps ? CM_MAXEFC : CM_MAXEFC_NARROW;
     return true;
 }
 

@@ -254,12 +254,13 @@ static int launch(phys_batch *b, int nsub, int integrate, hipStream_t s, bool sc
             io.chunk_fault = b->d_chunk_fault;
         }
         if (fast && b->d_handover_list && b->d_handover_list2) {
+            const bool wide_caps = hm.maxefc > CM_MAXEFC_NARROW;
             /* the pass behind the fast kernel walks the hand-over list with a small grid: twice what the range's last launch
              * handed over (the launcher learns that a launch late, through host memory) plus 16, at most one workgroup per env;
              * the 127-row pass behind that one likewise, plus 8 */
             hl.list1 = b->d_handover_list; hl.count1 = b->d_handover_count + 2 * (size_t)env0; hl.seen1 = b->d_handover_seen + env0;
-            hl.list2 = b->d_handover_list2; hl.count2 = b->d_handover_count2 + 2 * (size_t)env0; hl.seen2 = b->d_handover_seen2 + env0;
-            const int seen = b->h_handover_seen[env0], seen2 = b->h_handover_seen2[env0];
+            if (wide_caps) { hl.list2 = b->d_handover_list2; hl.count2 = b->d_handover_count2 + 2 * (size_t)env0; hl.seen2 = b->d_handover_seen2 + env0; }
+            const int seen = b->h_handover_seen[env0], seen2 = wide_caps ? b->h_handover_seen2[env0] : 0;
             const int seen12 = seen > seen2 ? seen : seen2; /* (the first pass is never smaller than the second: it feeds it) */
             const long want = 2L * (seen12 > 0 ? seen12 : 0) + 16, want2 = 2L * (seen2 > 0 ? seen2 : 0) + 8;
             /* (a floor of 256 workgroups under both grids was measured: no gain on the prism workload, -0.6 % on config 2, profiles/round5) */
@@ -269,12 +270,12 @@ static int launch(phys_batch *b, int nsub, int integrate, hipStream_t s, bool sc
     };
     if (matches(ck::TopoCassie32::table, ck::TopoCassie32::nv, ck::TopoCassie32::body_levels)) {
         /* stepping launches of the two Cassie instantiations go through the row-capped fast instantiation first; the 63-row pass
-         * behind it finishes the envs that met a substep with more rows, the 127-row pass behind that one what is left; forward /
-         * read-out passes and small batches take the 127-row instantiation alone */
+         * behind it finishes the envs that met a substep with more rows, and -- for a model with the wide caps (CM_FLAG_HFPRISM) -- the
+         * 127-row pass behind that one what is left; forward / read-out passes and small batches take one instantiation alone */
         const bool fast = b->fast_rows && integrate && !wp && !io.ext && b->d_progress;
         tiers(fast);
-        if (!hf && !wp) { launched = ck::launch_step_cassie(grid, tg, s, io, hl, fast, ev_after, b->waves_per_env); ev_after = nullptr; }
-        else if (hf && !wp) { launched = ck::launch_step_cassie_hfield(grid, tg, s, io, hl, fast, ev_after, b->waves_per_env); ev_after = nullptr; }
+        if (!hf && !wp) { launched = ck::launch_step_cassie(grid, tg, s, io, hl, fast, hm.maxefc > CM_MAXEFC_NARROW, ev_after, b->waves_per_env); ev_after = nullptr; }
+        else if (hf && !wp) { launched = ck::launch_step_cassie_hfield(grid, tg, s, io, hl, fast, hm.maxefc > CM_MAXEFC_NARROW, ev_after, b->waves_per_env); ev_after = nullptr; }
         else launched = ck::launch_step_cassie_all(grid, s, io);
     } else if (matches(ck::TopoCassieTray38::table, ck::TopoCassieTray38::nv, ck::TopoCassieTray38::body_levels)) {
         /* the 40-dof model: a fast instantiation of 47 rows (the boxes resting on the tray take it to 32 .. 40 routinely) -- one wave

@@ -28,8 +28,8 @@ struct TierGrids { dim3 mid, wide; };   /* grids of the passes behind the fast k
 /* io.progress must be set when fast is; io.resume / has_next / the hand-over lists are managed here */
 /* after_first (may be null): recorded behind the first kernel of the launch -- the one that does the work -- for per-kernel timing */
 /* waves: 2 = the row-capped fast instantiation in its two-wave form (two wavefronts per env, see env_step), 1 = one wave per env */
-bool launch_step_cassie(dim3 grid, const TierGrids &tg, hipStream_t s, PhysIO io, const HandoverLists &hl, bool fast, hipEvent_t after_first, int waves);            /* <32, TopoCassie32, 0>: plain cassie.xml */
-bool launch_step_cassie_hfield(dim3 grid, const TierGrids &tg, hipStream_t s, PhysIO io, const HandoverLists &hl, bool fast, hipEvent_t after_first, int waves);     /* <32, TopoCassie32, FEAT_HFIELD> */
+bool launch_step_cassie(dim3 grid, const TierGrids &tg, hipStream_t s, PhysIO io, const HandoverLists &hl, bool fast, bool wide_caps, hipEvent_t after_first, int waves);            /* <32, TopoCassie32, 0>: plain cassie.xml */
+bool launch_step_cassie_hfield(dim3 grid, const TierGrids &tg, hipStream_t s, PhysIO io, const HandoverLists &hl, bool fast, bool wide_caps, hipEvent_t after_first, int waves);     /* <32, TopoCassie32, FEAT_HFIELD> */
 /* the two-wave forms of the fast instantiations, in translation units of their own (kernels_*_2w.hip) */
 bool launch_fast_cassie_2w(dim3 grid, hipStream_t s, PhysIO io);
 bool launch_fast_cassie_hfield_2w(dim3 grid, hipStream_t s, PhysIO io);
@@ -38,7 +38,11 @@ bool launch_fast_cassie_hfield_2w(dim3 grid, hipStream_t s, PhysIO io);
  * range's kernel keeps every SIMD half full */
 bool launch_mid_cassie_2w(dim3 grid, hipStream_t s, PhysIO io);
 bool launch_mid_cassie_hfield_2w(dim3 grid, hipStream_t s, PhysIO io);
-/* ... the 127-row instantiations: two waves of 512 registers, 75 KB of LDS (kernels_*_wide.hip) -- alone, or walking the second list */
+/* ... alone, for models whose caps are 63 rows (forward / read-out passes, a cassie_sim_t, small batches): two waves of 512 registers
+ * (kernels_*_small.hip) -- a batch that cannot fill the chip has no use for the second workgroup per SIMD pair */
+bool launch_alone63_cassie(dim3 grid, hipStream_t s, PhysIO io);
+bool launch_alone63_cassie_hfield(dim3 grid, hipStream_t s, PhysIO io);
+/* ... the 127-row instantiations: two waves of 512 registers, 84 KB of LDS (kernels_*_wide.hip) -- alone, or walking the second list */
 bool launch_wide_cassie(dim3 grid, hipStream_t s, PhysIO io);
 bool launch_wide_cassie_hfield(dim3 grid, hipStream_t s, PhysIO io);
 bool launch_step_cassie_all(dim3 grid, hipStream_t s, PhysIO io);                   /* <32, TopoCassie32, FEAT_ALL> */
@@ -70,52 +74,47 @@ inline void no_tiers(PhysIO &io) {
     io.handover_list = nullptr; io.handover_count = nullptr; io.handover_seen = nullptr; io.handover_out_list = nullptr; io.handover_out_count = nullptr;
 }
 
-/* a model on the 32-dof Cassie dof tree: fast -> mid -> wide, or the wide instantiation alone */
+/* a model on the 32-dof Cassie dof tree: fast -> mid (-> wide where the model's caps are 127 rows: hl.list2 set), or one instantiation alone */
 template <int NVP, class TOPO, int FEAT>
-inline bool launch_three_tiers(dim3 grid, const TierGrids &tg, hipStream_t s, PhysIO io, const HandoverLists &hl, bool fast, hipEvent_t after_first,
-                               bool (*fast_2w)(dim3, hipStream_t, PhysIO), bool (*mid_2w)(dim3, hipStream_t, PhysIO), bool (*wide)(dim3, hipStream_t, PhysIO)) {
-    /* a small batch stepping a few substeps per launch (somebody's control loop around a handful of envs): one launch of the
-     * 127-row kernel instead of three -- a launch costs what four substeps' difference between the kernels saves */
+inline bool launch_three_tiers(dim3 grid, const TierGrids &tg, hipStream_t s, PhysIO io, const HandoverLists &hl, bool fast, bool wide_caps, hipEvent_t after_first,
+                               bool (*fast_2w)(dim3, hipStream_t, PhysIO), bool (*mid_2w)(dim3, hipStream_t, PhysIO), bool (*wide)(dim3, hipStream_t, PhysIO),
+                               bool (*alone63)(dim3, hipStream_t, PhysIO)) {
+    /* a small batch stepping a few substeps per launch (somebody's control loop around a handful of envs): one launch instead of two
+     * or three -- a launch costs what four substeps' difference between the kernels saves */
     if (fast && grid.x <= SMALL_BATCH && io.nsub <= SMALL_BATCH_NSUB) fast = false;
     /* (measurement aid: CASSIE_DEBUG_SKIP_RESUME_PASS -- what the passes behind the fast kernel cost; handed-over envs are then
      * left unfinished, so only for workloads that hand nothing over) */
     static const bool skip_passes = measurement_switch("CASSIE_DEBUG_SKIP_RESUME_PASS");
-    if (!fast || !hl.list2) {
+    if (!fast || !hl.list1 || (wide_caps && !hl.list2)) {
         /* alone: forward / read-out passes, batches with the read-out enabled such as a cassie_sim_t, the fast kernel switched off */
         no_tiers(io);
-        if (!wide(grid, s, io)) return false;
+        if (!(wide_caps ? wide : alone63)(grid, s, io)) return false;
         if (after_first) (void)hipEventRecord(after_first, s);
         return hipGetLastError() == hipSuccess;
     }
-    /* (measurement aid: CASSIE_DEBUG_SKIP_MID_PASS -- two tiers, the fast kernel handing over straight to the 127-row pass) */
-    static const bool skip_mid = measurement_switch("CASSIE_DEBUG_SKIP_MID_PASS");
     /* the fast kernel: every env of the launch (in chunks, perhaps) */
-    const bool walk1 = mid_2w != nullptr && hl.list1 != nullptr;   /* (the one-wave form's 63-row pass looks every env's record up instead) */
+    const bool walk1 = mid_2w != nullptr;   /* (the one-wave form's 63-row pass looks every env's record up instead) */
     io.resume = 0; io.has_next = 1;
     io.handover_list = nullptr; io.handover_count = nullptr; io.handover_seen = nullptr;
     io.handover_out_list = walk1 ? hl.list1 : nullptr; io.handover_out_count = walk1 ? hl.count1 : nullptr;
-    if (skip_mid) { io.handover_out_list = hl.list2; io.handover_out_count = hl.count2; }
     const dim3 fast_grid = chunked_grid(grid, io);
     if (fast_2w) { if (!fast_2w(fast_grid, s, io)) return false; }
     else hipLaunchKernelGGL((cassie_step_kernel<NVP, TOPO, FEAT, FAST_ROWS>), fast_grid, dim3(WV_WAVE), 0, s, io);
     if (hipGetLastError() != hipSuccess) return false;
     if (after_first) (void)hipEventRecord(after_first, s);
     if (skip_passes) return true;
-    if (skip_mid) {
-        io.resume = 1; io.nchunk = 1; io.has_next = 0; io.handover_out_list = nullptr; io.handover_out_count = nullptr;
-        io.handover_list = hl.list2; io.handover_count = hl.count2; io.handover_seen = hl.seen2;
-        return wide(tg.mid, s, io);    /* (sized like the pass it replaces) */
-    }
     /* the 63-row pass: walks the first list (two-wave form), or one workgroup per env that looks its env's record up (one-wave form);
-     * hands on to the second list */
-    io.resume = 1; io.nchunk = 1; io.has_next = 1;
-    io.handover_out_list = hl.list2; io.handover_out_count = hl.count2;
+     * with the wide caps it hands on to the second list, otherwise 63 rows are the model's cap and it is the last */
+    io.resume = 1; io.nchunk = 1; io.has_next = wide_caps ? 1 : 0;
+    io.handover_out_list = wide_caps ? hl.list2 : nullptr; io.handover_out_count = wide_caps ? hl.count2 : nullptr;
     if (walk1) {
         io.handover_list = hl.list1; io.handover_count = hl.count1; io.handover_seen = hl.seen1;
         if (!mid_2w(tg.mid, s, io)) return false;
     } else hipLaunchKernelGGL((cassie_step_kernel<NVP, TOPO, FEAT>), grid, dim3(WV_WAVE), 0, s, io);
     if (hipGetLastError() != hipSuccess) return false;
-    /* the 127-row pass: walks the second list */
+    if (!wide_caps) return true;
+    /* the 127-row pass: walks the second list.  (Its workgroups need two empty SIMDs and 84 KB of LDS: on a busy chip even an empty pass
+     * waits for the other env range's kernel to drain -- which is why it is launched only for models that can need it.) */
     io.has_next = 0; io.handover_out_list = nullptr; io.handover_out_count = nullptr;
     io.handover_list = hl.list2; io.handover_count = hl.count2; io.handover_seen = hl.seen2;
     return wide(tg.wide, s, io);

@@ -560,6 +560,7 @@ def test_127_row_instantiation_is_the_63_row_one_bit_for_bit_where_both_hold_the
     pod = cassie.pod
     keep = (pod.maxcon, pod.maxefc)
     try:
+        pod.maxcon, pod.maxefc = 32, 127       # (the caps CM_FLAG_HFPRISM gives a model: the 127-row instantiation steps it)
         wide, rows, _ = _two_wave_workload(cassie, True, fast=False, two_waves=True, schedule=1, poison=True, nlaunch=3)
         assert 31 < rows[:, :, 1].max() <= 63
         pod.maxcon, pod.maxefc = 16, 63
@@ -600,17 +601,22 @@ def test_guarded_sweeps_across_both_waves_reproduce_the_fast_ones(cassie):
     through its guarded form must give the trajectory of the unguarded sweeps to rounding, on the pose that needs 80 rows."""
     import emu_py
     pod = cassie.pod
+    keep = (pod.maxcon, pod.maxefc)
+    pod.maxcon, pod.maxefc = 32, 127           # (the caps CM_FLAG_HFPRISM gives a model)
     q0 = cassie.qpos_init().copy()
     q0[2] = 0.0
-    a, b = EmuBatch(pod, 1), EmuBatch(pod, 1)
-    for x in (a, b):
-        x.qpos[:] = q0
-    a.step(10)
-    emu_py.lib().emu_force_guarded_pgs(1)
     try:
-        b.step(10)
+        a, b = EmuBatch(pod, 1), EmuBatch(pod, 1)
+        for x in (a, b):
+            x.qpos[:] = q0
+        a.step(10)
+        emu_py.lib().emu_force_guarded_pgs(1)
+        try:
+            b.step(10)
+        finally:
+            emu_py.lib().emu_force_guarded_pgs(0)
     finally:
-        emu_py.lib().emu_force_guarded_pgs(0)
+        pod.maxcon, pod.maxefc = keep
     assert a.info[0, 1] > 64 and a.info[0, 3] == 0 and b.info[0, 3] > 0
     assert tuple(a.info[0, :3]) == tuple(b.info[0, :3])
     assert np.abs(a.qpos - b.qpos).max() < 1e-11 and np.abs(a.qvel - b.qvel).max() < 1e-9
