@@ -23,8 +23,6 @@ one prism_s4 X=1 -- $P --streams 4
 one prism_s8 X=1 -- $P --streams 8
 one prism_s2_floor256 CASSIE_PASS_GRID_MIN=256 -- $P --streams 2
 one prism_s4_floor256 CASSIE_PASS_GRID_MIN=256 -- $P --streams 4
-one prism_s2_skipmid CASSIE_DEBUG_SKIP_MID_PASS=1 -- $P --streams 2
-one prism_s4_skipmid CASSIE_DEBUG_SKIP_MID_PASS=1 -- $P --streams 4
 one cassie_s2 X=1 -- --streams 2
 one cassie_s2_floor256 CASSIE_PASS_GRID_MIN=256 -- --streams 2
 one cassie_s2 X=1 -- --streams 2
