@@ -537,3 +537,22 @@ def test_emulated_kernel_matches_oracle_with_prism_contacts(built):
             assert np.max(np.abs(emu.qpos[e] - o.qpos) / np.maximum(1, np.abs(o.qpos))) < 1e-7
     finally:
         oracle_py.set_hfield(None)
+
+
+def test_caps_follow_the_contact_definition(built):
+    """cm_model_t::maxcon / maxefc are set by the model compile with the contact definition: 16 contacts / 63 rows for the default
+    definitions -- the stepping launch then has two tiers and no 127-row pass behind it (that pass's workgroups need half a CU each
+    and cost config 2 4 % even when empty, profiles/round5/wide_pass_ab.txt) --, 32 / 127 with CM_FLAG_HFPRISM on a model of the
+    32-dof Cassie dof tree that has height-field pairs, and back when the flag is cleared."""
+    from cassie_amd import phys as P
+    for name in ("cassie", "cassie_hfield", "cassie_tray_box"):
+        pod = Model(name).pod
+        assert (pod.maxcon, pod.maxefc) == (16, 63), name
+    m = Model("cassie_hfield")
+    m.set_flag(P.FLAG_HFPRISM, True)
+    assert (m.pod.maxcon, m.pod.maxefc) == (32, 127)
+    m.set_flag(P.FLAG_HFPRISM, False)
+    assert (m.pod.maxcon, m.pod.maxefc) == (16, 63)
+    plain = Model("cassie")                      # (no height-field pairs: the flag changes nothing)
+    plain.set_flag(P.FLAG_HFPRISM, True)
+    assert (plain.pod.maxcon, plain.pod.maxefc) == (16, 63)
