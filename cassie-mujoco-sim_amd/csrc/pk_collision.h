@@ -309,39 +309,64 @@ WV_DEVICE void closest_on_triangle(const double *p, const double *a, const doubl
     double ab[3], ac[3], ap[3], bp[3], cp[3];
     for (int i = 0; i < 3; ++i) { ab[i] = b[i] - a[i]; ac[i] = c[i] - a[i]; ap[i] = p[i] - a[i]; bp[i] = p[i] - b[i]; cp[i] = p[i] - c[i]; }
     const double d1 = dot3(ab, ap), d2 = dot3(ac, ap), d3 = dot3(ab, bp), d4 = dot3(ac, bp), d5 = dot3(ab, cp), d6 = dot3(ac, cp);
-    double v = 0, w = 0;
     const double vc = d1 * d4 - d3 * d2, vb = d5 * d2 - d1 * d6, va = d3 * d6 - d5 * d4;
-    if (d1 <= 0 && d2 <= 0) { v = 0; w = 0; }
-    else if (d3 >= 0 && d4 <= d3) { v = 1; w = 0; }
-    else if (vc <= 0 && d1 >= 0 && d3 <= 0) { v = d1 / (d1 - d3); w = 0; }
-    else if (d6 >= 0 && d5 <= d6) { v = 0; w = 1; }
-    else if (vb <= 0 && d2 >= 0 && d6 <= 0) { v = 0; w = d2 / (d2 - d6); }
-    else if (va <= 0 && (d4 - d3) >= 0 && (d5 - d6) >= 0) { w = (d4 - d3) / ((d4 - d3) + (d5 - d6)); v = 1 - w; }
-    else { const double den = 1.0 / (va + vb + vc); v = vb * den; w = vc * den; }
+    /* the seven Voronoi regions, first match wins as in the oracle; the regions that divide (the three edges, the face) hand their
+     * numerator and denominator to ONE division -- a wave whose lanes fall into different regions would otherwise run all four */
+    int region;
+    double num = 0.0, den = 1.0;
+    if (d1 <= 0 && d2 <= 0) region = 0;                                  /* vertex a */
+    else if (d3 >= 0 && d4 <= d3) region = 1;                            /* vertex b */
+    else if (vc <= 0 && d1 >= 0 && d3 <= 0) { region = 2; num = d1; den = d1 - d3; }                                    /* edge ab */
+    else if (d6 >= 0 && d5 <= d6) region = 3;                            /* vertex c */
+    else if (vb <= 0 && d2 >= 0 && d6 <= 0) { region = 4; num = d2; den = d2 - d6; }                                    /* edge ac */
+    else if (va <= 0 && (d4 - d3) >= 0 && (d5 - d6) >= 0) { region = 5; num = d4 - d3; den = (d4 - d3) + (d5 - d6); }   /* edge bc */
+    else { region = 6; num = 1.0; den = va + vb + vc; }                  /* the face */
+    const double t = num / den;
+    double v = 0, w = 0;
+    if (region == 1) v = 1;
+    else if (region == 2) v = t;
+    else if (region == 3) w = 1;
+    else if (region == 4) w = t;
+    else if (region == 5) { w = t; v = 1 - w; }
+    else if (region == 6) { v = vb * t; w = vc * t; }
     for (int i = 0; i < 3; ++i) q[i] = a[i] + v * ab[i] + w * ac[i];
 }
-WV_DEVICE void hfield_triangle(const double *p, const double *a, const double *b, const double *c, double &best, double *bestn) {
+/* One grid triangle against the sample centre p (height-field frame): a closer feature replaces (best, bv, bdiv).  The contact
+ * normal of the winner is bdiv ? bv / best : bv -- the division of the closest point's offset by its length is left to whoever
+ * ends up with the winning candidate (three divisions per triangle otherwise, for candidates that mostly lose) -- and the
+ * triangle's unit normal is formed only where it is needed: under the triangle's plane, within rounding of it (the oracle decides
+ * above / below by the sign of the UNIT normal's product with the offset; the raw normal's product has the same sign wherever it is
+ * 1e-12 of its terms' magnitude away from zero), or for a centre on the surface itself.  Values are the oracle's bit for bit. */
+WV_DEVICE void hfield_triangle(const double *p, const double *a, const double *b, const double *c, double &best, double *bv, bool &bdiv) {
     double ab[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]}, ac[3] = {c[0] - a[0], c[1] - a[1], c[2] - a[2]}, n[3];
     cross3(n, ab, ac);
     if (n[2] < 0) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; }
-    const double inv = 1.0 / sqrt(dot3(n, n));
-    n[0] *= inv; n[1] *= inv; n[2] *= inv;
-    const double ap[3] = {p[0] - a[0], p[1] - a[1], p[2] - a[2]}, s = dot3(n, ap);
+    const double ap[3] = {p[0] - a[0], p[1] - a[1], p[2] - a[2]};
+    const double sraw = dot3(n, ap);
+    const double bound = (fabs(n[0]) + fabs(n[1]) + fabs(n[2])) * (fabs(ap[0]) + fabs(ap[1]) + fabs(ap[2]));
+    bool unit = false;
+    double s = sraw;
+    auto normalise = [&]() {
+        const double inv = 1.0 / sqrt(dot3(n, n));
+        n[0] *= inv; n[1] *= inv; n[2] *= inv;
+        unit = true;
+    };
+    if (!(sraw > 1e-12 * bound)) { normalise(); s = dot3(n, ap); }
     if (s >= 0) {
         double q[3];
         closest_on_triangle(p, a, b, c, q);
         const double d[3] = {p[0] - q[0], p[1] - q[1], p[2] - q[2]}, len = sqrt(dot3(d, d));
         if (len < best) {
             best = len;
-            if (len > 1e-12) { bestn[0] = d[0] / len; bestn[1] = d[1] / len; bestn[2] = d[2] / len; }
-            else { bestn[0] = n[0]; bestn[1] = n[1]; bestn[2] = n[2]; }
+            if (len > 1e-12) { bv[0] = d[0]; bv[1] = d[1]; bv[2] = d[2]; bdiv = true; }
+            else { if (!unit) normalise(); bv[0] = n[0]; bv[1] = n[1]; bv[2] = n[2]; bdiv = false; }
         }
     } else {
         const double e0 = (b[0] - a[0]) * (p[1] - a[1]) - (b[1] - a[1]) * (p[0] - a[0]);
         const double e1 = (c[0] - b[0]) * (p[1] - b[1]) - (c[1] - b[1]) * (p[0] - b[0]);
         const double e2 = (a[0] - c[0]) * (p[1] - c[1]) - (a[1] - c[1]) * (p[0] - c[0]);
         const bool inside = (e0 >= 0 && e1 >= 0 && e2 >= 0) || (e0 <= 0 && e1 <= 0 && e2 <= 0);
-        if (inside && s < best) { best = s; bestn[0] = n[0]; bestn[1] = n[1]; bestn[2] = n[2]; }
+        if (inside && s < best) { best = s; bv[0] = n[0]; bv[1] = n[1]; bv[2] = n[2]; bdiv = false; }
     }
 }
 WV_DEVICE int hfield_sphere(RawContact &c, ModelPtr m, const float *data, const double *ph, const double *mh, const double *ps,
@@ -360,7 +385,8 @@ WV_DEVICE int hfield_sphere(RawContact &c, ModelPtr m, const float *data, const 
     if (i0 < 0) i0 = 0;
     if (j1 > nc - 2) j1 = nc - 2;
     if (i1 > nr - 2) i1 = nr - 2;
-    double best = 1e300, bn[3] = {0, 0, 1};
+    double best = 1e300, bv[3] = {0, 0, 1};
+    bool bdiv = false;
     /* touch the first and the last sample of every grid row of the footprint before any of them is needed: all the
      * footprint's cache lines are then in flight together (one memory latency instead of one per cell) */
     float touch = 0.0f;
@@ -379,13 +405,15 @@ WV_DEVICE int hfield_sphere(RawContact &c, ModelPtr m, const float *data, const 
             const double z00 = sz * data[i * nc + j], z10 = sz * data[i * nc + j + 1], z01 = sz * data[(i + 1) * nc + j], z11 = sz * data[(i + 1) * nc + j + 1];
             if (p[2] - reach > fmax(fmax(z00, z10), fmax(z01, z11))) continue;
             const double v00[3] = {x0, y0, z00}, v10[3] = {x0 + dx, y0, z10}, v01[3] = {x0, y0 + dy, z01}, v11[3] = {x0 + dx, y0 + dy, z11};
-            hfield_triangle(p, v00, v10, v01, best, bn);
-            hfield_triangle(p, v11, v01, v10, best, bn);
+            hfield_triangle(p, v00, v10, v01, best, bv, bdiv);
+            hfield_triangle(p, v11, v01, v10, best, bv, bdiv);
         }
     }
     if (best > 1e299) return 0;
     const double dist = best - r;
     if (dist > margin) return 0;
+    double bn[3] = {bv[0], bv[1], bv[2]};
+    if (bdiv) { bn[0] = bv[0] / best; bn[1] = bv[1] / best; bn[2] = bv[2] / best; }
     double nw[3];
     mulmatvec3(nw, mh, bn);
     c.dist = dist;
@@ -401,12 +429,15 @@ WV_DEVICE int hfield_sphere(RawContact &c, ModelPtr m, const float *data, const 
  * sphere from that lane, tests the cell's two triangles -- and a segmented minimum scan over the lanes of one sphere hands the round's
  * closest feature to the sphere's record in LDS.  Ties go to the earlier task, and a sphere's earlier rounds win over later
  * ones, which is the strict `<` of the sequential scan: results are those of hfield_sphere bit for bit.
- * work: HF_WINDOW bytes (the sphere of every task of a window) + 4 doubles per lane (closest distance, normal). */
+ * work: HF_WINDOW bytes (the sphere of every task of a window) + HF_RECW doubles per lane (closest distance, the winning candidate's
+ * vector, whether the normal is that vector divided by the distance: hfield_triangle). */
 #ifdef CK_EMULATED
 constexpr int HF_WINDOW = 128;  /* (the CPU emulator's tests go through several windows per pass; results do not depend on the size) */
 #else
 constexpr int HF_WINDOW = 1024;
 #endif
+constexpr int HF_RECW = 5;
+constexpr int HF_WORK_BYTES = HF_WINDOW + (int)sizeof(double) * HF_RECW * WV_WAVE;
 WV_DEVICE int hfield_spheres_wave(RawContact &c, ModelPtr m, const float *data, const double *ph, const double *mh, bool mine, const double *ps,
                                   double r, double margin, int lane, double *work) {
     const bool grid_ok = data && m->hfield_nrow >= 2 && m->hfield_ncol >= 2;
@@ -438,8 +469,8 @@ WV_DEVICE int hfield_spheres_wave(RawContact &c, ModelPtr m, const float *data, 
 #pragma unroll
     for (int msk = WV_WAVE / 2; msk >= 1; msk /= 2) { const int o = wv::shfl_i(maxcell, lane ^ msk); maxcell = o > maxcell ? o : maxcell; }
     unsigned char *const owner = (unsigned char *)work;      /* the sphere (lane) of every task of a window of HF_WINDOW tasks */
-    double *const rec = work + HF_WINDOW / 8 + 4 * lane;
-    rec[0] = 1e300; rec[1] = 0; rec[2] = 0; rec[3] = 1;
+    double *const rec = work + HF_WINDOW / 8 + HF_RECW * lane;
+    rec[0] = 1e300; rec[1] = 0; rec[2] = 0; rec[3] = 1; rec[4] = 0;
     const int start = endx - ncell;
     for (int win = 0; win < total; win += HF_WINDOW) {
         /* every sphere writes its lane over its tasks of this window */
@@ -474,13 +505,14 @@ WV_DEVICE int hfield_spheres_wave(RawContact &c, ModelPtr m, const float *data, 
             if (base + WV_WAVE < wend) request(base + WV_WAVE, nxt); /* (wave-uniform) */
             else { nxt.act = false; nxt.cull = true; nxt.own = lane; }
             double best = 1e300, bn[3] = {0, 0, 1};
+            bool bdiv = false;
             if (!cur.cull) {
                 const double z00 = sz * cur.h00, z10 = sz * cur.h10, z01 = sz * cur.h01, z11 = sz * cur.h11;
                 if (!(cur.q2 - cur.qreach > fmax(fmax(z00, z10), fmax(z01, z11)))) {
                     const double q[3] = {cur.q0, cur.q1, cur.q2}, x0 = cur.x0, y0 = cur.y0;
                     const double v00[3] = {x0, y0, z00}, v10[3] = {x0 + dx, y0, z10}, v01[3] = {x0, y0 + dy, z01}, v11[3] = {x0 + dx, y0 + dy, z11};
-                    hfield_triangle(q, v00, v10, v01, best, bn);
-                    hfield_triangle(q, v11, v01, v10, best, bn);
+                    hfield_triangle(q, v00, v10, v01, best, bn, bdiv);
+                    hfield_triangle(q, v11, v01, v10, best, bn, bdiv);
                 }
             }
             /* the closest feature among the lanes of one sphere, earlier tasks first: segmented inclusive scan of (distance, lane) */
@@ -496,9 +528,10 @@ WV_DEVICE int hfield_spheres_wave(RawContact &c, ModelPtr m, const float *data, 
             }
             const int nseg = wv::shfl_i(seg, (lane + 1) & 63);
             const double w0 = wv::shfl(bn[0], ssrc), w1 = wv::shfl(bn[1], ssrc), w2 = wv::shfl(bn[2], ssrc);
+            const int wdiv = wv::shfl_i(bdiv ? 1 : 0, ssrc);
             if (cur.act && (lane == WV_WAVE - 1 || nseg != seg)) {
-                double *const o = work + HF_WINDOW / 8 + 4 * cur.own;
-                if (sv < o[0]) { o[0] = sv; o[1] = w0; o[2] = w1; o[3] = w2; }
+                double *const o = work + HF_WINDOW / 8 + HF_RECW * cur.own;
+                if (sv < o[0]) { o[0] = sv; o[1] = w0; o[2] = w1; o[3] = w2; o[4] = (double)wdiv; }
             }
             wv::sync();
             cur = nxt;
@@ -509,7 +542,8 @@ WV_DEVICE int hfield_spheres_wave(RawContact &c, ModelPtr m, const float *data, 
     if (!mine || best > 1e299) return 0;
     const double dist = best - r;
     if (dist > margin) return 0;
-    const double bn[3] = {rec[1], rec[2], rec[3]};
+    double bn[3] = {rec[1], rec[2], rec[3]};
+    if (rec[4] != 0.0) { bn[0] = rec[1] / best; bn[1] = rec[2] / best; bn[2] = rec[3] / best; } /* (the winner's division: hfield_triangle) */
     double nw[3];
     mulmatvec3(nw, mh, bn);
     c.dist = dist;
@@ -602,6 +636,7 @@ WV_DEVICE int hfield_prism_wave(SH &S, ModelPtr m, const float *data, int lane, 
         const double zmax = fmax(fmax(z00, z10), fmax(z01, z11));
         const double v00[3] = {x0, y0, z00}, v10[3] = {x0 + dx, y0, z10}, v01[3] = {x0, y0 + dy, z01}, v11[3] = {x0 + dx, y0 + dy, z11};
         double best = 1e300, bn[3] = {0, 0, 1}, bt = 0;
+        bool bdiv = false;
         for (int k = 0; k < CM_HP_MAXS; ++k) {
             if (wv::ballot(k < ns) == 0ull) break; /* (wave-uniform: no lane has a k-th sample) */
             if (k >= ns) continue;
@@ -613,9 +648,11 @@ WV_DEVICE int hfield_prism_wave(SH &S, ModelPtr m, const float *data, int lane, 
             const double ey = p[1] < y0 ? y0 - p[1] : (p[1] > y0 + dy ? p[1] - (y0 + dy) : 0.0);
             if (ex * ex + ey * ey > reach * reach || p[2] - reach > zmax) continue;
             double cur = 1e300, cn[3] = {0, 0, 1};
-            if (tri == 0) hfield_triangle(p, v00, v10, v01, cur, cn); else hfield_triangle(p, v11, v01, v10, cur, cn);
-            if (cur < best) { best = cur; bt = tk; bn[0] = cn[0]; bn[1] = cn[1]; bn[2] = cn[2]; }
+            bool cdiv = false;
+            if (tri == 0) hfield_triangle(p, v00, v10, v01, cur, cn, cdiv); else hfield_triangle(p, v11, v01, v10, cur, cn, cdiv);
+            if (cur < best) { best = cur; bt = tk; bn[0] = cn[0]; bn[1] = cn[1]; bn[2] = cn[2]; bdiv = cdiv; }
         }
+        if (bdiv) { bn[0] = bn[0] / best; bn[1] = bn[1] / best; bn[2] = bn[2] / best; } /* (the deepest sample's division: hfield_triangle) */
         const double dist = best - r;
         const bool hit = act && best < 1e299 && !(dist > margin);
         const unsigned long long hb = wv::ballot(hit);
