@@ -90,6 +90,8 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
      * cmd[1] (body forces), cmd[2] (the staged matrix).  Every value is computed by the
      * same instructions from the same operands as in the one-wave form, so the results are bit for bit the same. */
     const int wid = NW == 2 ? wv::wave_id() : 0;
+    /* (wave 0 is on its env's critical path from F to P: above a wave 1 in a stretch nobody waits for, below one in its tail -- env_step_wave1.inc) */
+    if constexpr (NW == 2) { if (wid == 0) wv::set_priority<CK_PRIO_W0>(); }
 
     static_assert(LP::covers() && LP::distinct(), "packed factor rows must hold every ancestor pair, each in its own slot");
     typedef EnvShared<NVP, LPack<TOPO, NVP>::count, MAXR> SH_T;

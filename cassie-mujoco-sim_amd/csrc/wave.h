@@ -96,6 +96,35 @@ WV_DEVICE int fresh_lane() {
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(x));
     return x;
 }
+/* the wave's priority in its SIMD's instruction arbitration (0 .. 3): a SIMD hosts the wave 0 of one env and the wave 1 of another,
+ * and a wave in a stretch the other wave of ITS env does not wait for can yield its issue slots to whoever shares the SIMD.
+ * Measured (profiles/round5/wave_priority_ab.txt; against no s_setprio at all): config 2 +0.6 %, config 4 +1.6 % (+3.0 % with wave
+ * 1 low from F to J there), config 5 +1.1 %; wave 0 higher in its PGS sweeps, or wave 1 low from F to J on cassie.xml: -0.5 .. -1 %. */
+#ifndef CK_PRIO
+#define CK_PRIO 1
+#endif
+#ifndef CK_PRIO_W0          /* wave 0, all of its substep */
+#define CK_PRIO_W0 1
+#endif
+#ifndef CK_PRIO_W0_PGS      /* ... its PGS sweeps */
+#define CK_PRIO_W0_PGS CK_PRIO_W0
+#endif
+#ifndef CK_PRIO_W1_FJ       /* wave 1 between the barriers F and J */
+#define CK_PRIO_W1_FJ 1
+#endif
+#ifndef CK_PRIO_W1_FJ_HFIELD /* ... in the height-field instantiations, whose wave 0 is 13 k clocks longer on that stretch */
+#define CK_PRIO_W1_FJ_HFIELD 0
+#endif
+#ifndef CK_PRIO_W1_JP       /* ... J and P */
+#define CK_PRIO_W1_JP 0
+#endif
+#ifndef CK_PRIO_W1_PE       /* ... P and E: the tail wave 0 waits for */
+#define CK_PRIO_W1_PE 3
+#endif
+#ifndef CK_PRIO_W1_EF       /* ... E and F: the outputs, then the wait for wave 0's kinematics */
+#define CK_PRIO_W1_EF 0
+#endif
+template <int P> WV_DEVICE void set_priority() { if (CK_PRIO) __builtin_amdgcn_s_setprio(P); }
 WV_DEVICE int env_id() { return (int)blockIdx.x; }
 WV_DEVICE int grid_size() { return (int)gridDim.x; }
 /* device-scope atomic add on an int in global memory, returns the old value */

@@ -76,6 +76,14 @@ inline long long wall_clock() { return 0; }
 inline long long hw_id() { return 0; }
 inline double max_raw(double a, double b) { return a > b ? a : b; }
 inline int opaque(int x) { return x; }
+template <int P> inline void set_priority() {}
+#define CK_PRIO_W0 0
+#define CK_PRIO_W0_PGS 0
+#define CK_PRIO_W1_FJ 0
+#define CK_PRIO_W1_FJ_HFIELD 0
+#define CK_PRIO_W1_JP 0
+#define CK_PRIO_W1_PE 0
+#define CK_PRIO_W1_EF 0
 inline void sched_fence() {}
 inline void keep(int &) {}
 inline void touch(double) {}
