@@ -99,12 +99,16 @@ WV_DEVICE int fresh_lane() {
 /* the wave's priority in its SIMD's instruction arbitration (0 .. 3): a SIMD hosts the wave 0 of one env and the wave 1 of another,
  * and a wave in a stretch the other wave of ITS env does not wait for can yield its issue slots to whoever shares the SIMD.
  * Measured (profiles/round5/wave_priority_ab.txt; against no s_setprio at all): config 2 +0.6 %, config 4 +1.6 % (+3.0 % with wave
- * 1 low from F to J there), config 5 +1.1 %; wave 0 higher in its PGS sweeps, or wave 1 low from F to J on cassie.xml: -0.5 .. -1 %. */
+ * 1 low from F to J there), config 5 +1.1 %; wave 0 at the top up to the barrier F: another +1.1 % on config 2 (none on config 5, -1 % on
+ * config 4: off there); wave 0 higher in its PGS sweeps, or wave 1 low from F to J on cassie.xml: -0.5 .. -1 %. */
 #ifndef CK_PRIO
 #define CK_PRIO 1
 #endif
 #ifndef CK_PRIO_W0          /* wave 0, all of its substep */
 #define CK_PRIO_W0 1
+#endif
+#ifndef CK_PRIO_W0_KIN      /* ... the stretch up to the barrier F (guard, drive I/O in, kinematics), which wave 1 waits for */
+#define CK_PRIO_W0_KIN 3
 #endif
 #ifndef CK_PRIO_W0_PGS      /* ... its PGS sweeps */
 #define CK_PRIO_W0_PGS CK_PRIO_W0

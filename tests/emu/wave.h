@@ -79,6 +79,7 @@ inline int opaque(int x) { return x; }
 template <int P> inline void set_priority() {}
 #define CK_PRIO_W0 0
 #define CK_PRIO_W0_PGS 0
+#define CK_PRIO_W0_KIN 0
 #define CK_PRIO_W1_FJ 0
 #define CK_PRIO_W1_FJ_HFIELD 0
 #define CK_PRIO_W1_JP 0
