@@ -70,3 +70,25 @@ def test_127_row_kernel_fits_a_cu(tmp_path):
     val = lambda key: int(re.search(key + r"[^:]*: *(\d+)", text).group(1))
     assert val("LDS Size") <= 86016, text
     assert val("ScratchSize") <= 512 and val("VGPRs Spill") <= 128, text
+
+
+@pytest.mark.skipif(not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")), reason="needs hipcc")
+def test_fast_hfield_kernel_keeps_its_registers_and_sets_its_wave_priorities(tmp_path):
+    """The height-field model's row-capped instantiation (config 4's dominant kernel): two waves per SIMD, four workgroups per CU, a
+    frame of launch-long values and next to no spilled vector values (round 4: 196 B / 29; today 156 B / 8), and the wave priorities
+    of round 5 (wave.h CK_PRIO_*: one s_setprio at each phase boundary of the two wave programs -- the step from none to these was
+    +3 % on config 4, profiles/round5/wave_priority_ab.txt) are still in the code."""
+    isa = tmp_path / "hf_fast.s"
+    env = dict(os.environ, MAXRS="31", NW="2", FEAT="1", KEEP=str(isa))
+    out = subprocess.run(["bash", os.path.join(REPO, "tools", "kernel_resources.sh")], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout + out.stderr
+    text = out.stdout
+    val = lambda key: int(re.search(key + r"[^:]*: *(\d+)", text).group(1))
+    assert val("VGPRs Spill") <= 24, text
+    assert val("ScratchSize") <= 256, text
+    assert val("LDS Size") <= 40960, text
+    assert val("Occupancy") == 2, text
+    body = [l.split(";")[0].strip() for l in isa.read_text().split("\n")]
+    assert sum(l.startswith(("scratch_load", "scratch_store")) for l in body) <= 48, "scratch traffic in the height-field model's fast kernel"
+    prios = sorted(set(int(l.split()[1]) for l in body if l.startswith("s_setprio")))
+    assert prios == [0, 1, 3], prios
