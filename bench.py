@@ -276,9 +276,10 @@ def pmc_traffic(env_steps_per_launch, model_name="cassie", envs_per_launch=None,
 class OracleEnvs:
     """A set of envs on the CPU reference (oracle/cassie_oracle.c), driven through the benchmark's schedule."""
 
-    def __init__(self, model, env_ids, hfield=None):
+    def __init__(self, model, env_ids, hfield=None, pods=None):
         import oracle_py
         self.op, self.model, self.ids = oracle_py, model, np.asarray(env_ids)
+        self.pods = pods            # per-env compiled models (domain randomisation: one cm_model_t per replayed env) or None
         self.L = oracle_py.lib()
         if hfield is not None:
             oracle_py.set_hfield(hfield)
@@ -289,8 +290,11 @@ class OracleEnvs:
         self.kp = np.tile(PD_KP, (len(self.ids), 1))
         self.kd = np.tile(PD_KD, (len(self.ids), 1))
 
+    def pod(self, i):
+        return self.pods[i] if self.pods is not None else self.model.pod
+
     def reset(self, i):
-        self.L.co_reset(ctypes.byref(self.model.pod), ctypes.byref(self.buf[i]))
+        self.L.co_reset(ctypes.byref(self.pod(i)), ctypes.byref(self.buf[i]))
         self.op.arr(self.buf[i].qpos)[: self.model.pod.nq] = self.q0
 
     def restart(self, group):
@@ -300,6 +304,10 @@ class OracleEnvs:
 
     def step(self, nsub, targets, threads):
         pt = np.ascontiguousarray(targets)
+        if self.pods is not None:   # (one model per env: env by env)
+            for i in range(len(self.ids)):
+                self.L.co_step_batch(ctypes.byref(self.pods[i]), ctypes.byref(self.buf[i]), 1, nsub, pt[i:i + 1].ctypes.data, self.kp.ctypes.data, self.kd.ctypes.data, 1)
+            return
         self.L.co_step_batch(ctypes.byref(self.model.pod), ctypes.byref(self.buf), len(self.ids), nsub, pt.ctypes.data,
                              self.kp.ctypes.data, self.kd.ctypes.data, threads)
 
@@ -310,10 +318,10 @@ class OracleEnvs:
         return np.array([[b.ncon, b.nefc, b.solver_iter] for b in self.buf])
 
 
-def replay_on_oracle(model, env_ids, targets_of, total_steps, hfield=None, threads=1, envs=None):
+def replay_on_oracle(model, env_ids, targets_of, total_steps, hfield=None, threads=1, envs=None, pods=None):
     """The schedule of the timed batch (restarts, PD targets, step count) for the envs `env_ids` on the CPU reference.
     targets_of(p) -> [len(env_ids)][10] targets of policy step p.  `envs`: OracleEnvs (exact-state PD) or HostChainEnvs."""
-    o = (envs or OracleEnvs)(model, env_ids, hfield)
+    o = (envs or OracleEnvs)(model, env_ids, hfield, pods=pods) if pods is not None else (envs or OracleEnvs)(model, env_ids, hfield)
     cur = {}
     sch = Schedule(step=lambda nsub: o.step(nsub, cur["t"], threads),
                    bind_targets=lambda p: cur.__setitem__("t", targets_of(p)),
@@ -391,10 +399,11 @@ class HostChainEnvs:
     """Envs on the CPU with the drive-level semantics of CM_DRIVE_PD: oracle physics + the host chain of
     csrc/cassie_hostpath.c (the reference's own encoder / motor arithmetic) + pd_input's motor PD on the measurements."""
 
-    def __init__(self, model, env_ids, hfield=None):
+    def __init__(self, model, env_ids, hfield=None, pods=None):
         import oracle_py
         from cassie_amd import phys as P
         from hostchain_py import HostChain
+        self.pods = pods            # per-env compiled models (domain randomisation) or None
         if hfield is not None:
             oracle_py.set_hfield(hfield)
         self.model, self.ids, self.P = model, np.asarray(env_ids), P
@@ -413,7 +422,7 @@ class HostChainEnvs:
 
     def reset(self, i, fresh_chain=True):
         from oracle_py import Oracle
-        self.orcs[i] = Oracle(self.model.pod, self.model.qpos_init())
+        self.orcs[i] = Oracle(self.pods[i] if self.pods is not None else self.model.pod, self.model.qpos_init())
         self.orcs[i].forward()                      # what cassie_sim_init leaves: the init pose's sensordata
         if fresh_chain:
             self.chains[i].reset()                  # a fresh cassie_sim_t: zero filter histories and delay lines
@@ -501,7 +510,7 @@ class GpuRuntime:
 
 
 def device_rollout(model, mode, n, steps, warmup, rank, world, local_rank, substeps_per_launch=HOLD, parity_envs=64, hfield=None, collect=None,
-                   all_outputs=False, repeats=1, nstreams=1, rt=None):
+                   all_outputs=False, repeats=1, nstreams=1, rt=None, randomise=None):
     """One device-resident rollout of the workload in `mode`, timed as `repeats` fenced regions of exactly `steps` steps:
 
       "drive-pd"  CM_DRIVE_PD: every substep runs pd_input's motor PD on the ENCODER measurements of the
@@ -572,6 +581,36 @@ def device_rollout(model, mode, n, steps, warmup, rank, world, local_rank, subst
         b.set_drive_mode(P.DRIVE_PD)
     else:
         b.set_pd_mode(True)
+    rand_info = None
+    if randomise is not None:
+        # Per-env domain randomisation ON THE DEVICE: every env of the batch gets masses x U(0.8, 1.2) (principal
+        # inertias scaled alike), inertial offsets + U(-5, 5) mm, joint damping x U(0.5, 1.5) and sliding friction U(0.4, 1.3) on every
+        # collision geom, drawn by torch ON the GPU and handed over as device pointers (phys_batch_randomize), then mj_setConst per env
+        # in one launch (phys_batch_set_const).  The shared 95 KB model stays shared; an env reads its own 10 KB block.
+        nb, ng = pod.nbody, pod.ngeom
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(int(randomise) + 7919 * rank)
+        u = lambda *shape: torch.rand(*shape, generator=gen, dtype=torch.float64, device=dev) * 2 - 1
+        t64 = lambda a: torch.tensor(np.asarray(a, dtype=np.float64), device=dev)
+        m0, d0 = t64(pod.body_mass[:nb]), t64(pod.dof_damping[:nv])
+        i0, in0 = t64([list(pod.body_ipos[k]) for k in range(nb)]), t64([list(pod.body_inertia[k]) for k in range(nb)])
+        f0 = t64([list(pod.geom_friction[g]) for g in range(ng)])
+        s_ = 1 + 0.2 * u(n, nb)
+        fr = f0.repeat(n, 1, 1)
+        fr[:, :, 0] = 0.85 + 0.45 * u(n, ng)
+        rows = {P.P_BODY_MASS: (m0 * s_).contiguous(), P.P_BODY_INERTIA: (in0[None] * s_[:, :, None]).reshape(n, -1).contiguous(),
+                P.P_BODY_IPOS: (i0[None] + 0.005 * u(n, nb, 3) * (m0 > 0)[None, :, None]).reshape(n, -1).contiguous(),
+                P.P_DOF_DAMPING: (d0 * (1 + 0.5 * u(n, nv))).contiguous(), P.P_GEOM_FRICTION: fr.reshape(n, -1).contiguous()}
+        rt.synchronize()
+        t0 = time.perf_counter()
+        for k_, t_ in rows.items():
+            b.randomize(k_, None, device_ptr=t_.data_ptr(), n=n)
+        b.set_const()
+        b.sync()
+        rand_info = {"seed": int(randomise), "randomise_and_set_const_ms": 1e3 * (time.perf_counter() - t0), "envs": n,
+                     "what": "body_mass x U(0.8, 1.2) with body_inertia scaled alike, body_ipos + U(-5, 5) mm, dof_damping x U(0.5, 1.5), geom_friction[0] ~ U(0.4, 1.3): "
+                             "EVERY env, drawn on the GPU (torch), phys_batch_randomize from device pointers + ONE phys_batch_set_const launch (mj_setConst per env on the device)",
+                     "bytes_per_env_block": int(ctypes.sizeof(type(b.params(0, 1)[0])))}
     ranges = half_ranges(n, nstreams)
     streams = [rt.Stream() for _ in ranges]
     obs_all = [torch.empty((world * cnt, nobs), dtype=torch.float64, device=dev) for _, cnt in ranges] if collect else None
@@ -683,6 +722,7 @@ def device_rollout(model, mode, n, steps, warmup, rank, world, local_rank, subst
         res["env_clocks_per_substep"] = None
         res["shader_clock_hz"] = None
         res.setdefault("wide_pass_envs_last_launch", None)
+    b_params = b.params() if rand_info is not None and rank == 0 else None
     # ---- the metric's second half: sampled envs of EVERY rank against the CPU reference, same schedule ----
     ids_sample = torch.from_numpy(env_ids[sample].astype(np.int64)).to(dev)
     if collect and world > 1:
@@ -691,8 +731,28 @@ def device_rollout(model, mode, n, steps, warmup, rank, world, local_rank, subst
         q_gpu, counts_gpu, ids = q_sample.cpu().numpy(), info_sample.cpu().numpy(), ids_sample.cpu().numpy()
         threads = rt.host_threads()
         tg_replay = pd_targets(ids, (replay_steps + HOLD - 1) // HOLD + 1)      # seeds depend on the global env id only
+        pods = None
+        if rand_info is not None:
+            # the oracle gets a per-env cm_model_t for every replayed env: a HOST model edited through the views the reference's setters
+            # write, phys_model_set_const + phys_model_compile -- and the device's parameter block must equal that compile's bit for bit
+            import randomise_check as rcheck
+            assert world == 1, "the randomised leg replays rank 0's envs"
+            hosts = rcheck.HostEnvModels(model.name)
+            blocks = [b_params[int(e)] for e in sample]
+            par = {f: [rcheck.params_as_arrays(blk, pod)[f].reshape(-1) for blk in blocks] for f in rcheck.INPUT_FIELDS}
+            pods, same = [], 0
+            for i in range(len(blocks)):
+                pods.append(hosts.pod(par, i))
+                try:
+                    rcheck.assert_blocks_equal(blocks[i], pods[-1].params, pod, "env %d" % int(sample[i]))
+                    same += 1
+                except AssertionError as ex:
+                    rand_info.setdefault("first_difference", str(ex))
+            rand_info["blocks_equal_to_the_host_compile_bit_for_bit"] = "%d of %d replayed envs" % (same, len(blocks))
+            mi = np.array([blk.meaninertia for blk in b_params])
+            rand_info["meaninertia_over_the_batch"] = {"min": float(mi.min()), "max": float(mi.max()), "shared_model": float(pod.meaninertia), "distinct": int(len(np.unique(mi)))}
         orc = replay_on_oracle(model, ids, lambda p: tg_replay[p], replay_steps, hfield, threads,
-                               envs=rt.replay_envs(drive))
+                               envs=rt.replay_envs(drive), pods=pods)
         q_ref = orc.qpos()
         err_abs = np.abs(q_gpu - q_ref)
         err_rel = err_abs / np.maximum(1.0, np.abs(q_ref))
@@ -707,6 +767,8 @@ def device_rollout(model, mode, n, steps, warmup, rank, world, local_rank, subst
         if drive:
             res["parity"]["note"] = ("an encoder count that truncates differently on a last-bit physics difference moves a motor torque by "
                                      "kp * 2 pi / 2^bits / gear for one step: agreement is to rounding only as long as no count flips")
+    if rand_info is not None:
+        res["randomised"] = rand_info
     b.close()
     return res
 
@@ -800,6 +862,8 @@ def main(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-step-pd", action="store_true")
     ap.add_argument("--no-other-mode", action="store_true", help="skip the short run of the other device mode")
+    ap.add_argument("--no-randomised", action="store_true", help="skip the short run with every env's physical parameters randomised on the device")
+    ap.add_argument("--randomise", type=int, default=None, metavar="SEED", help="randomise every env's masses / inertial offsets / damping / friction on the device for the MAIN timed regions too (SURVEY.md 8f-3)")
     ap.add_argument("--force-collectives", action="store_true",
                     help="validation aid: initialise the process group and run the observation all-gather / barriers even with one rank")
     ap.add_argument("--mode", default="drive-pd", choices=["drive-pd", "exact-pd"],
@@ -859,7 +923,7 @@ def main(argv=None):
         hfield[95:105, 95:105] = 0
     nstreams = max(1, args.streams)
     r = device_rollout(model, args.mode, n, args.steps, args.warmup, rank, world, local_rank, args.substeps_per_launch, args.parity_envs, hfield,
-                       collect=collect, repeats=repeats, nstreams=nstreams, rt=rt)
+                       collect=collect, repeats=repeats, nstreams=nstreams, rt=rt, randomise=args.randomise if world == 1 else None)
 
     if rank == 0:
         elapsed, kern_ms, timed_launches = r["elapsed"], r["kernel_ms"], r["launches"]
@@ -947,6 +1011,7 @@ def main(argv=None):
                               "note": "algorithmic flops (SURVEY.md 8a estimate), not counting lanes that idle or recompute"},
             "workgroup_slots": slot_occupancy(r["env_clocks_per_substep"], n, r["steps"], r["elapsed"], r.get("shader_clock_hz")),
             "envs_with_warnings": r["envs_with_warnings"],
+            **({"randomised": r["randomised"]} if r.get("randomised") else {}),   # (--randomise: the main regions ran with per-env parameters)
             **({"obs_allgather_ok": r.get("gather_ok")} if collect else {}),   # rank 0's rows of the last gathered block = its snapshot
             "frac_envs_handed_over_to_the_full_kernel_in_the_last_launch": r["frac_envs_handed_over_last_launch"],
             # ... and of those, the envs the 63-row pass passed on to the 127-row instantiation (rank 0's batch)
@@ -972,6 +1037,16 @@ def main(argv=None):
                 out["all_outputs_every_substep"] = {"value": n * a["steps"] / a["elapsed"], "unit": "env-steps/s", "steps": a["steps"],
                                                     "timed_regions": a["repeats"], "kernel_ms": a["kernel_ms"], "max_qpos_err": a["parity"]["max_qpos_err"]}
                 out["value_all_outputs_every_substep"] = out["all_outputs_every_substep"]["value"]
+                if not args.no_randomised:
+                    # every env with its own masses / inertial offsets / damping / friction: what domain randomisation costs
+                    # the step kernel (an env's parameters are a 10 KB block of its own instead of L2-hot shared scalars), replayed on the
+                    # oracle with per-env models
+                    dr = device_rollout(model, args.mode, n, side["steps"], side["warmup"], 0, 1, local_rank, args.substeps_per_launch, 16, hfield,
+                                        repeats=side["repeats"], nstreams=nstreams, randomise=4242)
+                    out["domain_randomised"] = {"value": n * dr["steps"] / dr["elapsed"], "unit": "env-steps/s", "steps": dr["steps"], "warmup": dr["warmup"],
+                                                "timed_regions": dr["repeats"], "kernel_ms": dr["kernel_ms"], "parity": dr["parity"], **dr["randomised"],
+                                                "mean_constraint_rows": dr["mean_constraint_rows"], "mean_pgs_iterations": dr["mean_pgs_iterations"]}
+                    out["value_domain_randomised"] = out["domain_randomised"]["value"]
                 if nstreams > 1:    # the whole batch as one launch per policy step (rounds 1-2, and what a consumer that needs every env's
                     # observation before it acts on any of them gets)
                     one = device_rollout(model, args.mode, n, side["steps"], side["warmup"], 0, 1, local_rank, args.substeps_per_launch, 4, hfield,

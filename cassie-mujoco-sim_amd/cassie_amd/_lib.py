@@ -18,6 +18,7 @@ MACROS = cstruct.parse_defines(_hdr)
 _structs = cstruct.parse_structs(_hdr, MACROS)
 CmModel = _structs["cm_model_t"]
 CmDriveState = _structs["cm_drive_state_t"]
+CmEnvParams = _structs["cm_envparams_t"]
 
 _lib = None
 
@@ -34,6 +35,8 @@ def lib():
         _declare(_lib)
         if _lib.phys_sizeof_model() != ctypes.sizeof(CmModel):
             raise RuntimeError("cm_model_t layout mismatch between cm_model.h and the built library")
+        if hasattr(_lib, "phys_sizeof_envparams") and _lib.phys_sizeof_envparams() != ctypes.sizeof(CmEnvParams):
+            raise RuntimeError("cm_envparams_t layout mismatch between cm_model.h and the built library")
     return _lib
 
 
@@ -73,6 +76,13 @@ def _declare(L):
     L.phys_batch_field_dim.argtypes = [vp, c.c_int]
     L.phys_batch_set_model.argtypes = [vp, c.POINTER(CmModel), c.c_int]
     L.phys_batch_set_hfield.argtypes = [vp, c.POINTER(c.c_float), c.c_int]
+    if hasattr(L, "phys_batch_randomize"):   # (absent from older variant builds selected with CASSIE_LIB)
+        L.phys_batch_param_dim.argtypes = [vp, c.c_int]
+        L.phys_batch_randomize.argtypes = [vp, c.c_int, vp, c.c_int, c.c_int, c.c_int, vp]
+        L.phys_batch_set_const.argtypes = [vp, c.c_int, c.c_int, vp]
+        L.phys_batch_download_params.argtypes = [vp, vp, c.c_int, c.c_int]
+        L.phys_batch_uses_env_params.argtypes = [vp]
+        L.phys_sizeof_envparams.restype = c.c_size_t
     L.phys_batch_set_hfield_env.argtypes = [vp, c.c_int, c.POINTER(c.c_float), c.c_int]
     L.phys_batch_upload.argtypes = [vp, c.c_int, vp, c.c_int, c.c_int]
     L.phys_batch_download.argtypes = [vp, c.c_int, vp, c.c_int, c.c_int]

@@ -10,7 +10,7 @@ import os
 
 import numpy as np
 
-from ._lib import CmDriveState, CmModel, MODEL_DIR, lib
+from ._lib import CmDriveState, CmEnvParams, CmModel, MODEL_DIR, lib
 
 # field ids (enum in cassie_phys.h)
 (F_QPOS, F_QVEL, F_QACC_WARMSTART, F_TIME, F_CTRL, F_QFRC_APPLIED, F_XFRC_APPLIED, F_QACC, F_SENSORDATA,
@@ -29,6 +29,15 @@ MEAS_ORIENTATION, MEAS_ANGVEL, MEAS_LINACC, MEAS_MAG, MEAS_DIM = 42, 46, 49, 52,
 
 FLAG_EULERDAMP, FLAG_WARMSTART, FLAG_REFSAFE, FLAG_HFDENSE, FLAG_HFMULTI, FLAG_HFPRISM = 1, 2, 4, 8, 16, 32      # CM_FLAG_* (cm_model.h)
 WARN_CONTACT_FULL, WARN_CONSTRAINT_FULL, WARN_UNSUPPORTED_PAIR, WARN_DIVERGED = 1, 2, 4, 8
+WARN_CHUNK_PLACEMENT = 16   # a chunk of a stepping launch found its predecessor on another XCD: the env's state may be stale, discard its results
+
+# per-env physical parameters (CM_P_* in cm_model.h): what Batch.randomize takes
+P_BODY_MASS, P_BODY_IPOS, P_BODY_INERTIA, P_DOF_DAMPING, P_GEOM_FRICTION = range(5)
+# views of the host model's arrays (PHYS_M_* in cassie_phys.h) that Model.array hands out
+(M_BODY_MASS, M_BODY_IPOS, M_BODY_POS, M_BODY_QUAT, M_DOF_DAMPING, M_JNT_STIFFNESS, M_QPOS_SPRING, M_GEOM_POS, M_GEOM_QUAT,
+ M_GEOM_SIZE, M_GEOM_FRICTION, M_ACTUATOR_GEAR, M_ACTUATOR_CTRLRANGE, M_ACTUATOR_USER, M_SENSOR_USER, M_HFIELD_SIZE, M_TIMESTEP,
+ M_QPOS0, M_JNT_RANGE, M_STAT_CENTER, M_STAT_EXTENT, M_GEOM_USER, M_BODY_INERTIA) = range(23)
+SIZE_NGEOM = 5               # PHYS_NGEOM: geoms in the host model's full list
 
 # joint configuration the reference writes at init (reference src/cassiemujoco.c:1023-1028)
 QPOS_INIT_JOINTS = np.array(
@@ -78,6 +87,14 @@ class Model:
     def save(self, path):
         if lib().phys_model_save(self._h, path.encode()) != 0:
             raise RuntimeError("cannot write " + path)
+
+    def array(self, which, n):
+        """Read-write numpy view of `n` doubles of a host-model array (M_*: the mjModel arrays the reference's setters write);
+        follow edits of masses / inertial frames with set_const(), of anything with compile()."""
+        p = lib().phys_model_array(self._h, int(which))
+        if not p:
+            raise ValueError("no such model array")
+        return np.ctypeslib.as_array(p, shape=(int(n),))
 
     def name2id(self, objtype, name):
         return lib().phys_model_name2id(self._h, objtype, name.encode())
@@ -148,6 +165,35 @@ class Batch:
     def clear_warnings(self, env0=0, n=None):
         if lib().phys_batch_clear_warn(self._h, env0, self.nenv - env0 if n is None else n) != 0:
             raise RuntimeError("clear_warn failed")
+
+    def param_dim(self, param):
+        return lib().phys_batch_param_dim(self._h, int(param))
+
+    def randomize(self, param, values, env0=0, device_ptr=None, n=None, stream=None):
+        """Per-env physical parameters (P_BODY_MASS [nbody], P_BODY_IPOS [nbody*3], P_BODY_INERTIA [nbody*3], P_DOF_DAMPING [nv],
+        P_GEOM_FRICTION [pod.ngeom*3], collision geoms in compiled order) for envs env0 ...: `values` is a host array
+        [n][dim], or pass `device_ptr` (+ n) to read rows that are already in HBM (a torch tensor's data_ptr()).  Masses /
+        inertial offsets / inertias: follow with set_const()."""
+        if device_ptr is not None:
+            rc = lib().phys_batch_randomize(self._h, int(param), device_ptr, 1, int(env0), int(n), stream)
+        else:
+            a = np.ascontiguousarray(values, dtype=np.float64).reshape(-1, self.param_dim(param))
+            rc = lib().phys_batch_randomize(self._h, int(param), a.ctypes.data, 0, int(env0), a.shape[0], stream)
+        if rc != 0:
+            raise RuntimeError("randomize failed: " + (lib().phys_last_error() or b"").decode())
+
+    def set_const(self, env0=0, n=None, stream=None):
+        """mj_setConst per env on the device: inverse weights and mean inertia from every env's own masses / inertial frames."""
+        if lib().phys_batch_set_const(self._h, int(env0), self.nenv - env0 if n is None else int(n), stream) != 0:
+            raise RuntimeError("set_const failed: " + (lib().phys_last_error() or b"").decode())
+
+    def params(self, env0=0, n=None):
+        """The envs' parameter blocks (ctypes array of CmEnvParams), downloaded."""
+        n = self.nenv - env0 if n is None else n
+        out = (CmEnvParams * n)()
+        if lib().phys_batch_download_params(self._h, ctypes.byref(out), int(env0), int(n)) != 0:
+            raise RuntimeError("parameter download failed")
+        return out
 
     def set_model(self, pod, env=-1):
         if lib().phys_batch_set_model(self._h, ctypes.byref(pod), env) != 0:

@@ -105,6 +105,33 @@ typedef struct cm_kinrec {
     double mat[9], quat[4], pos[3];
 } cm_kinrec_t;
 
+/* Per-env physical parameters (domain randomisation on the device).  The few fields of the model that
+ * the reference's setters change per simulator -- body masses, inertial frame offsets (and principal inertias), joint
+ * damping, geom friction (reference src/cassiemujoco.c:1323-1436) -- and everything mj_setConst derives from them
+ * (reference :949-977: the inverse weights at qpos0 behind the constraint regularisers, the mean inertia behind the solver's
+ * tolerance), already denormalised into the per-joint / per-equality / per-pair values the constraint stages read.  The
+ * step kernel reads THESE fields through one pointer per env: cm_model_t::params of the shared model, or the env's own
+ * block (PhysIO::envparams, [nenv], 10 KB each) once phys_batch_randomize has been used -- the other 95 KB of the model
+ * stay shared.  The first five arrays are the inputs (phys_batch_randomize), the rest is written by the device's set_const
+ * kernel (phys_batch_set_const) or, for the model's own block, by the host compile. */
+typedef struct cm_envparams {
+    double body_mass[CM_MAXBODY];
+    double body_ipos[CM_MAXBODY][3];
+    double body_inertia[CM_MAXBODY][3];
+    double dof_damping[CM_MAXV];
+    double geom_friction[CM_MAXGEOM][3];      /* collision geoms in compiled order (cm_model_t::geom_fullid maps to the full list) */
+    /* derived */
+    double meaninertia, pad;
+    double body_invweight0[CM_MAXBODY][2];
+    double dof_invweight0[CM_MAXV];
+    double jnt_liminvweight[CM_MAXJNT];
+    double eq_invweight[CM_MAXEQ];
+    double pair_invweight[CM_MAXPAIR];
+    double pair_friction[CM_MAXPAIR][3];
+} cm_envparams_t;
+/* the inputs of a cm_envparams_t, as phys_batch_randomize names them */
+enum { CM_P_BODY_MASS = 0, CM_P_BODY_IPOS = 1, CM_P_BODY_INERTIA = 2, CM_P_DOF_DAMPING = 3, CM_P_GEOM_FRICTION = 4, CM_P_COUNT = 5 };
+
 typedef struct cm_model {
     /* sizes */
     int nq, nv, nu, nbody, njnt, ngeom, npair, neq, nsite, nsensor, nsensordata;
@@ -241,6 +268,17 @@ typedef struct cm_model {
     double sensor_squat[CM_MAXSENSOR][4], sensor_spos[CM_MAXSENSOR][3]; /* frame sensors: site frame in its body */
     int sensor_slot[CM_MAXSENSOR];        /* accelerometers: 0, 1, ... in sensor order (-1 otherwise / beyond two) */
     int sensor_bits[CM_MAXSENSOR];        /* sensor user[0]: encoder resolution in bits (model/cassie.xml:272-287), 0 if none */
+
+    /* The pose-dependent constants of mj_setConst (reference src/cassiemujoco.c:952, :976): kinematics at qpos0, which no
+     * randomised parameter changes -- body frames, inertial frame orientations, and per dof the motion axis / anchor in
+     * world coordinates (dof_trans0: 1 = translational dof, the Jacobian column is the axis itself).  The device's set_const
+     * kernel (small_kernels.h) builds M(qpos0) and the inverse weights of an env from these and the env's masses / inertial
+     * offsets, in the host compile's order of operations. */
+    double body_xpos0[CM_MAXBODY][3], body_xmat0[CM_MAXBODY][9], body_ximat0[CM_MAXBODY][9];
+    double dof_axis0[CM_MAXV][3], dof_anchor0[CM_MAXV][3];
+    int dof_trans0[CM_MAXV];
+    /* the model's own parameter block: what every env uses until it is given one of its own */
+    cm_envparams_t params;
 } cm_model_t;
 
 /* Drive-level I/O state of one env: what `struct cassie_sim` keeps beside mjData for cassie_sim_step_ethercat

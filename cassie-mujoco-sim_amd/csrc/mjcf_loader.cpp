@@ -1375,6 +1375,57 @@ bool HostModel::compile(cm_model_t *o, std::string *err) const {
     const bool wide_caps = cassie32 && (o->flags & CM_FLAG_HFPRISM) != 0 && o->nhfpair > 0;
     o->maxcon = wide_caps ? CM_MAXCON : CM_MAXCON_NARROW;
     o->maxefc = wide_caps ? CM_MAXEFC : CM_MAXEFC_NARROW;
+
+    /* kinematics at qpos0 for the device's set_const kernel (cm_model_t::body_xpos0 ...): the very values set_const() above works
+     * with, per dof what HostKin::jac makes of the dof's joint */
+    {
+        HostKin kin(*this);
+        kin.run(qpos0.data());
+        for (int b = 0; b < nbody; ++b) {
+            for (int i = 0; i < 3; ++i) o->body_xpos0[b][i] = kin.xpos[3 * b + i];
+            for (int i = 0; i < 9; ++i) { o->body_xmat0[b][i] = kin.xmat[9 * b + i]; o->body_ximat0[b][i] = kin.ximat[9 * b + i]; }
+        }
+        for (int j = 0; j < njnt; ++j) {
+            const int b = jnt_bodyid[j], d = jnt_dofadr[j];
+            const double *an = &kin.xanchor[3 * j], *ax = &kin.xaxis[3 * j];
+            auto put = [&](int dd, int trans, const double *axis) {
+                o->dof_trans0[dd] = trans;
+                for (int i = 0; i < 3; ++i) { o->dof_axis0[dd][i] = axis[i]; o->dof_anchor0[dd][i] = trans ? 0.0 : an[i]; }
+            };
+            switch (jnt_type[j]) {
+                case CM_JNT_SLIDE: put(d, 1, ax); break;
+                case CM_JNT_HINGE: put(d, 0, ax); break;
+                case CM_JNT_BALL:
+                case CM_JNT_FREE: {
+                    const int r0 = jnt_type[j] == CM_JNT_FREE ? d + 3 : d;
+                    if (jnt_type[j] == CM_JNT_FREE)
+                        for (int k = 0; k < 3; ++k) { const double e[3] = {k == 0 ? 1.0 : 0.0, k == 1 ? 1.0 : 0.0, k == 2 ? 1.0 : 0.0}; put(d + k, 1, e); }
+                    for (int k = 0; k < 3; ++k) {
+                        const double a[3] = {kin.xmat[9 * b + k], kin.xmat[9 * b + 3 + k], kin.xmat[9 * b + 6 + k]};
+                        put(r0 + k, 0, a);
+                    }
+                } break;
+            }
+        }
+    }
+    /* the model's own parameter block (cm_envparams_t): what the step kernel reads where an env has no block of its own */
+    {
+        cm_envparams_t *p = &o->params;
+        for (int b = 0; b < nbody; ++b) {
+            p->body_mass[b] = o->body_mass[b];
+            for (int i = 0; i < 3; ++i) { p->body_ipos[b][i] = o->body_ipos[b][i]; p->body_inertia[b][i] = o->body_inertia[b][i]; }
+            for (int i = 0; i < 2; ++i) p->body_invweight0[b][i] = o->body_invweight0[b][i];
+        }
+        for (int d = 0; d < nv; ++d) { p->dof_damping[d] = o->dof_damping[d]; p->dof_invweight0[d] = o->dof_invweight0[d]; }
+        for (int g = 0; g < o->ngeom; ++g) for (int i = 0; i < 3; ++i) p->geom_friction[g][i] = o->geom_friction[g][i];
+        p->meaninertia = o->meaninertia;
+        for (int j = 0; j < njnt; ++j) p->jnt_liminvweight[j] = o->jnt_liminvweight[j];
+        for (int e = 0; e < neq; ++e) p->eq_invweight[e] = o->eq_invweight[e];
+        for (int i = 0; i < o->npair; ++i) {
+            p->pair_invweight[i] = o->pair_invweight[i];
+            for (int k = 0; k < 3; ++k) p->pair_friction[i][k] = o->pair_friction[i][k];
+        }
+    }
     return true;
 }
 

@@ -37,6 +37,7 @@ struct phys_batch {
     int nenv = 0, device = 0;
     cm_model_t host_model;          /* copy of the shared model (sizes) */
     cm_model_t *d_models = nullptr; /* 1 or nenv models in HBM */
+    cm_envparams_t *d_envparams = nullptr; /* null, or one parameter block per env (phys_batch_randomize: PhysIO::envparams) */
     int model_stride = 0;
     bool generic_kernel = false;   /* validation aid: never pick a compile-time-topology instantiation */
     int dim[PHYS_F_COUNT];
@@ -116,6 +117,7 @@ static ck::PhysIO make_io(phys_batch *b, int nsub, int integrate) {
     memset(&io, 0, sizeof io);
     io.models = b->d_models;
     io.model_stride = b->model_stride;
+    io.envparams = b->d_envparams;
     io.nenv = b->nenv; io.nsub = nsub; io.integrate = integrate;
     io.sq = b->stride[PHYS_F_QPOS]; io.sqv = b->stride[PHYS_F_QVEL]; io.sv = b->host_model.nv; io.su = b->host_model.nu;
     io.ssd = b->stride[PHYS_F_SENSORDATA]; io.sb = b->host_model.nbody;
@@ -442,6 +444,7 @@ void phys_batch_free(phys_batch_t *b) {
     for (int f = 0; f < PHYS_F_COUNT; ++f)
         if (b->owned[f] && b->d_field[f]) (void)hipFree(b->d_field[f]);
     if (b->d_models) (void)hipFree(b->d_models);
+    if (b->d_envparams) (void)hipFree(b->d_envparams);
     if (b->d_warn) (void)hipFree(b->d_warn);
     if (b->d_info) (void)hipFree(b->d_info);
     if (b->d_hfield) (void)hipFree(b->d_hfield);
@@ -483,6 +486,7 @@ int phys_batch_set_model(phys_batch_t *b, const cm_model_t *model, int env) {
     (void)hipSetDevice(b->device);
     if (!quiesce(b)) return -1;
     if (env < 0) {
+        if (b->d_envparams) { (void)hipFree(b->d_envparams); b->d_envparams = nullptr; } /* (the new model's own block again, for every env) */
         if (b->model_stride == 1) { /* back to one shared model */
             (void)hipFree(b->d_models);
             b->d_models = nullptr;
@@ -493,13 +497,17 @@ int phys_batch_set_model(phys_batch_t *b, const cm_model_t *model, int env) {
         return hip_ok(hipMemcpy(b->d_models, model, sizeof(cm_model_t), hipMemcpyHostToDevice), "hipMemcpy(model)") ? 0 : -1;
     }
     if (env >= b->nenv) return -1;
+    if (b->d_envparams) { phys_set_last_error("phys_batch_set_model: per-env models and per-env parameter blocks (phys_batch_randomize) do not mix"); return -1; }
     /* one launch serves every env with the kernel instantiation picked from the shared model: a per-env model may vary
      * parameters, not the dof tree or the kinds of collision pairs */
     if (memcmp(model->dof_ancmask, b->host_model.dof_ancmask, sizeof(model->dof_ancmask[0]) * (size_t)model->nv) != 0 ||
         model->kin_simple != b->host_model.kin_simple || model->maxdepth != b->host_model.maxdepth ||
         (model->nhfpair > 0) != (b->host_model.nhfpair > 0) || (model->hfield_geom >= 0) != (b->host_model.hfield_geom >= 0) ||
-        (model->npair > model->npair_simple) != (b->host_model.npair > b->host_model.npair_simple)) {
-        phys_set_last_error("phys_batch_set_model: a per-env model must keep the shared model's dof tree and collision pair kinds");
+        (model->npair > model->npair_simple) != (b->host_model.npair > b->host_model.npair_simple) ||
+        /* the tier chain behind a launch (63-row pass only, or 63 + 127) is picked from the SHARED model's caps, the kernel reads the env's */
+        model->maxefc != b->host_model.maxefc || model->maxcon != b->host_model.maxcon ||
+        ((model->flags ^ b->host_model.flags) & (CM_FLAG_HFPRISM | CM_FLAG_HFMULTI | CM_FLAG_HFDENSE)) != 0) {
+        phys_set_last_error("phys_batch_set_model: a per-env model must keep the shared model's dof tree, collision pair kinds, contact / row caps and height-field contact option");
         return -1;
     }
     if (b->model_stride == 0) { /* expand to one model per env */
@@ -810,7 +818,7 @@ int phys_batch_derive(phys_batch_t *b, const int ids[6], void *stream) {
     int rc = launch(b, 1, 0, s); /* forward: the read-out of the current state */
     ck::DeriveIO io;
     memset(&io, 0, sizeof io);
-    io.models = b->d_models; io.model_stride = b->model_stride; io.nenv = b->nenv;
+    io.models = b->d_models; io.model_stride = b->model_stride; io.nenv = b->nenv; io.envparams = b->d_envparams;
     io.ext = b->d_ext; io.xpos = b->d_field[PHYS_F_XPOS]; io.xquat = b->d_field[PHYS_F_XQUAT];
     io.derived = b->d_field[PHYS_F_DERIVED]; io.qM = b->d_field[PHYS_F_QM];
     for (int i = 0; i < 6; ++i) io.ids[i] = ids[i];
@@ -823,6 +831,80 @@ int phys_batch_derive(phys_batch_t *b, const int ids[6], void *stream) {
     }
     return rc;
 }
+
+/* ------------------------------------------------ per-env physical parameters ---- */
+static const struct { size_t off; int per; } PARAM_TABLE[CM_P_COUNT] = {
+    {offsetof(cm_envparams_t, body_mass), 1}, {offsetof(cm_envparams_t, body_ipos), 3}, {offsetof(cm_envparams_t, body_inertia), 3},
+    {offsetof(cm_envparams_t, dof_damping), 1}, {offsetof(cm_envparams_t, geom_friction), 3}};
+static int param_count(const phys_batch *b, int param) {
+    const cm_model_t &m = b->host_model;
+    return param == CM_P_DOF_DAMPING ? m.nv : param == CM_P_GEOM_FRICTION ? m.ngeom : m.nbody;
+}
+int phys_batch_param_dim(const phys_batch_t *b, int param) {
+    return (b && param >= 0 && param < CM_P_COUNT) ? param_count(b, param) * PARAM_TABLE[param].per : 0;
+}
+/* the per-env blocks, created on first use: every env starts from the shared model's own block */
+static bool ensure_envparams(phys_batch *b) {
+    if (b->d_envparams) return true;
+    if (b->model_stride != 0) { phys_set_last_error("per-env parameter blocks and per-env models (phys_batch_set_model with env >= 0) do not mix"); return false; }
+    if (!quiesce(b)) return false;
+    cm_envparams_t *all = nullptr;
+    if (!hip_ok(hipMalloc((void **)&all, sizeof(cm_envparams_t) * (size_t)b->nenv), "hipMalloc(env parameters)")) return false;
+    std::vector<cm_envparams_t> tmp((size_t)b->nenv, b->host_model.params);
+    if (!hip_ok(hipMemcpy(all, tmp.data(), sizeof(cm_envparams_t) * tmp.size(), hipMemcpyHostToDevice), "hipMemcpy(env parameters)")) { (void)hipFree(all); return false; }
+    b->d_envparams = all;
+    return true;
+}
+static int launch_setconst(phys_batch *b, int env0, int n, int derive_inertial, hipStream_t s) {
+    ck::SetConstIO io;
+    io.model = b->d_models; io.params = b->d_envparams; io.env0 = env0; io.nenv = n; io.derive_inertial = derive_inertial;
+    note_stream(b, s);
+    /* one wave per env, at most a few thousand workgroups walking the range (58 KB of LDS each: two to a CU) */
+    hipLaunchKernelGGL(ck::cassie_setconst_kernel, dim3((unsigned)(n < 2048 ? n : 2048)), dim3(WV_WAVE), 0, s, io);
+    return hip_ok(hipGetLastError(), "cassie_setconst_kernel launch") ? 0 : -1;
+}
+int phys_batch_randomize(phys_batch_t *b, int param, const double *values, int on_device, int env0, int n, void *stream) {
+    if (!b || !values || param < 0 || param >= CM_P_COUNT || env0 < 0 || n < 0 || env0 + n > b->nenv) { phys_set_last_error("phys_batch_randomize: bad arguments"); return -1; }
+    (void)hipSetDevice(b->device);
+    if (!ensure_envparams(b)) return -1;
+    if (n == 0) return 0;
+    hipStream_t s = stream ? (hipStream_t)stream : b->stream;
+    const int dim = phys_batch_param_dim(b, param);
+    const double *src = values;
+    double *staged = nullptr;
+    if (!on_device) {
+        const size_t bytes = sizeof(double) * (size_t)n * dim;
+        if (!hip_ok(hipMalloc((void **)&staged, bytes), "hipMalloc(parameter rows)")) return -1;
+        if (!hip_ok(hipMemcpyAsync(staged, values, bytes, hipMemcpyHostToDevice, s), "hipMemcpy(parameter rows)")) { (void)hipFree(staged); return -1; }
+        src = staged;
+    }
+    note_stream(b, s);
+    hipLaunchKernelGGL(ck::cassie_param_scatter_kernel, dim3((unsigned)(n < 1024 ? n : 1024)), dim3(WV_WAVE), 0, s, b->d_envparams,
+                       (int)(PARAM_TABLE[param].off / sizeof(double)), dim, src, env0, n);
+    int rc = hip_ok(hipGetLastError(), "cassie_param_scatter_kernel launch") ? 0 : -1;
+    /* friction needs no set_const in the reference (mj_contactParam mixes the geoms' values at every step): the pairs' mixed
+     * values are refreshed right away; so is nothing else -- masses, inertial offsets and inertias wait for phys_batch_set_const
+     * like mjModel edits wait for mj_setConst, damping takes effect as it is */
+    if (rc == 0 && param == CM_P_GEOM_FRICTION) rc = launch_setconst(b, env0, n, 0, s);
+    if (staged) { if (!hip_ok(hipStreamSynchronize(s), "randomize sync")) rc = -1; (void)hipFree(staged); }
+    return rc;
+}
+int phys_batch_set_const(phys_batch_t *b, int env0, int n, void *stream) {
+    if (!b || env0 < 0 || n < 0 || env0 + n > b->nenv) return -1;
+    (void)hipSetDevice(b->device);
+    if (!ensure_envparams(b)) return -1;
+    if (n == 0) return 0;
+    return launch_setconst(b, env0, n, 1, stream ? (hipStream_t)stream : b->stream);
+}
+int phys_batch_download_params(phys_batch_t *b, cm_envparams_t *host, int env0, int n) {
+    if (!b || !host || env0 < 0 || n < 0 || env0 + n > b->nenv) return -1;
+    (void)hipSetDevice(b->device);
+    if (!quiesce(b)) return -1;
+    if (!b->d_envparams) { for (int e = 0; e < n; ++e) host[e] = b->host_model.params; return 0; }
+    return hip_ok(hipMemcpy(host, b->d_envparams + env0, sizeof(cm_envparams_t) * (size_t)n, hipMemcpyDeviceToHost), "parameter download") ? 0 : -1;
+}
+int phys_batch_uses_env_params(const phys_batch_t *b) { return b && b->d_envparams ? 1 : 0; }
+size_t phys_sizeof_envparams(void) { return sizeof(cm_envparams_t); }
 
 int phys_batch_set_all_outputs_every_substep(phys_batch_t *b, int on) {
     if (!b) return -1;

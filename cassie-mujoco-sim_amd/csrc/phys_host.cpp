@@ -168,6 +168,7 @@ double *phys_model_array(phys_model_t *m, int which) {
     switch (which) {
         case PHYS_M_BODY_MASS: return h.body_mass.data();
         case PHYS_M_BODY_IPOS: return h.body_ipos.data();
+        case PHYS_M_BODY_INERTIA: return h.body_inertia.data();
         case PHYS_M_BODY_POS: return h.body_pos.data();
         case PHYS_M_BODY_QUAT: return h.body_quat.data();
         case PHYS_M_DOF_DAMPING: return h.dof_damping.data();

@@ -102,6 +102,8 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
     static_assert(!WIDE || (NW == 2 && MAXR == WIDE_ROWS), "the 127-row instantiation spreads its solve over the two wavefronts of an env");
     const ModelPtr m_launch = (ModelPtr)(io.models + (size_t)env * io.model_stride);
     ModelPtr m = m_launch;
+    /* the env's physical parameters: its own block, or the model's (wave-uniform either way: scalar loads) */
+    const ParamPtr P = io.envparams ? (ParamPtr)(io.envparams + (size_t)env) : (ParamPtr)&m_launch->params;
     int lane = wv::lane();
     const int nq = m->nq, nv = m->nv, nu = m->nu, nbody = m->nbody, njnt = m->njnt;
     /* rows / contacts a substep may use: what this instantiation holds, within the model's caps (cm_model_t::maxefc / maxcon) */
@@ -352,9 +354,9 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
          * recursion's four LDS rounds instead of in front of each of those stages. */
         const int pf_b = isbody ? b : 0, pf_g = lane < m->ngeom ? lane : -1, pf_gs = pf_g >= 0 ? pf_g : 0;
         const int pf_jpb = lane < njnt ? m->jnt_parentbody[lane] : -1, pf_gb = m->geom_bodyid[pf_gs];
-        const double pf_mass = m->body_mass[pf_b];
+        const double pf_mass = P->body_mass[pf_b];
         double pf_ipos[3], pf_imat[9], pf_iner[3], pf_gpos[3], pf_gmat[9];
-        for (int i = 0; i < 3; ++i) { pf_ipos[i] = m->body_ipos[pf_b][i]; pf_iner[i] = m->body_inertia[pf_b][i]; pf_gpos[i] = m->geom_pos[pf_gs][i]; }
+        for (int i = 0; i < 3; ++i) { pf_ipos[i] = P->body_ipos[pf_b][i]; pf_iner[i] = P->body_inertia[pf_b][i]; pf_gpos[i] = m->geom_pos[pf_gs][i]; }
         for (int i = 0; i < 9; ++i) { pf_imat[i] = m->body_imat[pf_b][i]; pf_gmat[i] = m->geom_mat[pf_gs][i]; }
         /* recursion over the tree by radix-3 pointer jumping: in round r every body composes its partial transform with
          * those of its 3^r-th and 2 * 3^r-th ancestors, after which it holds the product of the local transforms of its
@@ -464,9 +466,9 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
         if constexpr (NW == 2) {
             /* (wave 1) */
         } else if constexpr (by_height) {
-            factor_pair_by_height<NVP, TOPO>(m, h, S, col, colh, lane);
+            factor_pair_by_height<NVP, TOPO>(m, P, h, S, col, colh, lane);
         } else {
-            factor_pair_in_registers<NVP, TOPO>(m, h, col, colh, lane, nv, S.dinv, S.rsd, S.dinvH);
+            factor_pair_in_registers<NVP, TOPO>(m, P, h, col, colh, lane, nv, S.dinv, S.rsd, S.dinvH);
             if (isdof) {
 #pragma unroll
                 for (int k = 1; k < NVP; ++k) {
@@ -495,7 +497,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
         if (!isbody) blast = -1;
         if (!isdof) kvin = -1;
         const int kd = isdof ? k_ : 0;
-        const double kdamp = m->dof_damping[kd], kstiff = m->dof_stiffness[kd], kref = m->dof_springref[kd];
+        const double kdamp = P->dof_damping[kd], kstiff = m->dof_stiffness[kd], kref = m->dof_springref[kd];
         const double kgear = m->dof_gear[kd], klo = m->dof_ctrl_lo[kd], khi = m->dof_ctrl_hi[kd];
         const int kq = m->dof_qadr[kd], ka = m->dof_act[kd];
         auto chain_sums = [&](double (&acc)[6]) { /* acc: this dof's term in, its chain sum out; tile: buf */

@@ -680,7 +680,7 @@ WV_DEVICE int hfield_prism_wave(SH &S, ModelPtr m, const float *data, int lane, 
 /* lane = contact: contact frame from (normal, tangent hint) and the pair's pre-mixed parameters (model compile
  * time, cm_model_t::pair_*), once per contact and outside the divergent pair loops */
 template <class SH>
-WV_DEVICE void finish_contacts(SH &S, ModelPtr m, int lane, int ncon) {
+WV_DEVICE void finish_contacts(SH &S, ModelPtr m, ParamPtr P, int lane, int ncon) {
     if (lane < ncon) {
         const int p = S.c_pair[lane];
         double fr[9];
@@ -693,9 +693,9 @@ WV_DEVICE void finish_contacts(SH &S, ModelPtr m, int lane, int ncon) {
         S.c_dim[lane] = m->pair_condim[p];
         for (int i = 0; i < 2; ++i) S.c_solref[lane][i] = m->pair_solref[p][i];
         for (int i = 0; i < 5; ++i) S.c_solimp[lane][i] = m->pair_solimp[p][i];
-        for (int i = 0; i < 3; ++i) S.c_fri[lane][i] = m->pair_friction[p][i];
+        for (int i = 0; i < 3; ++i) S.c_fri[lane][i] = P->pair_friction[p][i];
         for (int k = 0; k < 2; ++k) { S.c_root[lane][k] = m->pair_root[p][k]; S.c_dofmask[lane][k] = m->pair_dofmask[p][k]; }
-        S.c_tran[lane] = m->pair_invweight[p];
+        S.c_tran[lane] = P->pair_invweight[p];
     }
 }
 

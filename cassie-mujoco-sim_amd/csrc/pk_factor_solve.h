@@ -103,14 +103,14 @@ WV_DEVICE double fast_rcp(double x) {
  * (col[i] in lanes j > i) are never read, so they may absorb harmless updates.  On exit col[k] holds L[k][j]
  * for k > j; the pivots are returned through dinv / rsd / dinvH (wave-uniform, written by lane 0). */
 template <int NVP, class TOPO>
-WV_DEVICE void factor_pair_in_registers(ModelPtr m, double h, double (&col)[NVP], double (&colh)[NVP], int lane, int nv,
+WV_DEVICE void factor_pair_in_registers(ModelPtr m, ParamPtr P, double h, double (&col)[NVP], double (&colh)[NVP], int lane, int nv,
                                         double *dinv, double *rsd, double *dinvH) {
 #pragma unroll
     for (int k = NVP - 1; k >= 0; --k) {
         if (TOPO::is_static ? k >= TOPO::nv : k >= nv) continue;
         const unsigned long long anc = anc_mask<TOPO>(m, k);
         const double arm = m->dof_armature[k]; /* diagonal terms, see the mass-matrix stage */
-        const double inv = fast_rcp(wv::readlane(col[k], k) + arm), invh = fast_rcp(wv::readlane(colh[k], k) + (arm + h * m->dof_damping[k]));
+        const double inv = fast_rcp(wv::readlane(col[k], k) + arm), invh = fast_rcp(wv::readlane(colh[k], k) + (arm + h * P->dof_damping[k]));
         if (lane == 0) { dinv[k] = inv; rsd[k] = sqrt(inv); dinvH[k] = invh; }
         if (anc == 0ull) continue;
 #pragma unroll
@@ -133,7 +133,7 @@ WV_DEVICE void factor_pair_in_registers(ModelPtr m, double h, double (&col)[NVP]
 /* WHICH: 2 = both factorisations, interleaved (their chains hide each other's latency); 0 = that of M alone, 1 = that of M + hB alone
  * (the two-wave form runs the second one behind the barrier J, while wave 0 solves: only the Euler step reads it) */
 template <int NVP, class TOPO, int WHICH = 2, class SH>
-WV_DEVICE void factor_pair_by_height(ModelPtr m, double h, SH &S, double (&col)[NVP], double (&colh)[NVP], int lane) {
+WV_DEVICE void factor_pair_by_height(ModelPtr m, ParamPtr P, double h, SH &S, double (&col)[NVP], double (&colh)[NVP], int lane) {
     /* The trunk dofs (the floating base: each one's ancestors are all the lower ones) come last and one to a height: a
      * round through LDS for a single dof is all latency.  They are eliminated in registers instead (below), with
      * v_readlane multipliers whose round trips overlap, so the height rounds stop where the trunk begins. */
@@ -149,7 +149,7 @@ WV_DEVICE void factor_pair_by_height(ModelPtr m, double h, SH &S, double (&col)[
              * unused slot of the row: an unpredicated store too */
             const int at = LPack<TOPO, NVP>::row_slot(k, lane);
             if constexpr (WHICH != 1) { const double inv = fast_rcp(wv::readlane(col[k], k) + arm); S.dinv[k] = inv; S.Lp[at] = col[k] * inv; }
-            if constexpr (WHICH != 0) { const double invh = fast_rcp(wv::readlane(colh[k], k) + (arm + h * m->dof_damping[k])); S.dinvH[k] = invh; S.LHp[at] = colh[k] * invh; }
+            if constexpr (WHICH != 0) { const double invh = fast_rcp(wv::readlane(colh[k], k) + (arm + h * P->dof_damping[k])); S.dinvH[k] = invh; S.LHp[at] = colh[k] * invh; }
         }
         wv::sync();
 #pragma unroll
@@ -190,7 +190,7 @@ WV_DEVICE void factor_pair_by_height(ModelPtr m, double h, SH &S, double (&col)[
             for (int i = k - 1; i >= 0; --i) col[i] -= t[i] * col[k];
         }
         if constexpr (WHICH != 0) {
-            const double invh = fast_rcp(wv::readlane(colh[k], k) + (arm + h * m->dof_damping[k]));
+            const double invh = fast_rcp(wv::readlane(colh[k], k) + (arm + h * P->dof_damping[k]));
             S.dinvH[k] = invh;
             S.LHp[at] = colh[k] * invh;
             double th[TOPO::trunk];

@@ -30,10 +30,16 @@ enum { WARN_CONTACT_FULL = 1, WARN_CONSTRAINT_FULL = 2, WARN_UNSUPPORTED_PAIR = 
 #define WV_OCC
 #endif
 typedef const WV_CONST_AS cm_model_t *ModelPtr;
+typedef const WV_CONST_AS cm_envparams_t *ParamPtr; /* an env's physical parameters (cm_model.h: cm_envparams_t) */
 
 struct PhysIO {
     const cm_model_t *models;   /* one shared model, or one per env */
     int model_stride;           /* 0 = shared, 1 = per-env */
+    /* per-env physical parameters (domain randomisation): null = every env reads its model's own block
+     * (cm_model_t::params); else one cm_envparams_t per env of the batch (indexed by the absolute env), written by
+     * phys_batch_randomize / phys_batch_set_const.  The step kernel reads masses, inertial offsets, principal inertias, joint
+     * damping, contact friction and the set_const-derived inverse weights / mean inertia through this pointer ONLY. */
+    const cm_envparams_t *envparams;
     int nenv, nsub;             /* envs of this launch; nsub physics steps per launch (ctrl / PD targets held) */
     int env0;                   /* first env of this launch: a launch may cover the env range [env0, env0 + nenv) of the batch (all
                                    per-env arrays are indexed by the absolute env) */

@@ -23,7 +23,7 @@ namespace ck {
  * Returns this lane's row force; iters / nguarded: the sweeps taken (valid in both waves when the substep has more than 64 rows,
  * in wave 0 otherwise). ---------------- */
 template <int NVP, class TOPO, class SH>
-WV_DEVICE double wide_solve(SH &S, ModelPtr m, const int wid, const int nefc, const int sub, int &iters, int &nguarded) {
+WV_DEVICE double wide_solve(SH &S, ModelPtr m, ParamPtr P, const int wid, const int nefc, const int sub, int &iters, int &nguarded) {
     constexpr int H = NROW, MAXR = WIDE_ROWS;
     static_assert(TOPO::is_static, "the 127-row instantiation exists for the compile-time topologies");
     const int lane = wv::fresh_lane();
@@ -111,7 +111,7 @@ WV_DEVICE double wide_solve(SH &S, ModelPtr m, const int wid, const int nefc, co
     double f = 0, res = isrow ? rb : 0.0;
     const int r_ = lane; /* the row's index within its wave */
     const int nvs = TOPO::nv;
-    const double scale = 1.0 / (m->meaninertia * (nvs > 1 ? nvs : 1));
+    const double scale = 1.0 / (P->meaninertia * (nvs > 1 ? nvs : 1));
     const double halfAii = 0.5 * Aii;
     const double flo = clampf ? 0.0 : -1e300;
     const double ninvAii = -invAii;

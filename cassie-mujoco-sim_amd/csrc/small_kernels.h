@@ -83,6 +83,7 @@ WV_GLOBAL void __launch_bounds__(WV_WAVE) cassie_drive_kernel(PhysIO io, double 
  * right toe site (-1 = the model has none). */
 struct DeriveIO {
     const cm_model_t *models; int model_stride; int nenv;
+    const cm_envparams_t *envparams; /* null, or one block per env (PhysIO::envparams) */
     const cm_ext_t *ext;
     const double *xpos, *xquat;   /* [nenv][nbody][3], [nenv][nbody][4] */
     double *derived;              /* [nenv][CM_DRV_DIM] */
@@ -92,6 +93,7 @@ struct DeriveIO {
 
 WV_DEVICE void derive_env(const DeriveIO &io, int env, int lane) {
     const ModelPtr m = (ModelPtr)(io.models + (size_t)env * io.model_stride);
+    const ParamPtr P = io.envparams ? (ParamPtr)(io.envparams + (size_t)env) : (ParamPtr)&m->params;
     const cm_ext_t *ex = io.ext + env;
     const int nb = m->nbody, nv = m->nv;
     double *out = io.derived + (size_t)env * CM_DRV_DIM;
@@ -99,7 +101,7 @@ WV_DEVICE void derive_env(const DeriveIO &io, int env, int lane) {
     /* lane = body: mass-weighted sums */
     const bool isb = lane > 0 && lane < nb;
     const int b = isb ? lane : 0;
-    const double mb = isb ? m->body_mass[b] : 0.0;
+    const double mb = isb ? P->body_mass[b] : 0.0;
     double xi[3], vb[3] = {0, 0, 0}, w[3] = {0, 0, 0};
     for (int i = 0; i < 3; ++i) xi[i] = ex->xipos[b][i];
     if (isb) {
@@ -121,7 +123,7 @@ WV_DEVICE void derive_env(const DeriveIO &io, int env, int lane) {
         quat2mat(R, q);
         double wl[3];
         mulmatTvec3(wl, R, w);
-        for (int i = 0; i < 3; ++i) wl[i] *= m->body_inertia[b][i];
+        for (int i = 0; i < 3; ++i) wl[i] *= P->body_inertia[b][i];
         mulmatvec3(L, R, wl);
         double r[3], mv[3], t[3];
         for (int i = 0; i < 3; ++i) { r[i] = xi[i] - com[i]; mv[i] = mb * (vb[i] - vcom[i]); }
@@ -191,6 +193,204 @@ WV_GLOBAL void __launch_bounds__(WV_WAVE) cassie_derive_kernel(DeriveIO io) {
     const int env = wv::env_id();
     if (env >= io.nenv) return;
     derive_env(io, env, wv::lane());
+}
+
+/* ------------------------------------------- per-env physical parameters ---- */
+/* phys_batch_randomize: rows [n][dim] of one input array of cm_envparams_t (cm_model.h: CM_P_*) into the blocks of envs
+ * env0 .. env0 + n - 1.  off = the array's offset in the block in doubles.  A few workgroups walk the rows. */
+WV_GLOBAL void __launch_bounds__(WV_WAVE) cassie_param_scatter_kernel(cm_envparams_t *params, int off, int dim, const double *src, int env0, int n) {
+#ifndef CK_EMULATED
+    for (int i = (int)blockIdx.x; i < n; i += (int)gridDim.x) {
+        double *dst = (double *)(params + env0 + i) + off;
+        for (int k = (int)threadIdx.x; k < dim; k += WV_WAVE) dst[k] = src[(size_t)i * dim + k];
+    }
+#endif
+}
+
+/* The mj_setConst role on the device (reference src/cassiemujoco.c:952, :976 after the mass / inertial-offset setters of
+ * :1367-1412), one wave per env: from the env's masses, inertial offsets and principal inertias and the model's kinematics at
+ * qpos0 (cm_model_t::body_xpos0 ...: no randomised parameter moves a body frame) it builds the dense joint-space inertia at qpos0,
+ * its Cholesky factor, and from it the mean inertia, the bodies' translational / rotational inverse weights
+ * (1/3 tr J M^-1 J^T at the inertial origin) and the dofs' (diag M^-1, averaged over ball / free joints); then the values the
+ * constraint stages read per joint limit / equality / contact pair, and the pairs' mixed friction.
+ *
+ * Every floating-point operation is an individually rounded IEEE operation in the order of HostModel::set_const /
+ * HostModel::compile (csrc/mjcf_loader.cpp), so an env's block is BIT FOR BIT what compiling a host model with the same
+ * parameters gives (tests/test_domain_randomisation.py on the emulator, tests/test_randomise_gpu.py on the device) -- the
+ * oracle, which is handed such per-env models, and the kernel then solve the same problem.
+ * Lanes: dofs (Jacobian columns, columns of M, rows of the factor), then (body, translational | rotational) for the bodies'
+ * solves, then dofs again for the unit-vector solves; the right-hand sides live one to a lane in LDS. */
+struct SetConstShared {
+    double M[CM_MAXV][CM_MAXV + 1];
+    double Jp[3][CM_MAXV], Jl[3][CM_MAXV];
+    double X[WV_WAVE][CM_MAXV + 1], X0[WV_WAVE][CM_MAXV + 1];
+    double xipos[CM_MAXBODY][3];
+    double bw[CM_MAXBODY][2], dinv[CM_MAXV], dw[CM_MAXV];
+    double piv;
+    int ok;
+};
+struct SetConstIO {
+    const cm_model_t *model;      /* the shared model (topology, kinematics at qpos0, armature, pair / equality tables) */
+    cm_envparams_t *params;       /* [nenv] blocks, indexed by the absolute env */
+    int env0, nenv;               /* the range to (re)derive */
+    int derive_inertial;          /* 0: only the friction / pair tables (phys_batch_randomize of CM_P_GEOM_FRICTION); 1: all */
+};
+
+/* Jacobian column of dof d for a world point p attached to body b (HostKin::jac): translational part jp, rotational jr */
+WV_DEVICE void setconst_jac_col(ModelPtr m, int b, int d, const double *p, double (&jp)[3], double (&jr)[3]) {
+    for (int i = 0; i < 3; ++i) { jp[i] = 0.0; jr[i] = 0.0; }
+    if (!((m->body_dofmask[b] >> d) & 1ull)) return;
+    double ax[3] = {m->dof_axis0[d][0], m->dof_axis0[d][1], m->dof_axis0[d][2]};
+    if (m->dof_trans0[d]) { for (int i = 0; i < 3; ++i) jp[i] = ax[i]; return; }
+    const double off[3] = {wv::sub_rn(p[0], m->dof_anchor0[d][0]), wv::sub_rn(p[1], m->dof_anchor0[d][1]), wv::sub_rn(p[2], m->dof_anchor0[d][2])};
+    jp[0] = wv::sub_rn(wv::mul_rn(ax[1], off[2]), wv::mul_rn(ax[2], off[1]));
+    jp[1] = wv::sub_rn(wv::mul_rn(ax[2], off[0]), wv::mul_rn(ax[0], off[2]));
+    jp[2] = wv::sub_rn(wv::mul_rn(ax[0], off[1]), wv::mul_rn(ax[1], off[0]));
+    for (int i = 0; i < 3; ++i) jr[i] = ax[i];
+}
+/* x = (L L^T)^-1 x with L in the lower triangle of S.M (chol_solve of the host compile), x in LDS */
+WV_DEVICE void setconst_chol_solve(const SetConstShared &S, int n, double *x) {
+    for (int i = 0; i < n; ++i) {
+        double s = x[i];
+        for (int k = 0; k < i; ++k) s = wv::sub_rn(s, wv::mul_rn(S.M[i][k], x[k]));
+        x[i] = wv::div_rn(s, S.M[i][i]);
+    }
+    for (int i = n - 1; i >= 0; --i) {
+        double s = x[i];
+        for (int k = i + 1; k < n; ++k) s = wv::sub_rn(s, wv::mul_rn(S.M[k][i], x[k]));
+        x[i] = wv::div_rn(s, S.M[i][i]);
+    }
+}
+
+WV_GLOBAL void __launch_bounds__(WV_WAVE) cassie_setconst_kernel(SetConstIO io) {
+    WV_SHARED SetConstShared S;
+    const int lane = wv::lane();
+    for (int idx = wv::env_id(); idx < io.nenv; idx += wv::grid_size()) {
+    const int env = io.env0 + idx;
+    const ModelPtr m = (ModelPtr)io.model;
+    cm_envparams_t *P = io.params + env;
+    const int nv = m->nv, nbody = m->nbody, njnt = m->njnt;
+    if (io.derive_inertial) {
+    /* inertial origins at qpos0: xipos = xmat0 ipos + xpos0 */
+    if (lane < nbody) {
+        const int b = lane;
+        double v[3] = {0, 0, 0};
+        if (b > 0) {
+            const double *ip = P->body_ipos[b];
+            for (int i = 0; i < 3; ++i)
+                v[i] = wv::add_rn(wv::add_rn(wv::add_rn(wv::mul_rn(m->body_xmat0[b][3 * i], ip[0]), wv::mul_rn(m->body_xmat0[b][3 * i + 1], ip[1])), wv::mul_rn(m->body_xmat0[b][3 * i + 2], ip[2])), m->body_xpos0[b][i]);
+        }
+        for (int i = 0; i < 3; ++i) S.xipos[b][i] = v[i];
+    }
+    if (lane < CM_MAXV) for (int r = 0; r < CM_MAXV; ++r) S.M[r][lane] = 0.0;
+    if (lane == 0) S.ok = 1;
+    wv::sync();
+    /* M(qpos0) = sum over bodies of J^T diag(m, I) J (lane = column), + armature */
+    for (int b = 1; b < nbody; ++b) {
+        const double mass = P->body_mass[b];
+        if (mass <= 0) continue;
+        if (lane < nv) {
+            double jp[3], jr[3];
+            setconst_jac_col(m, b, lane, S.xipos[b], jp, jr);
+            for (int i = 0; i < 3; ++i) {
+                S.Jp[i][lane] = jp[i];
+                S.Jl[i][lane] = wv::add_rn(wv::add_rn(wv::mul_rn(m->body_ximat0[b][i], jr[0]), wv::mul_rn(m->body_ximat0[b][3 + i], jr[1])), wv::mul_rn(m->body_ximat0[b][6 + i], jr[2]));
+            }
+        }
+        wv::sync();
+        if (lane < nv) {
+            const int c = lane;
+            for (int r = 0; r < nv; ++r) {
+                double s = 0;
+                for (int i = 0; i < 3; ++i)
+                    s = wv::add_rn(s, wv::add_rn(wv::mul_rn(wv::mul_rn(mass, S.Jp[i][r]), S.Jp[i][c]),
+                                                 wv::mul_rn(wv::mul_rn(P->body_inertia[b][i], S.Jl[i][r]), S.Jl[i][c])));
+                S.M[r][c] = wv::add_rn(S.M[r][c], s);
+            }
+        }
+        wv::sync();
+    }
+    if (lane < nv) S.M[lane][lane] = wv::add_rn(S.M[lane][lane], m->dof_armature[lane]);
+    wv::sync();
+    if (lane == 0) {
+        double mean = 0;
+        for (int d = 0; d < nv; ++d) mean = wv::add_rn(mean, S.M[d][d]);
+        P->meaninertia = nv > 0 ? wv::div_rn(mean, (double)nv) : 1.0;
+    }
+    /* Cholesky factor in place, column by column (lane = row) */
+    for (int j = 0; j < nv; ++j) {
+        double s = 0;
+        if (lane >= j && lane < nv) {
+            s = S.M[lane][j];
+            for (int k = 0; k < j; ++k) s = wv::sub_rn(s, wv::mul_rn(S.M[lane][k], S.M[j][k]));
+            if (lane == j) { if (s <= 0) S.ok = 0; S.piv = wv::sqrt_rn(s > 0 ? s : 1.0); }
+        }
+        wv::sync();
+        if (lane >= j && lane < nv) S.M[lane][j] = lane == j ? S.piv : wv::div_rn(s, S.piv);
+        wv::sync();
+    }
+    if (S.ok) { /* (a mass matrix that is not positive definite leaves the weights as they were, like the host compile) */
+    /* bodies: lane = 2 body + (0 translational | 1 rotational); three solves each, summed in order */
+    {
+        const int b = lane >> 1, kind = lane & 1;
+        const bool live = b > 0 && b < nbody && m->body_weldid[b] != 0;
+        double acc = 0;
+        for (int i = 0; i < 3; ++i) {
+            if (live) {
+                for (int d = 0; d < nv; ++d) {
+                    double jp[3], jr[3];
+                    setconst_jac_col(m, b, d, S.xipos[b], jp, jr);
+                    const double v = kind ? jr[i] : jp[i];
+                    S.X[lane][d] = v; S.X0[lane][d] = v;
+                }
+                setconst_chol_solve(S, nv, S.X[lane]);
+                for (int d = 0; d < nv; ++d) acc = wv::add_rn(acc, wv::mul_rn(S.X0[lane][d], S.X[lane][d]));
+            }
+        }
+        if (b < nbody) S.bw[b][kind] = live ? wv::div_rn(acc, 3.0) : 0.0;
+    }
+    wv::sync();
+    /* dofs: diag(M^-1) by unit-vector solves, averaged over the dofs of ball / free joints */
+    if (lane < nv) {
+        for (int d = 0; d < nv; ++d) S.X[lane][d] = d == lane ? 1.0 : 0.0;
+        setconst_chol_solve(S, nv, S.X[lane]);
+        S.dinv[lane] = S.X[lane][lane];
+    }
+    wv::sync();
+    if (lane < njnt) {
+        const int j = lane, d = m->jnt_dofadr[j], jt = m->jnt_type[j];
+        if (jt == CM_JNT_FREE) {
+            const double a = wv::div_rn(wv::add_rn(wv::add_rn(S.dinv[d], S.dinv[d + 1]), S.dinv[d + 2]), 3.0);
+            const double r = wv::div_rn(wv::add_rn(wv::add_rn(S.dinv[d + 3], S.dinv[d + 4]), S.dinv[d + 5]), 3.0);
+            for (int k = 0; k < 3; ++k) { S.dw[d + k] = a; S.dw[d + 3 + k] = r; }
+        } else if (jt == CM_JNT_BALL) {
+            const double r = wv::div_rn(wv::add_rn(wv::add_rn(S.dinv[d], S.dinv[d + 1]), S.dinv[d + 2]), 3.0);
+            for (int k = 0; k < 3; ++k) S.dw[d + k] = r;
+        } else S.dw[d] = S.dinv[d];
+    }
+    wv::sync();
+    if (lane < nbody) { P->body_invweight0[lane][0] = S.bw[lane][0]; P->body_invweight0[lane][1] = S.bw[lane][1]; }
+    if (lane < nv) P->dof_invweight0[lane] = S.dw[lane];
+    wv::sync();
+    }
+    /* what the constraint stages read: per limited joint, per equality, per candidate pair (HostModel::compile) */
+    if (lane < njnt) P->jnt_liminvweight[lane] = P->dof_invweight0[m->jnt_dofadr[lane]];
+    if (lane < m->neq) P->eq_invweight[lane] = wv::add_rn(wv::add_rn(0.0, P->body_invweight0[m->eq_body1[lane]][0]), P->body_invweight0[m->eq_body2[lane]][0]);
+    for (int p = lane; p < m->npair; p += WV_WAVE) {
+        const int g1 = m->pair_geom1[p], g2 = m->pair_geom2[p];
+        P->pair_invweight[p] = wv::add_rn(wv::add_rn(0.0, P->body_invweight0[m->geom_bodyid[g1]][0]), P->body_invweight0[m->geom_bodyid[g2]][0]);
+    }
+    }
+    /* contact friction of every candidate pair: the geom with the higher priority wins outright, else the larger coefficient */
+    for (int p = lane; p < m->npair; p += WV_WAVE) {
+        const int g1 = m->pair_geom1[p], g2 = m->pair_geom2[p], pa = m->geom_priority[g1], pb = m->geom_priority[g2];
+        for (int k = 0; k < 3; ++k) {
+            const double f1 = P->geom_friction[g1][k], f2 = P->geom_friction[g2][k];
+            P->pair_friction[p][k] = pa != pb ? (pa > pb ? f1 : f2) : (f1 > f2 ? f1 : f2);
+        }
+    }
+    wv::sync();
+    }
 }
 
 /* Episode restarts on the device (the batched form of what a fresh cassie_sim_t / cassie_sim_full_reset leaves, reference

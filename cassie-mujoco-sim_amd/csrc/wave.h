@@ -241,6 +241,7 @@ WV_DEVICE double mul_rn(double a, double b) { return __dmul_rn(a, b); }
 WV_DEVICE double add_rn(double a, double b) { return __dadd_rn(a, b); }
 WV_DEVICE double sub_rn(double a, double b) { return __dsub_rn(a, b); }
 WV_DEVICE double div_rn(double a, double b) { return __ddiv_rn(a, b); }
+WV_DEVICE double sqrt_rn(double a) { return __dsqrt_rn(a); }
 
 /* hardware reciprocal estimate (v_rcp_f64) */
 WV_DEVICE double rcp_estimate(double x) { return __builtin_amdgcn_rcp(x); }

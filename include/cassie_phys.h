@@ -60,7 +60,8 @@ int phys_model_size(const phys_model_t *m, int what);
 enum { PHYS_M_BODY_MASS, PHYS_M_BODY_IPOS, PHYS_M_BODY_POS, PHYS_M_BODY_QUAT, PHYS_M_DOF_DAMPING, PHYS_M_JNT_STIFFNESS,
        PHYS_M_QPOS_SPRING, PHYS_M_GEOM_POS, PHYS_M_GEOM_QUAT, PHYS_M_GEOM_SIZE, PHYS_M_GEOM_FRICTION,
        PHYS_M_ACTUATOR_GEAR, PHYS_M_ACTUATOR_CTRLRANGE, PHYS_M_ACTUATOR_USER, PHYS_M_SENSOR_USER, PHYS_M_HFIELD_SIZE,
-       PHYS_M_TIMESTEP, PHYS_M_QPOS0, PHYS_M_JNT_RANGE, PHYS_M_STAT_CENTER, PHYS_M_STAT_EXTENT, PHYS_M_GEOM_USER };
+       PHYS_M_TIMESTEP, PHYS_M_QPOS0, PHYS_M_JNT_RANGE, PHYS_M_STAT_CENTER, PHYS_M_STAT_EXTENT, PHYS_M_GEOM_USER,
+       PHYS_M_BODY_INERTIA /* [nbody][3] principal moments (mjModel.body_inertia) */ };
 double *phys_model_array(phys_model_t *m, int which);
 float *phys_model_geom_rgba(phys_model_t *m);
 float *phys_model_hfield_data(phys_model_t *m);
@@ -98,6 +99,29 @@ int phys_batch_field_dim(const phys_batch_t *b, int field);            /* double
  * shared model's sizes, dof tree, body-tree depth, joint make-up of the bodies (cm_model_t::kin_simple) and kinds of collision
  * pairs (-1 + phys_last_error() otherwise) */
 int phys_batch_set_model(phys_batch_t *b, const cm_model_t *model, int env);
+/* Per-env domain randomisation ON THE DEVICE (the batched form of the reference's per-simulator setters
+ * cassie_sim_set_body_mass / set_body_ipos / set_dof_damping / set_geom_friction, reference src/cassiemujoco.c:1323-1436, and of
+ * cassie_sim_just_set_const = mj_setConst, :974-977).  Every env gets a compact parameter block (cm_envparams_t in csrc/cm_model.h,
+ * 10 KB) that the step kernel reads INSTEAD OF the shared model's fields; the rest of the model (95 KB) stays shared.
+ *   phys_batch_randomize   writes rows [n][phys_batch_param_dim] of one parameter (CM_P_BODY_MASS [nbody], CM_P_BODY_IPOS
+ *                          [nbody][3], CM_P_BODY_INERTIA [nbody][3] principal moments, CM_P_DOF_DAMPING [nv], CM_P_GEOM_FRICTION
+ *                          [model->ngeom][3]: the COLLISION geoms in compiled order, cm_model_t::geom_fullid maps them to the
+ *                          reference's full geom list) for envs [env0, env0 + n); values may be a DEVICE pointer (on_device != 0:
+ *                          e.g. a torch tensor, nothing crosses PCIe) or host memory.  Damping and friction act from the next
+ *                          step on, like in the reference; masses / inertial offsets / inertias act on the dynamics at once and
+ *                          on the constraint regularisers after
+ *   phys_batch_set_const   which recomputes, per env and on the device, what mj_setConst derives: body_invweight0,
+ *                          dof_invweight0, meaninertia (M(qpos0) and its Cholesky factor per env) and the per-joint /
+ *                          per-equality / per-pair values the constraint stages read -- bit for bit what compiling a host model
+ *                          with the same parameters gives (phys_model_set_const + phys_model_compile).
+ * Both are asynchronous on `stream` (NULL = the batch's own) and ordered with the stepping launches there.  Replacing the shared
+ * model (phys_batch_set_model, env = -1) drops the blocks; per-env MODELS (env >= 0) and per-env parameter blocks do not mix. */
+int phys_batch_param_dim(const phys_batch_t *b, int param);
+int phys_batch_randomize(phys_batch_t *b, int param, const double *values, int on_device, int env0, int n, void *stream);
+int phys_batch_set_const(phys_batch_t *b, int env0, int n, void *stream);
+int phys_batch_download_params(phys_batch_t *b, cm_envparams_t *host, int env0, int n); /* (the model's own block where none exist yet) */
+int phys_batch_uses_env_params(const phys_batch_t *b);
+size_t phys_sizeof_envparams(void);
 /* height-field samples (nrow * ncol floats, MuJoCo's normalised 0..1 elevations): one grid shared by all envs, or --
  * per-env terrain randomisation -- a grid of its own for one env (the others keep what they had) */
 int phys_batch_set_hfield(phys_batch_t *b, const float *data, int n);

@@ -255,13 +255,27 @@ static double *g_meas = nullptr;
 extern "C" void emu_set_drive_io(int mode, cm_drive_state_t *state, const double *cmd, double *meas, const double *pd_dtarget, const double *pd_torque) {
     g_drive_mode = mode; g_drive_state = state; g_drive_cmd = cmd; g_meas = meas; g_pd_dtarget = pd_dtarget; g_pd_torque = pd_torque;
 }
+/* per-env physical parameter blocks of the next emu_phys_run / emu_derive calls ([nenv] cm_envparams_t, or null: the model's own) */
+static const cm_envparams_t *g_envparams = nullptr;
+extern "C" void emu_set_envparams(const cm_envparams_t *p) { g_envparams = p; }
+/* phys_batch_set_const / the friction refresh of phys_batch_randomize on the emulator: the device's set_const kernel, env by env */
+static ck::SetConstIO g_scio;
+static void body_setconst() { ck::cassie_setconst_kernel(g_scio); }
+extern "C" int emu_set_const(const cm_model_t *model, cm_envparams_t *params, int nenv, int derive_inertial) {
+    g_scio.model = model; g_scio.params = params; g_scio.env0 = 0; g_scio.nenv = nenv; g_scio.derive_inertial = derive_inertial;
+    g_grid = nenv;
+    for (int e = 0; e < nenv; ++e) { g_env = e; run_block(body_setconst); }
+    g_grid = 1;
+    return 0;
+}
+extern "C" unsigned long emu_sizeof_envparams(void) { return sizeof(cm_envparams_t); }
 extern "C" int emu_phys_run(const cm_model_t *model, int nenv, int nsub, int integrate, double *qpos, double *qvel,
                             double *qacc_warmstart, double *time, const double *ctrl, const double *qfrc_applied,
                             const double *xfrc_applied, double *qacc, double *sensordata, double *actuator_velocity,
                             int *warn, int *info, double *xpos_out, double *xquat_out, const double *pd_ptarget,
                             const double *pd_kp, const double *pd_kd, const float *hfield) {
     memset(&g_io, 0, sizeof g_io);
-    g_io.models = model; g_io.model_stride = 0;
+    g_io.models = model; g_io.model_stride = 0; g_io.envparams = g_envparams;
     g_io.nenv = nenv; g_io.nsub = nsub; g_io.integrate = integrate;
     g_io.sq = model->nq; g_io.sqv = model->nv; g_io.sv = model->nv; g_io.su = model->nu; g_io.ssd = model->nsensordata; g_io.sb = model->nbody;
     g_io.qpos = qpos; g_io.qvel = qvel; g_io.qacc_warmstart = qacc_warmstart; g_io.time = time;
@@ -349,13 +363,13 @@ extern "C" int emu_derive(const cm_model_t *model, int nenv, double *qpos, doubl
     cm_ext_t *ext = (cm_ext_t *)calloc((size_t)nenv, sizeof(cm_ext_t));
     double *xpos = (double *)calloc((size_t)nenv * model->nbody * 3, sizeof(double)), *xquat = (double *)calloc((size_t)nenv * model->nbody * 4, sizeof(double));
     memset(&g_io, 0, sizeof g_io);
-    g_io.models = model; g_io.nenv = nenv; g_io.nsub = 1; g_io.integrate = 0;
+    g_io.models = model; g_io.nenv = nenv; g_io.nsub = 1; g_io.integrate = 0; g_io.envparams = g_envparams;
     g_io.sq = model->nq; g_io.sqv = model->nv; g_io.sv = model->nv; g_io.su = model->nu; g_io.ssd = model->nsensordata; g_io.sb = model->nbody;
     g_io.qpos = qpos; g_io.qvel = qvel; g_io.qacc_warmstart = qacc_warmstart; g_io.time = time; g_io.ctrl = (double *)ctrl;
     g_io.qacc = qacc; g_io.sensordata = sensordata; g_io.actuator_velocity = actuator_velocity; g_io.warn = warn; g_io.info = info;
     g_io.xpos_out = xpos; g_io.xquat_out = xquat; g_io.hfield = hfield; g_io.ext = ext;
     memset(&g_dio, 0, sizeof g_dio);
-    g_dio.models = model; g_dio.nenv = nenv; g_dio.ext = ext; g_dio.xpos = xpos; g_dio.xquat = xquat; g_dio.derived = derived; g_dio.qM = qM;
+    g_dio.models = model; g_dio.nenv = nenv; g_dio.envparams = g_envparams; g_dio.ext = ext; g_dio.xpos = xpos; g_dio.xquat = xquat; g_dio.derived = derived; g_dio.qM = qM;
     for (int i = 0; i < 6; ++i) g_dio.ids[i] = ids[i];
     for (int e = 0; e < nenv; ++e) {
         g_env = e;

@@ -113,6 +113,7 @@ inline double mul_rn(double a, double b) { volatile double r = a * b; return r; 
 inline double add_rn(double a, double b) { volatile double r = a + b; return r; }
 inline double sub_rn(double a, double b) { volatile double r = a - b; return r; }
 inline double div_rn(double a, double b) { volatile double r = a / b; return r; }
+inline double sqrt_rn(double a) { volatile double r = sqrt(a); return r; }
 inline int popc64(unsigned long long x) { return __builtin_popcountll(x); }
 }  // namespace wv
 #endif
