@@ -281,6 +281,28 @@ typedef struct cm_model {
     cm_envparams_t params;
 } cm_model_t;
 
+/* A cm_model_t handed over by a caller may have been edited field by field (tests and tools do: a heavier pelvis, another
+ * damping): its top-level arrays are the authority, and its parameter block is brought in line with them before the model is
+ * used (phys_batch_create / phys_batch_set_model do this on their copy). */
+static inline void cm_model_sync_params(cm_model_t *m) {
+    cm_envparams_t *p = &m->params;
+    int i, k;
+    for (i = 0; i < CM_MAXBODY; ++i) {
+        p->body_mass[i] = m->body_mass[i];
+        for (k = 0; k < 3; ++k) { p->body_ipos[i][k] = m->body_ipos[i][k]; p->body_inertia[i][k] = m->body_inertia[i][k]; }
+        for (k = 0; k < 2; ++k) p->body_invweight0[i][k] = m->body_invweight0[i][k];
+    }
+    for (i = 0; i < CM_MAXV; ++i) { p->dof_damping[i] = m->dof_damping[i]; p->dof_invweight0[i] = m->dof_invweight0[i]; }
+    for (i = 0; i < CM_MAXGEOM; ++i) for (k = 0; k < 3; ++k) p->geom_friction[i][k] = m->geom_friction[i][k];
+    p->meaninertia = m->meaninertia;
+    for (i = 0; i < CM_MAXJNT; ++i) p->jnt_liminvweight[i] = m->jnt_liminvweight[i];
+    for (i = 0; i < CM_MAXEQ; ++i) p->eq_invweight[i] = m->eq_invweight[i];
+    for (i = 0; i < CM_MAXPAIR; ++i) {
+        p->pair_invweight[i] = m->pair_invweight[i];
+        for (k = 0; k < 3; ++k) p->pair_friction[i][k] = m->pair_friction[i][k];
+    }
+}
+
 /* Drive-level I/O state of one env: what `struct cassie_sim` keeps beside mjData for cassie_sim_step_ethercat
  * (reference src/cassiemujoco.c:210-217, :255-265): the encoder velocity filters and the motors' torque delay lines.
  * Layout-compatible with the host env's drive_filter_t[10] / joint_filter_t[6] / torque_delay[10][6]. */

@@ -376,6 +376,8 @@ phys_batch_t *phys_batch_create(const cm_model_t *model, int nenv, int device) {
     b->nenv = nenv; b->device = device;
     if (const char *tw = getenv("CASSIE_TRAY_TWO_WAVES")) b->waves_per_env_tray = atoi(tw) ? 2 : 1;
     b->host_model = *model;
+    cm_model_sync_params(&b->host_model);
+    model = &b->host_model;
     const int d[PHYS_F_COUNT] = {model->nq, model->nv, model->nv, 1, model->nu, model->nv, model->nbody * 6,
                                  model->nv, model->nsensordata, model->nu, model->nbody * 3, model->nbody * 4,
                                  model->nu, model->nu, model->nu, model->nbody * 3,
@@ -485,6 +487,9 @@ int phys_batch_set_model(phys_batch_t *b, const cm_model_t *model, int env) {
     }
     (void)hipSetDevice(b->device);
     if (!quiesce(b)) return -1;
+    cm_model_t synced = *model;     /* (the caller's top-level arrays are the authority: cm_model_sync_params) */
+    cm_model_sync_params(&synced);
+    model = &synced;
     if (env < 0) {
         if (b->d_envparams) { (void)hipFree(b->d_envparams); b->d_envparams = nullptr; } /* (the new model's own block again, for every env) */
         if (b->model_stride == 1) { /* back to one shared model */

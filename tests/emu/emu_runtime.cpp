@@ -274,6 +274,9 @@ extern "C" int emu_phys_run(const cm_model_t *model, int nenv, int nsub, int int
                             const double *xfrc_applied, double *qacc, double *sensordata, double *actuator_velocity,
                             int *warn, int *info, double *xpos_out, double *xquat_out, const double *pd_ptarget,
                             const double *pd_kp, const double *pd_kd, const float *hfield) {
+    /* (tests edit compiled models field by field: the top-level arrays are the authority, as in phys_batch_create / _set_model) */
+    static cm_model_t synced;
+    synced = *model; cm_model_sync_params(&synced); model = &synced;
     memset(&g_io, 0, sizeof g_io);
     g_io.models = model; g_io.model_stride = 0; g_io.envparams = g_envparams;
     g_io.nenv = nenv; g_io.nsub = nsub; g_io.integrate = integrate;
@@ -360,6 +363,8 @@ static void body_derive() { ck::cassie_derive_kernel(g_dio); }
 extern "C" int emu_derive(const cm_model_t *model, int nenv, double *qpos, double *qvel, double *qacc_warmstart, double *time,
                           const double *ctrl, double *qacc, double *sensordata, double *actuator_velocity, int *warn, int *info,
                           const float *hfield, const int *ids, double *derived, double *qM) {
+    static cm_model_t synced;
+    synced = *model; cm_model_sync_params(&synced); model = &synced;
     cm_ext_t *ext = (cm_ext_t *)calloc((size_t)nenv, sizeof(cm_ext_t));
     double *xpos = (double *)calloc((size_t)nenv * model->nbody * 3, sizeof(double)), *xquat = (double *)calloc((size_t)nenv * model->nbody * 4, sizeof(double));
     memset(&g_io, 0, sizeof g_io);
