@@ -67,6 +67,24 @@ PD_KP = np.array([70, 70, 100, 100, 50] * 2, dtype=np.float64)
 PD_KD = np.array([7, 7, 8, 8, 5] * 2, dtype=np.float64)
 
 
+# the multi-GPU layer is part of the product: sharding, the observation block the kernel writes in place, its
+# all-gather beside the next launch, rank start-up
+from cassie_amd.distributed import (ObservationBlock, OverlappedGather, env_ranges as half_ranges, free_port, gather_observations,  # noqa: E402,F401
+                                    gather_rows, shard_env_ids)
+from cassie_amd import distributed as cdist  # noqa: E402
+
+
+def rows_of_group_in_range(group, global_first, first, count):
+    """Rows of the range [first, first + count) whose global env id is in restart phase group `group` (NGROUP apart)."""
+    return cdist.rows_of_group_in_range(group, global_first, first, count, NGROUP)
+
+
+def launch_ranks(ngpus, argv):
+    """`python bench.py --gpus N` without a launcher around it (WORLD_SIZE unset): start the N ranks ourselves -- this very file
+    under torch.distributed.run, one rank per GPU -- and pass rank 0's ONE JSON line through (cassie_amd.distributed.launch_ranks)."""
+    return cdist.launch_ranks(ngpus, __file__, argv)
+
+
 TARGET_SPREAD = 0.3                 # rad; --target-spread 10 is the stress workload (reference example/cassietest_jac.py:106)
 
 
@@ -76,11 +94,6 @@ def pd_targets(env_ids, npolicy):
     for i, e in enumerate(env_ids):
         out[:, i, :] = PD_OFFSET + np.random.default_rng(1234 + int(e)).uniform(-TARGET_SPREAD, TARGET_SPREAD, (npolicy, 10))
     return out
-
-
-def shard_env_ids(rank, world, envs_per_rank):
-    """Contiguous block of global env ids owned by `rank` (weak scaling: the per-rank count is fixed)."""
-    return np.arange(rank * envs_per_rank, (rank + 1) * envs_per_rank)
 
 
 ENVS_PER_GPU_SINGLE = 4096          # BASELINE configs[1]: the headline, one GPU
@@ -128,26 +141,6 @@ def snapshot_region(steps, warmup, repeats):
 def restart_group(policy_step):
     """The phase group whose envs restart from the init pose at this policy step."""
     return policy_step % NGROUP
-
-
-def gather_observations(obs, world, out=None):
-    """All-gather of the per-rank observation block [n, 96] into [world * n, 96], rank-major = global env order.
-    RCCL over xGMI on GPUs ('nccl' backend), gloo in the CPU tests."""
-    import torch
-    import torch.distributed as dist
-    if out is None:
-        out = torch.empty((world * obs.shape[0], obs.shape[1]), dtype=obs.dtype, device=obs.device)
-    dist.all_gather_into_tensor(out, obs)
-    return out
-
-
-def gather_rows(x, world):
-    """All-gather of equally shaped per-rank row blocks, rank-major (the sampled parity rows of every rank -> rank 0)."""
-    import torch
-    import torch.distributed as dist
-    out = torch.empty((world * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
-    dist.all_gather_into_tensor(out, x.contiguous())
-    return out
 
 
 class Schedule:
@@ -456,20 +449,6 @@ class HostChainEnvs:
         return self.orcs[0].sensordata.copy()
 
 
-def half_ranges(n, nstreams):
-    """Contiguous env ranges [(first, count)] a rank's batch is stepped in, one per stream (the last takes the remainder)."""
-    k = max(1, min(int(nstreams), n))
-    base = n // k
-    return [(i * base, base if i < k - 1 else n - i * base) for i in range(k)]
-
-
-def rows_of_group_in_range(group, global_first, first, count):
-    """Rows of the range [first, first + count) whose global env id (global_first + row) is in phase group `group`:
-    (first row, number of rows), the rows being NGROUP apart."""
-    r0 = first + (group - (global_first + first)) % NGROUP
-    return r0, len(range(r0, first + count, NGROUP))
-
-
 class GpuRuntime:
     """What device_rollout asks of the machine under it: the device, streams / events, the batch, the CPU reference for the
     replay.  This is the real one (HIP through torch, RCCL); tests/bench_standin.py has a CPU stand-in (gloo, no physics)
@@ -560,12 +539,9 @@ def device_rollout(model, mode, n, steps, warmup, rank, world, local_rank, subst
     init_row[:nq] = torch.from_numpy(model.qpos_init()).to(dev)
     if drive:   # the drive-level models read the previous step's sensordata: a restarted env carries the init pose's
         init_row[nq + nv:] = torch.from_numpy(rt.init_sensordata(model, hfield)).to(dev)
-    obs = init_row.repeat(n, 1).contiguous()
+    obs = ObservationBlock(b, pod, dev, init_row).tensor      # (cassie_amd.distributed: bound with a row stride, no staging copy)
     warm = torch.zeros((n, nv), dtype=torch.float64, device=dev)
     esz = obs.element_size()
-    b.bind(P.F_QPOS, obs.data_ptr(), row_stride=nobs)
-    b.bind(P.F_QVEL, obs.data_ptr() + nq * esz, row_stride=nobs)
-    b.bind(P.F_SENSORDATA, obs.data_ptr() + (nq + nv) * esz, row_stride=nobs)
     b.bind(P.F_QACC_WARMSTART, warm.data_ptr())
     targets_host = pd_targets(env_ids, npolicy)
     targets = torch.from_numpy(targets_host).to(dev)       # [npolicy][n][10]
@@ -613,7 +589,6 @@ def device_rollout(model, mode, n, steps, warmup, rank, world, local_rank, subst
                      "bytes_per_env_block": int(ctypes.sizeof(type(b.params(0, 1)[0])))}
     ranges = half_ranges(n, nstreams)
     streams = [rt.Stream() for _ in ranges]
-    obs_all = [torch.empty((world * cnt, nobs), dtype=torch.float64, device=dev) for _, cnt in ranges] if collect else None
 
     def restart(group):
         """The envs of a phase group start a new episode: a fresh cassie_sim_t -- init pose, zero velocities and warm start,
@@ -624,26 +599,11 @@ def device_rollout(model, mode, n, steps, warmup, rank, world, local_rank, subst
             if k:
                 b.reset_envs(r0, NGROUP, k, init_row.data_ptr(), init_row.data_ptr() + (nq + nv) * esz if drive else None, st.cuda_stream)
 
-    # The all-gather runs beside the next launch: a range's observation block is snapshotted on its launch stream (device to
-    # device), RCCL sends the snapshot from a second stream, and the range's next snapshot waits for that gather to have read it.
-    snap = [torch.empty((cnt, nobs), dtype=torch.float64, device=dev) for _, cnt in ranges] if collect else None
-    comm_streams = [rt.Stream() for _ in ranges] if collect else None
-    gather_done = [None] * len(ranges)
-
-    def gather():
-        for i, ((first, cnt), st) in enumerate(zip(ranges, streams)):
-            if gather_done[i] is not None:
-                st.wait_event(gather_done[i])
-            with rt.use(st):
-                snap[i].copy_(obs[first:first + cnt], non_blocking=True)
-            ready = rt.Event()
-            ready.record(st)
-            with rt.use(comm_streams[i]):
-                comm_streams[i].wait_event(ready)
-                gather_observations(snap[i], world, obs_all[i])
-                done = rt.Event()
-                done.record(comm_streams[i])
-            gather_done[i] = done
+    # The all-gather runs beside the next launch (cassie_amd.distributed.OverlappedGather): a range's observation block is
+    # snapshotted on its launch stream (device to device), RCCL sends the snapshot from a second stream, and the range's next
+    # snapshot waits for that gather to have read it.
+    og = OverlappedGather(obs, ranges, streams, world, rt) if collect else None
+    gather = og.gather if collect else None
 
     last_launch = {"nsub": 0}
 
@@ -700,7 +660,7 @@ def device_rollout(model, mode, n, steps, warmup, rank, world, local_rank, subst
            "region_s": region_s, "elapsed": float(np.median(region_s))}
     if collect and rank == 0:
         # the gathered block of the last policy boundary must hold this rank's rows (global env order, rank-major)
-        res["gather_ok"] = bool(sch.gathers > 0 and all(torch.equal(oa[rank * cnt:(rank + 1) * cnt], sn) for oa, sn, (_, cnt) in zip(obs_all, snap, ranges)))
+        res["gather_ok"] = bool(sch.gathers > 0 and og.holds_own_rows(rank))
     w, info = b.warnings()
     # envs the row-capped fast kernel handed over to the full kernel in the last launch: those whose record of
     # completed substeps is short of THAT launch's substep count; NaN (-> null in the line) for a model without a fast kernel
@@ -809,27 +769,6 @@ def true_reference(model_name, q0, targets, nsteps):
     except Exception as exc:  # the harness is opportunistic: never let it take the bench line down
         print("true reference harness failed: %r" % (exc,), file=sys.stderr)
         return "unavailable"
-
-
-def free_port():
-    """A TCP port that is free on 127.0.0.1 right now (the rendezvous of the ranks bench.py starts itself)."""
-    import socket
-    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
-
-
-def launch_ranks(ngpus, argv):
-    """`python bench.py --gpus N` without a launcher around it (WORLD_SIZE unset): start the N ranks ourselves -- this very
-    file under torch.distributed.run, one rank per GPU (rank r binds GPU r through LOCAL_RANK), rendezvous on 127.0.0.1 at a
-    port picked free -- pass their output through (rank 0 prints the ONE JSON line) and return the launcher's exit code."""
-    import subprocess
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ngpus), "--master-addr", "127.0.0.1",
-           "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC (RCCL between the ranks' processes)
-    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // ngpus)))
-    return subprocess.call(cmd, env=env)
 
 
 def main(argv=None):

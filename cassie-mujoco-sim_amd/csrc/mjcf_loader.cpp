@@ -1003,6 +1003,8 @@ bool HostModel::compile(cm_model_t *o, std::string *err) const {
         return fail("model exceeds the compiled capacity limits (cm_model.h)");
     o->nq = nq; o->nv = nv; o->nu = nu; o->nbody = nbody; o->njnt = njnt; o->neq = neq; o->nsite = nsite;
     o->nsensor = nsensor; o->nsensordata = nsensordata;
+    /* (the 127-row solve's cross-wave turn word counts two per sweep in 12 bits, pk_wide_solve.h) */
+    if (iterations > 2000) return fail("option iterations > 2000 is not supported (the in-scope models ask for 50)");
     o->iterations = iterations; o->flags = flags;
     o->timestep = timestep; o->tolerance = tolerance; o->meaninertia = meaninertia;
     for (int i = 0; i < 3; ++i) { o->gravity[i] = gravity[i]; o->magnetic[i] = magnetic[i]; }

@@ -117,6 +117,9 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
     /* ---------------- load state (coalesced, env-major) ---------------- */
     if (NW == 1 || wid == 0) {
     if (lane == 0) { S.cmd[0] = 0; S.cmd[1] = 0; S.cmd[2] = 0; S.cmd[3] = 0; S.cmd[4] = 0; }
+    /* (the 127-row solve's turn words: wave 1 polls turn[1] for an odd value before anybody wrote it -- whatever an earlier env of
+     * this workgroup or raw LDS left there must not look like one) */
+    if constexpr (WIDE) { if (lane == 0) { S.x.turn[0] = 0; S.x.turn[1] = 0; S.x.turn[2] = 0; S.x.turn[3] = 0; } }
     if (lane < nq) S.qpos[lane] = io.qpos[(size_t)env * io.sq + lane];
     if (lane < nv) {
         S.qvel[lane] = io.qvel[(size_t)env * io.sqv + lane];

@@ -88,7 +88,12 @@ inline bool launch_three_tiers(dim3 grid, const TierGrids &tg, hipStream_t s, Ph
     if (!fast || !hl.list1 || (wide_caps && !hl.list2)) {
         /* alone: forward / read-out passes, batches with the read-out enabled such as a cassie_sim_t, the fast kernel switched off */
         no_tiers(io);
-        if (!(wide_caps ? wide : alone63)(grid, s, io)) return false;
+        /* (a LARGE grid alone -- phys_batch_derive / forward passes of a whole batch, the fast kernel switched off -- and 63-row caps:
+         * the one-wave form, whose 421 registers leave room for four envs per CU; the two-wave 512-register form halves that and only
+         * pays where the chip is not full anyway.  CASSIE_ALONE_512: the A/B switch) */
+        static const bool alone512 = measurement_switch("CASSIE_ALONE_512");
+        if (!wide_caps && grid.x > SMALL_BATCH && !alone512) hipLaunchKernelGGL((cassie_step_kernel<NVP, TOPO, FEAT>), grid, dim3(WV_WAVE), 0, s, io);
+        else if (!(wide_caps ? wide : alone63)(grid, s, io)) return false;
         if (after_first) (void)hipEventRecord(after_first, s);
         return hipGetLastError() == hipSuccess;
     }

@@ -249,3 +249,65 @@ def test_bench_refuses_a_rank_count_that_is_not_the_launchers():
     env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--dry-run-cpu"], env=env, capture_output=True, text=True, timeout=120)
     assert out.returncode != 0 and "WORLD_SIZE" in (out.stderr + out.stdout)
+
+
+def _product_worker(rank, world, port, n, ret):
+    """cassie_amd.distributed itself on two gloo ranks: shard ids, the observation block bound with a row stride, the
+    overlapped gather of two env ranges per rank over three policy steps."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    sys.path.insert(0, os.path.join(REPO, "cassie-mujoco-sim_amd"))
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from cassie_amd import distributed as cd
+    import bench_standin
+    r, w, _ = cd.init_ranks("gloo")
+    assert (r, w) == (rank, world)
+    ids = cd.shard_env_ids(rank, world, n)
+
+    class Pod:
+        nq, nv, nsensordata = 35, 32, 29
+
+    class FakeBatch:
+        nenv = n
+        bound = {}
+
+        def bind(self, field, ptr, row_stride=None):
+            self.bound[field] = (ptr, row_stride)
+
+    fb = FakeBatch()
+    init = torch.arange(96, dtype=torch.float64)
+    ob = cd.ObservationBlock(fb, Pod, torch.device("cpu"), init)
+    from cassie_amd import phys as P
+    esz = ob.tensor.element_size()
+    assert fb.bound[P.F_QPOS] == (ob.tensor.data_ptr(), 96) and fb.bound[P.F_QVEL] == (ob.tensor.data_ptr() + 35 * esz, 96)
+    assert fb.bound[P.F_SENSORDATA] == (ob.tensor.data_ptr() + 67 * esz, 96)
+    assert ob.qpos.shape == (n, 35) and ob.qvel.shape == (n, 32) and ob.sensordata.shape == (n, 29) and torch.equal(ob.tensor[3], init)
+    rt = bench_standin.CpuRuntime(rank)
+    ranges = cd.env_ranges(n, 2)
+    streams = [rt.Stream() for _ in ranges]
+    og = cd.OverlappedGather(ob.tensor, ranges, streams, world, rt)
+    seen = []
+    for p in range(3):
+        ob.tensor[:, 0] = torch.from_numpy(ids.astype(np.float64)) * 1000 + p      # "a launch wrote the block"
+        og.gather()
+        seen.append([res[:, 0].clone().numpy() for res in og.result])
+    ret[rank] = (seen, og.holds_own_rows(rank), og.count)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_product_module_shards_and_gathers_on_two_ranks():
+    """cassie_amd.distributed (the multi-GPU layer is product code, not bench code): every gather delivers both ranks' rows of
+    the SAME policy step, range by range, in global env order."""
+    from cassie_amd import distributed as cd
+    world, n = 2, 10
+    ret = mp.Manager().dict()
+    mp.spawn(_product_worker, args=(world, cd.free_port(), n, ret), nprocs=world, join=True)
+    ranges = cd.env_ranges(n, 2)
+    for r in range(world):
+        seen, own, count = ret[r]
+        assert own and count == 3
+        for p in range(3):
+            for (first, cnt), col in zip(ranges, seen[p]):
+                want = np.concatenate([(cd.shard_env_ids(k, world, n)[first:first + cnt]) * 1000.0 + p for k in range(world)])
+                assert np.array_equal(col, want), (r, p, first)
+    assert cd.rows_of_group_in_range(3, 100, 0, 50, 20) == (3, 3)     # global ids 103, 123, 143 -> rows 3, 23, 43
