@@ -359,7 +359,9 @@ def test_two_wave_form_of_the_fast_kernel_equals_the_one_wave_form_bit_for_bit(b
     if name == "cassie_tray_box":       # (one wave per env: the full instantiation alone; two waves: a 47-row fast one ahead of it, rarely left)
         pass
     else:
-        assert out[0][1] == out[1][1] and out[0][1] > 20
+        # (round 6: a frictionless leg-leg contact counts as the ONE row it is in the hand-over verdict, so fewer substeps that fit are
+        # handed over than in round 5: 18 env-launches of this workload on cassie.xml, not 25)
+        assert out[0][1] == out[1][1] and out[0][1] > 10
     for a, c in zip(out[0][0], out[1][0]):
         assert a.tobytes() == c.tobytes()
 
@@ -418,7 +420,7 @@ def test_launch_in_chunks_equals_the_launch_in_one_piece_bit_for_bit(built, name
     print("%s, %d wave(s): %s env-launches handed over (1 / 4 / 3 chunks)" % (name, waves, [o[1] for o in out]))
     assert out[0][1] == out[1][1] == out[2][1]
     if name != "cassie_tray_box":
-        assert out[0][1] > 20
+        assert out[0][1] > 10
     for k in (1, 2):
         for a, c in zip(out[0][0], out[k][0]):
             assert a.tobytes() == c.tobytes(), k
