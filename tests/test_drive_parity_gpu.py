@@ -420,7 +420,7 @@ def test_launch_in_chunks_equals_the_launch_in_one_piece_bit_for_bit(built, name
     print("%s, %d wave(s): %s env-launches handed over (1 / 4 / 3 chunks)" % (name, waves, [o[1] for o in out]))
     assert out[0][1] == out[1][1] == out[2][1]
     if name != "cassie_tray_box":
-        assert out[0][1] > 10
+        assert out[0][1] > 3     # (round 6: the verdict counts a frictionless contact as one row -- 6 env-launches of this workload on cassie.xml, 30 in round 5; cassie_hfield hands over far more)
     for k in (1, 2):
         for a, c in zip(out[0][0], out[k][0]):
             assert a.tobytes() == c.tobytes(), k
