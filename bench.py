@@ -392,11 +392,14 @@ class HostChainEnvs:
     """Envs on the CPU with the drive-level semantics of CM_DRIVE_PD: oracle physics + the host chain of
     csrc/cassie_hostpath.c (the reference's own encoder / motor arithmetic) + pd_input's motor PD on the measurements."""
 
+    safe = False                # True: cassie_core_sim_step of the REAL Agility block between the PD law and the motor model (CM_DRIVE_PD_SAFE)
+
     def __init__(self, model, env_ids, hfield=None, pods=None):
         import oracle_py
         from cassie_amd import phys as P
         from hostchain_py import HostChain
         self.pods = pods            # per-env compiled models (domain randomisation) or None
+        self.msgs = [[0, 0, 0, 0] for _ in env_ids]   # (safe: the block's message queue after the last step)
         if hfield is not None:
             oracle_py.set_hfield(hfield)
         self.model, self.ids, self.P = model, np.asarray(env_ids), P
@@ -435,7 +438,10 @@ class HostChainEnvs:
                 near = np.abs(v - k)[k != 0]
                 if near.size:
                     self.flip_margin[i] = min(self.flip_margin[i], float(near.min()))
-                ctrl, self.meas[i], _y = hc.ethercat(pd_command(self.meas[i], targets[i], PD_KP, PD_KD), False, o.sensordata.copy(), o.actuator_velocity.copy())
+                cmd = pd_command(self.meas[i], targets[i], PD_KP, PD_KD)
+                if self.safe:
+                    cmd, self.msgs[i] = hc.core_sim(cmd)
+                ctrl, self.meas[i], _y = hc.ethercat(cmd, False, o.sensordata.copy(), o.actuator_velocity.copy())
                 o.ctrl[:] = ctrl
                 o.step()
 
@@ -447,6 +453,12 @@ class HostChainEnvs:
 
     def init_sensordata(self):
         return self.orcs[0].sensordata.copy()
+
+
+class SafeHostChainEnvs(HostChainEnvs):
+    """HostChainEnvs with the REAL cassie_core_sim_step (libagilitycassie.a, linked into the product library) between pd_input's PD
+    law and the motor model: the reference of CM_DRIVE_PD_SAFE."""
+    safe = True
 
 
 class GpuRuntime:
@@ -497,6 +509,10 @@ def device_rollout(model, mode, n, steps, warmup, rank, world, local_rank, subst
                   speed-torque curve and six-cycle torque delay, then the physics -- the drive-level semantics of
                   cassie_sim_step_pd, bit for bit the host chain of csrc/cassie_hostpath.c, minus the closed Agility blocks'
                   safety layer and estimator.  An episode restart is a fresh cassie_sim_t (init pose, zero filters / delays).
+      "drive-pd-safe"  CM_DRIVE_PD_SAFE: the same with cassie_core_sim's safety layer between the PD law and the motor model
+                  (joint-limit attenuation / restoring torques, torque-limit clamp, STO; csrc/pk_safety.h, bit for bit the closed
+                  Agility block): the WHOLE torque path of cassie_sim_step_pd (reference src/cassiemujoco.c:1147-1157); what stays on
+                  the host is the state estimator, which feeds nothing back into the simulation.
       "exact-pd"  the PD law on the exact joint state + the motor's speed-torque limit, no delay, no quantisation.
 
     nstreams > 1: the rank's batch is stepped as that many contiguous env ranges, each on its own stream at its own pace
@@ -512,7 +528,8 @@ def device_rollout(model, mode, n, steps, warmup, rank, world, local_rank, subst
     from cassie_amd import phys as P
     rt = rt or GpuRuntime(local_rank)
     pod = model.pod
-    drive = mode == "drive-pd"
+    drive = mode in ("drive-pd", "drive-pd-safe")
+    safe = mode == "drive-pd-safe"
     collect = world > 1 if collect is None else collect       # the observation all-gather, barriers, max-over-ranks reduction
     env_ids = shard_env_ids(rank, world, n)
     snap_r = snapshot_region(steps, warmup, repeats)
@@ -554,7 +571,7 @@ def device_rollout(model, mode, n, steps, warmup, rank, world, local_rank, subst
         meas = torch.zeros((n, P.MEAS_DIM), dtype=torch.float64, device=dev)
         b.bind(P.F_ACTUATOR_VELOCITY, actvel.data_ptr())
         b.bind(P.F_MEAS, meas.data_ptr())
-        b.set_drive_mode(P.DRIVE_PD)
+        b.set_drive_mode(P.DRIVE_PD_SAFE if safe else P.DRIVE_PD)
     else:
         b.set_pd_mode(True)
     rand_info = None
@@ -711,8 +728,14 @@ def device_rollout(model, mode, n, steps, warmup, rank, world, local_rank, subst
             rand_info["blocks_equal_to_the_host_compile_bit_for_bit"] = "%d of %d replayed envs" % (same, len(blocks))
             mi = np.array([blk.meaninertia for blk in b_params])
             rand_info["meaninertia_over_the_batch"] = {"min": float(mi.min()), "max": float(mi.max()), "shared_model": float(pod.meaninertia), "distinct": int(len(np.unique(mi)))}
-        orc = replay_on_oracle(model, ids, lambda p: tg_replay[p], replay_steps, hfield, threads,
-                               envs=rt.replay_envs(drive), pods=pods)
+        envs_cls = rt.replay_envs(drive)
+        if safe and envs_cls is HostChainEnvs:
+            envs_cls = SafeHostChainEnvs     # the REAL cassie_core_sim_step between the PD law and the motor model
+        orc = replay_on_oracle(model, ids, lambda p: tg_replay[p], replay_steps, hfield, threads, envs=envs_cls, pods=pods)
+        if safe:
+            bits = np.array([st.safety_msg for st in b.get_drive_state()])[sample] if hasattr(b, "get_drive_state") else None
+            res["safety_messages"] = None if bits is None else {"envs_with_code_635_joint_limit": int(np.count_nonzero(bits & 1)), "envs_with_code_630_torque_limit": int(np.count_nonzero(bits & 2)),
+                                                               "of_replayed_envs": int(len(bits))}
         q_ref = orc.qpos()
         err_abs = np.abs(q_gpu - q_ref)
         err_rel = err_abs / np.maximum(1.0, np.abs(q_ref))
@@ -805,7 +828,7 @@ def main(argv=None):
     ap.add_argument("--randomise", type=int, default=None, metavar="SEED", help="randomise every env's masses / inertial offsets / damping / friction on the device for the MAIN timed regions too (SURVEY.md 8f-3)")
     ap.add_argument("--force-collectives", action="store_true",
                     help="validation aid: initialise the process group and run the observation all-gather / barriers even with one rank")
-    ap.add_argument("--mode", default="drive-pd", choices=["drive-pd", "exact-pd"],
+    ap.add_argument("--mode", default="drive-pd-safe", choices=["drive-pd-safe", "drive-pd", "exact-pd"],
                     help="what the device-resident kernel computes per substep (see device_rollout)")
     ap.add_argument("--dry-run-cpu", action="store_true",
                     help="TEST INFRASTRUCTURE (tests/test_multirank.py): run main()'s launch / sharding / gather / reduction path on CPU "
@@ -880,7 +903,11 @@ def main(argv=None):
         # (per launch of the dominant kernel, like `achieved_one_launch`: one env range's launch)
         chunks = launch_chunks(n // r["streams"], steps_per_launch, r["streams"] == 1)
         traffic, traffic_src = pmc_traffic(n * steps_per_launch / r["streams"], args.model, envs_per_launch=n / r["streams"], pod=pod, chunks=chunks)
-        api = {"drive-pd": "phys_batch_step in CM_DRIVE_PD mode (device-resident, include/cassie_phys.h): pd_input's motor PD on the encoder "
+        api = {"drive-pd-safe": "phys_batch_step in CM_DRIVE_PD_SAFE mode (device-resident, include/cassie_phys.h): pd_input's motor PD on the encoder measurements + "
+                                "cassie_core_sim's safety layer (joint-limit attenuation / restoring torques, torque-limit clamp, STO: csrc/pk_safety.h, bit for bit the "
+                                "closed Agility block) + motor model with torque delay + physics in one kernel -- the whole torque path of cassie_sim_step_pd "
+                                "(reference src/cassiemujoco.c:1147-1157); only the state estimator (which feeds nothing back) stays on the host",
+               "drive-pd": "phys_batch_step in CM_DRIVE_PD mode (device-resident, include/cassie_phys.h): pd_input's motor PD on the encoder "
                            "measurements + motor model with torque delay + physics in one kernel -- cassie_sim_step_pd's drive-level semantics "
                            "without the Agility safety layer / estimator",
                "exact-pd": "phys_batch_step with phys_batch_set_pd_mode (device-resident): PD law on the exact joint state + motor speed-torque "
@@ -892,7 +919,7 @@ def main(argv=None):
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f64",
             "data": "synthetic" if not args.dry_run_cpu else rt.name,
-            "config": {"workload": "READ FIRST -- `value` is the device-resident API (phys_batch_step_range in CM_DRIVE_PD mode), the batch stepped as %d "
+            "config": {"workload": "READ FIRST -- `value` is the device-resident API (phys_batch_step_range, mode `%s`: see api_of_value), the batch stepped as %d "
                                    "env ranges on %d streams that nothing joins between policy steps; beside it in this line: `value_step_pd` = "
                                    "cassie_sim_step_pd itself, batched (the API BASELINE configs[1] names; Agility blocks on host threads, PCIe every "
                                    "step), `value_one_stream` = the whole batch as ONE launch per policy step, `value_all_outputs_every_substep` = "
@@ -900,7 +927,7 @@ def main(argv=None):
                                    "%d-step episodes from the cassie_sim_init pose restarted at staggered phases (untimed pre-roll of %d steps), "
                                    "random joint-PD targets re-drawn every %d steps; `value` is the MEDIAN of %d fenced timed regions of %d steps "
                                    "each (value_min / value_max: the slowest / fastest region)"
-                                   % (r["streams"], r["streams"], n, world, world * n, shape, args.model, EPISODE, PREROLL, HOLD, repeats, args.steps),
+                                   % (args.mode, r["streams"], r["streams"], n, world, world * n, shape, args.model, EPISODE, PREROLL, HOLD, repeats, args.steps),
                        "api_of_value": api, "mode": args.mode,
                        "hfield_contacts": args.hfield_contacts if args.model == "cassie_hfield" else None,
                        "pd_target_spread_rad": args.target_spread,
@@ -923,6 +950,7 @@ def main(argv=None):
                                               "`value_all_outputs_every_substep` is the rate with every output of every P-row formed by every substep",
                        "preroll_steps": PREROLL, "episode_steps": EPISODE},
             "parity": r["parity"],
+            **({"safety_messages": r["safety_messages"]} if r.get("safety_messages") else {}),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          # `achieved`, `peak`, `frac`, `traffic` and `kernel_ms` are PER GPU at every N (a rank's env-steps over the
@@ -960,7 +988,7 @@ def main(argv=None):
         if world == 1 and args.model == "cassie" and args.total_envs is None and not args.dry_run_cpu:
             # the GPU legs first, back to back with the timed region; the CPU legs (tens of seconds with an idle GPU) last
             if not args.no_other_mode:
-                other = "exact-pd" if args.mode == "drive-pd" else "drive-pd"
+                other = "exact-pd" if args.mode != "exact-pd" else "drive-pd-safe"
                 side = dict(steps=min(args.steps, 400), warmup=min(args.warmup, 50), repeats=min(repeats, 5))
                 o = device_rollout(model, other, n, side["steps"], side["warmup"], 0, 1, local_rank, args.substeps_per_launch, 16, hfield, repeats=side["repeats"],
                                    nstreams=nstreams)
@@ -968,6 +996,11 @@ def main(argv=None):
                                                 "timed_regions": o["repeats"], "kernel_ms": o["kernel_ms"], "parity": o["parity"],
                                                 "mean_constraint_rows": o["mean_constraint_rows"], "mean_pgs_iterations": o["mean_pgs_iterations"]}
                 out["value_" + other.replace("-", "_")] = out[other.replace("-", "_")]["value"]
+                if args.mode == "drive-pd-safe":   # what the safety layer costs: the same mode without it (round 5's headline mode)
+                    ns = device_rollout(model, "drive-pd", n, side["steps"], side["warmup"], 0, 1, local_rank, args.substeps_per_launch, 4, hfield, repeats=side["repeats"], nstreams=nstreams)
+                    out["drive_pd_without_safety_layer"] = {"value": n * ns["steps"] / ns["elapsed"], "unit": "env-steps/s", "steps": ns["steps"], "timed_regions": ns["repeats"],
+                                                            "kernel_ms": ns["kernel_ms"], "max_qpos_err": ns["parity"]["max_qpos_err"]}
+                    out["value_drive_pd_without_safety_layer"] = out["drive_pd_without_safety_layer"]["value"]
                 # `value` with every output evaluated by every substep: a fused launch returns its last substep's outputs, so by
                 # default the IMU sensor words and body quaternions of the substeps in between -- values nobody can read -- are
                 # not formed; this is what forming them anyway costs

@@ -23,7 +23,8 @@ DRV_COM_POS, DRV_COM_VEL, DRV_ANGMOM, DRV_FOOT_POS, DRV_FOOT_VEL, DRV_FOOT_FORCE
 DRV_FOOT_JACP, DRV_FOOT_JACR, DRV_DIM = 52, 52 + 6 * MAXV, 52 + 12 * MAXV
 
 # drive modes (CM_DRIVE_* in cm_model.h) and the layout of the measurement block F_MEAS (CM_MEAS_*)
-DRIVE_OFF, DRIVE_TORQUE, DRIVE_PD = 0, 1, 2
+DRIVE_OFF, DRIVE_TORQUE, DRIVE_PD, DRIVE_PD_SAFE = 0, 1, 2, 3     # (PD_SAFE: + cassie_core_sim's safety layer, csrc/pk_safety.h)
+SAFETY_MSG_LIMIT, SAFETY_MSG_TORQUE = 1, 2    # bits of cm_drive_state_t::safety_msg: diagnostic codes 635 / 630
 MEAS_DRIVE_POS, MEAS_DRIVE_VEL, MEAS_DRIVE_TORQUE, MEAS_JOINT_POS, MEAS_JOINT_VEL = 0, 10, 20, 30, 36
 MEAS_ORIENTATION, MEAS_ANGVEL, MEAS_LINACC, MEAS_MAG, MEAS_DIM = 42, 46, 49, 52, 56
 

@@ -314,7 +314,9 @@ static inline void cm_model_sync_params(cm_model_t *m) {
 #define CM_TORQUE_DELAY_CYCLES 6
 typedef struct cm_drive_state {
     int drive_x[CM_NUM_DRIVES][CM_DRIVE_FILTER_NB];                    /* integer FIR history of the drive encoders */
-    int pad[6];
+    int safety_msg;   /* CM_DRIVE_PD_SAFE: diagnostic messages the safety layer has raised since the state was cleared (bit 0: code 635,
+                         a joint-limit constraint violated; bit 1: code 630, a torque at its limit) -- the block's sticky message queue */
+    int pad[5];
     double joint_x[CM_NUM_JOINTS][CM_JOINT_FILTER_NB], joint_y[CM_NUM_JOINTS][CM_JOINT_FILTER_NA]; /* IIR history */
     double torque_delay[CM_NUM_DRIVES][CM_TORQUE_DELAY_CYCLES];
 } cm_drive_state_t;
@@ -339,7 +341,11 @@ enum { CM_DRV_COM_POS = 0, CM_DRV_COM_VEL = 3, CM_DRV_ANGMOM = 6,
 /* drive modes of the step kernel */
 enum { CM_DRIVE_OFF = 0,     /* ctrl (or the exact-state PD of phys_batch_set_pd_mode) goes straight to the actuators */
        CM_DRIVE_TORQUE = 1,  /* cassie_sim_step_ethercat on the device: commanded drive torques -> motor model + delay line */
-       CM_DRIVE_PD = 2 };    /* pd_input's motor PD on the ENCODER measurements of the previous step, then the same */
+       CM_DRIVE_PD = 2,      /* pd_input's motor PD on the ENCODER measurements of the previous step, then the same */
+       CM_DRIVE_PD_SAFE = 3 }; /* ... with cassie_core_sim's safety layer between the PD law and the motor model (joint-limit attenuation /
+                                restoring torques, torque-limit clamp, STO: csrc/pk_safety.h) -- cassie_sim_step_pd's whole torque path,
+                                reference src/cassiemujoco.c:1147-1157, on the device; cm_drive_state_t::safety_msg collects the block's
+                                diagnostic messages */
 
 /* Optional per-env "extended" outputs of a step (what the reference reads out of mjData for its
  * derived getters: contact list + forces, body velocities, site frames, com; SURVEY.md 8b field census). */

@@ -141,7 +141,7 @@ static ck::PhysIO make_io(phys_batch *b, int nsub, int integrate) {
         io.drive_state = b->d_drive;
         io.drive_cmd = b->d_field[PHYS_F_DRIVE_CMD];
         io.meas = b->d_field[PHYS_F_MEAS];
-        if (io.drive_mode == CM_DRIVE_PD) {
+        if (io.drive_mode == CM_DRIVE_PD || io.drive_mode == CM_DRIVE_PD_SAFE) {
             io.pd_ptarget = b->d_field[PHYS_F_PD_PTARGET]; io.pd_kp = b->d_field[PHYS_F_PD_KP]; io.pd_kd = b->d_field[PHYS_F_PD_KD];
             io.pd_dtarget = b->use_pd_dtarget ? b->d_field[PHYS_F_PD_DTARGET] : nullptr;
             io.pd_torque = b->use_pd_torque ? b->d_field[PHYS_F_PD_TORQUE] : nullptr;
@@ -693,7 +693,7 @@ static bool ensure_drive_state(phys_batch *b) {
 }
 
 int phys_batch_set_drive_mode(phys_batch_t *b, int mode) {
-    if (!b || mode < CM_DRIVE_OFF || mode > CM_DRIVE_PD) return -1;
+    if (!b || mode < CM_DRIVE_OFF || mode > CM_DRIVE_PD_SAFE) return -1;
     (void)hipSetDevice(b->device);
     if (mode != CM_DRIVE_OFF && !ensure_drive_state(b)) return -1;
     b->drive_mode = mode;
@@ -701,7 +701,7 @@ int phys_batch_set_drive_mode(phys_batch_t *b, int mode) {
 }
 
 int phys_batch_drive_pass(phys_batch_t *b, int mode, void *stream) {
-    if (!b || (mode != CM_DRIVE_TORQUE && mode != CM_DRIVE_PD)) return -1;
+    if (!b || (mode != CM_DRIVE_TORQUE && mode != CM_DRIVE_PD && mode != CM_DRIVE_PD_SAFE)) return -1;
     (void)hipSetDevice(b->device);
     if (!ensure_drive_state(b)) return -1;
     const int keep = b->drive_mode;

@@ -60,6 +60,7 @@
 
 #include "pk_types.h"
 #include "pk_math.h"
+#include "pk_safety.h"
 #include "pk_collision.h"
 #include "pk_factor_solve.h"
 #include "pk_stages.h"

@@ -28,6 +28,7 @@ WV_DEVICE void drive_state_load(const PhysIO &io, SH &S, int env, int lane) {
         for (int k = 0; k < CM_DRIVE_FILTER_NB; ++k) S.drv_x[lane][k] = ds->drive_x[lane][k];
         for (int k = 0; k < CM_TORQUE_DELAY_CYCLES; ++k) S.drv_delay[lane][k] = ds->torque_delay[lane][k];
         S.drv_pos[lane] = meas[CM_MEAS_DRIVE_POS + lane]; S.drv_vel[lane] = meas[CM_MEAS_DRIVE_VEL + lane];
+        if (lane == 0) S.drv_msg[0] = ds->safety_msg;
     } else if (lane < CM_NUM_DRIVES + CM_NUM_JOINTS) {
         const int j = lane - CM_NUM_DRIVES;
         for (int k = 0; k < CM_JOINT_FILTER_NB; ++k) S.drv_jx[j][k] = ds->joint_x[j][k];
@@ -40,6 +41,7 @@ WV_DEVICE void drive_state_store(const PhysIO &io, SH &S, int env, int lane) {
     if (lane < CM_NUM_DRIVES) {
         for (int k = 0; k < CM_DRIVE_FILTER_NB; ++k) ds->drive_x[lane][k] = S.drv_x[lane][k];
         for (int k = 0; k < CM_TORQUE_DELAY_CYCLES; ++k) ds->torque_delay[lane][k] = S.drv_delay[lane][k];
+        if (lane == 0) ds->safety_msg = S.drv_msg[0];
     } else if (lane < CM_NUM_DRIVES + CM_NUM_JOINTS) {
         const int j = lane - CM_NUM_DRIVES;
         for (int k = 0; k < CM_JOINT_FILTER_NB; ++k) ds->joint_x[j][k] = S.drv_jx[j][k];
@@ -71,6 +73,8 @@ WV_DEVICE void drive_consts_load(const PhysIO &io, SH &S, ModelPtr m, int env, i
             const size_t o = (size_t)env * nu + i;
             c[DRVC_U_OR_PT] = io.pd_ptarget[o]; c[DRVC_STO_OR_DT] = io.pd_dtarget ? io.pd_dtarget[o] : 0.0;
             c[DRVC_FF] = io.pd_torque ? io.pd_torque[o] : 0.0; c[DRVC_KP] = io.pd_kp[o]; c[DRVC_KD] = io.pd_kd[o];
+            /* CM_DRIVE_PD_SAFE: the STO switch (radio channel 8 of cassie_out_t) travels in the last word of the env's drive command */
+            if (i == 0) S.drv_msg[1] = (io.drive_mode == CM_DRIVE_PD_SAFE && io.drive_cmd && io.drive_cmd[(size_t)env * (nu + 1) + nu] != 0.0) ? 1 : 0;
         }
     } else if (lane < CM_NUM_DRIVES + CM_NUM_JOINTS) {
         const int j = lane - CM_NUM_DRIVES, bits = m->sensor_bits[joint_sensor_slot(j)];
@@ -83,6 +87,27 @@ template <class SH>
 WV_DRIVE_FN void drive_level_io(const PhysIO &io, SH &S, ModelPtr m, int env, int lane, bool write_meas) {
     const double TWO_PI = 2 * 3.14159265358979323846, PI = 3.14159265358979323846;
     double *meas = io.meas + (size_t)env * CM_MEAS_DIM;
+    /* CM_DRIVE_PD_SAFE: cassie_core_sim's safety layer between pd_input's PD law and the motor model (pk_safety.h).  A drive's
+     * torque depends on ALL ten measured positions (the 22 limit constraints) and the message bits on all ten torques: every
+     * drive's lane forms the ten PD commands from LDS, takes its own torque, a ballot collects the torque-limit bit, and the wave
+     * meets once before any lane overwrites the measurements the others have just read. */
+    double u_safe = 0.0;
+    if (io.drive_mode == CM_DRIVE_PD_SAFE) {
+        int msg = 0;
+        const bool sto = S.drv_msg[1] != 0;
+        if (lane < CM_NUM_DRIVES) {
+            double uu[CM_NUM_DRIVES], qq[CM_NUM_DRIVES], ww[CM_NUM_DRIVES];
+            for (int k = 0; k < CM_NUM_DRIVES; ++k) {
+                const double *c = S.drv_c[k];
+                qq[k] = S.drv_pos[k]; ww[k] = S.drv_vel[k];
+                uu[k] = wv::add_rn(wv::add_rn(c[DRVC_FF], wv::mul_rn(c[DRVC_KP], wv::sub_rn(c[DRVC_U_OR_PT], qq[k]))), wv::mul_rn(c[DRVC_KD], wv::sub_rn(c[DRVC_STO_OR_DT], ww[k])));
+            }
+            u_safe = safety::drive_torque(lane, uu, qq, ww, safety::torque_limit(lane), sto, &msg);
+        }
+        const bool lim = wv::ballot((msg & safety::MSG_LIMIT) != 0) != 0ull, trq = wv::ballot((msg & safety::MSG_TORQUE) != 0) != 0ull;
+        wv::sync();
+        if (lane == 0 && io.integrate) S.drv_msg[0] |= (lim ? safety::MSG_LIMIT : 0) | (trq ? safety::MSG_TORQUE : 0);
+    }
     if (lane < CM_NUM_DRIVES) {
         const int i = lane;
         double cst[10];
@@ -94,6 +119,9 @@ WV_DRIVE_FN void drive_level_io(const PhysIO &io, SH &S, ModelPtr m, int env, in
         if (io.drive_mode == CM_DRIVE_TORQUE) {
             u = cst[DRVC_U_OR_PT];
             sto = cst[DRVC_STO_OR_DT] != 0.0;
+        } else if (io.drive_mode == CM_DRIVE_PD_SAFE) {
+            u = u_safe;
+            sto = S.drv_msg[1] != 0;      /* (cassie_motor_data reads the same radio channel, reference :784) */
         } else {
             const double p = S.drv_pos[i], v = S.drv_vel[i];
             const double pt = cst[DRVC_U_OR_PT], dt = cst[DRVC_STO_OR_DT], ff = cst[DRVC_FF];

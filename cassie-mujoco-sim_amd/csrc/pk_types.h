@@ -172,6 +172,7 @@ struct EnvShared {
     /* what a launch's drive-level passes read and no substep changes (drive_consts_load): gear ratio, torque limit, no-load
      * speed in rad/s, encoder counts and scale; the launch's command (torque + STO, or PD targets and gains) */
     double drv_c[CM_NUM_DRIVES][10], drv_jc[CM_NUM_JOINTS][2];
+    int drv_msg[2];                 /* CM_DRIVE_PD_SAFE: message bits of the safety layer (cm_drive_state_t::safety_msg), the STO switch */
     /* contacts */
     double c_dist[MAXC], c_pos[MAXC][3], c_frame[MAXC][9], c_fri[MAXC][3];
     double c_solref[MAXC][2], c_solimp[MAXC][5], c_margin[MAXC];

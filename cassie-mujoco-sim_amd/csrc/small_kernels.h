@@ -55,6 +55,7 @@ struct DriveShared {
     double drv_delay[CM_NUM_DRIVES][CM_TORQUE_DELAY_CYCLES];
     double drv_pos[CM_NUM_DRIVES], drv_vel[CM_NUM_DRIVES];
     double drv_c[CM_NUM_DRIVES][10], drv_jc[CM_NUM_JOINTS][2];
+    int drv_msg[2];
 };
 
 WV_GLOBAL void __launch_bounds__(WV_WAVE) cassie_drive_kernel(PhysIO io, double *ctrl_out) {

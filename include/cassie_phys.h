@@ -183,7 +183,11 @@ int phys_batch_set_pd_mode(phys_batch_t *b, int on);
  * on the sensordata / actuator_velocity the previous step left in HBM, writes PHYS_F_MEAS and takes ctrl from the
  * delay line.  CM_DRIVE_TORQUE reads the command from PHYS_F_DRIVE_CMD (cassie_sim_step_ethercat semantics);
  * CM_DRIVE_PD computes it as torque + kp (ptarget - position) + kd (dtarget - velocity) on the measured drive
- * position / velocity of the previous step (pd_input_step's motor PD, reference include/pd_input.h:34).  The filter
+ * position / velocity of the previous step (pd_input_step's motor PD, reference include/pd_input.h:34); CM_DRIVE_PD_SAFE
+ * passes that command through cassie_core_sim's safety layer first (reference include/cassie_core_sim.h:34, called at
+ * src/cassiemujoco.c:1141: joint-limit attenuation and restoring torques, torque-limit clamp, STO -- restated in
+ * csrc/pk_safety.h bit for bit the closed binary), i.e. the whole torque path of cassie_sim_step_pd; the STO switch (radio
+ * channel 8) is the last word of PHYS_F_DRIVE_CMD, the block's diagnostic messages collect in cm_drive_state_t::safety_msg.  The filter
  * histories and delay lines live in HBM (one cm_drive_state_t per env, zero-initialised like a fresh cassie_sim_t). */
 int phys_batch_set_drive_mode(phys_batch_t *b, int mode);
 /* the drive-level pass alone (no physics), whatever the drive mode of the step kernel is: reads PHYS_F_DRIVE_CMD (mode

@@ -64,3 +64,45 @@ int ref_sizes(int which)
     }
     return 0;
 }
+
+/* cassie_core_sim_step of the closed Agility library on n samples (golden vectors / live comparison of the safety-layer
+ * restatement csrc/pk_safety.h): user torques u, measured drive positions q / velocities w, torque limits L ([n][10] each, left
+ * leg first), radio channel 8 ([n]), telemetry ([n][9] shorts or NULL); fresh != 0: cassie_core_sim_setup before every sample,
+ * else one block instance sees the samples in order (the message queue is sticky).  Out: the ten torques, the 14 radio shorts
+ * and the (sto, piezoState, piezoTone) bytes of cassie_in_t, and the controlWords. */
+static elmo_out_t *ref_drive_out(cassie_out_t *o, int i) {
+    cassie_leg_out_t *l = i < 5 ? &o->leftLeg : &o->rightLeg;
+    elmo_out_t *d[5] = {&l->hipRollDrive, &l->hipYawDrive, &l->hipPitchDrive, &l->kneeDrive, &l->footDrive};
+    return d[i % 5];
+}
+static elmo_in_t *ref_drive_in(cassie_in_t *o, int i) {
+    cassie_leg_in_t *l = i < 5 ? &o->leftLeg : &o->rightLeg;
+    elmo_in_t *d[5] = {&l->hipRollDrive, &l->hipYawDrive, &l->hipPitchDrive, &l->kneeDrive, &l->footDrive};
+    return d[i % 5];
+}
+void ref_core_sim_batch(int n, const double *u, const double *q, const double *w, const double *L, const double *ch8,
+                        const short *telemetry, int fresh, double *tau_out, short *radio_out, unsigned char *flags_out,
+                        unsigned short *cw_out)
+{
+    cassie_core_sim_t *c = cassie_core_sim_alloc();
+    cassie_core_sim_setup(c);
+    for (int s = 0; s < n; ++s) {
+        cassie_out_t out;
+        cassie_user_in_t uin;
+        cassie_in_t in;
+        memset(&out, 0, sizeof out); memset(&uin, 0, sizeof uin); memset(&in, 0xA5, sizeof in);
+        for (int i = 0; i < 10; ++i) {
+            elmo_out_t *d = ref_drive_out(&out, i);
+            d->position = q[10 * s + i]; d->velocity = w[10 * s + i]; d->torqueLimit = L[10 * s + i];
+            uin.torque[i] = u[10 * s + i];
+        }
+        out.pelvis.radio.channel[8] = ch8[s];
+        if (telemetry) for (int i = 0; i < 9; ++i) uin.telemetry[i] = telemetry[9 * s + i];
+        if (fresh) cassie_core_sim_setup(c);
+        cassie_core_sim_step(c, &uin, &out, &in);
+        for (int i = 0; i < 10; ++i) { tau_out[10 * s + i] = ref_drive_in(&in, i)->torque; cw_out[10 * s + i] = ref_drive_in(&in, i)->controlWord; }
+        for (int i = 0; i < 14; ++i) radio_out[14 * s + i] = in.pelvis.radio.channel[i];
+        flags_out[3 * s] = in.pelvis.sto; flags_out[3 * s + 1] = in.pelvis.piezoState; flags_out[3 * s + 2] = in.pelvis.piezoTone;
+    }
+    cassie_core_sim_free(c);
+}

@@ -386,6 +386,18 @@ extern "C" int emu_derive(const cm_model_t *model, int nenv, double *qpos, doubl
     free(ext); free(xpos); free(xquat);
     return 0;
 }
+/* cassie_core_sim's safety layer as the step kernel computes it (csrc/pk_safety.h), sample by sample and drive by drive: the
+ * ten torques and the message bits of n samples (u, q, w, L: [n][10]; sto: [n]) */
+extern "C" void emu_core_safety(int n, const double *u, const double *q, const double *w, const double *L, const unsigned char *sto,
+                                double *tau_out, int *msg_out) {
+    for (int s = 0; s < n; ++s) {
+        int msg = 0;
+        for (int k = 0; k < 10; ++k)
+            tau_out[10 * s + k] = ck::safety::drive_torque(k, u + 10 * s, q + 10 * s, w + 10 * s, L[10 * s + k], sto[s] != 0, &msg);
+        msg_out[s] = msg;
+    }
+}
+extern "C" double emu_core_safety_torque_limit(int k) { return ck::safety::torque_limit(k); }
 /* the kinematics stage's own elementary functions, for direct accuracy tests */
 extern "C" void emu_sincos_reduced(double x, double *s, double *c) { ck::sincos_reduced(x, *s, *c); }
 extern "C" void emu_normalize4_fast(double *q) { ck::normalize4_fast(q); }

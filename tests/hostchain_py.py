@@ -31,6 +31,11 @@ def _setup():
     L.cassie_hostenv_torque_delay.restype = ctypes.POINTER(ctypes.c_double)
     L.cassie_hostenv_torque_delay.argtypes = [VP]
     L.cassie_hostmodel_from_model.argtypes = [VP, VP]
+    # the closed Agility block itself (libagilitycassie.a, whole-archived into the product library like reference Makefile:18)
+    L.cassie_core_sim_alloc.restype = VP
+    L.cassie_core_sim_setup.argtypes = [VP]
+    L.cassie_core_sim_free.argtypes = [VP]
+    L.cassie_core_sim_step.argtypes = [VP] * 4
     return L
 
 
@@ -81,10 +86,26 @@ class HostChain:
         self.L.cassie_hostenv_ethercat(self.env, ctypes.byref(self.hm), ctypes.byref(u), sd.ctypes.data, av.ctypes.data, ctrl.ctypes.data, ctypes.byref(y))
         return ctrl, meas_of(y), y
 
+    def core_sim(self, user_torques):
+        """cassie_core_sim_step of the REAL Agility block on this env's cassie_out_t (the previous step's measurements, as in
+        cassie_sim_step, reference src/cassiemujoco.c:1141) -> (the ten torques of cassie_in_t, radio.channel[1..4] = the message queue)."""
+        if getattr(self, "core", None) is None:
+            self.core = self.L.cassie_core_sim_alloc()
+            self.L.cassie_core_sim_setup(self.core)
+        u, cin = T.cassie_user_in_t(), T.cassie_in_t()
+        for i in range(10):
+            u.torque[i] = float(user_torques[i])
+        self.L.cassie_core_sim_step(self.core, ctypes.byref(u), self.L.cassie_hostenv_cassie_out(self.env), ctypes.byref(cin))
+        legs = [cin.leftLeg, cin.rightLeg]
+        tau = np.array([[legs[i // 5].hipRollDrive, legs[i // 5].hipYawDrive, legs[i // 5].hipPitchDrive, legs[i // 5].kneeDrive, legs[i // 5].footDrive][i % 5].torque for i in range(10)])
+        return tau, [int(cin.pelvis.radio.channel[k]) for k in range(1, 5)]
+
     def reset(self):
-        """A fresh cassie_sim_t's host state: zero filter histories and delay lines."""
+        """A fresh cassie_sim_t's host state: zero filter histories and delay lines (and a fresh safety block: empty message queue)."""
         self.L.cassie_hostenv_free(self.env)
         self.env = self.L.cassie_hostenv_alloc()
+        if getattr(self, "core", None) is not None:
+            self.L.cassie_core_sim_setup(self.core)
 
     def state_bytes(self):
         """(drive FIR histories, joint IIR histories, torque delay lines) as raw bytes, in cm_drive_state_t's field order."""
