@@ -83,34 +83,43 @@ WV_DEVICE double violation(int i, const double *q) {
 }
 
 /* The torque the block sends to drive k, and the message bits the step raises (*msg |= ...; the torque-limit bit concerns
- * drive k only: OR it over the drives).  u / q / w: the ten user torques, measured positions and velocities; L_k: the drive's
- * limit; sto: radio channel 8 != 1. */
-WV_DEVICE double drive_torque(int k, const double *u, const double *q, const double *w, double Lk, bool sto, int *msg) {
+ * drive k only: OR it over the drives).  uk / wk: the drive's user torque and measured velocity; q: the ten measured positions (a
+ * drive's torque depends on the others' only through the constraints); L_k: the drive's limit; sto: radio channel 8 != 1. */
+WV_DEVICE double drive_torque(int k, double uk, const double *q, double wk, double Lk, bool sto, int *msg) {
     double c[NROW];
     bool any = false;
 #pragma unroll
     for (int i = 0; i < NROW; ++i) { c[i] = violation(i, q); any |= c[i] > 0.0; }
     if (any) *msg |= MSG_LIMIT;
-    /* attenuation of the user torque */
-    double t = u[k];
+    const double kp = gain_p(k), kq = gain_q(k), D = wv::mul_rn(gain_d(k), wk);
+    double t;
+    if (!any && fabs(D) <= 1.7976931348623157e308) {
+        /* No constraint violated (the same verdict in every drive's lane: it depends on q alone) and a finite damper term: the
+         * attenuation loop multiplies nothing, and the 44 terms of the restoring loop are signed zeros -- among them (+0) x (-1) =
+         * -0 from the drive's own lower-bound row -- whose only trace in the binary's result is that a NEGATIVE zero torque leaves
+         * as a positive one.  u + 0 does exactly that, bit for bit, without the loops' 22 divisions. */
+        t = wv::add_rn(uk, 0.0);
+    } else {
+        /* attenuation of the user torque (x_i = c_i / 0.15 is used by both loops: divided once) */
+        double x[NROW];
+        t = uk;
 #pragma unroll
-    for (int i = 0; i < NROW; ++i) {
-        const double x = wv::div_rn(c[i], BLEND);
-        if (x > 0.0) t = wv::mul_rn(t, 1.0 > x ? wv::sub_rn(1.0, x) : 0.0);
-    }
-    /* restoring spring and damper of every constraint, violated or not (the others contribute signed zeros, which matter
-     * for the sign of a zero torque only -- kept, so that the bits are the binary's) */
-    const double kp = gain_p(k), kq = gain_q(k), D = wv::mul_rn(gain_d(k), w[k]);
+        for (int i = 0; i < NROW; ++i) {
+            x[i] = wv::div_rn(c[i], BLEND);
+            if (x[i] > 0.0) t = wv::mul_rn(t, 1.0 > x[i] ? wv::sub_rn(1.0, x[i]) : 0.0);
+        }
+        /* restoring spring and damper of every constraint, violated or not (the others contribute signed zeros, which matter
+         * for the sign of a zero torque only -- kept, so that the bits are the binary's) */
 #pragma unroll
-    for (int i = 0; i < NROW; ++i) {
-        const double ci = c[i];
-        const double p = ci >= 0.0 ? ci : 0.0;                           /* fmax(c, 0) */
-        const double x = wv::div_rn(ci, BLEND);
-        const double s = x > 0.0 ? (x < 1.0 ? x : 1.0) : 0.0;
-        const double g = wv::add_rn(wv::mul_rn(p, kp), wv::mul_rn(wv::mul_rn(p, p), kq));
-        const double a = (double)coeff(i, k);
-        t = wv::sub_rn(t, wv::mul_rn(g, a));
-        t = wv::sub_rn(t, wv::mul_rn(wv::mul_rn(fabs(a), D), s));
+        for (int i = 0; i < NROW; ++i) {
+            const double ci = c[i];
+            const double p = ci >= 0.0 ? ci : 0.0;                           /* fmax(c, 0) */
+            const double s = x[i] > 0.0 ? (x[i] < 1.0 ? x[i] : 1.0) : 0.0;
+            const double g = wv::add_rn(wv::mul_rn(p, kp), wv::mul_rn(wv::mul_rn(p, p), kq));
+            const double a = (double)coeff(i, k);
+            t = wv::sub_rn(t, wv::mul_rn(g, a));
+            t = wv::sub_rn(t, wv::mul_rn(wv::mul_rn(fabs(a), D), s));
+        }
     }
     /* message 630: |torque| >= limit (ordered compare), before the clamp */
     if (fabs(t) >= Lk) *msg |= MSG_TORQUE;

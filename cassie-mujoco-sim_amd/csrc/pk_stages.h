@@ -89,20 +89,19 @@ WV_DRIVE_FN void drive_level_io(const PhysIO &io, SH &S, ModelPtr m, int env, in
     double *meas = io.meas + (size_t)env * CM_MEAS_DIM;
     /* CM_DRIVE_PD_SAFE: cassie_core_sim's safety layer between pd_input's PD law and the motor model (pk_safety.h).  A drive's
      * torque depends on ALL ten measured positions (the 22 limit constraints) and the message bits on all ten torques: every
-     * drive's lane forms the ten PD commands from LDS, takes its own torque, a ballot collects the torque-limit bit, and the wave
+     * drive's lane reads the ten positions from LDS and takes its own torque, a ballot collects the torque-limit bit, and the wave
      * meets once before any lane overwrites the measurements the others have just read. */
     double u_safe = 0.0;
     if (io.drive_mode == CM_DRIVE_PD_SAFE) {
         int msg = 0;
         const bool sto = S.drv_msg[1] != 0;
         if (lane < CM_NUM_DRIVES) {
-            double uu[CM_NUM_DRIVES], qq[CM_NUM_DRIVES], ww[CM_NUM_DRIVES];
-            for (int k = 0; k < CM_NUM_DRIVES; ++k) {
-                const double *c = S.drv_c[k];
-                qq[k] = S.drv_pos[k]; ww[k] = S.drv_vel[k];
-                uu[k] = wv::add_rn(wv::add_rn(c[DRVC_FF], wv::mul_rn(c[DRVC_KP], wv::sub_rn(c[DRVC_U_OR_PT], qq[k]))), wv::mul_rn(c[DRVC_KD], wv::sub_rn(c[DRVC_STO_OR_DT], ww[k])));
-            }
-            u_safe = safety::drive_torque(lane, uu, qq, ww, safety::torque_limit(lane), sto, &msg);
+            double qq[CM_NUM_DRIVES];
+            for (int k = 0; k < CM_NUM_DRIVES; ++k) qq[k] = S.drv_pos[k];
+            const double *c = S.drv_c[lane];
+            const double wk = S.drv_vel[lane];
+            const double uk = wv::add_rn(wv::add_rn(c[DRVC_FF], wv::mul_rn(c[DRVC_KP], wv::sub_rn(c[DRVC_U_OR_PT], S.drv_pos[lane]))), wv::mul_rn(c[DRVC_KD], wv::sub_rn(c[DRVC_STO_OR_DT], wk)));
+            u_safe = safety::drive_torque(lane, uk, qq, wk, safety::torque_limit(lane), sto, &msg);
         }
         const bool lim = wv::ballot((msg & safety::MSG_LIMIT) != 0) != 0ull, trq = wv::ballot((msg & safety::MSG_TORQUE) != 0) != 0ull;
         wv::sync();

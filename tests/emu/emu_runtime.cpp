@@ -393,7 +393,7 @@ extern "C" void emu_core_safety(int n, const double *u, const double *q, const d
     for (int s = 0; s < n; ++s) {
         int msg = 0;
         for (int k = 0; k < 10; ++k)
-            tau_out[10 * s + k] = ck::safety::drive_torque(k, u + 10 * s, q + 10 * s, w + 10 * s, L[10 * s + k], sto[s] != 0, &msg);
+            tau_out[10 * s + k] = ck::safety::drive_torque(k, u[10 * s + k], q + 10 * s, w[10 * s + k], L[10 * s + k], sto[s] != 0, &msg);
         msg_out[s] = msg;
     }
 }
