@@ -28,7 +28,7 @@ SAFETY_MSG_LIMIT, SAFETY_MSG_TORQUE = 1, 2    # bits of cm_drive_state_t::safety
 MEAS_DRIVE_POS, MEAS_DRIVE_VEL, MEAS_DRIVE_TORQUE, MEAS_JOINT_POS, MEAS_JOINT_VEL = 0, 10, 20, 30, 36
 MEAS_ORIENTATION, MEAS_ANGVEL, MEAS_LINACC, MEAS_MAG, MEAS_DIM = 42, 46, 49, 52, 56
 
-FLAG_EULERDAMP, FLAG_WARMSTART, FLAG_REFSAFE, FLAG_HFDENSE, FLAG_HFMULTI, FLAG_HFPRISM = 1, 2, 4, 8, 16, 32      # CM_FLAG_* (cm_model.h)
+FLAG_EULERDAMP, FLAG_WARMSTART, FLAG_REFSAFE, FLAG_HFDENSE, FLAG_HFMULTI, FLAG_HFPRISM, FLAG_BOX8 = 1, 2, 4, 8, 16, 32, 64      # CM_FLAG_* (cm_model.h)
 WARN_CONTACT_FULL, WARN_CONSTRAINT_FULL, WARN_UNSUPPORTED_PAIR, WARN_DIVERGED = 1, 2, 4, 8
 WARN_CHUNK_PLACEMENT = 16   # a chunk of a stepping launch found its predecessor on another XCD: the env's state may be stale, discard its results
 

@@ -84,6 +84,10 @@ enum { CM_CNSTR_EQUALITY = 0, CM_CNSTR_LIMIT_JOINT = 3, CM_CNSTR_CONTACT_FRICTIO
                                    deepest sample sphere (ties: the sample nearer the +axis end), and every triangle whose deepest sample is within
                                    the margin gives a contact, in grid order.  Off by default: a Cassie standing on rough terrain
                                    then needs 36 rows on average and up to the 127 of the widest instantiation.  Overrides HFMULTI / HFDENSE. */
+#define CM_FLAG_BOX8      64u   /* box vs box: keep up to EIGHT points of the clipped incident face (MuJoCo's mjc_BoxBox returns up to eight: the
+                                   corners of the octagon two partly overlapping faces have in common) instead of its four deepest.  A cube resting
+                                   flat on a larger face has four candidates either way (model/cassie_tray_box.xml:213-216, :230-237 at rest), so
+                                   the option matters for faces that overlap partly.  Off by default */
 #define CM_FLAG_HFDENSE    8u   /* capsule vs height field: up to CM_HF_SLOTS_DENSE - 2 interior samples instead of CM_HF_SLOTS - 2 (a grid
                                    cell apart along Cassie's 0.43 m shin on the 5 cm grid of example/test_hfield.py); off by default: -10 % on
                                    BASELINE config 4 */

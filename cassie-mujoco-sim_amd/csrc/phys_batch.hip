@@ -511,7 +511,7 @@ int phys_batch_set_model(phys_batch_t *b, const cm_model_t *model, int env) {
         (model->npair > model->npair_simple) != (b->host_model.npair > b->host_model.npair_simple) ||
         /* the tier chain behind a launch (63-row pass only, or 63 + 127) is picked from the SHARED model's caps, the kernel reads the env's */
         model->maxefc != b->host_model.maxefc || model->maxcon != b->host_model.maxcon ||
-        ((model->flags ^ b->host_model.flags) & (CM_FLAG_HFPRISM | CM_FLAG_HFMULTI | CM_FLAG_HFDENSE)) != 0) {
+        ((model->flags ^ b->host_model.flags) & (CM_FLAG_HFPRISM | CM_FLAG_HFMULTI | CM_FLAG_HFDENSE | CM_FLAG_BOX8)) != 0) {
         phys_set_last_error("phys_batch_set_model: a per-env model must keep the shared model's dof tree, collision pair kinds, contact / row caps and height-field contact option");
         return -1;
     }

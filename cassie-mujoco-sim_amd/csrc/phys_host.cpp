@@ -125,7 +125,7 @@ unsigned long long phys_hash_floats(const float *data, size_t n) {
 
 unsigned phys_model_flags(const phys_model_t *m) { return m ? m->h.flags : 0u; }
 int phys_model_set_flag(phys_model_t *m, unsigned flag, int on) {
-    if (!m || (flag & ~(CM_FLAG_EULERDAMP | CM_FLAG_WARMSTART | CM_FLAG_REFSAFE | CM_FLAG_HFDENSE | CM_FLAG_HFMULTI | CM_FLAG_HFPRISM)) != 0) return -1;
+    if (!m || (flag & ~(CM_FLAG_EULERDAMP | CM_FLAG_WARMSTART | CM_FLAG_REFSAFE | CM_FLAG_HFDENSE | CM_FLAG_HFMULTI | CM_FLAG_HFPRISM | CM_FLAG_BOX8)) != 0) return -1;
     if (on) m->h.flags |= flag; else m->h.flags &= ~flag;
     return 0;
 }

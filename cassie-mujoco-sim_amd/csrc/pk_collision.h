@@ -141,7 +141,7 @@ WV_DEVICE void row3(double (&r)[3], const double (&M)[3][3], int i) {
 }
 
 WV_DEVICE bool box_box_lane(RawContact &rc, int lane, const double *p1, const double *m1, const double *s1, const double *p2, const double *m2,
-                            const double *s2, double margin) {
+                            const double *s2, double margin, int keepmax) {
     const double BB_TIE = 1e-10;
     double A[3][3], B[3][3], d[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]}, ta[3], tb[3], C[3][3], Q[3][3];
     const double sa[3] = {s1[0], s1[1], s1[2]}, sb[3] = {s2[0], s2[1], s2[2]};
@@ -282,14 +282,14 @@ WV_DEVICE bool box_box_lane(RawContact &rc, int lane, const double *p1, const do
     if (valid && cw > margin) valid = false;
     const unsigned long long vmask = wv::ballot(valid);
     bool keep = valid;
-    if (wv::popc64(vmask) > 4) {
+    if (wv::popc64(vmask) > keepmax) {     /* (keepmax: 4, or 8 with CM_FLAG_BOX8) */
         int rank = 0;
         for (int r = 0; r < 24; ++r) {
             const double wr = wv::readlane(cw, r);
             if (r == lane || !((vmask >> r) & 1ull)) continue;
             if (wr < cw - 1e-9 || (fabs(wr - cw) <= 1e-9 && r < lane)) ++rank;
         }
-        if (rank >= 4) keep = false;
+        if (rank >= keepmax) keep = false;
     }
     if (keep) {
         rc.dist = cw;

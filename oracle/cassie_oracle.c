@@ -505,7 +505,7 @@ static int plane_box(raw_contact_t *c, const double *pp, const double *mp, const
  * resting and edge-crossing configurations but are not bit-compatible. */
 typedef struct { double u, v, w; int valid; } bb_cand_t;
 #define BB_TIE 1e-10
-static int box_box(raw_contact_t *c, const double *p1, const double *m1, const double *s1, const double *p2, const double *m2, const double *s2,
+static int box_box_keep(raw_contact_t *c, int keep, const double *p1, const double *m1, const double *s1, const double *p2, const double *m2, const double *s2,
                    double margin) {
     double A[3][3], B[3][3], d[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]}, ta[3], tb[3], C[3][3], Q[3][3];
     for (int i = 0; i < 3; ++i) for (int k = 0; k < 3; ++k) { A[i][k] = m1[3 * k + i]; B[i][k] = m2[3 * k + i]; }
@@ -622,9 +622,9 @@ static int box_box(raw_contact_t *c, const double *p1, const double *m1, const d
     int nvalid = 0;
     for (int q = 0; q < 24; ++q) { if (cand[q].valid && cand[q].w > margin) cand[q].valid = 0; nvalid += cand[q].valid; }
 #ifdef CO_STUDY
-    const int bb_keep = g_study_box_keep;
+    const int bb_keep = g_study_box_keep > keep ? g_study_box_keep : keep;
 #else
-    const int bb_keep = 4;
+    const int bb_keep = keep;      /* 4, or 8 with CM_FLAG_BOX8 */
 #endif
     if (nvalid > bb_keep)                                             /* keep the 4 deepest; within 1e-9 the earlier candidate wins */
         for (int q = 0; q < 24; ++q) {
@@ -653,9 +653,15 @@ static int box_box(raw_contact_t *c, const double *p1, const double *m1, const d
 
 /* test hook: box-box contacts for two boxes given by centre, rotation matrix (row-major, axes in columns) and half sizes;
  * out[4][7] = dist, pos, normal */
+int co_test_box_box_keep(int keep, const double *p1, const double *m1, const double *s1, const double *p2, const double *m2, const double *s2, double margin, double *out) {
+    raw_contact_t c[8];
+    int n = box_box_keep(c, keep < 1 ? 1 : (keep > 8 ? 8 : keep), p1, m1, s1, p2, m2, s2, margin);
+    for (int k = 0; k < n; ++k) { out[7 * k] = c[k].dist; for (int i = 0; i < 3; ++i) { out[7 * k + 1 + i] = c[k].pos[i]; out[7 * k + 4 + i] = c[k].normal[i]; } }
+    return n;
+}
 int co_test_box_box(const double *p1, const double *m1, const double *s1, const double *p2, const double *m2, const double *s2, double margin, double *out) {
-    raw_contact_t c[4];
-    int n = box_box(c, p1, m1, s1, p2, m2, s2, margin);
+    raw_contact_t c[8];
+    int n = box_box_keep(c, 4, p1, m1, s1, p2, m2, s2, margin);
     for (int k = 0; k < n; ++k) { out[7 * k] = c[k].dist; for (int i = 0; i < 3; ++i) { out[7 * k + 1 + i] = c[k].pos[i]; out[7 * k + 4 + i] = c[k].normal[i]; } }
     return n;
 }
@@ -1030,7 +1036,7 @@ void co_collision(const cm_model_t *m, co_data_t *d) {
         else if (t1 == CM_GEOM_SPHERE && t2 == CM_GEOM_BOX) n = sphere_box(rc, p1, m->geom_size[g1][0], p2, m2, m->geom_size[g2], margin);
         else if (t1 == CM_GEOM_CAPSULE && t2 == CM_GEOM_BOX) n = capsule_box(rc, p1, m1, m->geom_size[g1], p2, m2, m->geom_size[g2], margin);
         else if (t1 == CM_GEOM_PLANE && t2 == CM_GEOM_BOX) n = plane_box(rc, p1, m1, p2, m2, m->geom_size[g2], margin);
-        else if (t1 == CM_GEOM_BOX && t2 == CM_GEOM_BOX) n = box_box(rc, p1, m1, m->geom_size[g1], p2, m2, m->geom_size[g2], margin);
+        else if (t1 == CM_GEOM_BOX && t2 == CM_GEOM_BOX) n = box_box_keep(rc, (m->flags & CM_FLAG_BOX8) ? 8 : 4, p1, m1, m->geom_size[g1], p2, m2, m->geom_size[g2], margin);
         else { d->warn_unsupported_pair = 1; continue; }
         for (int k = 0; k < n; ++k) {
             if (d->ncon >= maxcon) { d->warn_contact_full = 1; break; }

@@ -91,6 +91,7 @@ void co_jac(const cm_model_t *m, const co_data_t *d, int body, const double poin
             double jacp[3][CM_MAXV], double jacr[3][CM_MAXV]);
 void co_integrate_pos(const cm_model_t *m, double *qpos, const double *qvel, double dt);
 unsigned long co_sizeof_data(void);
+int co_test_box_box_keep(int keep, const double *p1, const double *m1, const double *s1, const double *p2, const double *m2, const double *s2, double margin, double *out); /* out[8][7] */
 int co_test_box_box(const double *p1, const double *m1, const double *s1, const double *p2, const double *m2, const double *s2, double margin, double *out);
 int co_test_hfield_capsule(const cm_model_t *m, const double *pc, const double *mc, double radius, double halflen, double margin, double *out);
 int co_test_hfield_sphere(const cm_model_t *m, const double *ps, double r, double margin, double *out);

@@ -269,3 +269,76 @@ def test_box_box_depth_grows_as_the_boxes_approach():
         assert np.allclose(c2[:, 0], c[:, 0] - eps, atol=1e-8)
         checked += 1
     assert checked > 60
+
+
+def _bb_keep(keep, p1, R1, s1, p2, R2, s2):
+    from oracle_py import lib
+    L = lib()
+    L.co_test_box_box_keep.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 6 + [ctypes.c_double, ctypes.c_void_p]
+    a = [np.ascontiguousarray(x, dtype=np.float64) for x in (p1, R1, s1, p2, R2, s2)]
+    out = np.zeros(56)
+    n = L.co_test_box_box_keep(keep, *[x.ctypes.data for x in a], 0.0, out.ctypes.data)
+    return n, out.reshape(8, 7)[:n]
+
+
+def test_box_box_eight_contact_option_keeps_the_whole_clipped_polygon():
+    """CM_FLAG_BOX8 (MuJoCo's mjc_BoxBox returns up to eight points; reference model/cassie_tray_box.xml:213-216, :230-237 is where
+    box meets box): a plate turned 45 degrees on the tray overlaps it in an OCTAGON -- eight rim crossings, all at the same depth:
+    the option keeps the eight, the default its first four; a face wholly inside the other gives four either way."""
+    plate = [0.12, 0.12, 0.05]
+    args = (*TRAY, [0.0, 0.0, 0.05], _rot([0, 0, 1], np.pi / 4), plate)
+    n8, c8 = _bb_keep(8, *args)
+    n4, c4 = _bb_keep(4, *args)
+    assert n8 == 8 and n4 == 4
+    assert np.allclose(c8[:, 0], -0.005) and np.allclose(c8[:, 4:], [0, 0, 1])
+    r = np.hypot(c8[:, 1], c8[:, 2])
+    assert np.allclose(np.maximum(np.abs(c8[:, 1]), np.abs(c8[:, 2])), 0.14)            # every point on the tray's rim ...
+    k = 0.12 * np.sqrt(2) - 0.14
+    assert np.allclose(np.minimum(np.abs(c8[:, 1]), np.abs(c8[:, 2])), k)                # ... where the plate's edges cross it
+    assert len({(round(x, 9), round(y, 9)) for x, y in c8[:, 1:3]}) == 8 and np.allclose(r, r[0])
+    assert all(any(np.allclose(a, b) for b in c8) for a in c4)                           # the default's four are among them
+    for Rz in (np.eye(3), _rot([0, 0, 1], 0.3)):                                         # the resting cube: four candidates, four contacts
+        assert _bb_keep(8, *TRAY, [0.02, 0.03, 0.05], Rz, CUBE)[0] == 4
+    # a corner of the cube past the tray's corner: a pentagon / hexagon -- more than four, fewer than eight
+    n, c = _bb_keep(8, *TRAY, [0.12, 0.12, 0.05], _rot([0, 0, 1], 0.5), CUBE)
+    assert 4 < n <= 8 and _bb_keep(4, *TRAY, [0.12, 0.12, 0.05], _rot([0, 0, 1], 0.5), CUBE)[0] == 4
+
+
+def test_emulated_kernel_matches_oracle_with_the_eight_contact_option():
+    """The cube sliding about the tray's corner under CM_FLAG_BOX8: the emulated kernel follows the oracle contact for contact
+    through box-box contact sets of five and more points, and the option is not a no-op against the default there."""
+    from cassie_amd import phys as P
+    from cassie_amd._lib import CmModel
+    tray = Model("cassie_tray_box")
+    tray.set_flag(P.FLAG_BOX8, True)
+    outs = []
+    for flag in (True, False):
+        pod = CmModel.from_buffer_copy(tray.pod)
+        if not flag:
+            pod.flags &= ~P.FLAG_BOX8
+        q = tray.qpos_init()
+        for i in range(3):
+            pod.jnt_stiffness[i], pod.dof_damping[i], pod.qpos_spring[i] = 1e5, 1e4, q[i]
+            pod.dof_stiffness[i], pod.dof_springref[i] = 1e5, q[i]
+        for i in range(3, 6):
+            pod.dof_damping[i] = 1e4
+        for k in range(6, 32):
+            pod.dof_damping[k] = 50
+        q[35:38] = [0.13, 0.12, 1.01 + 0.17 + 0.005 + 0.05 + 0.002]       # just above the tray, over its corner
+        q[38:42] = [np.cos(0.25), 0, 0, np.sin(0.25)]                      # turned about z
+        o = Oracle(pod, q)
+        o.qvel[32:35] = [-0.05, 0.03, 0]                                   # sliding slowly
+        emu = EmuBatch(pod, 1)
+        emu.qpos[:] = q
+        emu.qvel[0, 32:35] = [-0.05, 0.03, 0]
+        cube = tray.name2id(1, "cup_box")
+        most = 0
+        for s in range(150):
+            emu.step()
+            o.step()
+            assert (emu.info[0, 0], emu.info[0, 1], emu.info[0, 2]) == (o.d.ncon, o.d.nefc, o.d.solver_iter), (flag, s)
+            most = max(most, sum(1 for i in range(o.d.ncon) if cube in (pod.geom_bodyid[o.d.contact[i].geom1], pod.geom_bodyid[o.d.contact[i].geom2])))
+        assert np.max(np.abs(emu.qpos[0] - o.qpos)) < 1e-9
+        outs.append((most, o.qpos.copy()))
+    assert outs[0][0] > 4 and outs[1][0] == 4
+    assert np.max(np.abs(outs[0][1] - outs[1][1])) > 1e-9

@@ -335,3 +335,40 @@ def test_prism_contacts_heightfield_flag_on_the_gpu(built):
         return q
     worst, rows, q = _pd_rollout(hf, 256, np.arange(0, 256, 8), nsteps=600, hfield=h, q0_of=place, allow_caps=True)
     assert rows > 64
+
+
+def test_box_box_eight_contact_option_on_the_gpu(built):
+    """CM_FLAG_BOX8 (up to eight box-box contacts like MuJoCo's mjc_BoxBox; reference model/cassie_tray_box.xml:213-216, :230-237):
+    256 envs of config 5 with the cube started at random places on and around the tray's rim, turned about the vertical, 300 steps:
+    the HIP kernel against the oracle, counts equal at every check point, qpos to 1e-9; box-box sets of more than four points occur."""
+    from oracle_py import Oracle
+    model = Model("cassie_tray_box")
+    model.set_flag(P.FLAG_BOX8, True)
+    pod = model.pod
+    n = 256
+    rng = np.random.default_rng(12)
+    q0 = np.tile(model.qpos_init(), (n, 1))
+    q0[:, 35] = rng.uniform(-0.15, 0.15, n); q0[:, 36] = rng.uniform(-0.15, 0.15, n)
+    q0[:, 37] = 1.01 + 0.17 + 0.005 + 0.05 + rng.uniform(0.001, 0.01, n)
+    ang = rng.uniform(0, np.pi / 2, n)
+    q0[:, 38], q0[:, 41] = np.cos(ang / 2), np.sin(ang / 2)
+    b = Batch(model, n)
+    try:
+        b.set(P.F_QPOS, q0)
+        orcs = [Oracle(pod, q0[e]) for e in range(n)]
+        cube = model.name2id(1, "cup_box")
+        most = 0
+        for chunk in range(6):
+            b.step(50)
+            q = b.get(P.F_QPOS)
+            w, info = b.warnings()
+            for e, o in enumerate(orcs):
+                o.step(50)
+                assert (info[e, 0], info[e, 1], info[e, 2]) == (o.d.ncon, o.d.nefc, o.d.solver_iter), (chunk, e, info[e].tolist(), (o.d.ncon, o.d.nefc, o.d.solver_iter))
+                most = max(most, sum(1 for i in range(o.d.ncon) if cube in (pod.geom_bodyid[o.d.contact[i].geom1], pod.geom_bodyid[o.d.contact[i].geom2])))
+            qo = np.array([o.qpos.copy() for o in orcs])
+            assert np.max(np.abs(q - qo) / np.maximum(1.0, np.abs(qo))) < 1e-9, chunk
+        assert most > 4, most
+        assert not (w & ~(P.WARN_CONTACT_FULL | P.WARN_CONSTRAINT_FULL)).any()
+    finally:
+        b.close()
