@@ -817,6 +817,8 @@ def main(argv=None):
     ap.add_argument("--hfield-contacts", default="default", choices=["default", "prism"],
                     help="cassie_hfield only: `prism` = CM_FLAG_HFPRISM, one contact per penetrated grid triangle (the MuJoCo-shaped contact set; "
                          "up to 32 contacts / 127 rows, envs pass through the 31 / 63 / 127-row instantiations); default = at most two per capsule")
+    ap.add_argument("--box-contacts", type=int, default=4, choices=[4, 8],
+                    help="cassie_tray_box: contacts a box-box pair keeps -- 4 (default) or 8 = CM_FLAG_BOX8, MuJoCo's count")
     ap.add_argument("--target-spread", type=float, default=TARGET_SPREAD,
                     help="half-width in rad of the uniform PD targets around the standing pose (0.3: the metric's workload; 10: the "
                          "stress targets of reference example/cassietest_jac.py:106, joints driven into their limits)")
@@ -876,6 +878,9 @@ def main(argv=None):
             raise SystemExit("--hfield-contacts prism applies to --model cassie_hfield")
         from cassie_amd import phys as _P
         model.set_flag(_P.FLAG_HFPRISM, True)
+    if args.box_contacts == 8:
+        from cassie_amd import phys as _P
+        model.set_flag(_P.FLAG_BOX8, True)      # box-box keeps up to eight points like MuJoCo's mjc_BoxBox
     pod = model.pod
     n, scaling, shape = resolve_envs(world, args.envs_per_gpu, args.total_envs)
     repeats = max(1, args.repeats)
@@ -930,6 +935,7 @@ def main(argv=None):
                                    % (args.mode, r["streams"], r["streams"], n, world, world * n, shape, args.model, EPISODE, PREROLL, HOLD, repeats, args.steps),
                        "api_of_value": api, "mode": args.mode,
                        "hfield_contacts": args.hfield_contacts if args.model == "cassie_hfield" else None,
+                       "box_contacts": args.box_contacts if args.model == "cassie_tray_box" else None,
                        "pd_target_spread_rad": args.target_spread,
                        "envs_per_gpu": n, "envs_total": world * n, "baseline_config": shape, "parallelism": "env-sharded x%d" % world,
                        "obs_allgather_every_steps": HOLD if collect else None,
