@@ -2,10 +2,12 @@
  * pk_safety.h -- cassie_core_sim's safety layer, restated (reference include/cassie_core_sim.h:30-35,
  * called at reference src/cassiemujoco.c:1141 between pd_input_step and cassie_sim_step_ethercat).
  *
- * The block exists only as the closed binary src/libagilitycassie.a(cassie_core_sim.o).  What follows is its LAW as read
- * from that binary's behaviour and disassembly (tools/core_sim_probe.py documents the probes; nothing of the binary is
- * carried here but its constants), written so that every floating-point operation is the individually rounded IEEE
- * operation the binary performs, in its order -- the outputs are BIT FOR BIT the binary's:
+ * The block exists only as the closed binary src/libagilitycassie.a(cassie_core_sim.o).  What follows is its LAW: every
+ * constant and every piece of it can be recovered from the block's behaviour alone (tools/core_sim_probe.py does so with
+ * black-box probes of the live binary: bounds by bisection, gains by fits, the blend width, the coupling, the clamp, the queue;
+ * profiles/round6/core_sim_probe.txt), the order of the floating-point operations was read off its disassembly; nothing of the
+ * binary is carried here.  Every operation is the individually rounded IEEE operation the binary performs, in its order -- the
+ * outputs are BIT FOR BIT the binary's:
  * tests/test_core_safety.py (goldens generated from the real .a by tools/make_golden_core_safety.py through oracle/_ref;
  * 10^7 random + adversarial samples against the live binary where it is present).
  *
