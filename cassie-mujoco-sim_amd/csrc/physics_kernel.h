@@ -74,9 +74,10 @@ namespace ck {
  * pairs handled by the whole wave.  The launcher picks the instantiation from the model (phys_batch.hip). */
 
 template <int NVP, class TOPO, int FEAT, int MAXR, int NW>
-WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count, MAXR> &S, int env, int sub_start, int nsub) {
+WV_DEVICE int env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count, MAXR> &S, int env, int sub_start, int nsub) {
     /* nsub: the substep this call ends in front of -- io.nsub, or the end of this workgroup's chunk of the launch (PhysIO::nchunk):
-     * the call then ends like a launch of nsub substeps */
+     * the call then ends like a launch of nsub substeps.  Returns (wave 0; wave 1 of the two-wave form returns -1) the substep the
+     * call really ended in front of: nsub, or the substep it handed over / found the state diverged at */
     typedef LPack<TOPO, NVP> LP;
     static_assert(NW == 1 || NW == 2, "one or two wavefronts per env");
     static_assert(NW == 1 || TOPO::is_static, "the two-wave form exists for the compile-time topologies");
@@ -618,6 +619,7 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
             if (wv::ballot((warn & bit) != 0) != 0ull) w |= bit;
         if (lane == 0 && w) io.warn[env] |= w;
     }
+    return (warn & WARN_DIVERGED) ? -2 : (bailed ? sub : nsub);
 }
 
 /* one workgroup (NW wavefronts) per environment.
@@ -632,7 +634,12 @@ WV_DEVICE void env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count
  * run-time branch: env_step is inlined, and two call sites would be two copies of it in one kernel.) */
 /* WPS: wavefronts per SIMD the registers are budgeted for (NW: 512 / NW registers a lane; 1 with NW = 2: two wavefronts per env with
  * 512 registers each, for batches that cannot fill the chip anyway -- a single simulator) */
-template <int NVP, class TOPO, int FEAT = FEAT_ALL, int MAXR = MID_ROWS, int NW = 1, bool WALK = false, int WPS = NW>
+/* INROWS (round 6; 0 = none): rows of the instantiation whose code finishes, inside this workgroup, a substep that needs more rows
+ * than this one holds -- the fast kernel then goes on with the next substep itself (PhysIO::inplace_*).  A handed-over env used to
+ * take ALL its remaining substeps to the pass behind the kernel, one serial chain per env while the range's stream waited (23 % of
+ * the stress workload's time for 0.3 % of the env-launches); in place it costs that one substep's longer code path.  Results are
+ * the same bit for bit: a substep is computed by the same instructions whichever instantiation holds it. */
+template <int NVP, class TOPO, int FEAT = FEAT_ALL, int MAXR = MID_ROWS, int NW = 1, bool WALK = false, int WPS = NW, int INROWS = 0>
 WV_GLOBAL void __launch_bounds__(WV_WAVE * NW) WV_OCC WV_WAVES_PER_SIMD(WPS) cassie_step_kernel(PhysIO io) {
     WV_SHARED EnvShared<NVP, LPack<TOPO, NVP>::count, MAXR> S;
     const int slot = wv::env_id();
@@ -683,7 +690,27 @@ WV_GLOBAL void __launch_bounds__(WV_WAVE * NW) WV_OCC WV_WAVES_PER_SIMD(WPS) cas
         }
     }
     const long long t0 = io.cost ? wv::clock() : 0, t0w = io.cost_wall ? wv::wall_clock() : 0;
-    env_step<NVP, TOPO, FEAT, MAXR, NW>(io, S, env, sub_start, sub_end);
+    if constexpr (INROWS > 0) {
+        static_assert(NW == 2 && INROWS > MAXR && INROWS <= MID_ROWS, "the in-place form: a two-wave fast instantiation with the 63-row code behind it");
+        static_assert(sizeof(EnvShared<NVP, LPack<TOPO, NVP>::count, MAXR>) == sizeof(EnvShared<NVP, LPack<TOPO, NVP>::count, INROWS>), "both instantiations use the env's LDS block alike");
+        auto &S2 = reinterpret_cast<EnvShared<NVP, LPack<TOPO, NVP>::count, INROWS> &>(S);
+        PhysIO io2 = io;            /* what the substep's inner call sees: it hands on (if at all) to the 127-row pass's list */
+        io2.has_next = io.inplace_has_next; io2.handover_out_list = io.inplace_out_list; io2.handover_out_count = io.inplace_out_count;
+        for (int s = sub_start;;) {
+            int at = env_step<NVP, TOPO, FEAT, MAXR, NW>(io, S, env, s, sub_end);
+            /* (wave 0 knows where the call ended; both waves' stores of the state are out before either loads it again) */
+            if (wv::lane() == 0 && wv::wave_id() == 0) S.cmd[5] = at;
+            wv::drain_vmem(); wv::block_barrier();
+            at = wv::opaque(S.cmd[5]);
+            if (at < 0 || at >= sub_end) break;                 /* done (or the state diverged: flagged, left alone) */
+            int at2 = env_step<NVP, TOPO, FEAT, INROWS, NW>(io2, S2, env, at, at + 1);
+            if (wv::lane() == 0 && wv::wave_id() == 0) S.cmd[5] = at2;
+            wv::drain_vmem(); wv::block_barrier();
+            at2 = wv::opaque(S.cmd[5]);
+            if (at2 != at + 1 || at + 1 >= sub_end) break;      /* handed on to the 127-row pass (or diverged), or that was the last substep */
+            s = at + 1;
+        }
+    } else env_step<NVP, TOPO, FEAT, MAXR, NW>(io, S, env, sub_start, sub_end);
     if (sub_end < io.nsub) wv::publish_global<NW>(io.chunk_flag + env, io.chunk_seq, chunk + 1);
     if (io.prof && wv::lane() == 0) io.prof[(size_t)env * NSTAMP + 40 + (NW == 2 ? wv::wave_id() : 0)] = wv::hw_id(); /* (profiling aid: the CU / SIMD of the wave) */
     if (io.prof && wv::lane() == 0 && (NW == 1 || wv::wave_id() == 0)) { /* (profiling aid: the shader clock against the 100 MHz wall clock at the env's end) */

@@ -113,6 +113,13 @@ struct PhysIO {
      * pass appends the envs it hands over (the list the pass behind it walks; same layout as handover_list / handover_count). */
     int has_next;
     int *handover_out_list, *handover_out_count;
+    /* A fast instantiation that finishes, IN PLACE, the substeps it cannot hold (cassie_step_kernel's INROWS, round 6): the substep is
+     * run by the 63-row instantiation's code inside the same workgroup and the env goes back to the fast code for the next one --
+     * no hand-over list, no pass behind the kernel, no serial chain of the remaining substeps.  What that inner call uses in place
+     * of has_next / handover_out_*: whether an instantiation with still more rows runs behind the kernel (models with the wide
+     * caps) and the list it walks. */
+    int inplace_has_next;
+    int *inplace_out_list, *inplace_out_count;
 };
 
 /* MAXR: constraint rows this instantiation can hold (WIDE_ROWS, MID_ROWS, or fewer in the row-capped fast instantiations, see

@@ -33,6 +33,9 @@ bool launch_step_cassie_hfield(dim3 grid, const TierGrids &tg, hipStream_t s, Ph
 /* the two-wave forms of the fast instantiations, in translation units of their own (kernels_*_2w.hip) */
 bool launch_fast_cassie_2w(dim3 grid, hipStream_t s, PhysIO io);
 bool launch_fast_cassie_hfield_2w(dim3 grid, hipStream_t s, PhysIO io);
+/* ... with the 63-row code behind them in the same kernel (kernels_*_2w_inplace.hip: cassie_step_kernel's INROWS) */
+bool launch_fast_cassie_2w_inplace(dim3 grid, hipStream_t s, PhysIO io);
+bool launch_fast_cassie_hfield_2w_inplace(dim3 grid, hipStream_t s, PhysIO io);
 /* ... and of the 63-row instantiations in their role as the pass behind the fast kernel: there a workgroup must be placeable
  * wherever a fast kernel's is -- two waves of 256 registers, 40 KB of LDS -- or it waits for a SIMD to empty while the other env
  * range's kernel keeps every SIMD half full */
@@ -78,7 +81,7 @@ inline void no_tiers(PhysIO &io) {
 template <int NVP, class TOPO, int FEAT>
 inline bool launch_three_tiers(dim3 grid, const TierGrids &tg, hipStream_t s, PhysIO io, const HandoverLists &hl, bool fast, bool wide_caps, hipEvent_t after_first,
                                bool (*fast_2w)(dim3, hipStream_t, PhysIO), bool (*mid_2w)(dim3, hipStream_t, PhysIO), bool (*wide)(dim3, hipStream_t, PhysIO),
-                               bool (*alone63)(dim3, hipStream_t, PhysIO)) {
+                               bool (*alone63)(dim3, hipStream_t, PhysIO), bool (*fast_2w_inplace)(dim3, hipStream_t, PhysIO) = nullptr) {
     /* a small batch stepping a few substeps per launch (somebody's control loop around a handful of envs): one launch instead of two
      * or three -- a launch costs what four substeps' difference between the kernels saves */
     if (fast && grid.x <= SMALL_BATCH && io.nsub <= SMALL_BATCH_NSUB) fast = false;
@@ -96,6 +99,23 @@ inline bool launch_three_tiers(dim3 grid, const TierGrids &tg, hipStream_t s, Ph
         else if (!(wide_caps ? wide : alone63)(grid, s, io)) return false;
         if (after_first) (void)hipEventRecord(after_first, s);
         return hipGetLastError() == hipSuccess;
+    }
+    /* Round 6: the fast kernel that finishes the substeps it cannot hold IN PLACE (the 63-row code inside the same workgroup): no
+     * list, no 63-row pass; with the wide caps the inner 63-row call hands on to the second list, which the 127-row pass walks.
+     * CASSIE_NO_INPLACE: the A/B switch back to the pass behind the kernel. */
+    static const bool no_inplace = measurement_switch("CASSIE_NO_INPLACE");
+    if (fast_2w && fast_2w_inplace && !no_inplace) {
+        io.resume = 0; io.has_next = 1;
+        io.handover_list = nullptr; io.handover_count = nullptr; io.handover_seen = nullptr;
+        io.handover_out_list = nullptr; io.handover_out_count = nullptr;
+        io.inplace_has_next = wide_caps ? 1 : 0;
+        io.inplace_out_list = wide_caps ? hl.list2 : nullptr; io.inplace_out_count = wide_caps ? hl.count2 : nullptr;
+        if (!fast_2w_inplace(chunked_grid(grid, io), s, io)) return false;
+        if (after_first) (void)hipEventRecord(after_first, s);
+        if (!wide_caps || skip_passes) return hipGetLastError() == hipSuccess;
+        io.resume = 1; io.nchunk = 1; io.has_next = 0; io.handover_out_list = nullptr; io.handover_out_count = nullptr;
+        io.handover_list = hl.list2; io.handover_count = hl.count2; io.handover_seen = hl.seen2;
+        return wide(tg.wide, s, io);
     }
     /* the fast kernel: every env of the launch (in chunks, perhaps) */
     const bool walk1 = mid_2w != nullptr;   /* (the one-wave form's 63-row pass looks every env's record up instead) */

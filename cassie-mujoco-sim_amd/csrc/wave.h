@@ -42,6 +42,8 @@ WV_DEVICE void wait_for(const int *flag, int value) {
     while (__builtin_amdgcn_readfirstlane(*(const volatile int *)flag) != value) __builtin_amdgcn_s_sleep(1);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
+/* every vector memory operation of this wave has completed (loads returned, stores acknowledged) */
+WV_DEVICE void drain_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 WV_DEVICE void block_barrier() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     __builtin_amdgcn_s_barrier();

@@ -210,6 +210,10 @@ static void body32s_2w_walk() { ck::cassie_step_kernel<32, ck::TopoCassie32, ck:
 static void body32s_wide() { ck::cassie_step_kernel<32, ck::TopoCassie32, ck::FEAT_ALL, ck::WIDE_ROWS, 2, false, 1>(g_io); }
 static void body32s_wide_walk() { ck::cassie_step_kernel<32, ck::TopoCassie32, ck::FEAT_ALL, ck::WIDE_ROWS, 2, true, 1>(g_io); }
 static void body32s_fast_2w() { ck::cassie_step_kernel<32, ck::TopoCassie32, ck::FEAT_ALL, ck::FAST_ROWS, 2>(g_io); }
+/* ... with the 63-row code behind it in the same kernel (cassie_step_kernel's INROWS): substeps it cannot hold are finished in place */
+static void body32s_fast_2w_inplace() { ck::cassie_step_kernel<32, ck::TopoCassie32, ck::FEAT_ALL, ck::FAST_ROWS, 2, false, 2, ck::MID_ROWS>(g_io); }
+static int g_inplace = 0;
+extern "C" void emu_inplace(int on) { g_inplace = on; }
 static void body40s_2w() { ck::cassie_step_kernel<40, ck::TopoCassieTray38, ck::FEAT_WAVEPAIRS, ck::MID_ROWS, 2>(g_io); } /* (no height-field pairs) */
 static int g_two_waves = 0, g_resume_grid = 2;
 extern "C" void emu_resume_grid(int n) { g_resume_grid = n > 0 ? n : 1; }
@@ -305,6 +309,12 @@ extern "C" int emu_phys_run(const cm_model_t *model, int nenv, int nsub, int int
         g_io.progress = progress; g_io.resume = 0; g_io.has_next = 1;
         g_io.handover_list = nullptr; g_io.handover_count = nullptr; g_io.handover_seen = nullptr;
         g_io.handover_out_list = list; g_io.handover_out_count = count;
+        /* the in-place form (cassie_step_kernel's INROWS): no first list, no 63-row pass; the inner 63-row call appends to the second list */
+        const bool inplace = g_inplace && cassie32 && g_two_waves;
+        if (inplace) {
+            g_io.handover_out_list = nullptr; g_io.handover_out_count = nullptr;
+            g_io.inplace_has_next = third ? 1 : 0; g_io.inplace_out_list = third ? list2 : nullptr; g_io.inplace_out_count = third ? count2 : nullptr;
+        }
         static int chunk_flag[1 << 16];
         const int nchunk = (g_chunks > 1 && nsub >= 2) ? g_chunks : 1;
         g_io.nchunk = nchunk; g_io.chunk_seq = ++g_chunk_seq; g_io.chunk_flag = chunk_flag; g_io.chunk_fault = &g_chunk_fault;
@@ -312,6 +322,7 @@ extern "C" int emu_phys_run(const cm_model_t *model, int nenv, int nsub, int int
         for (int wg = 0; wg < nenv * nchunk; ++wg) {
             g_env = wg;
             if (tray38) run_block(body40s_fast);
+            else if (inplace) run_block(body32s_fast_2w_inplace, 2);
             else if (g_two_waves) run_block(body32s_fast_2w, 2); else run_block(body32s_fast);
         }
         for (int e = 0; e < nenv; ++e) if (progress[e] < nsub) ++g_fast_bails;
@@ -321,12 +332,12 @@ extern "C" int emu_phys_run(const cm_model_t *model, int nenv, int nsub, int int
         g_io.handover_list = list; g_io.handover_count = count; g_io.handover_seen = &seen;
         g_io.handover_out_list = third ? list2 : nullptr; g_io.handover_out_count = third ? count2 : nullptr;
         g_grid = g_resume_grid;
-        for (int wg = 0; wg < g_resume_grid; ++wg) {
+        for (int wg = 0; wg < g_resume_grid && !inplace; ++wg) {
             g_env = wg;
             if (tray38) { if (g_two_waves) run_block(body40s_2w_walk, 2); else run_block(body40s_walk); }
             else if (g_two_waves) run_block(body32s_2w_walk, 2); else run_block(body32s_walk);
         }
-        if (count[0] != 0 || count[1] != 0 || seen != handed) { fprintf(stderr, "emu: the pass behind the fast kernel left count %d ticket %d seen %d (handed %d)\n", count[0], count[1], (int)seen, handed); abort(); }
+        if (!inplace && (count[0] != 0 || count[1] != 0 || seen != handed)) { fprintf(stderr, "emu: the pass behind the fast kernel left count %d ticket %d seen %d (handed %d)\n", count[0], count[1], (int)seen, handed); abort(); }
         if (third) {
             const int handed2 = count2[0];
             g_wide_envs += handed2;

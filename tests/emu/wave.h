@@ -34,6 +34,7 @@ inline int atomic_add(int *p, int v) { const int old = *p; *p = old + v; return 
 inline int atomic_or(int *p, int v) { const int old = *p; *p = old | v; return old; }
 void sync();
 void block_barrier();
+inline void drain_vmem() {}
 void spin_yield();
 inline void publish(int *flag, int value) { sync(); if (lane() == 0) *flag = value; sync(); }
 int shfl_i(int v, int src_lane);

@@ -620,3 +620,48 @@ def test_guarded_sweeps_across_both_waves_reproduce_the_fast_ones(cassie):
     assert a.info[0, 1] > 64 and a.info[0, 3] == 0 and b.info[0, 3] > 0
     assert tuple(a.info[0, :3]) == tuple(b.info[0, :3])
     assert np.abs(a.qpos - b.qpos).max() < 1e-11 and np.abs(a.qvel - b.qvel).max() < 1e-9
+
+
+# ---- round 6: the fast kernel that finishes the substeps it cannot hold in place (cassie_step_kernel's INROWS) ----
+@pytest.mark.parametrize("drive", [False, True])
+def test_in_place_form_equals_the_pass_behind_the_kernel_bit_for_bit(cassie, drive):
+    """A substep that needs more than 31 rows is run by the 63-row code INSIDE the fast kernel's workgroup, and the env returns to the
+    fast code for the next one -- instead of taking all its remaining substeps to the list-walking pass.  Every substep is computed by
+    the same instructions either way, so everything a launch leaves must be identical: under the stress targets (hand-overs in the
+    middle of fused launches), all three wave schedules, NaN-poisoned LDS, and with the launch in chunks."""
+    import emu_py
+    lib = emu_py.lib()
+    ref, rows, bails0 = _two_wave_workload(cassie, drive, fast=True, two_waves=True, schedule=0)
+    assert rows[:, :, 1].max() > 31, "the workload never left the 31-row tier"
+    for schedule, chunks in ((0, 1), (1, 1), (2, 1), (1, 3)):
+        lib.emu_inplace(1); lib.emu_chunks(chunks)
+        try:
+            got, _, _ = _two_wave_workload(cassie, drive, fast=True, two_waves=True, schedule=schedule, poison=True)
+        finally:
+            lib.emu_inplace(0); lib.emu_chunks(1)
+        assert got == ref, (schedule, chunks)
+    # ... and the one-wave form of the full kernel alone agrees too (the yardstick of every form)
+    alone, _, _ = _two_wave_workload(cassie, drive, fast=False, two_waves=False, schedule=0)
+    assert alone == ref
+
+
+def test_in_place_form_hands_on_to_the_127_row_pass(built):
+    """With the wide caps (CM_FLAG_HFPRISM) the in-place 63-row call hands a substep of more than 63 rows on to the second list, which
+    the 127-row pass walks: same results as the 127-row instantiation alone."""
+    from cassie_amd import Model
+    from cassie_amd import phys as P
+    import emu_py
+    lib = emu_py.lib()
+    model = Model("cassie_hfield")
+    model.set_flag(P.FLAG_HFPRISM, True)
+    ref, rows, _ = _two_wave_workload(model, True, fast=False, two_waves=True, schedule=0, nlaunch=3, nsub=12, stress=False)
+    assert rows[:, :, 1].max() > 63 and rows[:, :, 1].min() <= 31
+    for schedule, chunks in ((0, 1), (2, 3)):
+        before = lib.emu_wide_envs()
+        lib.emu_inplace(1); lib.emu_chunks(chunks); lib.emu_resume_grid((2, 1, 3)[schedule])
+        try:
+            got, _, _ = _two_wave_workload(model, True, fast=True, two_waves=True, schedule=schedule, poison=True, nlaunch=3, nsub=12, stress=False)
+        finally:
+            lib.emu_inplace(0); lib.emu_chunks(1); lib.emu_resume_grid(2)
+        assert lib.emu_wide_envs() > before, "no env reached the 127-row pass"
+        assert got == ref, (schedule, chunks)

@@ -12,9 +12,9 @@ cat > $T/one.hip <<EOS
 #include "wave.h"
 #include "physics_kernel.h"
 #include "topo_static.h"
-template __global__ void ck::cassie_step_kernel<${NVP:-32}, ck::${TOPO:-TopoCassie32}, ${FEAT:-0}, $MAXR, ${NW:-1}, ${WALK:-false}, ${WPS:-${NW:-1}}>(ck::PhysIO);
+template __global__ void ck::cassie_step_kernel<${NVP:-32}, ck::${TOPO:-TopoCassie32}, ${FEAT:-0}, $MAXR, ${NW:-1}, ${WALK:-false}, ${WPS:-${NW:-1}}${INROWS:+, $INROWS}>(ck::PhysIO);
 EOS
-echo "cassie_step_kernel<${NVP:-32}, ${TOPO:-TopoCassie32}, FEAT=${FEAT:-0}, MAXR=$MAXR, NW=${NW:-1}, WALK=${WALK:-false}, WPS=${WPS:-${NW:-1}}>:"
+echo "cassie_step_kernel<${NVP:-32}, ${TOPO:-TopoCassie32}, FEAT=${FEAT:-0}, MAXR=$MAXR, NW=${NW:-1}, WALK=${WALK:-false}, WPS=${WPS:-${NW:-1}}${INROWS:+, INROWS=$INROWS}>:"
 /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 --offload-device-only -Iinclude -Icassie-mujoco-sim_amd/csrc \
   -ffp-contract=on ${SCHED--mllvm -amdgpu-sched-strategy=iterative-ilp} ${LICM--mllvm -disable-machine-licm} $EXTRA -Rpass-analysis=kernel-resource-usage ${KEEP:+-save-temps=obj} -c $T/one.hip -o $T/one.o 2>&1 |
   grep -E "VGPRs:|AGPRs|Spill|ScratchSize|Occupancy|LDS Size|SGPRs:" | sed 's/.*remark: *//; s/ \[-Rpass.*//' | tail -8 | sed 's/^/    /'
