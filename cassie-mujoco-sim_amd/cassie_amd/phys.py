@@ -295,6 +295,16 @@ class Batch:
         """Row-capped fast kernel ahead of the full one (default on; results are bit for bit the same either way)."""
         lib().phys_batch_set_fast_rows(self._h, 1 if on else 0)
 
+    def set_inplace(self, mode=2):
+        """Form of the two-wave fast kernel: 0 = kernel + list-walking pass, 1 = finishes the substeps it cannot hold in place,
+        2 = per env range by what its recent launches needed (default).  Same results bit for bit."""
+        if lib().phys_batch_set_inplace(self._h, int(mode)) != 0:
+            raise ValueError("in-place mode: 0, 1 or 2")
+
+    def inplace_ranges(self):
+        """Diagnostics: env ranges whose next stepping launch takes the in-place form of the fast kernel."""
+        return lib().phys_batch_debug_inplace_ranges(self._h)
+
     def set_waves_per_env(self, waves=2):
         """Two-wave form of the fast kernels (default 2; results are bit for bit the same either way)."""
         if lib().phys_batch_set_waves_per_env(self._h, int(waves)) != 0:

@@ -97,6 +97,15 @@ struct phys_batch {
     int *d_handover_list2 = nullptr, *d_handover_count2 = nullptr;
     int *h_handover_seen2 = nullptr, *d_handover_seen2 = nullptr;
     bool fast_rows = true;          /* use the row-capped fast instantiation where one exists (phys_batch_set_fast_rows) */
+    /* Which form of the two-wave fast kernel a range's launches take (phys_batch_set_inplace): 0 = the kernel + the list-walking pass
+     * behind it, 1 = the kernel that finishes the substeps it cannot hold in place, 2 (default) = per range by what its recent launches
+     * needed.  The in-place form costs the default workload 1.8 % (both codes share one register allocation) and gains 8 - 24 % where
+     * envs leave the fast tier at all (profiles/round6/inplace_ab.txt): a range switches to it when its last launch handed envs over
+     * and back after INPLACE_QUIET launches in which no env needed the wider code.  h_handover_seen[env0] is the signal in both forms
+     * (the pass reports the list's length; in the in-place form the order kernel reports the kernel's count). */
+    int inplace_mode = 2;
+    struct RangeForm { int env0; bool inplace; int quiet; };
+    std::vector<RangeForm> range_forms;
     int waves_per_env = 2;          /* two-wave form of the fast instantiations (phys_batch_set_waves_per_env) */
     int waves_per_env_tray = DEFAULT_TRAY_WAVES; /* ... of the 40-dof instantiations (CASSIE_TRAY_TWO_WAVES=0/1 overrides the default: A/B aid) */
     double *d_scratch_out = nullptr; /* [nenv][nv + nsensordata + nu]: where phys_batch_forward_kinematics sends qacc / sensordata / actuator_velocity */
@@ -270,14 +279,34 @@ static int launch(phys_batch *b, int nsub, int integrate, hipStream_t s, bool sc
             tg.wide = dim3((unsigned)(want2 < n ? want2 : n));
         }
     };
+    bool inplace_launch = false;
     if (matches(ck::TopoCassie32::table, ck::TopoCassie32::nv, ck::TopoCassie32::body_levels)) {
         /* stepping launches of the two Cassie instantiations go through the row-capped fast instantiation first; the 63-row pass
          * behind it finishes the envs that met a substep with more rows, and -- for a model with the wide caps (CM_FLAG_HFPRISM) -- the
          * 127-row pass behind that one what is left; forward / read-out passes and small batches take one instantiation alone */
         const bool fast = b->fast_rows && integrate && !wp && !io.ext && b->d_progress;
         tiers(fast);
-        if (!hf && !wp) { launched = ck::launch_step_cassie(grid, tg, s, io, hl, fast, hm.maxefc > CM_MAXEFC_NARROW, ev_after, b->waves_per_env); ev_after = nullptr; }
-        else if (hf && !wp) { launched = ck::launch_step_cassie_hfield(grid, tg, s, io, hl, fast, hm.maxefc > CM_MAXEFC_NARROW, ev_after, b->waves_per_env); ev_after = nullptr; }
+        if (fast && hl.list1 && b->waves_per_env == 2 && !wp) {
+            /* the form of this range's fast kernel (see phys_batch::inplace_mode) */
+            constexpr int INPLACE_QUIET = 8;
+            phys_batch::RangeForm *rf = nullptr;
+            for (auto &r : b->range_forms) if (r.env0 == env0) rf = &r;
+            if (!rf) { b->range_forms.push_back({env0, false, 0}); rf = &b->range_forms.back(); }
+            const bool was = rf->inplace;
+            const int seen = b->h_handover_seen[env0];
+            if (b->inplace_mode != 2 || !(io.order && seg)) rf->inplace = b->inplace_mode == 1;   /* (auto needs the order kernel: it reports the in-place count) */
+            else if (!rf->inplace) { if (seen > 0) { rf->inplace = true; rf->quiet = 0; } }
+            else if (seen > 0) rf->quiet = 0;
+            else if (++rf->quiet >= INPLACE_QUIET) rf->inplace = false;
+            if (was != rf->inplace) {
+                /* the first list's count word changes its meaning with the form: start the new form from zero (stream-ordered) */
+                (void)hipMemsetAsync(hl.count1, 0, 2 * sizeof(int), s);
+                b->h_handover_seen[env0] = 0;
+            }
+            inplace_launch = rf->inplace;
+        }
+        if (!hf && !wp) { launched = ck::launch_step_cassie(grid, tg, s, io, hl, fast, hm.maxefc > CM_MAXEFC_NARROW, ev_after, b->waves_per_env, inplace_launch); ev_after = nullptr; }
+        else if (hf && !wp) { launched = ck::launch_step_cassie_hfield(grid, tg, s, io, hl, fast, hm.maxefc > CM_MAXEFC_NARROW, ev_after, b->waves_per_env, inplace_launch); ev_after = nullptr; }
         else launched = ck::launch_step_cassie_all(grid, s, io);
     } else if (matches(ck::TopoCassieTray38::table, ck::TopoCassieTray38::nv, ck::TopoCassieTray38::body_levels)) {
         /* the 40-dof model: a fast instantiation of 47 rows (the boxes resting on the tray take it to 32 .. 40 routinely) -- one wave
@@ -295,7 +324,8 @@ static int launch(phys_batch *b, int nsub, int integrate, hipStream_t s, bool sc
     /* the next launch's order from this one's per-env cost: after every long launch, now and then after short ones */
     if (io.order && integrate && (nsub >= 8 || ++seg->launches_since_sort >= 16)) {
         seg->launches_since_sort = 0;
-        hipLaunchKernelGGL(ck::cassie_order_kernel, dim3(1), dim3(ck::ORDER_THREADS), 0, s, b->d_cost, b->d_order, n, env0);
+        hipLaunchKernelGGL(ck::cassie_order_kernel, dim3(1), dim3(ck::ORDER_THREADS), 0, s, b->d_cost, b->d_order, n, env0,
+                           inplace_launch ? hl.count1 : (int *)nullptr, inplace_launch ? hl.seen1 : (volatile int *)nullptr);
         if (!hip_ok(hipGetLastError(), "cassie_order_kernel launch")) return -1;
     }
     return 0;
@@ -949,6 +979,19 @@ int phys_batch_kernel_timing(phys_batch_t *b, int *launches, double *total_ms) {
 int phys_batch_set_fast_rows(phys_batch_t *b, int on) {
     if (!b) return -1;
     b->fast_rows = on != 0;
+    return 0;
+}
+
+int phys_batch_debug_inplace_ranges(const phys_batch_t *b) {
+    if (!b) return -1;
+    int k = 0;
+    for (const auto &r : b->range_forms) k += r.inplace ? 1 : 0;
+    return k;
+}
+
+int phys_batch_set_inplace(phys_batch_t *b, int mode) {
+    if (!b || mode < 0 || mode > 2) return -1;
+    b->inplace_mode = mode;
     return 0;
 }
 

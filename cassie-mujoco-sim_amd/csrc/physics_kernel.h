@@ -696,6 +696,7 @@ WV_GLOBAL void __launch_bounds__(WV_WAVE * NW) WV_OCC WV_WAVES_PER_SIMD(WPS) cas
         auto &S2 = reinterpret_cast<EnvShared<NVP, LPack<TOPO, NVP>::count, INROWS> &>(S);
         PhysIO io2 = io;            /* what the substep's inner call sees: it hands on (if at all) to the 127-row pass's list */
         io2.has_next = io.inplace_has_next; io2.handover_out_list = io.inplace_out_list; io2.handover_out_count = io.inplace_out_count;
+        bool did = false;
         for (int s = sub_start;;) {
             int at = env_step<NVP, TOPO, FEAT, MAXR, NW>(io, S, env, s, sub_end);
             /* (wave 0 knows where the call ended; both waves' stores of the state are out before either loads it again) */
@@ -703,6 +704,7 @@ WV_GLOBAL void __launch_bounds__(WV_WAVE * NW) WV_OCC WV_WAVES_PER_SIMD(WPS) cas
             wv::drain_vmem(); wv::block_barrier();
             at = wv::opaque(S.cmd[5]);
             if (at < 0 || at >= sub_end) break;                 /* done (or the state diverged: flagged, left alone) */
+            did = true;
             int at2 = env_step<NVP, TOPO, FEAT, INROWS, NW>(io2, S2, env, at, at + 1);
             if (wv::lane() == 0 && wv::wave_id() == 0) S.cmd[5] = at2;
             wv::drain_vmem(); wv::block_barrier();
@@ -710,6 +712,7 @@ WV_GLOBAL void __launch_bounds__(WV_WAVE * NW) WV_OCC WV_WAVES_PER_SIMD(WPS) cas
             if (at2 != at + 1 || at + 1 >= sub_end) break;      /* handed on to the 127-row pass (or diverged), or that was the last substep */
             s = at + 1;
         }
+        if (did && io.inplace_count && wv::lane() == 0 && wv::wave_id() == 0) wv::atomic_add(io.inplace_count, 1);
     } else env_step<NVP, TOPO, FEAT, MAXR, NW>(io, S, env, sub_start, sub_end);
     if (sub_end < io.nsub) wv::publish_global<NW>(io.chunk_flag + env, io.chunk_seq, chunk + 1);
     if (io.prof && wv::lane() == 0) io.prof[(size_t)env * NSTAMP + 40 + (NW == 2 ? wv::wave_id() : 0)] = wv::hw_id(); /* (profiling aid: the CU / SIMD of the wave) */

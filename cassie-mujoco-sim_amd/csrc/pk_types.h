@@ -120,6 +120,8 @@ struct PhysIO {
      * caps) and the list it walks. */
     int inplace_has_next;
     int *inplace_out_list, *inplace_out_count;
+    int *inplace_count;         /* (may be null) device word: += 1 per env-launch (chunk) that finished a substep in place -- the launcher's
+                                   signal for which form of the fast kernel the range's next launches take (phys_batch.hip) */
 };
 
 /* MAXR: constraint rows this instantiation can hold (WIDE_ROWS, MID_ROWS, or fewer in the row-capped fast instantiations, see

@@ -20,10 +20,13 @@ namespace ck {
  * but 0.8 KB of a CU's LDS) a workgroup is dispatched only when a wave slot frees, and a 1024-thread workgroup only when a
  * whole CU does -- which, measured, took milliseconds and stalled the launching stream (round 3, two-stream stepping) */
 constexpr int ORDER_THREADS = 64, ORDER_NBIN = 256;
-WV_GLOBAL void __launch_bounds__(ORDER_THREADS) cassie_order_kernel(const unsigned *cost, int *order, int nenv, int base) {
+WV_GLOBAL void __launch_bounds__(ORDER_THREADS) cassie_order_kernel(const unsigned *cost, int *order, int nenv, int base, int *inplace_count, volatile int *inplace_seen) {
     /* sorts the env range [base, base + nenv): cost / order are indexed by the absolute env, the order entries are absolute */
     cost += base; order += base;
 #ifndef CK_EMULATED
+    /* (round 6: the kernel that runs behind every stepping launch of a range also reports, through host memory, how many env-launches
+     * of the in-place fast kernel finished a substep in place since the last report -- the launcher picks the range's next form by it) */
+    if (inplace_count && threadIdx.x == 0) { *inplace_seen = *inplace_count; *inplace_count = 0; }
     __shared__ unsigned lo_s, hi_s, count[ORDER_NBIN], start[ORDER_NBIN];
     const int t = threadIdx.x;
     if (t == 0) { lo_s = 0xffffffffu; hi_s = 0; }

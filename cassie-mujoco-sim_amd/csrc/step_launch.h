@@ -28,8 +28,9 @@ struct TierGrids { dim3 mid, wide; };   /* grids of the passes behind the fast k
 /* io.progress must be set when fast is; io.resume / has_next / the hand-over lists are managed here */
 /* after_first (may be null): recorded behind the first kernel of the launch -- the one that does the work -- for per-kernel timing */
 /* waves: 2 = the row-capped fast instantiation in its two-wave form (two wavefronts per env, see env_step), 1 = one wave per env */
-bool launch_step_cassie(dim3 grid, const TierGrids &tg, hipStream_t s, PhysIO io, const HandoverLists &hl, bool fast, bool wide_caps, hipEvent_t after_first, int waves);            /* <32, TopoCassie32, 0>: plain cassie.xml */
-bool launch_step_cassie_hfield(dim3 grid, const TierGrids &tg, hipStream_t s, PhysIO io, const HandoverLists &hl, bool fast, bool wide_caps, hipEvent_t after_first, int waves);     /* <32, TopoCassie32, FEAT_HFIELD> */
+/* inplace: the fast kernel in the form that finishes the substeps it cannot hold inside its own workgroups (kernels_*_2w_inplace.hip) */
+bool launch_step_cassie(dim3 grid, const TierGrids &tg, hipStream_t s, PhysIO io, const HandoverLists &hl, bool fast, bool wide_caps, hipEvent_t after_first, int waves, bool inplace);            /* <32, TopoCassie32, 0>: plain cassie.xml */
+bool launch_step_cassie_hfield(dim3 grid, const TierGrids &tg, hipStream_t s, PhysIO io, const HandoverLists &hl, bool fast, bool wide_caps, hipEvent_t after_first, int waves, bool inplace);     /* <32, TopoCassie32, FEAT_HFIELD> */
 /* the two-wave forms of the fast instantiations, in translation units of their own (kernels_*_2w.hip) */
 bool launch_fast_cassie_2w(dim3 grid, hipStream_t s, PhysIO io);
 bool launch_fast_cassie_hfield_2w(dim3 grid, hipStream_t s, PhysIO io);
@@ -102,10 +103,10 @@ inline bool launch_three_tiers(dim3 grid, const TierGrids &tg, hipStream_t s, Ph
     }
     /* Round 6: the fast kernel that finishes the substeps it cannot hold IN PLACE (the 63-row code inside the same workgroup): no
      * list, no 63-row pass; with the wide caps the inner 63-row call hands on to the second list, which the 127-row pass walks.
-     * CASSIE_NO_INPLACE: the A/B switch back to the pass behind the kernel. */
-    static const bool no_inplace = measurement_switch("CASSIE_NO_INPLACE");
-    if (fast_2w && fast_2w_inplace && !no_inplace) {
+     * The caller (phys_batch.hip) picks this form per env range and launch: see phys_batch_set_inplace. */
+    if (fast_2w && fast_2w_inplace) {
         io.resume = 0; io.has_next = 1;
+        io.inplace_count = hl.count1;       /* (the first list's count word is free in this form: it counts the env-launches that needed the wider code) */
         io.handover_list = nullptr; io.handover_count = nullptr; io.handover_seen = nullptr;
         io.handover_out_list = nullptr; io.handover_out_count = nullptr;
         io.inplace_has_next = wide_caps ? 1 : 0;

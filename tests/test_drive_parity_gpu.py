@@ -275,10 +275,11 @@ def test_row_capped_fast_kernel_equals_the_full_kernel_bit_for_bit(built, name, 
         for e in range(n):
             q0[e, 0], q0[e, 1] = G.start_xy(name, e)
     out = []
-    for fast in (False, True):
+    for fast in (False, True, "in place"):      # (round 6: ... and the fast kernel that finishes such substeps in place)
         b = Batch(model, n)
         try:
-            b.set_fast_rows(fast)
+            b.set_fast_rows(bool(fast))
+            b.set_inplace(1 if fast == "in place" else 0)
             if hf is not None:
                 b.set_hfield(hf)
             b.set(P.F_QPOS, q0)
@@ -294,7 +295,7 @@ def test_row_capped_fast_kernel_equals_the_full_kernel_bit_for_bit(built, name, 
                 b.set(P.F_PD_PTARGET, tg[p])
                 b.step(bench.HOLD)
                 rows.append(b.warnings()[1][:, 1].copy())
-                if fast:
+                if fast is True:
                     handed += int(np.count_nonzero(b.fast_rows_progress() < bench.HOLD))
             w, info = b.warnings()
             rec = [b.get(P.F_QPOS), b.get(P.F_QVEL), b.get(P.F_QACC_WARMSTART), b.get(P.F_SENSORDATA), b.get(P.F_TIME), w, info[:, :3].copy(), np.array(rows)]
@@ -309,8 +310,8 @@ def test_row_capped_fast_kernel_equals_the_full_kernel_bit_for_bit(built, name, 
         assert handed < n * npol // 2
     else:
         assert 50 < handed < n * npol // 2             # the hand-over happened often, and most launches stayed in the fast kernel
-    for a, c in zip(out[0], out[1]):
-        assert a.tobytes() == c.tobytes()
+    for a, c, d in zip(out[0], out[1], out[2]):
+        assert a.tobytes() == c.tobytes() and a.tobytes() == d.tobytes()
 
 
 @pytest.mark.parametrize("name", ["cassie", "cassie_hfield", "cassie_tray_box"])
@@ -385,11 +386,12 @@ def test_launch_in_chunks_equals_the_launch_in_one_piece_bit_for_bit(built, name
             q0[e, 0], q0[e, 1] = G.start_xy(name, e)
     streams = [torch.cuda.Stream(), torch.cuda.Stream()]
     out = []
-    for chunks in (1, 4, 3):
+    for chunks, inplace in ((1, 0), (4, 0), (3, 0), (4, 1), (2, 2)):   # (round 6: ... the in-place form of the fast kernel in chunks, and the form picked per range)
         b = Batch(model, n)
         try:
             b.set_waves_per_env(waves)
             b.set_chunks(chunks)
+            b.set_inplace(inplace)
             if hf is not None:
                 b.set_hfield(hf)
             b.set(P.F_QPOS, q0)
@@ -419,9 +421,11 @@ def test_launch_in_chunks_equals_the_launch_in_one_piece_bit_for_bit(built, name
             b.close()
     print("%s, %d wave(s): %s env-launches handed over (1 / 4 / 3 chunks)" % (name, waves, [o[1] for o in out]))
     assert out[0][1] == out[1][1] == out[2][1]
+    if name != "cassie_tray_box" and waves == 2:
+        assert out[3][1] == 0 and out[4][1] < out[0][1]     # (in place nothing is handed over; the per-range choice went in place once envs were)
     if name != "cassie_tray_box":
         assert out[0][1] > 3     # (round 6: the verdict counts a frictionless contact as one row -- 6 env-launches of this workload on cassie.xml, 30 in round 5; cassie_hfield hands over far more)
-    for k in (1, 2):
+    for k in (1, 2, 3, 4):
         for a, c in zip(out[0][0], out[k][0]):
             assert a.tobytes() == c.tobytes(), k
 
@@ -592,3 +596,43 @@ def test_launch_order_survives_a_change_of_the_range_partition(cassie):
     for other in (halves_after_whole, straddling):
         for a, c in zip(whole, other):
             assert a.tobytes() == c.tobytes()
+
+
+def test_fast_kernel_form_follows_what_the_range_needs(built):
+    """phys_batch_set_inplace(2), the default: a range whose launch handed envs over takes the in-place form of the fast kernel from the
+    next launch on, and goes back to the plain form after eight launches in which no env left the fast tier -- with the same bits as the
+    plain form throughout (the choice is about time only)."""
+    model = Model("cassie")
+    n = 4096
+    out = []
+    for mode in (0, 2):
+        b = Batch(model, n)
+        try:
+            b.set_inplace(mode)
+            b.set(P.F_QPOS, np.tile(model.qpos_init(), (n, 1)))
+            b.set(P.F_PD_KP, np.tile(bench.PD_KP, (n, 1)))
+            b.set(P.F_PD_KD, np.tile(bench.PD_KD, (n, 1)))
+            b.forward()
+            b.set_drive_mode(P.DRIVE_PD)
+            forms = []
+            tg = _stress_targets(np.arange(n), 12)
+            for p in range(12):                                   # joints slammed into their limits: envs leave the 31-row tier
+                b.set(P.F_PD_PTARGET, tg[p]); b.step(bench.HOLD); b.sync()
+                forms.append(b.inplace_ranges())
+            # every env back on its feet (what a fresh cassie_sim_t is), gentle targets
+            b.set(P.F_QPOS, np.tile(model.qpos_init(), (n, 1))); b.set(P.F_QVEL, np.zeros((n, model.pod.nv))); b.set(P.F_QACC_WARMSTART, np.zeros((n, model.pod.nv)))
+            b.set(P.F_MEAS, np.zeros((n, P.MEAS_DIM))); b.clear_drive_state(); b.sync()
+            b.set_drive_mode(P.DRIVE_OFF); b.forward(); b.set_drive_mode(P.DRIVE_PD)
+            gentle = bench.pd_targets(np.arange(n), 14)
+            for p in range(14):
+                b.set(P.F_PD_PTARGET, gentle[p]); b.step(bench.HOLD); b.sync()
+                forms.append(b.inplace_ranges())
+            out.append((forms, [b.get(P.F_QPOS), b.get(P.F_QVEL), b.get(P.F_SENSORDATA), b.get(P.F_MEAS), b.warnings()[1][:, :3].copy()]))
+        finally:
+            b.close()
+    assert not any(out[0][0])                                      # mode 0 never goes in place
+    forms = out[1][0]
+    assert forms[0] == 0 and max(forms[:12]) == 1 and forms[11] == 1, forms   # in place from the launch after the first hand-over
+    assert forms[-1] == 0, forms                                     # ... and plain again once the range has been quiet
+    for a, c in zip(out[0][1], out[1][1]):
+        assert a.tobytes() == c.tobytes()
