@@ -100,11 +100,12 @@ struct phys_batch {
     /* Which form of the two-wave fast kernel a range's launches take (phys_batch_set_inplace): 0 = the kernel + the list-walking pass
      * behind it, 1 = the kernel that finishes the substeps it cannot hold in place, 2 (default) = per range by what its recent launches
      * needed.  The in-place form costs the default workload 1.8 % (both codes share one register allocation) and gains 8 - 24 % where
-     * envs leave the fast tier at all (profiles/round6/inplace_ab.txt): a range switches to it when its last launch handed envs over
-     * and back after INPLACE_QUIET launches in which no env needed the wider code.  h_handover_seen[env0] is the signal in both forms
-     * (the pass reports the list's length; in the in-place form the order kernel reports the kernel's count). */
+     * envs leave the fast tier at all (profiles/round6/inplace_ab.txt): a range switches to it once a launch handed envs over
+     * and back after INPLACE_QUIET reports in a row in which no env needed the wider code.  h_handover_seen[env0] is the signal in both
+     * forms (the pass reports the list's length; in the in-place form the order kernel reports the kernel's count, or the run of
+     * reports without one -- counted on the device, in stream order, because the launcher may run far ahead of it). */
     int inplace_mode = 2;
-    struct RangeForm { int env0; bool inplace; int quiet; };
+    struct RangeForm { int env0; bool inplace; };
     std::vector<RangeForm> range_forms;
     int waves_per_env = 2;          /* two-wave form of the fast instantiations (phys_batch_set_waves_per_env) */
     int waves_per_env_tray = DEFAULT_TRAY_WAVES; /* ... of the 40-dof instantiations (CASSIE_TRAY_TWO_WAVES=0/1 overrides the default: A/B aid) */
@@ -291,13 +292,14 @@ static int launch(phys_batch *b, int nsub, int integrate, hipStream_t s, bool sc
             constexpr int INPLACE_QUIET = 8;
             phys_batch::RangeForm *rf = nullptr;
             for (auto &r : b->range_forms) if (r.env0 == env0) rf = &r;
-            if (!rf) { b->range_forms.push_back({env0, false, 0}); rf = &b->range_forms.back(); }
+            if (!rf) { b->range_forms.push_back({env0, false}); rf = &b->range_forms.back(); }
             const bool was = rf->inplace;
-            const int seen = b->h_handover_seen[env0];
+            /* the range's word in host memory: > 0 = env-launches the last reporting launch handed over (plain form: the pass behind the
+             * kernel writes it) or finished in place (the order kernel does); -k = the last k reports of the in-place form had none */
+            const int seen = *(volatile int *)(b->h_handover_seen + env0);
             if (b->inplace_mode != 2 || !(io.order && seg)) rf->inplace = b->inplace_mode == 1;   /* (auto needs the order kernel: it reports the in-place count) */
-            else if (!rf->inplace) { if (seen > 0) { rf->inplace = true; rf->quiet = 0; } }
-            else if (seen > 0) rf->quiet = 0;
-            else if (++rf->quiet >= INPLACE_QUIET) rf->inplace = false;
+            else if (!rf->inplace) { if (seen > 0) rf->inplace = true; }
+            else if (seen <= -INPLACE_QUIET) rf->inplace = false;
             if (was != rf->inplace) {
                 /* the first list's count word changes its meaning with the form: start the new form from zero (stream-ordered) */
                 (void)hipMemsetAsync(hl.count1, 0, 2 * sizeof(int), s);
@@ -1037,6 +1039,9 @@ int phys_batch_debug_handover_pending(phys_batch_t *b) {
     for (int *d : {b->d_handover_count, b->d_handover_count2}) {
         if (!d) continue;
         if (!hip_ok(hipMemcpy(h.data(), d, sizeof(int) * h.size(), hipMemcpyDeviceToHost), "hand-over count download")) return -1;
+        /* (a range in the in-place form keeps other things in its first list's words: the in-place count since the order kernel's last
+         * report and the run of quiet reports) */
+        if (d == b->d_handover_count) for (const auto &r : b->range_forms) if (r.inplace) h[2 * (size_t)r.env0] = h[2 * (size_t)r.env0 + 1] = 0;
         for (int v : h) total += v < 0 ? -(long)v : v;
     }
     return total > 0x7fffffff ? 0x7fffffff : (int)total;

@@ -24,9 +24,15 @@ WV_GLOBAL void __launch_bounds__(ORDER_THREADS) cassie_order_kernel(const unsign
     /* sorts the env range [base, base + nenv): cost / order are indexed by the absolute env, the order entries are absolute */
     cost += base; order += base;
 #ifndef CK_EMULATED
-    /* (round 6: the kernel that runs behind every stepping launch of a range also reports, through host memory, how many env-launches
-     * of the in-place fast kernel finished a substep in place since the last report -- the launcher picks the range's next form by it) */
-    if (inplace_count && threadIdx.x == 0) { *inplace_seen = *inplace_count; *inplace_count = 0; }
+    /* (round 6: the kernel that runs behind the stepping launches of a range also reports, through host memory, how many env-launches
+     * of the in-place fast kernel finished a substep in place since the last report -- or, negated, how many reports in a row had none:
+     * the launcher picks the range's next form by it.  The run length is counted HERE, in stream order: the launcher may be hundreds
+     * of launches ahead of the device and would count the same stale word again and again) */
+    if (inplace_count && threadIdx.x == 0) {
+        const int c = inplace_count[0], quiet = c > 0 ? 0 : inplace_count[1] + 1;
+        inplace_count[0] = 0; inplace_count[1] = quiet;
+        *inplace_seen = c > 0 ? c : -quiet;
+    }
     __shared__ unsigned lo_s, hi_s, count[ORDER_NBIN], start[ORDER_NBIN];
     const int t = threadIdx.x;
     if (t == 0) { lo_s = 0xffffffffu; hi_s = 0; }

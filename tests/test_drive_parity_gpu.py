@@ -274,7 +274,7 @@ def test_row_capped_fast_kernel_equals_the_full_kernel_bit_for_bit(built, name, 
     if name == "cassie_hfield":
         for e in range(n):
             q0[e, 0], q0[e, 1] = G.start_xy(name, e)
-    out = []
+    out, handed = [], 0
     for fast in (False, True, "in place"):      # (round 6: ... and the fast kernel that finishes such substeps in place)
         b = Batch(model, n)
         try:
@@ -290,7 +290,7 @@ def test_row_capped_fast_kernel_equals_the_full_kernel_bit_for_bit(built, name, 
                 b.set_drive_mode(P.DRIVE_PD)
             else:
                 b.set_pd_mode(True)
-            rows, handed = [], 0
+            rows = []
             for p in range(npol):
                 b.set(P.F_PD_PTARGET, tg[p])
                 b.step(bench.HOLD)
