@@ -544,6 +544,8 @@ def device_rollout(model, mode, n, steps, warmup, rank, world, local_rank, subst
         b.set_fast_rows(False)          # A/B switch: the full step kernel alone (the row-capped fast kernel)
     if os.environ.get("CASSIE_WAVES_PER_ENV"):
         b.set_waves_per_env(int(os.environ["CASSIE_WAVES_PER_ENV"]))   # A/B switch: one wave per env instead of two
+    if os.environ.get("CASSIE_FAST_KERNEL_FORM"):
+        b.set_inplace({"plain": 0, "in-place": 1, "auto": 2}[os.environ["CASSIE_FAST_KERNEL_FORM"]])   # A/B switch (the in-place form)
     if os.environ.get("CASSIE_NO_BALANCE"):
         b.set_balance(False)            # A/B switch for the longest-job-first launch order
     if hfield is not None:
@@ -691,6 +693,7 @@ def device_rollout(model, mode, n, steps, warmup, rank, world, local_rank, subst
     res["frac_envs_handed_over_last_launch"] = None if np.isnan(stats[4]) else float(stats[4] / (world * n))
     # what the last launch cost an env, first to last instruction, in shader clocks per substep (phys_batch_download_cost: batches
     # that keep a launch order) -> how full the GPU's workgroup slots were over the timed regions, see main()
+    res["fast_kernel_launches_plain_in_place"] = list(b.form_launches())
     try:
         res["wide_pass_envs_last_launch"] = sum(b.wide_pass_envs(first) for first, _ in ranges) if hasattr(b, "wide_pass_envs") else None
         res["env_clocks_per_substep"] = float(np.mean(b.launch_cost())) / max(1, last_launch["nsub"])
@@ -988,6 +991,8 @@ def main(argv=None):
             **({"obs_allgather_ok": r.get("gather_ok")} if collect else {}),   # rank 0's rows of the last gathered block = its snapshot
             "frac_envs_handed_over_to_the_full_kernel_in_the_last_launch": r["frac_envs_handed_over_last_launch"],
             # ... and of those, the envs the 63-row pass passed on to the 127-row instantiation (rank 0's batch)
+            # stepping launches of rank 0's batch by the form of the fast kernel (phys_batch_set_inplace: picked per env range)
+            "fast_kernel_launches_plain_in_place": r.get("fast_kernel_launches_plain_in_place"),
             "frac_envs_in_the_127_row_pass_in_the_last_launch": (r.get("wide_pass_envs_last_launch") / float(n)) if r.get("wide_pass_envs_last_launch") is not None else None,
             "mean_constraint_rows": r["mean_constraint_rows"], "mean_pgs_iterations": r["mean_pgs_iterations"], "mean_pgs_guarded_sweeps": r["mean_pgs_guarded_sweeps"],
         }

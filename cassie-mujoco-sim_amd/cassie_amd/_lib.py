@@ -106,9 +106,9 @@ def _declare(L):
     L.phys_batch_set_balance.argtypes = [vp, c.c_int]
     L.phys_batch_set_fast_rows.argtypes = [vp, c.c_int]
     L.phys_batch_set_waves_per_env.argtypes = [vp, c.c_int]
-    if hasattr(L, "phys_batch_set_inplace"):
-        L.phys_batch_set_inplace.argtypes = [vp, c.c_int]
-        L.phys_batch_debug_inplace_ranges.argtypes = [vp]
+    L.phys_batch_set_inplace.argtypes = [vp, c.c_int]
+    L.phys_batch_debug_inplace_ranges.argtypes = [vp]
+    L.phys_batch_debug_form_launches.argtypes = [vp, c.POINTER(c.c_longlong), c.POINTER(c.c_longlong)]
     L.phys_batch_download_cost.argtypes = [vp, vp]
     L.phys_batch_measured_shader_clock.argtypes = [vp, vp]
     L.phys_batch_wide_pass_envs.argtypes = [vp, c.c_int]

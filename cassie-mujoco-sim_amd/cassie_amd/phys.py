@@ -301,6 +301,13 @@ class Batch:
         if lib().phys_batch_set_inplace(self._h, int(mode)) != 0:
             raise ValueError("in-place mode: 0, 1 or 2")
 
+    def form_launches(self):
+        """Diagnostics: (plain, in place) -- stepping launches of the two-wave fast kernel so far, by form."""
+        import ctypes
+        a, c_ = ctypes.c_longlong(0), ctypes.c_longlong(0)
+        lib().phys_batch_debug_form_launches(self._h, ctypes.byref(a), ctypes.byref(c_))
+        return int(a.value), int(c_.value)
+
     def inplace_ranges(self):
         """Diagnostics: env ranges whose next stepping launch takes the in-place form of the fast kernel."""
         return lib().phys_batch_debug_inplace_ranges(self._h)

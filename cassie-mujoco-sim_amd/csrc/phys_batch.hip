@@ -107,6 +107,7 @@ struct phys_batch {
     int inplace_mode = 2;
     struct RangeForm { int env0; bool inplace; };
     std::vector<RangeForm> range_forms;
+    long long form_launches[2] = {0, 0};   /* stepping launches of the two-wave fast kernel in the plain / the in-place form (diagnostics) */
     int waves_per_env = 2;          /* two-wave form of the fast instantiations (phys_batch_set_waves_per_env) */
     int waves_per_env_tray = DEFAULT_TRAY_WAVES; /* ... of the 40-dof instantiations (CASSIE_TRAY_TWO_WAVES=0/1 overrides the default: A/B aid) */
     double *d_scratch_out = nullptr; /* [nenv][nv + nsensordata + nu]: where phys_batch_forward_kinematics sends qacc / sensordata / actuator_velocity */
@@ -306,6 +307,7 @@ static int launch(phys_batch *b, int nsub, int integrate, hipStream_t s, bool sc
                 b->h_handover_seen[env0] = 0;
             }
             inplace_launch = rf->inplace;
+            ++b->form_launches[inplace_launch ? 1 : 0];
         }
         if (!hf && !wp) { launched = ck::launch_step_cassie(grid, tg, s, io, hl, fast, hm.maxefc > CM_MAXEFC_NARROW, ev_after, b->waves_per_env, inplace_launch); ev_after = nullptr; }
         else if (hf && !wp) { launched = ck::launch_step_cassie_hfield(grid, tg, s, io, hl, fast, hm.maxefc > CM_MAXEFC_NARROW, ev_after, b->waves_per_env, inplace_launch); ev_after = nullptr; }
@@ -989,6 +991,13 @@ int phys_batch_debug_inplace_ranges(const phys_batch_t *b) {
     int k = 0;
     for (const auto &r : b->range_forms) k += r.inplace ? 1 : 0;
     return k;
+}
+
+int phys_batch_debug_form_launches(const phys_batch_t *b, long long *plain, long long *inplace) {
+    if (!b) return -1;
+    if (plain) *plain = b->form_launches[0];
+    if (inplace) *inplace = b->form_launches[1];
+    return 0;
 }
 
 int phys_batch_set_inplace(phys_batch_t *b, int mode) {

@@ -258,11 +258,13 @@ int phys_batch_set_fast_rows(phys_batch_t *b, int on);
  * pass that walks the list of envs it handed over (an env's remaining substeps then run as one serial chain while the range's stream
  * waits); 1 = the fast kernel that finishes a substep it cannot hold IN PLACE -- the 63-row code inside the same workgroup -- and goes
  * on with the next one itself; 2 (default) = per range by what its recent launches needed: in place once a launch handed envs over,
- * back to the plain form after eight launches in which no env left the fast tier.  Same results, bit for bit.  The in-place form costs
+ * back to the plain form after eight launches in a row (as the device reports them) in which no env left the fast tier.  Same results, bit for bit.  The in-place form costs
  * a workload that never leaves the fast tier 1.8 % and gains 8 - 24 % on one that does (profiles/round6/inplace_ab.txt). */
 int phys_batch_set_inplace(phys_batch_t *b, int mode);
 /* diagnostics: env ranges whose next stepping launch takes the in-place form */
 int phys_batch_debug_inplace_ranges(const phys_batch_t *b);
+/* ... and the stepping launches of the two-wave fast kernel so far, by form */
+int phys_batch_debug_form_launches(const phys_batch_t *b, long long *plain, long long *inplace);
 /* 2 (default): the row-capped fast kernels run in their two-wave form -- two wavefronts per env, the mass-matrix stage group
  * (centres of mass, composite inertias, M, its two factorisations) on the second wave beside the first wave's collision,
  * velocity and constraint-row stages; 1: one wavefront per env.  Same results, bit for bit (a measurement aid). */
