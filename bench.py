@@ -693,7 +693,7 @@ def device_rollout(model, mode, n, steps, warmup, rank, world, local_rank, subst
     res["frac_envs_handed_over_last_launch"] = None if np.isnan(stats[4]) else float(stats[4] / (world * n))
     # what the last launch cost an env, first to last instruction, in shader clocks per substep (phys_batch_download_cost: batches
     # that keep a launch order) -> how full the GPU's workgroup slots were over the timed regions, see main()
-    res["fast_kernel_launches_plain_in_place"] = list(b.form_launches())
+    res["fast_kernel_launches_plain_in_place"] = list(b.form_launches()) if hasattr(b, "form_launches") else None   # (the CPU dry run's stand-in has no kernels)
     try:
         res["wide_pass_envs_last_launch"] = sum(b.wide_pass_envs(first) for first, _ in ranges) if hasattr(b, "wide_pass_envs") else None
         res["env_clocks_per_substep"] = float(np.mean(b.launch_cost())) / max(1, last_launch["nsub"])
