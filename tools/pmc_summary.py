@@ -59,6 +59,15 @@ derived = {
     "frac_fetch_stall_upper_bound": 125.0 * g("SQC_ICACHE_MISSES") / g("SQ_WAVE_CYCLES"),
     "lds_bank_conflict_frac_of_lds_active": g("SQ_LDS_BANK_CONFLICT") / g("SQ_ACTIVE_INST_LDS"),
     "icache_hit": g("SQC_ICACHE_HITS") / g("SQC_ICACHE_REQ"),
+    # the dynamic VALU instruction mix by class, per env-step (round 6; SQ_INSTS_VALU_* of gfx950).  "other" = VALU instructions in
+    # none of the counted classes: moves, v_cndmask, compares, v_readlane / v_writelane (cross-lane reads, SGPR spill traffic), DPP moves
+    "valu_mix_per_env_step": {k: g("SQ_INSTS_VALU_" + k) / n_env_steps for k in
+                              ("ADD_F64", "MUL_F64", "FMA_F64", "TRANS_F64", "MFMA_F64", "INT32", "INT64", "CVT", "ADD_F32", "MUL_F32", "FMA_F32", "TRANS_F32")},
+    "valu_other_per_env_step": (g("SQ_INSTS_VALU") - sum(g("SQ_INSTS_VALU_" + k) for k in
+                                ("ADD_F64", "MUL_F64", "FMA_F64", "TRANS_F64", "MFMA_F64", "INT32", "INT64", "CVT", "ADD_F32", "MUL_F32", "FMA_F32", "TRANS_F32"))) / n_env_steps,
+    "branches_per_env_step": g("SQ_INSTS_BRANCH") / n_env_steps,
+    "lds_loads_per_env_step": g("SQ_INSTS_LDS_LOAD") / n_env_steps,
+    "lds_stores_per_env_step": g("SQ_INSTS_LDS_STORE") / n_env_steps,
     "hbm_read_bytes_per_launch": 2 * 1024 * g("FETCH_SIZE"),
     "hbm_write_bytes_per_launch": 1024 * g("WRITE_SIZE"),
     "note": "SQ_* cycle counters are quad-cycles; FETCH_SIZE/WRITE_SIZE are KB, FETCH_SIZE doubled per MI355X_MICROARCH.md "
