@@ -92,3 +92,22 @@ def test_fast_hfield_kernel_keeps_its_registers_and_sets_its_wave_priorities(tmp
     assert sum(l.startswith(("scratch_load", "scratch_store")) for l in body) <= 48, "scratch traffic in the height-field model's fast kernel"
     prios = sorted(set(int(l.split()[1]) for l in body if l.startswith("s_setprio")))
     assert prios == [0, 1, 3], prios
+
+
+@pytest.mark.skipif(not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")), reason="needs hipcc")
+def test_in_place_form_of_the_fast_kernel_is_placed_like_the_plain_form(tmp_path):
+    """Round 6: the fast kernel with the 63-row code behind its own 31-row code (INROWS) must run where the plain form runs -- two
+    waves per SIMD, 40 KB of LDS per env, i.e. four envs per CU -- or switching a range to it would halve the chip.  The 63-row code in
+    256 registers spills (it runs for the one substep that needs it); the frame stays under 1 KB per lane."""
+    isa = tmp_path / "inplace.s"
+    env = dict(os.environ, MAXRS="31", NW="2", INROWS="63", KEEP=str(isa))
+    out = subprocess.run(["bash", os.path.join(REPO, "tools", "kernel_resources.sh")], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout + out.stderr
+    text = out.stdout
+    val = lambda key: int(re.search(key + r"[^:]*: *(\d+)", text).group(1))
+    assert val("Occupancy") == 2, text
+    assert val("LDS Size") <= 40960, text
+    assert val("ScratchSize") <= 1024, text
+    body = [l.split(";")[0].strip() for l in isa.read_text().split("\n")]
+    # both codes are there: the 31-row Gram matrix (3 tiles x 8 dof blocks) and the 63-row one (10 tiles x 8), + the composite inertias twice
+    assert sum(l.startswith("v_mfma_f64_16x16x4_f64") for l in body) > 24 + 16
