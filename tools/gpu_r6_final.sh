@@ -1,4 +1,4 @@
-# round 6, final measurement set (v36: per-env parameter blocks + device set_const, CM_DRIVE_PD_SAFE as the benchmarked mode, tighter
+# round 6, final measurement set (v36; v37 = the same with the fast kernel's form picked per env range: per-env parameter blocks + device set_const, CM_DRIVE_PD_SAFE as the benchmarked mode, tighter
 # hand-over verdict, CM_FLAG_BOX8, one-wave form for large alone launches).  PART=1 suite + bench lines, PART=2 rocprofv3 kernel stats +
 # stage stamps + resources, PART=3 PMC passes + soak.  Box clocks differ between leases: the first bench line says what this box is.
 mkdir -p gpurun_out; nproc > gpurun_out/nproc.txt
