@@ -140,6 +140,40 @@ def test_randomised_batch_in_the_benchmarked_mode_1000_steps(built):
             hc.close()
 
 
+def test_randomised_envs_under_stress_targets_do_not_depend_on_the_form_of_the_fast_kernel(built):
+    """Per-env parameter blocks + joints slammed into their limits (envs leave the 31-row tier in the middle of fused launches) + the
+    three ways such substeps are finished (phys_batch_set_inplace 0 / 1 / 2, the launch in chunks or in one piece): every env reads
+    its own block in every instantiation, so state, outputs and solver statistics must be the same bits throughout."""
+    import test_drive_parity_gpu as D
+    n, npol = 4096, 12
+    tg = D._stress_targets(np.arange(n), npol)
+    out = []
+    for mode, chunks in ((0, 1), (1, 4), (2, 2)):
+        model, params, b = _randomised_batch("cassie", n, seed=91)
+        try:
+            b.set_inplace(mode); b.set_chunks(chunks)
+            b.set(P.F_QPOS, np.tile(model.qpos_init(), (n, 1)))
+            b.forward()
+            b.set(P.F_PD_KP, np.tile(bench.PD_KP, (n, 1)))
+            b.set(P.F_PD_KD, np.tile(bench.PD_KD, (n, 1)))
+            b.set_drive_mode(P.DRIVE_PD)
+            rows = 0
+            for p in range(npol):
+                b.set(P.F_PD_PTARGET, tg[p])
+                b.step((bench.HOLD, 20, 11)[p % 3])
+                rows = max(rows, int(b.warnings()[1][:, 1].max()))
+            w, info = b.warnings()
+            out.append([b.get(P.F_QPOS), b.get(P.F_QVEL), b.get(P.F_QACC_WARMSTART), b.get(P.F_SENSORDATA), b.get(P.F_MEAS), b.get(P.F_CTRL), w, info[:, :3].copy()])
+            forms = b.form_launches()
+        finally:
+            b.close()
+        assert rows > 31, "the workload never left the 31-row tier"
+        assert (forms[1] == 0) if mode == 0 else (forms[0] == 0) if mode == 1 else (forms[0] > 0 and forms[1] > 0), (mode, forms)
+    for k in (1, 2):
+        for a, c in zip(out[0], out[k]):
+            assert a.tobytes() == c.tobytes(), k
+
+
 def test_parameter_blocks_and_per_env_models_do_not_mix(built):
     model = Model("cassie")
     b = Batch(model, 4)
