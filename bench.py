@@ -1048,6 +1048,23 @@ def main(argv=None):
             tsample = np.arange(8)
             out["true_reference"] = true_reference(args.model, model.qpos_init(), pd_targets(tsample, EPISODE // HOLD + 1), EPISODE)
         elif world == 1 and args.total_envs is None and not args.dry_run_cpu and not args.no_cpu_baseline:
+            if args.model == "cassie_hfield" and args.hfield_contacts == "default" and not args.no_other_mode:
+                # config 4 carries BOTH height-field contact definitions: `value` is the default one (one contact per geom pair, the
+                # deepest sample), this leg the MuJoCo-shaped set (CM_FLAG_HFPRISM: one contact per penetrated grid triangle, up to 32
+                # contacts / 127 rows, three kernel tiers) on the same terrain and schedule, replayed on the oracle with the same flag
+                from cassie_amd import phys as _P
+                pm = Model(args.model)
+                pm.set_flag(_P.FLAG_HFPRISM, True)
+                side_steps = min(args.steps, 500)
+                pr = device_rollout(pm, args.mode, n, side_steps, min(args.warmup, 100), 0, 1, local_rank, args.substeps_per_launch, 16, hfield,
+                                    repeats=min(repeats, 4), nstreams=nstreams)
+                out["hfield_contacts_prism"] = {"value": n * pr["steps"] / pr["elapsed"], "unit": "env-steps/s", "steps": pr["steps"], "warmup": pr["warmup"],
+                                                "timed_regions": pr["repeats"], "kernel_ms": pr["kernel_ms"], "stream_ms_per_policy_step": pr["stream_ms"],
+                                                "parity": pr["parity"], "envs_with_warnings": pr["envs_with_warnings"],
+                                                "frac_envs_leaving_the_31_row_tier_in_the_last_launch": pr["frac_envs_handed_over_last_launch"],
+                                                "mean_constraint_rows": pr["mean_constraint_rows"], "mean_pgs_iterations": pr["mean_pgs_iterations"],
+                                                "what": "CM_FLAG_HFPRISM: MuJoCo's per-prism height-field contact set; off by default (DESIGN.md 4.2, 7.3)"}
+                out["value_hfield_contacts_prism"] = out["hfield_contacts_prism"]["value"]
             out["cpu_baseline"] = cpu_baseline(model, hfield=hfield)      # configs 4 / 5: the oracle on this box's cores, same workload
         elif world > 1 and not args.no_cpu_baseline:
             # N > 1 (a SCALE line): rank 0 alone times the CPU oracle on the node's host cores, after the timed regions, while the
