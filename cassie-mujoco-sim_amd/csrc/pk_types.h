@@ -154,6 +154,10 @@ template <int NVP, int MAXR> struct TilesAndY<NVP, MAXR, true> {
     double vx[2][NVP];
     double sums[8];
     int turn[4];
+    /* (round 6) a half's steps, one per row, for the image's two half-wave partial sums; wave 0's per-row cost changes of a sweep, for
+     * the rare sweep whose cost change has to be summed in row order (the convergence test within a factor two of the tolerance) */
+    double stepv[2][NROW];
+    double chg[NROW];
 };
 template <int NVP, int NL = NVP * (NVP + 1) / 2, int MAXR = MID_ROWS>
 struct EnvShared {

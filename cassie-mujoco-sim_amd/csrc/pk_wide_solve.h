@@ -5,6 +5,10 @@
 #ifndef CASSIE_PK_WIDE_SOLVE_H
 #define CASSIE_PK_WIDE_SOLVE_H
 
+#ifndef CK_WIDE_SWEEP_V2     /* (A/B switch: 0 = round 5's sweep) */
+#define CK_WIDE_SWEEP_V2 1
+#endif
+
 namespace ck {
 
 /* ---------------- the solve of the 127-row instantiation (MAXR = WIDE_ROWS, two wavefronts): both waves call it behind the barrier
@@ -187,8 +191,26 @@ WV_DEVICE double wide_solve(SH &S, ModelPtr m, ParamPtr P, const int wid, const 
     }
 
     /* ======== more than 64 rows: the sweep crosses the waves ======== */
-    /* v[wid] = sum over this wave's rows t < nown of (staged row) x val_t, lane = dof (four partial sums, rows four to a branch) */
+    /* v[wid] = sum over this wave's rows t < nown of (staged row) x val_t, lane = dof.  Round 6: the steps go through LDS and the two
+     * halves of the wave take the even and the odd rows (lanes 32 .. 63 used to idle here, and every row cost two lane reads): two
+     * partial sums per half, the halves' sums added at the end */
     auto image_of = [&](double val) {
+        if constexpr (CK_WIDE_SWEEP_V2) {
+            S.x.stepv[wid][lane] = val;     /* (val is 0 in lanes that are not rows; their rows of the tile are zeros) */
+            wv::sync();
+            const int half = lane >> 5, k = lane & 31;
+            double v0 = 0, v1 = 0;
+#pragma unroll
+            for (int t = 0; t < H; t += 4) {
+                if (t < nown) {
+                    v0 = fma(S.x.Yr[rbase + t + half][k], S.x.stepv[wid][t + half], v0);
+                    v1 = fma(S.x.Yr[rbase + t + 2 + half][k], S.x.stepv[wid][t + 2 + half], v1);
+                }
+            }
+            const double mine = v0 + v1, other = wv::from_upper_half(mine);
+            if (lane < NVP) S.x.vx[wid][lane] = mine + other;
+            return;
+        }
         double v0 = 0, v1 = 0, v2 = 0, v3 = 0;
 #pragma unroll
         for (int t = 0; t < H; t += 4) {
@@ -203,6 +225,15 @@ WV_DEVICE double wide_solve(SH &S, ModelPtr m, ParamPtr P, const int wid, const 
     };
     /* this lane's staged row times the other wave's image: what the other wave's values contribute to this row's A x */
     auto cross = [&]() {
+        if constexpr (CK_WIDE_SWEEP_V2) {   /* (four chains of eight instead of one of 32) */
+            double d0 = 0, d1 = 0, d2 = 0, d3 = 0;
+#pragma unroll
+            for (int k = 0; k < NVP; k += 4) {
+                d0 = fma(ycol[k], S.x.vx[1 - wid][k], d0); d1 = fma(ycol[k + 1], S.x.vx[1 - wid][k + 1], d1);
+                d2 = fma(ycol[k + 2], S.x.vx[1 - wid][k + 2], d2); d3 = fma(ycol[k + 3], S.x.vx[1 - wid][k + 3], d3);
+            }
+            return (d0 + d1) + (d2 + d3);
+        }
         double d = 0;
 #pragma unroll
         for (int k = 0; k < NVP; ++k) d = fma(ycol[k], S.x.vx[1 - wid][k], d);
@@ -241,6 +272,87 @@ WV_DEVICE double wide_solve(SH &S, ModelPtr m, ParamPtr P, const int wid, const 
     /* the turn word: base + 2 s + 1 = wave 0 has finished its half of sweep s, base + 2 s + 2 = wave 1 has (and has left its verdict) */
     const int base = (sub + 1) << 12;
     const int sweeps_max = maxiter < 2000 ? maxiter : 2000;
+    if constexpr (CK_WIDE_SWEEP_V2) {
+        /* Round 6.  A sweep's cost change only feeds the convergence test, and summing it in row order was a chain of up to 64 lane
+         * reads + additions per half and sweep.  Now, as in the 63-row solve: each half forms a single-precision tree sum; wave 1 adds
+         * the two and decides unless the sum lands within a factor two of the tolerance -- only then (or when a half's guard fired,
+         * whose guarded re-run sums in order anyway) is the ordered double-precision sum formed, wave 0's part from the per-row
+         * changes it left in LDS.  What wave 0 hands over with its turn: sums[2] = its part (exact when sums[4] != 0, else the
+         * estimate), chg[] = its rows' changes. */
+        const float tolf = (float)tolerance, scalef = (float)scale;
+        for (int sweep = 0;; ++sweep) {
+            if (wid == 0) {
+                if (sweep > 0) {
+                    wv::wait_for(&S.x.turn[1], base + 2 * sweep);
+                    if (wv::opaque(S.x.turn[2])) break;
+                    sres = fma(ninvAii, cross(), sres);
+                }
+            } else {
+                wv::wait_for(&S.x.turn[1], base + 2 * sweep + 1);
+                sres = fma(ninvAii, cross(), sres);
+            }
+            const int nrows = wv::opaque(nown);
+            /* wave 0's part of the sweep's cost change in row order, from what it left in LDS (wave 1 only, when it is needed) */
+            auto ordered_part_of_wave0 = [&]() {
+                if (S.x.sums[4] != 0.0) return S.x.sums[2];
+                const double c0 = S.x.chg[lane];
+                double imp = 0.0;
+                for (int t = 0; t < H; ++t) imp -= wv::readlane(c0, t);   /* (a sweep that crosses the waves has all 64 rows of wave 0) */
+                return imp;
+            };
+            double dstep, exact = 0.0, change = 0.0;
+            float est = 0.0f;
+            bool guarded;
+            {
+                const double f0 = f, s0 = sres;
+                double mys = 0;
+                const double lo_f = flo - f;
+                pgs_rows_fast<0, H>(arow, nrows, r_, lo_f, sres, mys);
+                const double mydelta = wv::max_raw(mys, lo_f);
+                change = (r_ < nrows) ? mydelta * (halfAii * mydelta - Aii * mys) : 0.0;
+                guarded = wv::ballot(change > 1e-10) != 0ull || wv::debug_force_guarded();
+                if (guarded) {  /* some row of this half would have raised the cost: redo it guarded, the cost change summed in row order */
+                    f = f0; sres = s0;
+                    ++nguarded;
+                    exact = wid == 0 ? 0.0 : ordered_part_of_wave0();
+                    pgs_rows<0, H>(arow, nrows, r_, Aii, halfAii, flo, f, sres, exact);
+                    sres = fma(cdiag, f - f0, sres);
+                    dstep = f - f0;
+                } else {
+                    dstep = (r_ < nrows) ? mydelta : 0.0;
+                    if (r_ < nrows) { f += mydelta; sres = fma(cdiag, mydelta, sres); }
+                    est = -wv::wave_sum_f32((float)change);
+                }
+            }
+            image_of(dstep);
+            if (wid == 0) {
+                if (!guarded) S.x.chg[lane] = change;
+                if (lane == 0) { S.x.sums[2] = guarded ? exact : (double)est; S.x.sums[4] = guarded ? 1.0 : 0.0; }
+                wv::publish(&S.x.turn[1], base + 2 * sweep + 1);
+            } else {
+                iters = sweep + 1;
+                bool converged;
+                if (guarded) converged = exact * scale < tolerance;
+                else {
+                    const bool exact0 = S.x.sums[4] != 0.0;
+                    /* (wave 0's exact part is a double; in single precision it is as good an estimate as a tree sum) */
+                    const float total = ((float)S.x.sums[2] + est) * scalef;
+                    if (total < 0.5f * tolf) converged = true;
+                    else if (total > 2.0f * tolf) converged = false;
+                    else {
+                        double imp = ordered_part_of_wave0();
+                        (void)exact0;
+                        for (int t = 0; t < nrows; ++t) imp -= wv::readlane(change, t);
+                        converged = imp * scale < tolerance;
+                    }
+                }
+                const bool stop = converged || iters >= sweeps_max;
+                if (lane == 0) { S.x.turn[2] = stop ? 1 : 0; S.x.turn[3] = iters; S.x.sums[3] = (double)nguarded; }
+                wv::publish(&S.x.turn[1], base + 2 * sweep + 2);
+                if (stop) break;
+            }
+        }
+    } else
     for (int sweep = 0;; ++sweep) {
         double carried = 0.0; /* the sweep's cost change summed in row order up to this wave's first row */
         if (wid == 0) {
