@@ -73,6 +73,10 @@ namespace ck {
  * register pressure of paths it never takes: FEAT_HFIELD = height-field pairs, FEAT_WAVEPAIRS = plane-box / box-box
  * pairs handled by the whole wave.  The launcher picks the instantiation from the model (phys_batch.hip). */
 
+/* (env_step's return value: the substep it ended in front of, with this bit set when it ended there because the substep fits the
+ * fast code again -- PhysIO::down_rows -- and not because it needs more than this code holds) */
+constexpr int ENV_STEP_WENT_DOWN = 1 << 20;
+
 template <int NVP, class TOPO, int FEAT, int MAXR, int NW>
 WV_DEVICE int env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count, MAXR> &S, int env, int sub_start, int nsub) {
     /* nsub: the substep this call ends in front of -- io.nsub, or the end of this workgroup's chunk of the launch (PhysIO::nchunk):
@@ -177,7 +181,7 @@ WV_DEVICE int env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count,
 
 #include "env_step_wave1.inc"
 
-    bool bailed = false;
+    bool bailed = false, bailed_down = false;
     int sub = sub_start;
     for (; sub < nsub; ++sub) {
         /* Outputs that every substep recomputes (sensordata, qacc, actuator_velocity, xpos / xquat, the solver statistics)
@@ -589,7 +593,7 @@ WV_DEVICE int env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count,
         /* (a pass behind the fast kernel leaves the record of an env it completes; one that hands the env on -- the 63-row pass of a
          * model that may use 127 -- moves it to the substep the next pass starts from) */
         io.progress[env] = bailed ? sub : nsub;
-        if (bailed && io.handover_out_list) io.handover_out_list[io.env0 + wv::atomic_add(io.handover_out_count, 1)] = env;
+        if (bailed && !bailed_down && io.handover_out_list) io.handover_out_list[io.env0 + wv::atomic_add(io.handover_out_count, 1)] = env;
     }
     if (io.integrate && io.drive_mode) {
         drive_state_store(io, S, env, lane);
@@ -619,7 +623,7 @@ WV_DEVICE int env_step(const PhysIO &io, EnvShared<NVP, LPack<TOPO, NVP>::count,
             if (wv::ballot((warn & bit) != 0) != 0ull) w |= bit;
         if (lane == 0 && w) io.warn[env] |= w;
     }
-    return (warn & WARN_DIVERGED) ? -2 : (bailed ? sub : nsub);
+    return (warn & WARN_DIVERGED) ? -2 : (bailed ? (bailed_down ? sub | ENV_STEP_WENT_DOWN : sub) : nsub);
 }
 
 /* one workgroup (NW wavefronts) per environment.
@@ -696,6 +700,8 @@ WV_GLOBAL void __launch_bounds__(WV_WAVE * NW) WV_OCC WV_WAVES_PER_SIMD(WPS) cas
         auto &S2 = reinterpret_cast<EnvShared<NVP, LPack<TOPO, NVP>::count, INROWS> &>(S);
         PhysIO io2 = io;            /* what the substep's inner call sees: it hands on (if at all) to the 127-row pass's list */
         io2.has_next = io.inplace_has_next; io2.handover_out_list = io.inplace_out_list; io2.handover_out_count = io.inplace_out_count;
+        io2.down_rows = io.inplace_stay_rows;
+        const bool stay = io.inplace_stay_rows > 0;
         bool did = false;
         for (int s = sub_start;;) {
             int at = env_step<NVP, TOPO, FEAT, MAXR, NW>(io, S, env, s, sub_end);
@@ -705,12 +711,17 @@ WV_GLOBAL void __launch_bounds__(WV_WAVE * NW) WV_OCC WV_WAVES_PER_SIMD(WPS) cas
             at = wv::opaque(S.cmd[5]);
             if (at < 0 || at >= sub_end) break;                 /* done (or the state diverged: flagged, left alone) */
             did = true;
-            int at2 = env_step<NVP, TOPO, FEAT, INROWS, NW>(io2, S2, env, at, at + 1);
+            /* the 63-row code: for this one substep, or (PhysIO::inplace_stay_rows) until a substep fits the fast code again */
+            int at2 = env_step<NVP, TOPO, FEAT, INROWS, NW>(io2, S2, env, at, stay ? sub_end : at + 1);
             if (wv::lane() == 0 && wv::wave_id() == 0) S.cmd[5] = at2;
             wv::drain_vmem(); wv::block_barrier();
             at2 = wv::opaque(S.cmd[5]);
-            if (at2 != at + 1 || at + 1 >= sub_end) break;      /* handed on to the 127-row pass (or diverged), or that was the last substep */
-            s = at + 1;
+            if (at2 < 0) break;                                 /* diverged */
+            const bool down = (at2 & ENV_STEP_WENT_DOWN) != 0;
+            at2 &= ENV_STEP_WENT_DOWN - 1;
+            if (at2 >= sub_end) break;                          /* that was the last substep */
+            if (stay ? !down : at2 != at + 1) break;            /* handed on to the 127-row pass */
+            s = at2;
         }
         if (did && io.inplace_count && wv::lane() == 0 && wv::wave_id() == 0) wv::atomic_add(io.inplace_count, 1);
     } else env_step<NVP, TOPO, FEAT, MAXR, NW>(io, S, env, sub_start, sub_end);

@@ -120,6 +120,12 @@ struct PhysIO {
      * caps) and the list it walks. */
     int inplace_has_next;
     int *inplace_out_list, *inplace_out_count;
+    /* ... and how long the env STAYS in the 63-row code once it is there: 0 = for that one substep; r > 0 = until a substep needs at
+     * most r rows again (the inner call then ends in front of that substep the way a hand-over does, and the fast code goes on from
+     * there).  An env whose substeps mostly need more rows than the fast code holds -- CM_FLAG_HFPRISM: 82 % of them -- would
+     * otherwise pay a fast attempt, a store and a load of its state per substep.  down_rows: what the inner call sees of it. */
+    int inplace_stay_rows;
+    int down_rows;
     int *inplace_count;         /* (may be null) device word: += 1 per env-launch (chunk) that finished a substep in place -- the launcher's
                                    signal for which form of the fast kernel the range's next launches take (phys_batch.hip) */
 };

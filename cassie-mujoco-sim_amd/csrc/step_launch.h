@@ -109,6 +109,11 @@ inline bool launch_three_tiers(dim3 grid, const TierGrids &tg, hipStream_t s, Ph
         io.inplace_count = hl.count1;       /* (the first list's count word is free in this form: it counts the env-launches that needed the wider code) */
         io.handover_list = nullptr; io.handover_count = nullptr; io.handover_seen = nullptr;
         io.handover_out_list = nullptr; io.handover_out_count = nullptr;
+        /* once in the 63-row code an env stays there until a substep needs at most FAST_ROWS - 4 rows again (the margin keeps an env
+         * that hovers about the fast code's capacity from changing codes every substep); CASSIE_INPLACE_STAY_ROWS: the A/B switch, 0 =
+         * back to the fast code after every substep */
+        static const int stay_rows = getenv("CASSIE_INPLACE_STAY_ROWS") ? atoi(getenv("CASSIE_INPLACE_STAY_ROWS")) : FAST_ROWS - 4;
+        io.inplace_stay_rows = stay_rows < 0 ? 0 : (stay_rows > FAST_ROWS ? FAST_ROWS : stay_rows);
         io.inplace_has_next = wide_caps ? 1 : 0;
         io.inplace_out_list = wide_caps ? hl.list2 : nullptr; io.inplace_out_count = wide_caps ? hl.count2 : nullptr;
         if (!fast_2w_inplace(chunked_grid(grid, io), s, io)) return false;

@@ -213,7 +213,9 @@ static void body32s_fast_2w() { ck::cassie_step_kernel<32, ck::TopoCassie32, ck:
 /* ... with the 63-row code behind it in the same kernel (cassie_step_kernel's INROWS): substeps it cannot hold are finished in place */
 static void body32s_fast_2w_inplace() { ck::cassie_step_kernel<32, ck::TopoCassie32, ck::FEAT_ALL, ck::FAST_ROWS, 2, false, 2, ck::MID_ROWS>(g_io); }
 static int g_inplace = 0;
+static int g_inplace_stay = 0;
 extern "C" void emu_inplace(int on) { g_inplace = on; }
+extern "C" void emu_inplace_stay_rows(int rows) { g_inplace_stay = rows; }   /* PhysIO::inplace_stay_rows (0: one substep at a time) */
 static void body40s_2w() { ck::cassie_step_kernel<40, ck::TopoCassieTray38, ck::FEAT_WAVEPAIRS, ck::MID_ROWS, 2>(g_io); } /* (no height-field pairs) */
 static int g_two_waves = 0, g_resume_grid = 2;
 extern "C" void emu_resume_grid(int n) { g_resume_grid = n > 0 ? n : 1; }
@@ -314,6 +316,7 @@ extern "C" int emu_phys_run(const cm_model_t *model, int nenv, int nsub, int int
         if (inplace) {
             g_io.handover_out_list = nullptr; g_io.handover_out_count = nullptr;
             g_io.inplace_has_next = third ? 1 : 0; g_io.inplace_out_list = third ? list2 : nullptr; g_io.inplace_out_count = third ? count2 : nullptr;
+            g_io.inplace_stay_rows = g_inplace_stay;
         }
         static int chunk_flag[1 << 16];
         const int nchunk = (g_chunks > 1 && nsub >= 2) ? g_chunks : 1;

@@ -633,13 +633,15 @@ def test_in_place_form_equals_the_pass_behind_the_kernel_bit_for_bit(cassie, dri
     lib = emu_py.lib()
     ref, rows, bails0 = _two_wave_workload(cassie, drive, fast=True, two_waves=True, schedule=0)
     assert rows[:, :, 1].max() > 31, "the workload never left the 31-row tier"
-    for schedule, chunks in ((0, 1), (1, 1), (2, 1), (1, 3)):
-        lib.emu_inplace(1); lib.emu_chunks(chunks)
+    # (stay: PhysIO::inplace_stay_rows -- 0 = back to the fast code after every substep, r = the env stays in the 63-row code until a
+    # substep needs at most r rows again: 27 is what the product launches with, 31 the narrowest margin, 12 practically never back)
+    for schedule, chunks, stay in ((0, 1, 0), (1, 1, 27), (2, 1, 31), (1, 3, 27), (0, 2, 12)):
+        lib.emu_inplace(1); lib.emu_chunks(chunks); lib.emu_inplace_stay_rows(stay)
         try:
             got, _, _ = _two_wave_workload(cassie, drive, fast=True, two_waves=True, schedule=schedule, poison=True)
         finally:
-            lib.emu_inplace(0); lib.emu_chunks(1)
-        assert got == ref, (schedule, chunks)
+            lib.emu_inplace(0); lib.emu_chunks(1); lib.emu_inplace_stay_rows(0)
+        assert got == ref, (schedule, chunks, stay)
     # ... and the one-wave form of the full kernel alone agrees too (the yardstick of every form)
     alone, _, _ = _two_wave_workload(cassie, drive, fast=False, two_waves=False, schedule=0)
     assert alone == ref
@@ -656,12 +658,12 @@ def test_in_place_form_hands_on_to_the_127_row_pass(built):
     model.set_flag(P.FLAG_HFPRISM, True)
     ref, rows, _ = _two_wave_workload(model, True, fast=False, two_waves=True, schedule=0, nlaunch=3, nsub=12, stress=False)
     assert rows[:, :, 1].max() > 63 and rows[:, :, 1].min() <= 31
-    for schedule, chunks in ((0, 1), (2, 3)):
+    for schedule, chunks, stay in ((0, 1, 0), (2, 3, 27), (1, 1, 31)):
         before = lib.emu_wide_envs()
-        lib.emu_inplace(1); lib.emu_chunks(chunks); lib.emu_resume_grid((2, 1, 3)[schedule])
+        lib.emu_inplace(1); lib.emu_chunks(chunks); lib.emu_resume_grid((2, 1, 3)[schedule]); lib.emu_inplace_stay_rows(stay)
         try:
             got, _, _ = _two_wave_workload(model, True, fast=True, two_waves=True, schedule=schedule, poison=True, nlaunch=3, nsub=12, stress=False)
         finally:
-            lib.emu_inplace(0); lib.emu_chunks(1); lib.emu_resume_grid(2)
+            lib.emu_inplace(0); lib.emu_chunks(1); lib.emu_resume_grid(2); lib.emu_inplace_stay_rows(0)
         assert lib.emu_wide_envs() > before, "no env reached the 127-row pass"
-        assert got == ref, (schedule, chunks)
+        assert got == ref, (schedule, chunks, stay)
