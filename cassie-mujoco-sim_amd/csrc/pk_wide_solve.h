@@ -200,11 +200,16 @@ WV_DEVICE double wide_solve(SH &S, ModelPtr m, ParamPtr P, const int wid, const 
             wv::sync();
             const int half = lane >> 5, k = lane & 31;
             double v0 = 0, v1 = 0;
+            /* (sixteen rows to a wave-uniform branch: their eight pairs of LDS reads are requested together) */
 #pragma unroll
-            for (int t = 0; t < H; t += 4) {
-                if (t < nown) {
-                    v0 = fma(S.x.Yr[rbase + t + half][k], S.x.stepv[wid][t + half], v0);
-                    v1 = fma(S.x.Yr[rbase + t + 2 + half][k], S.x.stepv[wid][t + 2 + half], v1);
+            for (int t0 = 0; t0 < H; t0 += 16) {
+                if (t0 < nown) {
+                    double y[8], sv[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) { y[i] = S.x.Yr[rbase + t0 + 2 * i + half][k]; sv[i] = S.x.stepv[wid][t0 + 2 * i + half]; }
+                    wv::sched_fence();
+#pragma unroll
+                    for (int i = 0; i < 8; i += 2) { v0 = fma(y[i], sv[i], v0); v1 = fma(y[i + 1], sv[i + 1], v1); }
                 }
             }
             const double mine = v0 + v1, other = wv::from_upper_half(mine);
@@ -283,12 +288,12 @@ WV_DEVICE double wide_solve(SH &S, ModelPtr m, ParamPtr P, const int wid, const 
         for (int sweep = 0;; ++sweep) {
             if (wid == 0) {
                 if (sweep > 0) {
-                    wv::wait_for(&S.x.turn[1], base + 2 * sweep);
+                    wv::wait_for_spin(&S.x.turn[1], base + 2 * sweep);
                     if (wv::opaque(S.x.turn[2])) break;
                     sres = fma(ninvAii, cross(), sres);
                 }
             } else {
-                wv::wait_for(&S.x.turn[1], base + 2 * sweep + 1);
+                wv::wait_for_spin(&S.x.turn[1], base + 2 * sweep + 1);
                 sres = fma(ninvAii, cross(), sres);
             }
             const int nrows = wv::opaque(nown);

@@ -42,6 +42,11 @@ WV_DEVICE void wait_for(const int *flag, int value) {
     while (__builtin_amdgcn_readfirstlane(*(const volatile int *)flag) != value) __builtin_amdgcn_s_sleep(1);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
+/* the same without the s_sleep between two looks: for a wave that has its SIMD to itself (the 127-row instantiation) */
+WV_DEVICE void wait_for_spin(const int *flag, int value) {
+    while (__builtin_amdgcn_readfirstlane(*(const volatile int *)flag) != value) {}
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
 /* every vector memory operation of this wave has completed (loads returned, stores acknowledged) */
 WV_DEVICE void drain_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 WV_DEVICE void block_barrier() {

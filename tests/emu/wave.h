@@ -39,6 +39,7 @@ void spin_yield();
 inline void publish(int *flag, int value) { sync(); if (lane() == 0) *flag = value; sync(); }
 int shfl_i(int v, int src_lane);
 inline void wait_for(const int *flag, int value) { while (shfl_i(*flag, 0) != value) spin_yield(); } /* (lane 0's reading decides for the wave) */
+inline void wait_for_spin(const int *flag, int value) { wait_for(flag, value); }
 double shfl(double v, int src_lane);
 double shfl_xor(double v, int mask);
 int shfl_i(int v, int src_lane);
