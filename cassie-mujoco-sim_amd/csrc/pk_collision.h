@@ -563,11 +563,11 @@ WV_DEVICE void write_raw_contact(SH &S, int slot, int pair, const RawContact &r)
  * PENETRATED GRID TRIANGLE under every sphere / capsule that has a height-field pair.  Lane = pair first (its capsule in the
  * height field's frame, the cells under its bounding rectangle, its sample count -> a record in `hp`), then lane = (pair, cell,
  * triangle) KEY in the oracle's order -- pair order, cells row-major, the triangle (v00, v10, v01) of a cell before (v11, v01, v10) --
- * 64 keys to a round: a key's lane walks the capsule's sample spheres (no further apart than the radius; exact culls by plan
- * distance and by the cell's highest corner skip most), keeps the deepest, and a key whose deepest sample is within the margin is a
- * contact.  Ballots put the contacts into the list in key order, which is the oracle's.  Returns the number of contacts FOUND;
+ * 64 keys to a round (round 6: the keys of the cells that survive a cull pass over (pair, cell), see below): a key's lane walks the
+ * capsule's sample spheres (no further apart than the radius; exact culls by plan distance and by the cell's highest corner skip
+ * most), keeps the deepest, and a key whose deepest sample is within the margin is a contact.  Ballots put the contacts into the list in key order, which is the oracle's.  Returns the number of contacts FOUND;
  * those past the list's `room` slots are not written (the caller caps or hands the substep over).
- * hp: scratch, HP_REC doubles per height-field pair of the model (the idle velocity tiles). */
+ * hp: scratch, HP_REC doubles per height-field pair the model format allows + 2 KB for the task table (the idle velocity tiles). */
 constexpr int HP_REC = 16;
 template <class SH>
 WV_DEVICE int hfield_prism_wave(SH &S, ModelPtr m, const float *data, int lane, double *hp, int room) {
@@ -605,7 +605,7 @@ WV_DEVICE int hfield_prism_wave(SH &S, ModelPtr m, const float *data, int lane, 
         for (int i = 0; i < 3; ++i) { rec[i] = p0[i]; rec[3 + i] = ax[i]; }
         rec[6] = r; rec[7] = h; rec[8] = margin; rec[9] = (double)ns; rec[10] = (double)i0; rec[11] = (double)j0; rec[12] = (double)wj;
         rec[13] = (double)p; rec[14] = (double)g2;
-        nkeys = 2 * ncell;
+        nkeys = ncell;      /* (round 6: the scan below is over CELLS; a cell that survives the cull pass is two keys) */
     }
     int endx = nkeys;
 #pragma unroll
@@ -613,65 +613,158 @@ WV_DEVICE int hfield_prism_wave(SH &S, ModelPtr m, const float *data, int lane, 
     const int total = wv::shfl_i(endx, WV_WAVE - 1);
     const int start = endx - nkeys;
     wv::sync();
-    /* ---- lane = key ---- */
     int ncon = 0;
     const int g1h = m->hfield_geom;
-    for (int base = 0; base < total; base += WV_WAVE) {
-        const int t = base + lane;
-        const bool act = t < total;
+    const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    /* Round 6: THREE STEPS per batch of 64 cells.  A key's lane used to walk the capsule's samples itself, and a round of keys cost
+     * what its busiest sample index cost: under a foot every index has some key in reach, so a round was ns (9 .. 12) point-triangle
+     * tests long whatever a single key needed, and most cells under a capsule's bounding rectangle are out of every sample's reach.
+     *   1. lane = (pair, cell): WHICH samples come within the culls' distance of the cell -- pass 3's culls with a 1e-9 margin and
+     *      cheap sample positions -- as a bit mask; a cell with an empty mask is done.
+     *   2. the TASKS (cell, triangle, sample of the mask) of the surviving cells are numbered in the oracle's order -- cell, triangle
+     *      0 before 1, samples ascending -- by a running count over the lanes; a byte table maps task -> cell lane.
+     *   3. lane = task, 64 to a round: ONE exact cull + point-triangle test (the very expressions of the one-pass version); the cell's
+     *      lane then walks ITS tasks of the round in order and keeps the first strict minimum per triangle -- the comparisons the key's
+     *      lane used to make, in their order -- and picks the winner's normal up from the task's lane.
+     * The contacts and their order are what the one-pass version gave, bit for bit. */
+    unsigned char *const tabb = (unsigned char *)(hp + HP_REC * CM_MAXHFPAIR);   /* 64 cells x at most 2 x 16 tasks */
+    for (int cbase = 0; cbase < total; cbase += WV_WAVE) {
+        const int c = cbase + lane;
+        const bool actc = c < total;
         int h = 0, hstart = 0;
         for (int hh = 0; hh < nhf; ++hh) {
             const int st = wv::shfl_i(start, hh), en = wv::shfl_i(endx, hh);
-            if (t >= st && t < en) { h = hh; hstart = st; }
+            if (c >= st && c < en) { h = hh; hstart = st; }
         }
-        const double *rec = hp + HP_REC * h;
-        const double p0[3] = {rec[0], rec[1], rec[2]}, ax[3] = {rec[3], rec[4], rec[5]}, r = rec[6], hl = rec[7], margin = rec[8];
-        const int ns = act ? (int)rec[9] : 0, i0 = (int)rec[10], j0 = (int)rec[11], wj = (int)rec[12], pidx = (int)rec[13], g2 = (int)rec[14];
-        const int q = act ? t - hstart : 0, cell = q >> 1, tri = q & 1;
-        const int ci = (int)(((float)cell + 0.5f) * (1.0f / (float)wj)); /* cell / wj: the quotient's distance from an integer is at least 0.5 / wj */
-        const int i = i0 + ci, j = j0 + (cell - ci * wj);
-        const double x0 = -sx + j * dx, y0 = -sy + i * dy, reach = r + (margin > 0 ? margin : 0);
-        double z00 = 0, z10 = 0, z01 = 0, z11 = 0;
-        if (act) { z00 = sz * data[i * nc + j]; z10 = sz * data[i * nc + j + 1]; z01 = sz * data[(i + 1) * nc + j]; z11 = sz * data[(i + 1) * nc + j + 1]; }
-        const double zmax = fmax(fmax(z00, z10), fmax(z01, z11));
-        const double v00[3] = {x0, y0, z00}, v10[3] = {x0 + dx, y0, z10}, v01[3] = {x0, y0 + dy, z01}, v11[3] = {x0 + dx, y0 + dy, z11};
-        double best = 1e300, bn[3] = {0, 0, 1}, bt = 0;
-        bool bdiv = false;
-        for (int k = 0; k < CM_HP_MAXS; ++k) {
-            if (wv::ballot(k < ns) == 0ull) break; /* (wave-uniform: no lane has a k-th sample) */
-            if (k >= ns) continue;
-            const double tk = ns > 1 ? hl * (1.0 - 2.0 * k / (ns - 1)) : 0.0;
-            const double p[3] = {p0[0] + tk * ax[0], p0[1] + tk * ax[1], p0[2] + tk * ax[2]};
-            /* exact culls: a sample further from the cell's rectangle than the reach in plan, or more than the reach above the
-             * cell's highest corner, is not within contact distance of either of its triangles */
-            const double ex = p[0] < x0 ? x0 - p[0] : (p[0] > x0 + dx ? p[0] - (x0 + dx) : 0.0);
-            const double ey = p[1] < y0 ? y0 - p[1] : (p[1] > y0 + dy ? p[1] - (y0 + dy) : 0.0);
-            if (ex * ex + ey * ey > reach * reach || p[2] - reach > zmax) continue;
-            double cur = 1e300, cn[3] = {0, 0, 1};
-            bool cdiv = false;
-            if (tri == 0) hfield_triangle(p, v00, v10, v01, cur, cn, cdiv); else hfield_triangle(p, v11, v01, v10, cur, cn, cdiv);
-            if (cur < best) { best = cur; bt = tk; bn[0] = cn[0]; bn[1] = cn[1]; bn[2] = cn[2]; bdiv = cdiv; }
-        }
-        if (bdiv) { bn[0] = bn[0] / best; bn[1] = bn[1] / best; bn[2] = bn[2] / best; } /* (the deepest sample's division: hfield_triangle) */
-        const double dist = best - r;
-        const bool hit = act && best < 1e299 && !(dist > margin);
-        const unsigned long long hb = wv::ballot(hit);
-        const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-        const int slot = ncon + wv::popc64(hb & below);
-        if (hit && slot < room) {
-            const double *mh = S.x.s.geom_xmat[g1h], *pc = S.x.s.geom_xpos[g2], *mc = S.x.s.geom_xmat[g2];
-            const double axw[3] = {mc[2], mc[5], mc[8]};
-            double nw[3];
-            mulmatvec3(nw, mh, bn);
-            RawContact rc;
-            rc.dist = dist;
-            for (int x = 0; x < 3; ++x) {
-                const double psw = pc[x] + bt * axw[x];
-                rc.normal[x] = nw[x]; rc.pos[x] = psw - nw[x] * (r + 0.5 * dist); rc.tangent[x] = hl > 0 ? axw[x] : 0.0;
+        const int q = actc ? c - hstart : 0;
+        const double *recc = hp + HP_REC * h;
+        int smask = 0;
+        {
+            const double p0[3] = {recc[0], recc[1], recc[2]}, ax[3] = {recc[3], recc[4], recc[5]}, r = recc[6], hl = recc[7], margin = recc[8];
+            const int ns = actc ? (int)recc[9] : 0, i0 = (int)recc[10], j0 = (int)recc[11], wj = (int)recc[12];
+            const int ci = (int)(((float)q + 0.5f) * (1.0f / (float)wj));
+            const int i = i0 + ci, j = j0 + (q - ci * wj);
+            const double x0 = -sx + j * dx, y0 = -sy + i * dy, reach = r + (margin > 0 ? margin : 0);
+            double zmax = 0;
+            if (actc) {
+                const double z00 = sz * data[i * nc + j], z10 = sz * data[i * nc + j + 1], z01 = sz * data[(i + 1) * nc + j], z11 = sz * data[(i + 1) * nc + j + 1];
+                zmax = fmax(fmax(z00, z10), fmax(z01, z11));
             }
-            write_raw_contact(S, slot, pidx, rc);
+            const double step = ns > 1 ? 2.0 * hl / (ns - 1) : 0.0, reach2 = reach * reach * (1.0 + 1e-9) + 1e-18;
+            const double ztop = zmax + reach + 1e-9 * (1.0 + fabs(zmax) + fabs(p0[2]) + hl);
+            for (int k = 0; k < CM_HP_MAXS; ++k) {
+                if (wv::ballot(k < ns) == 0ull) break; /* (wave-uniform: no lane has a k-th sample) */
+                if (k >= ns) continue;
+                const double tk = ns > 1 ? hl - k * step : 0.0;
+                const double px = p0[0] + tk * ax[0], py = p0[1] + tk * ax[1], pz = p0[2] + tk * ax[2];
+                const double ex = px < x0 ? x0 - px : (px > x0 + dx ? px - (x0 + dx) : 0.0);
+                const double ey = py < y0 ? y0 - py : (py > y0 + dy ? py - (y0 + dy) : 0.0);
+                if (!(ex * ex + ey * ey > reach2 || pz > ztop)) smask |= 1 << k;
+            }
         }
-        ncon += wv::popc64(hb);
+        const int mynp = wv::popc64((unsigned long long)(unsigned)smask), cnt = 2 * mynp;
+        int tend = cnt;
+#pragma unroll
+        for (int dlt = 1; dlt < WV_WAVE; dlt *= 2) { const int t = wv::shfl_i(tend, (lane - dlt) & 63); if (lane >= dlt) tend += t; }
+        const int ttot = wv::shfl_i(tend, WV_WAVE - 1), tstart = tend - cnt;
+        if (ttot == 0) continue; /* (wave-uniform) */
+        for (int i = 0; i < 2 * CM_HP_MAXS; ++i) {
+            if (wv::ballot(i < cnt) == 0ull) break;
+            if (i < cnt) tabb[tstart + i] = (unsigned char)lane;
+        }
+        wv::sync();
+        double best0 = 1e300, best1 = 1e300, bn0[3] = {0, 0, 1}, bn1[3] = {0, 0, 1}, bt0 = 0, bt1 = 0;
+        bool bdiv0 = false, bdiv1 = false;
+        for (int tbase = 0; tbase < ttot; tbase += WV_WAVE) {
+            const int t = tbase + lane;
+            const bool act = t < ttot;
+            const int src = act ? (int)tabb[t] : 0;
+            const int h2 = wv::shfl_i(h, src), cell = wv::shfl_i(q, src), sm2 = wv::shfl_i(smask, src), ts2 = wv::shfl_i(tstart, src);
+            const int np2 = wv::popc64((unsigned long long)(unsigned)sm2), li = act ? t - ts2 : 0, tri = li >= np2 ? 1 : 0, kidx = tri ? li - np2 : li;
+            int k = 0;
+            {
+                int seen = 0;
+#pragma unroll
+                for (int bpos = 0; bpos < CM_HP_MAXS; ++bpos) { if ((sm2 >> bpos) & 1) { if (seen == kidx) k = bpos; ++seen; } }
+            }
+            const double *rec = hp + HP_REC * h2;
+            const double p0[3] = {rec[0], rec[1], rec[2]}, ax[3] = {rec[3], rec[4], rec[5]}, r = rec[6], hl = rec[7], margin = rec[8];
+            const int ns = (int)rec[9], i0 = (int)rec[10], j0 = (int)rec[11], wj = (int)rec[12];
+            const int ci = (int)(((float)cell + 0.5f) * (1.0f / (float)wj)); /* cell / wj: the quotient's distance from an integer is at least 0.5 / wj */
+            const int i = i0 + ci, j = j0 + (cell - ci * wj);
+            const double x0 = -sx + j * dx, y0 = -sy + i * dy, reach = r + (margin > 0 ? margin : 0);
+            double cur = 1e300, cn[3] = {0, 0, 1}, tk = 0;
+            bool cdiv = false;
+            if (act) {
+                const double z00 = sz * data[i * nc + j], z10 = sz * data[i * nc + j + 1], z01 = sz * data[(i + 1) * nc + j], z11 = sz * data[(i + 1) * nc + j + 1];
+                const double zmax = fmax(fmax(z00, z10), fmax(z01, z11));
+                const double v00[3] = {x0, y0, z00}, v10[3] = {x0 + dx, y0, z10}, v01[3] = {x0, y0 + dy, z01}, v11[3] = {x0 + dx, y0 + dy, z11};
+                tk = ns > 1 ? hl * (1.0 - 2.0 * k / (ns - 1)) : 0.0;
+                const double p[3] = {p0[0] + tk * ax[0], p0[1] + tk * ax[1], p0[2] + tk * ax[2]};
+                /* exact culls: a sample further from the cell's rectangle than the reach in plan, or more than the reach above the
+                 * cell's highest corner, is not within contact distance of either of its triangles */
+                const double ex = p[0] < x0 ? x0 - p[0] : (p[0] > x0 + dx ? p[0] - (x0 + dx) : 0.0);
+                const double ey = p[1] < y0 ? y0 - p[1] : (p[1] > y0 + dy ? p[1] - (y0 + dy) : 0.0);
+                if (!(ex * ex + ey * ey > reach * reach || p[2] - reach > zmax)) {
+                    if (tri == 0) hfield_triangle(p, v00, v10, v01, cur, cn, cdiv); else hfield_triangle(p, v11, v01, v10, cur, cn, cdiv);
+                }
+            }
+            /* lane = cell again: its tasks of this round, in order */
+            const int lo = tstart > tbase ? tstart : tbase, hi = tstart + cnt < tbase + WV_WAVE ? tstart + cnt : tbase + WV_WAVE;
+            int win0 = -1, win1 = -1;
+            for (int i2 = 0; i2 < 2 * CM_HP_MAXS; ++i2) {
+                const bool mine = lo + i2 < hi;
+                if (wv::ballot(mine) == 0ull) break;
+                const int sl = mine ? lo + i2 - tbase : lane;
+                const double v = wv::shfl(cur, sl);
+                if (mine) {
+                    if (lo + i2 - tstart < mynp) { if (v < best0) { best0 = v; win0 = sl; } }
+                    else if (v < best1) { best1 = v; win1 = sl; }
+                }
+            }
+            if (wv::ballot(win0 >= 0 || win1 >= 0) != 0ull) {
+                const int s0 = win0 >= 0 ? win0 : lane, s1 = win1 >= 0 ? win1 : lane;
+                const double a0 = wv::shfl(cn[0], s0), a1 = wv::shfl(cn[1], s0), a2 = wv::shfl(cn[2], s0), at = wv::shfl(tk, s0);
+                const int ad = wv::shfl_i(cdiv ? 1 : 0, s0);
+                const double c0 = wv::shfl(cn[0], s1), c1 = wv::shfl(cn[1], s1), c2 = wv::shfl(cn[2], s1), ct = wv::shfl(tk, s1);
+                const int cd = wv::shfl_i(cdiv ? 1 : 0, s1);
+                if (win0 >= 0) { bn0[0] = a0; bn0[1] = a1; bn0[2] = a2; bt0 = at; bdiv0 = ad != 0; }
+                if (win1 >= 0) { bn1[0] = c0; bn1[1] = c1; bn1[2] = c2; bt1 = ct; bdiv1 = cd != 0; }
+            }
+        }
+        /* lane = cell: its two keys' verdicts, into the list in key order */
+        {
+            const double r = recc[6], hl = recc[7], margin = recc[8];
+            const int pidx = (int)recc[13], g2 = (int)recc[14];
+            if (bdiv0) { bn0[0] = bn0[0] / best0; bn0[1] = bn0[1] / best0; bn0[2] = bn0[2] / best0; } /* (the deepest sample's division: hfield_triangle) */
+            if (bdiv1) { bn1[0] = bn1[0] / best1; bn1[1] = bn1[1] / best1; bn1[2] = bn1[2] / best1; }
+            const double dist0 = best0 - r, dist1 = best1 - r;
+            const bool hit0 = cnt > 0 && best0 < 1e299 && !(dist0 > margin), hit1 = cnt > 0 && best1 < 1e299 && !(dist1 > margin);
+            const unsigned long long hb0 = wv::ballot(hit0), hb1 = wv::ballot(hit1);
+            const int slot0 = ncon + wv::popc64(hb0 & below) + wv::popc64(hb1 & below), slot1 = slot0 + (hit0 ? 1 : 0);
+            if (hit0 || hit1) {
+                const double *mh = S.x.s.geom_xmat[g1h], *pc = S.x.s.geom_xpos[g2], *mc = S.x.s.geom_xmat[g2];
+                const double axw[3] = {mc[2], mc[5], mc[8]};
+                for (int which = 0; which < 2; ++which) {
+                    const bool hit = which ? hit1 : hit0;
+                    const int slot = which ? slot1 : slot0;
+                    if (!hit || slot >= room) continue;
+                    const double *bn = which ? bn1 : bn0;
+                    const double bt = which ? bt1 : bt0, dist = which ? dist1 : dist0;
+                    double nw[3];
+                    mulmatvec3(nw, mh, bn);
+                    RawContact rc;
+                    rc.dist = dist;
+                    for (int x = 0; x < 3; ++x) {
+                        const double psw = pc[x] + bt * axw[x];
+                        rc.normal[x] = nw[x]; rc.pos[x] = psw - nw[x] * (r + 0.5 * dist); rc.tangent[x] = hl > 0 ? axw[x] : 0.0;
+                    }
+                    write_raw_contact(S, slot, pidx, rc);
+                }
+            }
+            ncon += wv::popc64(hb0) + wv::popc64(hb1);
+        }
+        wv::sync(); /* (the table is free again) */
     }
     wv::sync();
     return ncon;

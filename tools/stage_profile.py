@@ -9,6 +9,8 @@ from cassie_amd import phys as P
 names = ["kinematics", "geoms+com+cinert+cdof", "crba", "factor", "collision", "velocity+rne", "qfrc_smooth",
          "rows+J", "halfsolve", "A", "pgs", "qacc", "sensors", "euler"]
 m = Model(os.environ.get("MODEL", "cassie"))   # MODEL=cassie_tray_box: the 40-dof instantiation (one wave per env by default)
+if os.environ.get("PRISM"):
+    m.set_flag(P.FLAG_HFPRISM, True)          # PRISM=1 MODEL=cassie_hfield: the MuJoCo-shaped height-field contact set
 NSUB = int(os.environ.get("NSUB", "1"))   # substeps fused per launch (the bench uses 50)
 for n in (int(a) for a in (sys.argv[1:] or ["512", "4096"])):
     b = Batch(m, n)
