@@ -231,11 +231,15 @@ WV_DEVICE double wide_solve(SH &S, ModelPtr m, ParamPtr P, const int wid, const 
     /* this lane's staged row times the other wave's image: what the other wave's values contribute to this row's A x */
     auto cross = [&]() {
         if constexpr (CK_WIDE_SWEEP_V2) {   /* (four chains of eight instead of one of 32) */
-            double d0 = 0, d1 = 0, d2 = 0, d3 = 0;
+            double vo[NVP], d0 = 0, d1 = 0, d2 = 0, d3 = 0;
+            const double *const vother = &S.x.vx[1 - wid][0];
+#pragma unroll
+            for (int k = 0; k < NVP; ++k) vo[k] = vother[k];       /* (all the broadcast reads requested together) */
+            wv::sched_fence();
 #pragma unroll
             for (int k = 0; k < NVP; k += 4) {
-                d0 = fma(ycol[k], S.x.vx[1 - wid][k], d0); d1 = fma(ycol[k + 1], S.x.vx[1 - wid][k + 1], d1);
-                d2 = fma(ycol[k + 2], S.x.vx[1 - wid][k + 2], d2); d3 = fma(ycol[k + 3], S.x.vx[1 - wid][k + 3], d3);
+                d0 = fma(ycol[k], vo[k], d0); d1 = fma(ycol[k + 1], vo[k + 1], d1);
+                d2 = fma(ycol[k + 2], vo[k + 2], d2); d3 = fma(ycol[k + 3], vo[k + 3], d3);
             }
             return (d0 + d1) + (d2 + d3);
         }
@@ -285,21 +289,37 @@ WV_DEVICE double wide_solve(SH &S, ModelPtr m, ParamPtr P, const int wid, const 
          * changes it left in LDS.  What wave 0 hands over with its turn: sums[2] = its part (exact when sums[4] != 0, else the
          * estimate), chg[] = its rows' changes. */
         const float tolf = (float)tolerance, scalef = (float)scale;
+#ifdef CK_WIDE_PROFILE
+        long long pt_wait = 0, pt_cross = 0, pt_rows = 0, pt_post = 0, pt_image = 0, pt_pub = 0, pt_t;
+#define CK_WP(acc) do { const long long now_ = wv::clock(); acc += now_ - pt_t; pt_t = now_; } while (0)
+#else
+#define CK_WP(acc) do {} while (0)
+#endif
         for (int sweep = 0;; ++sweep) {
+            double w0_part = 0.0;
+            bool w0_exact = false;
+#ifdef CK_WIDE_PROFILE
+            pt_t = wv::clock();
+#endif
             if (wid == 0) {
                 if (sweep > 0) {
                     wv::wait_for_spin(&S.x.turn[1], base + 2 * sweep);
+                    CK_WP(pt_wait);
                     if (wv::opaque(S.x.turn[2])) break;
                     sres = fma(ninvAii, cross(), sres);
+                    CK_WP(pt_cross);
                 }
             } else {
                 wv::wait_for_spin(&S.x.turn[1], base + 2 * sweep + 1);
+                CK_WP(pt_wait);
+                w0_part = S.x.sums[2]; w0_exact = S.x.sums[4] != 0.0;     /* (wave 0's part of the cost change, for the verdict below: requested here) */
                 sres = fma(ninvAii, cross(), sres);
+                CK_WP(pt_cross);
             }
             const int nrows = wv::opaque(nown);
             /* wave 0's part of the sweep's cost change in row order, from what it left in LDS (wave 1 only, when it is needed) */
             auto ordered_part_of_wave0 = [&]() {
-                if (S.x.sums[4] != 0.0) return S.x.sums[2];
+                if (w0_exact) return w0_part;
                 const double c0 = S.x.chg[lane];
                 double imp = 0.0;
                 for (int t = 0; t < H; ++t) imp -= wv::readlane(c0, t);   /* (a sweep that crosses the waves has all 64 rows of wave 0) */
@@ -313,6 +333,7 @@ WV_DEVICE double wide_solve(SH &S, ModelPtr m, ParamPtr P, const int wid, const 
                 double mys = 0;
                 const double lo_f = flo - f;
                 pgs_rows_fast<0, H>(arow, nrows, r_, lo_f, sres, mys);
+                CK_WP(pt_rows);
                 const double mydelta = wv::max_raw(mys, lo_f);
                 change = (r_ < nrows) ? mydelta * (halfAii * mydelta - Aii * mys) : 0.0;
                 guarded = wv::ballot(change > 1e-10) != 0ull || wv::debug_force_guarded();
@@ -329,24 +350,25 @@ WV_DEVICE double wide_solve(SH &S, ModelPtr m, ParamPtr P, const int wid, const 
                     est = -wv::wave_sum_f32((float)change);
                 }
             }
+            CK_WP(pt_post);
             image_of(dstep);
+            CK_WP(pt_image);
             if (wid == 0) {
                 if (!guarded) S.x.chg[lane] = change;
                 if (lane == 0) { S.x.sums[2] = guarded ? exact : (double)est; S.x.sums[4] = guarded ? 1.0 : 0.0; }
                 wv::publish(&S.x.turn[1], base + 2 * sweep + 1);
+                CK_WP(pt_pub);
             } else {
                 iters = sweep + 1;
                 bool converged;
                 if (guarded) converged = exact * scale < tolerance;
                 else {
-                    const bool exact0 = S.x.sums[4] != 0.0;
                     /* (wave 0's exact part is a double; in single precision it is as good an estimate as a tree sum) */
-                    const float total = ((float)S.x.sums[2] + est) * scalef;
+                    const float total = ((float)w0_part + est) * scalef;
                     if (total < 0.5f * tolf) converged = true;
                     else if (total > 2.0f * tolf) converged = false;
                     else {
                         double imp = ordered_part_of_wave0();
-                        (void)exact0;
                         for (int t = 0; t < nrows; ++t) imp -= wv::readlane(change, t);
                         converged = imp * scale < tolerance;
                     }
@@ -354,9 +376,14 @@ WV_DEVICE double wide_solve(SH &S, ModelPtr m, ParamPtr P, const int wid, const 
                 const bool stop = converged || iters >= sweeps_max;
                 if (lane == 0) { S.x.turn[2] = stop ? 1 : 0; S.x.turn[3] = iters; S.x.sums[3] = (double)nguarded; }
                 wv::publish(&S.x.turn[1], base + 2 * sweep + 2);
+                CK_WP(pt_pub);
                 if (stop) break;
             }
         }
+#ifdef CK_WIDE_PROFILE
+        /* (profiling aid: this wave's clocks by part of the sweep, summed over the sweeps, for the caller to put into the stamp array) */
+        if (lane == 0) { double *o = &S.x.stepv[wid][0]; o[0] = (double)pt_wait; o[1] = (double)pt_cross; o[2] = (double)pt_rows; o[3] = (double)pt_post; o[4] = (double)pt_image; o[5] = (double)pt_pub; }
+#endif
     } else
     for (int sweep = 0;; ++sweep) {
         double carried = 0.0; /* the sweep's cost change summed in row order up to this wave's first row */

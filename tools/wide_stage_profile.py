@@ -40,4 +40,9 @@ for nm, a, c in [("w0 drive io + kinematics (incl. F)", 0, 1), ("w0 geoms", 1, 1
     print("  %-48s %9.0f cycles  %5.1f%%" % (nm, dur(a, c), 100 * dur(a, c) / tot0))
 sw = (st[:, 11] - st[:, 30]).astype(float)
 print("  per sweep: %.0f clocks (mean over envs of sweeps' clocks / sweeps); per (sweep x row): %.1f" % ((sw / info[wide, 2]).mean(), (sw / info[wide, 2] / info[wide, 1]).mean()))
+if os.environ.get("CASSIE_LIB", "").endswith("wprof.so"):     # (a library built with -DCK_WIDE_PROFILE: the sweeps' clocks by part)
+    names = ["wait", "cross", "rows", "post (change, guard, estimate)", "image", "publish / verdict"]
+    it = info[wide, 2].astype(float)
+    for w_, base in ((0, 16), (1, 28)):
+        print("  wave %d, clocks per sweep:" % w_, ", ".join("%s %.0f" % (nm, (st[:, base + i] / it).mean()) for i, nm in enumerate(names)), "| sum %.0f" % (st[:, base:base + 6].sum(axis=1) / it).mean())
 b.close()
