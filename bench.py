@@ -717,7 +717,7 @@ def device_rollout(model, mode, n, steps, warmup, rank, world, local_rank, subst
             # write, phys_model_set_const + phys_model_compile -- and the device's parameter block must equal that compile's bit for bit
             import randomise_check as rcheck
             assert world == 1, "the randomised leg replays rank 0's envs"
-            hosts = rcheck.HostEnvModels(model.name)
+            hosts = rcheck.HostEnvModels(model.name, flags=int(model.pod.flags))   # (with the shared model's contact options)
             blocks = [b_params[int(e)] for e in sample]
             par = {f: [rcheck.params_as_arrays(blk, pod)[f].reshape(-1) for blk in blocks] for f in rcheck.INPUT_FIELDS}
             pods, same = [], 0

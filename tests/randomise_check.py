@@ -46,8 +46,11 @@ PARAM_IDS = {"body_mass": P.P_BODY_MASS, "body_ipos": P.P_BODY_IPOS, "body_inert
 class HostEnvModels:
     """One host model edited env by env: pod(e) = the compiled model of env e (a copy), params(e) = its parameter block."""
 
-    def __init__(self, name):
+    def __init__(self, name, flags=0):
         self.m = Model(name)
+        for bit in (P.FLAG_HFDENSE, P.FLAG_HFMULTI, P.FLAG_HFPRISM, P.FLAG_BOX8):     # the contact options of the model the envs share
+            if flags & bit:
+                self.m.set_flag(bit, True)
         pod = self.m.pod
         self.nb, self.nv, self.ng = pod.nbody, pod.nv, pod.ngeom
         self.ngeom_full = self.m.size(P.SIZE_NGEOM)
