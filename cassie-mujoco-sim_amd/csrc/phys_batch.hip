@@ -79,6 +79,7 @@ struct phys_batch {
     /* stepping launches of the fast instantiations in chunks (PhysIO::nchunk): chunks per env-launch asked for (1 = off), the
      * words the chunks of an env hand over through, and the tag of the last chunked launch */
     int chunks = DEFAULT_CHUNKS_WHOLE, chunks_range = DEFAULT_CHUNKS_RANGE; /* (launches over the whole batch / over an env range) */
+    bool chunks_default = true;    /* nobody has asked for a chunk count: a range's SHORT launches go as three (see launch) */
     int *d_chunk_flag = nullptr;
     int chunk_seq = 0;
     bool chunks_allowed = true;     /* (false: this device does not place workgroup w on XCD w % 8 -- launches stay in one piece) */
@@ -252,7 +253,11 @@ static int launch(phys_batch *b, int nsub, int integrate, hipStream_t s, bool sc
             stream_may_chunk(b, s)) {
             /* (n % 8: workgroup w runs on XCD w % 8, so the chunks of an env -- workgroups n apart -- share an XCD and its L2) */
             /* the fast kernel's launch as chunks of at least CHUNK_MIN_SUBSTEPS substeps (the launchers size its grid) */
-            const int most = nsub / CHUNK_MIN_SUBSTEPS, asked = n == b->nenv ? b->chunks : b->chunks_range;
+            /* (round 6: a range's launch of 15 .. 25 substeps -- a consumer that fences every few substeps, the driver's 20-step regions --
+             * as three chunks instead of two: nothing fills the end of such a launch's queue, finer jobs shorten it, + 1.5 %; at 50
+             * substeps between fences three cost 0.6 %, profiles/round6/chunks3_ab.txt) */
+            const int range_chunks = b->chunks_default && nsub <= 25 ? 3 : b->chunks_range;
+            const int most = nsub / CHUNK_MIN_SUBSTEPS, asked = n == b->nenv ? b->chunks : range_chunks;
             io.nchunk = asked < most ? asked : most;
             if (b->chunk_seq >= (1 << 24)) { /* (the tag has 25 bits: start over once NOTHING is in flight on the device -- the words of
                                                * envs in flight on a stream this batch does not remember must not be cleared under them --
@@ -444,7 +449,7 @@ phys_batch_t *phys_batch_create(const cm_model_t *model, int nenv, int device) {
     ok = ok && hip_ok(hipMemset(b->d_progress, 0, sizeof(int) * (size_t)nenv), "hipMemset(progress)");
     ok = ok && hip_ok(hipMalloc((void **)&b->d_chunk_flag, sizeof(int) * (size_t)nenv), "hipMalloc(chunk words)");
     ok = ok && hip_ok(hipMemset(b->d_chunk_flag, 0, sizeof(int) * (size_t)nenv), "hipMemset(chunk words)");
-    if (const char *ck = getenv("CASSIE_CHUNKS")) b->chunks = b->chunks_range = atoi(ck) > 1 ? (atoi(ck) < 7 ? atoi(ck) : 7) : 1; /* (A/B switch) */
+    if (const char *ck = getenv("CASSIE_CHUNKS")) { b->chunks = b->chunks_range = atoi(ck) > 1 ? (atoi(ck) < 7 ? atoi(ck) : 7) : 1; b->chunks_default = false; } /* (A/B switch) */
     ok = ok && hip_ok(hipHostMalloc((void **)&b->h_chunk_fault, sizeof(int), hipHostMallocMapped), "hipHostMalloc(chunk fault word)");
     if (ok) *b->h_chunk_fault = 0;
     ok = ok && hip_ok(hipHostGetDevicePointer((void **)&b->d_chunk_fault, b->h_chunk_fault, 0), "hipHostGetDevicePointer");
@@ -1009,6 +1014,7 @@ int phys_batch_set_inplace(phys_batch_t *b, int mode) {
 int phys_batch_set_chunks(phys_batch_t *b, int chunks) {
     if (!b || chunks < 1 || chunks > 7) return -1;
     b->chunks = b->chunks_range = chunks;
+    b->chunks_default = false;
     return 0;
 }
 
