@@ -330,8 +330,12 @@ static int launch(phys_batch *b, int nsub, int integrate, hipStream_t s, bool sc
     if (ev_after) (void)hipEventRecord(ev_after, s);
     if (!launched) { (void)hip_ok(hipErrorLaunchFailure, "cassie_step_kernel launch"); return -1; }
     if (!hip_ok(hipGetLastError(), "cassie_step_kernel launch")) return -1;
-    /* the next launch's order from this one's per-env cost: after every long launch, now and then after short ones */
-    if (io.order && integrate && (nsub >= 8 || ++seg->launches_since_sort >= 16)) {
+    /* the next launch's order from this one's per-env cost: after every long launch, now and then after short ones.  (Round 6: "long" is
+     * more than 25 substeps, not 8 -- the sort is 20 - 25 us at the end of the launch's stream, 0.7 % of a fenced 20-substep launch, and the
+     * order itself is worth nothing either way since launches go in chunks: profiles/round6/launch_order_ab.txt.  The CASSIE_ORDER_EVERY
+     * switch: the A/B.) */
+    static const int sort_every_above = getenv("CASSIE_ORDER_EVERY") ? atoi(getenv("CASSIE_ORDER_EVERY")) : 25;
+    if (io.order && integrate && (nsub > sort_every_above || ++seg->launches_since_sort >= 16)) {
         seg->launches_since_sort = 0;
         hipLaunchKernelGGL(ck::cassie_order_kernel, dim3(1), dim3(ck::ORDER_THREADS), 0, s, b->d_cost, b->d_order, n, env0,
                            inplace_launch ? hl.count1 : (int *)nullptr, inplace_launch ? hl.seen1 : (volatile int *)nullptr);
