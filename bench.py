@@ -229,9 +229,9 @@ def launch_io_bytes_per_env(pod, drive=True):
 
 def launch_chunks(envs_per_launch, substeps_per_launch, whole_batch):
     """Workgroups per env a stepping launch of this shape is dispatched as (phys_batch.hip: launches in chunks -- 4 for a launch
-    over the whole batch, 2 for one over an env range -- 3 when that launch is at most 25 substeps long --, chunks of at least 5
+    over the whole batch (7 since round 6), 2 for one over an env range -- 3 when that launch is at most 25 substeps long --, chunks of at least 5
     substeps, launches of at least 2048 envs)."""
-    asked = int(os.environ.get("CASSIE_CHUNKS") or (4 if whole_batch else (3 if substeps_per_launch <= 25 else 2)))
+    asked = int(os.environ.get("CASSIE_CHUNKS") or (7 if whole_batch else (3 if substeps_per_launch <= 25 else 2)))
     if envs_per_launch < 2048 or envs_per_launch % 8 or substeps_per_launch < 10:
         return 1
     return max(1, min(asked, int(substeps_per_launch) // 5))

@@ -30,7 +30,7 @@ void phys_set_last_error(const char *s);
 /* Defaults by measurement (profiles/round4/chunks_ab.txt): a launch over the whole batch has nothing to fill the end of its queue
  * with: 4 chunks (+7 %); launches over env ranges (phys_batch_step_range: other ranges' launches fill in) gain nothing from more
  * than 2 in steady state, and as much as the whole-batch launch when they stand alone between two synchronisations. */
-constexpr int DEFAULT_CHUNKS_WHOLE = 4, DEFAULT_CHUNKS_RANGE = 2, CHUNK_MIN_ENVS = 2048, CHUNK_MIN_SUBSTEPS = 5;
+constexpr int DEFAULT_CHUNKS_WHOLE = 7 /* (round 6; 4 before: jobs of 7 substeps leave the shortest end of a queue, profiles/round6/one_stream_chunks.txt) */, DEFAULT_CHUNKS_RANGE = 2, CHUNK_MIN_ENVS = 2048, CHUNK_MIN_SUBSTEPS = 5;
 constexpr int DEFAULT_TRAY_WAVES = 2; /* the 40-dof model's default form (by measurement: round 5, 17.77 against 15.72 M with one wave, profiles/round5/tray_two_waves_ab.txt; round 4 had it at -7.5 %) */
 
 struct phys_batch {

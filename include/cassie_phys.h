@@ -269,7 +269,7 @@ int phys_batch_debug_form_launches(const phys_batch_t *b, long long *plain, long
  * (centres of mass, composite inertias, M, its two factorisations) on the second wave beside the first wave's collision,
  * velocity and constraint-row stages; 1: one wavefront per env.  Same results, bit for bit (a measurement aid). */
 int phys_batch_set_waves_per_env(phys_batch_t *b, int waves);
-/* Stepping launches of the row-capped fast kernels in CHUNKS (1 = off .. 7; default: 4 for launches over the whole batch, 2 for
+/* Stepping launches of the row-capped fast kernels in CHUNKS (1 = off .. 7; default: 7 for launches over the whole batch, 2 for
  * launches over an env range, whose neighbours' launches fill the end of its queue anyway -- 3 for a range's launch of at most 25
  * substeps, the shape of a consumer that fences every few substeps): a launch of at least 2048 envs and 10 substeps is
  * dispatched as `chunks` workgroups per env, each stepping a share of the substeps (5 at least) from the state the chunk before it

@@ -147,8 +147,9 @@ def test_pmc_traffic_scales_only_the_per_substep_part(cassie):
     # launches in chunks: every chunk of an env's launch loads and stores like a launch of its own
     t50_4, _ = bench.pmc_traffic(4096 * 50, "cassie", envs_per_launch=4096, pod=pod, chunks=4)
     assert abs((t50_4 - t50) - 3 * fixed * 4096) < 1e-6 * t50
-    assert bench.launch_chunks(2048, 50, False) == 2 and bench.launch_chunks(4096, 50, True) == 4 and bench.launch_chunks(4096, 20, True) == 4
-    assert bench.launch_chunks(2048, 14, False) == 2 and bench.launch_chunks(2048, 9, False) == 1 and bench.launch_chunks(1024, 50, True) == 1
+    # (round 6: whole-batch launches go as 7 chunks where they are long enough, a range's launch of at most 25 substeps as 3)
+    assert bench.launch_chunks(2048, 50, False) == 2 and bench.launch_chunks(4096, 50, True) == 7 and bench.launch_chunks(4096, 20, True) == 4
+    assert bench.launch_chunks(2048, 20, False) == 3 and bench.launch_chunks(2048, 14, False) == 2 and bench.launch_chunks(2048, 9, False) == 1 and bench.launch_chunks(1024, 50, True) == 1
 
 
 def test_slot_occupancy_figure():

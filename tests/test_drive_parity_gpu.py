@@ -386,7 +386,7 @@ def test_launch_in_chunks_equals_the_launch_in_one_piece_bit_for_bit(built, name
             q0[e, 0], q0[e, 1] = G.start_xy(name, e)
     streams = [torch.cuda.Stream(), torch.cuda.Stream()]
     out = []
-    for chunks, inplace in ((1, 0), (4, 0), (3, 0), (4, 1), (2, 2)):   # (round 6: ... the in-place form of the fast kernel in chunks, and the form picked per range)
+    for chunks, inplace in ((1, 0), (4, 0), (3, 0), (4, 1), (2, 2), (7, 0)):   # (7: the default of whole-batch launches since round 6)   # (round 6: ... the in-place form of the fast kernel in chunks, and the form picked per range)
         b = Batch(model, n)
         try:
             b.set_waves_per_env(waves)
@@ -425,7 +425,7 @@ def test_launch_in_chunks_equals_the_launch_in_one_piece_bit_for_bit(built, name
         assert out[3][1] == 0 and out[4][1] < out[0][1]     # (in place nothing is handed over; the per-range choice went in place once envs were)
     if name != "cassie_tray_box":
         assert out[0][1] > 3     # (round 6: the verdict counts a frictionless contact as one row -- 6 env-launches of this workload on cassie.xml, 30 in round 5; cassie_hfield hands over far more)
-    for k in (1, 2, 3, 4):
+    for k in (1, 2, 3, 4, 5):
         for a, c in zip(out[0][0], out[k][0]):
             assert a.tobytes() == c.tobytes(), k
 

@@ -38,7 +38,8 @@ g = lambda k: per.get(k, float("nan"))
 derived = {
     "env_steps_per_launch": n_env_steps,
     "envs_per_launch": 4096,
-    "chunks_per_env_launch": 4,   # whole-batch launches of 4096 envs x 50 substeps go as four chunks per env (phys_batch.hip)
+    # whole-batch launches of 4096 envs x 50 substeps go as PMC_CHUNKS chunks per env (phys_batch.hip: 7 since round 6; the v36 / v37 files: 4)
+    "chunks_per_env_launch": int(__import__("os").environ.get("PMC_CHUNKS", "7")),
     "valu_insts_per_env_step": g("SQ_INSTS_VALU") / n_env_steps,
     "salu_insts_per_env_step": g("SQ_INSTS_SALU") / n_env_steps,
     "lds_insts_per_env_step": g("SQ_INSTS_LDS") / n_env_steps,
